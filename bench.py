@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py -- the fused flash-attention forward on MI355X: fwd ms, achieved TFLOP/s, fraction of the MFMA roofline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c3|c2|c5] [--causal]
+
+Contract (one JSON line on stdout from rank 0):
+  * a "step" is one forward over one rank's (batch*heads, N, d) shard of synthetic randn data already resident in
+    HBM; W untimed steps, then exactly K timed steps bracketed by barrier + torch.cuda.synchronize() on both sides;
+    the time is the MAX over ranks; `value` = algorithmic FLOP of all ranks / that time, in TFLOP/s.
+  * N = 1 workload = the configuration BASELINE.json's metric is quoted on: B=2 H=8 d=64 N=8192, bf16 MFMA path
+    (config "c4").  N > 1: every rank runs that same shard (weak scaling; the batch*head axis shards
+    with NO collective on the data path -- each slab is independent, /root/reference/src/flashattention.cu:144).
+    `--workload c5` instead splits B=64 H=16 (1024 slabs) across the ranks (strong scaling) and says so.
+  * "roofline": dominant kernel's algorithmic FLOP per launch / its mean launch duration measured with HIP events on
+    the launch stream (fa_time_forward in the C ABI) against the dense MFMA peak of the dtype.
+  * "cpu_baseline": the CPU oracle (oracle/attention_oracle.c, OpenMP) timed on this box's host cores on a bounded
+    sample of the same workload (rank 0, N = 1 only) -- a reported baseline, not the optimisation target.  PyTorch's
+    CPU SDPA on the full fp32 shape is reported next to it ("cpu_sdpa").
+The product path has no fallback: if the HIP library is missing this script fails.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+
+WORKLOADS = {
+    # name: (B, H, d, N, dtype, scaling)
+    "c2": (8, 16, 64, 1024, "f32", "weak"),
+    "c3": (2, 8, 64, 8192, "f32", "weak"),
+    "c4": (2, 8, 64, 8192, "bf16", "weak"),
+    "c5": (64, 16, 64, 8192, "bf16", "strong"),
+}
+
+
+def fwd_flop(bh: int, n: int, d: int, causal: bool) -> float:
+    """Algorithmic FLOP of one forward: two GEMMs of 2*N*N*d per slab (softmax not counted), half of it when causal."""
+    return (2.0 if causal else 4.0) * bh * float(n) * float(n) * d
+
+
+def algorithmic_bytes(bh: int, n: int, d: int, elem: int) -> float:
+    """HBM minimum: read Q, K, V once, write O once."""
+    return 4.0 * bh * n * d * elem
+
+
+def dist_env():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    return rank, world, local
+
+
+def init_dist(world: int, backend: str):
+    import torch.distributed as dist
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend=backend)
+    return dist
+
+
+def timed_region(step_fn, steps: int, warmup: int, sync_fn, world: int, dist=None, device=None) -> float:
+    """W untimed steps, then K timed steps bracketed by barrier + sync on both sides; returns MAX-over-ranks seconds."""
+    import torch
+    for _ in range(warmup):
+        step_fn()
+    sync_fn()
+    if world > 1:
+        dist.barrier()
+    sync_fn()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync_fn()
+    if world > 1:
+        dist.barrier()
+    sync_fn()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device if device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def make_inputs(bh: int, n: int, d: int, dtype: str, device, seed: int):
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    # generated on the host in fp32 (as the reference bench does, bench_flashattention.py:31-33), then moved
+    return [torch.randn(bh, n, d, generator=g, dtype=torch.float32).to(tdt).to(device) for _ in range(3)]
+
+
+def cpu_baseline(n: int, d: int, causal: bool, scale: float):
+    """Oracle ("port") on a bounded sample: whole heads of the same N and d, count chosen for ~10-30 s of CPU work."""
+    import numpy as np
+    from oracle import oracle as orc
+    rng = np.random.default_rng(0)
+    cores = orc.num_threads()
+    q, k, v = (rng.standard_normal((1, n, d)).astype(np.float32) for _ in range(3))
+    t0 = time.perf_counter()
+    orc.attention_f64(q, k, v, causal=causal, scale=scale)   # one full head: sizes the sample (and warms the threads)
+    dt = time.perf_counter() - t0
+    heads = int(max(1, min(16, 15.0 // max(dt, 1e-3))))
+    if heads > 1:
+        q, k, v = (rng.standard_normal((heads, n, d)).astype(np.float32) for _ in range(3))
+        t0 = time.perf_counter()
+        orc.attention_f64(q, k, v, causal=causal, scale=scale)
+        dt = time.perf_counter() - t0
+    tf = fwd_flop(heads, n, d, causal) / dt / 1e12
+    return {"value": round(tf, 5), "unit": "TFLOP/s", "cores": cores, "kind": "port",
+            "sample": f"{heads} of 16 heads at N={n} d={d} fp64-accumulate C oracle (OpenMP), {dt:.1f} s",
+            "ms_per_full_workload_est": round(dt / heads * 16 * 1e3, 1)}
+
+
+def cpu_sdpa(bh: int, n: int, d: int, causal: bool, scale: float):
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn(bh, n, d, generator=g) for _ in range(3))
+    F.scaled_dot_product_attention(q, k, v, is_causal=causal, scale=scale)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        F.scaled_dot_product_attention(q, k, v, is_causal=causal, scale=scale)
+        ts.append(time.perf_counter() - t0)
+    med = sorted(ts)[1]
+    return {"ms": round(med * 1e3, 1), "tflops": round(fwd_flop(bh, n, d, causal) / med / 1e12, 4),
+            "threads": torch.get_num_threads(), "host_cpus": os.cpu_count(), "dtype": "f32",
+            "what": "torch.nn.functional.scaled_dot_product_attention on the host, full fp32 shape"}
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch from the committed PMC profile of this same command (profiles/), if present."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(p):
+        try:
+            with open(p) as f:
+                return json.load(f)
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c4")
+    ap.add_argument("--causal", action="store_true")
+    ap.add_argument("--scale", type=float, default=1.0, help="softmax scale; the reference hard-wires 1.0")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary fp32 measurement")
+    args = ap.parse_args()
+
+    import torch
+    rank, world, local = dist_env()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the flash-attention forward has no CPU path")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = init_dist(world, "nccl") if world > 1 else None
+
+    import flashattention_c_amd as fa  # raises if libflashattn_amd.so is missing -- no fallback
+
+    B, H, d, n, dtype, scaling = WORKLOADS[args.workload]
+    total_bh = B * H
+    if scaling == "strong":
+        b0, b1 = fa.shard_range(total_bh, world, rank)
+        bh = b1 - b0
+        global_bh = total_bh
+    else:
+        bh = total_bh
+        global_bh = total_bh * world
+    causal = bool(args.causal)
+    q, k, v = make_inputs(bh, n, d, dtype, device, seed=rank)
+    out = torch.empty_like(q)
+
+    def step():
+        fa.forward(q, k, v, causal, scale=args.scale, out=out)
+
+    dt = timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, world, dist, device)
+    ms_per_step = dt / args.steps * 1e3
+    value = fwd_flop(global_bh, n, d, causal) * args.steps / dt / 1e12
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream, inside the C ABI
+    roof = None
+    extras = {}
+    if rank == 0:
+        kms = fa.time_forward(q, k, v, causal, scale=args.scale, warmup=3, iters=max(10, min(args.steps, 50)), out=out)
+        achieved = fwd_flop(bh, n, d, causal) / (kms * 1e-3) / 1e12
+        elem = 2 if dtype == "bf16" else 4
+        pmc = load_pmc_traffic()
+        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_TFLOPS[dtype], 4),
+                "traffic": (pmc or {}).get(f"{args.workload}_hbm_bytes_per_launch"),
+                "kernel": "fa_fwd_bf16_kernel" if dtype == "bf16" else "fa_fwd_f32_kernel",
+                "kernel_ms": round(kms, 4),
+                "algorithmic_flop_per_launch": fwd_flop(bh, n, d, causal),
+                "algorithmic_hbm_bytes_per_launch": algorithmic_bytes(bh, n, d, elem),
+                "hbm_gbps_at_algorithmic_bytes": round(algorithmic_bytes(bh, n, d, elem) / (kms * 1e-3) / 1e9, 1)}
+        if not args.no_extras and world == 1 and args.workload == "c4":
+            # the same shape in exact fp32 (config c3) and the README shape (c2), a few launches each
+            for name in ("c3", "c2"):
+                B2, H2, d2, n2, dt2, _ = WORKLOADS[name]
+                q2, k2, v2 = make_inputs(B2 * H2, n2, d2, dt2, device, seed=1)
+                ms2 = fa.time_forward(q2, k2, v2, causal, scale=args.scale, warmup=2, iters=10)
+                tf2 = fwd_flop(B2 * H2, n2, d2, causal) / (ms2 * 1e-3) / 1e12
+                extras[name] = {"workload": f"B={B2} H={H2} d={d2} N={n2} {dt2}", "ms": round(ms2, 4), "tflops": round(tf2, 2),
+                                "frac_mfma_peak": round(tf2 / PEAK_TFLOPS[dt2], 4)}
+                del q2, k2, v2
+            torch.cuda.synchronize()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(n, d, causal, args.scale)
+        try:
+            extras["cpu_sdpa"] = cpu_sdpa(total_bh, n, d, causal, args.scale)
+        except Exception as e:  # pragma: no cover - informational only
+            extras["cpu_sdpa"] = {"error": repr(e)}
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        line = {
+            "metric": "flash-attention fwd achieved TFLOP/s (fwd ms in ms_per_step; % MFMA peak in roofline.frac), B=2 H=8 d=64 N=8192"
+            if args.workload in ("c3", "c4") else f"flash-attention fwd achieved TFLOP/s, workload {args.workload}",
+            "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": dtype, "data": "synthetic randn (seeded), resident in HBM",
+            "config": {"workload": f"{args.workload}: B={B} H={H} d={d} N={n} {dtype}, {'causal' if causal else 'non-causal'}, "
+                                   f"scale={args.scale:g}" + (" per GPU" if scaling == "weak" and world > 1 else ""),
+                       "global_bh": global_bh, "bh_per_gpu": bh, "seq_len": n, "head_dim": d,
+                       "parallelism": f"batch*head sharded x{world}, no collective"},
+            "roofline": roof, "cpu_baseline": cpu, "extra": extras,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,234 @@
+// fa_api.cpp -- the extern "C" boundary declared in include/flashattn_amd.h.
+//
+// Host-side counterpart of forward() + run_flash_tiled_coarse{,_causal}
+// (/root/reference/src/flashattention.cu:590-617): argument validation, parameter block, kernel choice, launch.
+// Unlike the reference it never allocates, never synchronises (except fa_time_forward) and reports errors by
+// return code + thread-local message instead of assert().
+#include "../../include/flashattn_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "fa_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+bool head_dim_supported(int d) { return d == 32 || d == 64 || d == 128; }
+
+// Decode the `kernel` argument: low byte = fa_kernel, bits 8.. = tiling variant (ablation driver only).
+struct KernelSel {
+    int kind;
+    int variant;
+};
+KernelSel decode_kernel(int32_t kernel) { return KernelSel{kernel & 0xff, (kernel >> 8) & 0xff}; }
+
+int validate_common(const void* q, const void* k, const void* v, const void* o, int64_t bh, int64_t n, int32_t d,
+                    float scale, int32_t dtype)
+{
+    if (!q || !k || !v || !o) return fail(FA_ERR_INVALID_ARGUMENT, "null tensor pointer (q=%p k=%p v=%p o=%p)", q, k, v, o);
+    if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(o))
+        return fail(FA_ERR_INVALID_ARGUMENT, "tensor pointers must be 16-byte aligned");
+    if (bh < 1 || n < 1) return fail(FA_ERR_INVALID_ARGUMENT, "bh (%lld) and n (%lld) must be >= 1", (long long)bh, (long long)n);
+    if (bh > 0x7fffffffLL || n > (1LL << 24))
+        return fail(FA_ERR_INVALID_ARGUMENT, "bh (%lld) or n (%lld) out of range", (long long)bh, (long long)n);
+    if (d < 1) return fail(FA_ERR_INVALID_ARGUMENT, "head dim %d must be >= 1", d);
+    if (!(scale > 0.0f) || !std::isfinite(scale)) return fail(FA_ERR_INVALID_ARGUMENT, "scale must be finite and > 0 (got %g)", (double)scale);
+    if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_BF16_OUT_F32)
+        return fail(FA_ERR_UNSUPPORTED, "unknown dtype %d", dtype);
+    return FA_OK;
+}
+
+fa::FwdParams make_params(const void* q, const void* k, const void* v, void* o, float* lse, int64_t bh, int64_t n, int32_t d,
+                          float scale)
+{
+    fa::FwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.q = q;
+    p.k = k;
+    p.v = v;
+    p.o = o;
+    p.lse = lse;
+    p.q_batch_stride = p.kv_batch_stride = p.o_batch_stride = n * d;  // batch_stride of flashattention.cu:593
+    p.q_row_stride = p.kv_row_stride = p.o_row_stride = d;
+    p.n = (int32_t)n;
+    p.bh = (int32_t)bh;
+    p.scale = scale;
+    p.scale_log2e = scale * fa::kLog2e;
+    p.heads = 1;
+    return p;
+}
+
+int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int32_t kernel, hipStream_t stream)
+{
+    const KernelSel sel = decode_kernel(kernel);
+    hipError_t e = hipSuccess;
+    if (sel.kind == FA_KERNEL_NAIVE) {
+        if (dtype != FA_DTYPE_F32) return fail(FA_ERR_UNSUPPORTED, "the naive kernel is fp32 only");
+        if (d > 256) return fail(FA_ERR_UNSUPPORTED, "naive kernel supports head dim <= 256 (got %d)", d);
+        e = fa::launch_naive_f32(p, d, causal ? 1 : 0, stream);
+    } else if (sel.kind == FA_KERNEL_AUTO || sel.kind == FA_KERNEL_MFMA) {
+        if (!head_dim_supported(d))
+            return fail(FA_ERR_UNSUPPORTED, "head dim %d not instantiated for the MFMA kernels (32, 64, 128)", d);
+        e = (dtype == FA_DTYPE_F32)
+                ? fa::launch_fwd_f32(p, d, causal ? 1 : 0, sel.variant, stream)
+                : fa::launch_fwd_bf16(p, d, causal ? 1 : 0, dtype == FA_DTYPE_BF16_OUT_F32 ? 1 : 0, sel.variant, stream);
+    } else {
+        return fail(FA_ERR_UNSUPPORTED, "unknown kernel id %d", sel.kind);
+    }
+    if (e != hipSuccess) return fail(FA_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return FA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fa_forward_ex(const void* q, const void* k, const void* v, void* o, float* lse, int64_t bh, int64_t n, int32_t d, float scale,
+                  int32_t causal, int32_t dtype, int32_t kernel, void* stream)
+{
+    g_err[0] = 0;
+    if (int rc = validate_common(q, k, v, o, bh, n, d, scale, dtype)) return rc;
+    const fa::FwdParams p = make_params(q, k, v, o, lse, bh, n, d, scale);
+    return launch(p, d, causal, dtype, kernel, static_cast<hipStream_t>(stream));
+}
+
+int fa_forward(const void* q, const void* k, const void* v, void* o, int64_t bh, int64_t n, int32_t d, float scale, int32_t causal,
+               int32_t dtype, void* stream)
+{
+    return fa_forward_ex(q, k, v, o, nullptr, bh, n, d, scale, causal, dtype, FA_KERNEL_AUTO, stream);
+}
+
+int fa_forward_sharded(int32_t n_shards, const int32_t* device_ids, const void* const* q, const void* const* k, const void* const* v,
+                       void* const* o, const int64_t* bh, int64_t n, int32_t d, float scale, int32_t causal, int32_t dtype,
+                       void* const* streams)
+{
+    g_err[0] = 0;
+    if (n_shards < 1 || !device_ids || !q || !k || !v || !o || !bh)
+        return fail(FA_ERR_INVALID_ARGUMENT, "fa_forward_sharded: bad shard table");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(FA_ERR_NO_DEVICE, "no HIP device visible");
+    for (int i = 0; i < n_shards; ++i) {
+        if (device_ids[i] < 0 || device_ids[i] >= ndev)
+            return fail(FA_ERR_INVALID_ARGUMENT, "shard %d: device %d not in [0, %d)", i, device_ids[i], ndev);
+        if (bh[i] < 0) return fail(FA_ERR_INVALID_ARGUMENT, "shard %d: negative bh", i);
+        if (bh[i] == 0) continue;
+        if (int rc = validate_common(q[i], k[i], v[i], o[i], bh[i], n, d, scale, dtype)) return rc;
+    }
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess) return fail(FA_ERR_HIP, "hipGetDevice failed");
+    int rc = FA_OK;
+    for (int i = 0; i < n_shards && rc == FA_OK; ++i) {
+        if (bh[i] == 0) continue;  // more devices than slabs: this shard is empty
+        hipError_t e = hipSetDevice(device_ids[i]);
+        if (e != hipSuccess) {
+            rc = fail(FA_ERR_HIP, "hipSetDevice(%d): %s", device_ids[i], hipGetErrorString(e));
+            break;
+        }
+        const fa::FwdParams p = make_params(q[i], k[i], v[i], o[i], nullptr, bh[i], n, d, scale);
+        rc = launch(p, d, causal, dtype, FA_KERNEL_AUTO, streams ? static_cast<hipStream_t>(streams[i]) : nullptr);
+    }
+    (void)hipSetDevice(prev);
+    return rc;
+}
+
+int fa_forward_packed_qkv(const float* inp, float* out, int32_t B, int32_t T, int32_t C, int32_t NH, void* stream)
+{
+    g_err[0] = 0;
+    if (!inp || !out) return fail(FA_ERR_INVALID_ARGUMENT, "null pointer");
+    if (B < 1 || T < 1 || C < 1 || NH < 1 || C % NH != 0)
+        return fail(FA_ERR_INVALID_ARGUMENT, "bad shape B=%d T=%d C=%d NH=%d", B, T, C, NH);
+    const int hs = C / NH;
+    if (!head_dim_supported(hs)) return fail(FA_ERR_UNSUPPORTED, "head size %d not instantiated (32, 64, 128)", hs);
+    if (!aligned16(inp) || !aligned16(out)) return fail(FA_ERR_INVALID_ARGUMENT, "buffers must be 16-byte aligned");
+    if ((int64_t)B * NH > 0x7fffffffLL) return fail(FA_ERR_INVALID_ARGUMENT, "B*NH too large");
+    // (B, T, 3C): q at column h*hs, k at C + h*hs, v at 2C + h*hs of each token row
+    // (attention_forward_cpu, /root/reference/src/llm.c/attention_forward.cu:66,74,115)
+    fa::FwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.q = inp;
+    p.k = inp + C;
+    p.v = inp + 2 * (int64_t)C;
+    p.o = out;
+    p.lse = nullptr;
+    p.q_batch_stride = p.kv_batch_stride = (int64_t)T * 3 * C;
+    p.o_batch_stride = (int64_t)T * C;
+    p.q_row_stride = p.kv_row_stride = 3 * C;
+    p.o_row_stride = C;
+    p.q_head_stride = p.kv_head_stride = p.o_head_stride = hs;
+    p.heads = NH;
+    p.n = T;
+    p.bh = B * NH;
+    p.scale = 1.0f / sqrtf((float)hs);  // attention_forward.cu:61,1123
+    p.scale_log2e = p.scale * fa::kLog2e;
+    return launch(p, hs, /*causal=*/1, FA_DTYPE_F32, FA_KERNEL_AUTO, static_cast<hipStream_t>(stream));
+}
+
+int fa_time_forward(const void* q, const void* k, const void* v, void* o, int64_t bh, int64_t n, int32_t d, float scale,
+                    int32_t causal, int32_t dtype, int32_t kernel, void* stream, int32_t warmup, int32_t iters, float* ms_per_forward)
+{
+    g_err[0] = 0;
+    if (!ms_per_forward || iters < 1 || warmup < 0) return fail(FA_ERR_INVALID_ARGUMENT, "bad timing arguments");
+    if (int rc = validate_common(q, k, v, o, bh, n, d, scale, dtype)) return rc;
+    const fa::FwdParams p = make_params(q, k, v, o, nullptr, bh, n, d, scale);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        return fail(FA_ERR_HIP, "hipEventCreate failed");
+    }
+    int rc = FA_OK;
+    for (int i = 0; i < warmup && rc == FA_OK; ++i) rc = launch(p, d, causal, dtype, kernel, s);
+    if (rc == FA_OK) {
+        (void)hipEventRecord(e0, s);
+        for (int i = 0; i < iters && rc == FA_OK; ++i) rc = launch(p, d, causal, dtype, kernel, s);
+        (void)hipEventRecord(e1, s);
+        const hipError_t e = hipEventSynchronize(e1);
+        if (rc == FA_OK && e != hipSuccess) rc = fail(FA_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(e));
+        if (rc == FA_OK) {
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            *ms_per_forward = ms / (float)iters;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+const char* fa_last_error(void) { return g_err; }
+
+int fa_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* fa_version(void) { return "flashattn_amd abi 1 gfx950 (hip, mfma f32 32x32x2 / bf16 32x32x16, lds-dma)"; }
+
+const char* fa_kernel_name(int32_t dtype, int32_t d, int32_t causal)
+{
+    if (!head_dim_supported(d)) return nullptr;
+    if (dtype == FA_DTYPE_F32) return causal ? "fa_fwd_f32_kernel<causal>" : "fa_fwd_f32_kernel";
+    if (dtype == FA_DTYPE_BF16 || dtype == FA_DTYPE_BF16_OUT_F32) return causal ? "fa_fwd_bf16_kernel<causal>" : "fa_fwd_bf16_kernel";
+    return nullptr;
+}
+
+}  // extern "C"

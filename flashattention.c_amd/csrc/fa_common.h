@@ -1,0 +1,79 @@
+// fa_common.h -- shared host/device helpers for the gfx950 flash-attention forward kernels.
+//
+// Everything in csrc/ is written for CDNA4 (gfx950, wave64) only: MFMA builtins, LDS-DMA
+// (global_load_lds), ds_read_b64_tr_b16 and the 64-lane cross-lane ops are used directly.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fa {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+constexpr int kWave = 64;          // CDNA wavefront width
+constexpr int kNumXcd = 8;         // MI355X: 8 XCDs, each with a private 4 MiB L2
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+// Launch parameters shared by every kernel (all strides in elements).
+struct FwdParams {
+    const void* q;
+    const void* k;
+    const void* v;
+    void* o;
+    float* lse;            // nullable, (bh, n) fp32, natural log
+    int64_t q_batch_stride; // elements between consecutive (batch*head) slabs of Q
+    int64_t kv_batch_stride;
+    int64_t o_batch_stride;
+    int32_t q_row_stride;   // elements between consecutive sequence positions
+    int32_t kv_row_stride;
+    int32_t o_row_stride;
+    int32_t n;              // sequence length
+    int32_t bh;             // batch * heads
+    int32_t q_tiles;        // ceil(n / rows-per-workgroup)
+    float scale_log2e;      // scale * log2(e): softmax runs in the exp2 domain
+    float scale;
+    // packed-QKV (llm.c layout) addressing: slab index b*NH + h -> b * batch_stride + h * head_stride
+    int32_t heads;          // NH (1 for the plain (BH, N, d) layout)
+    int64_t q_head_stride;
+    int64_t kv_head_stride;
+    int64_t o_head_stride;
+};
+
+// Map the linear workgroup id onto (slab, q-tile) so that each XCD owns a contiguous range of work items
+// and therefore whole (batch*head) slabs: the dispatcher places workgroup b on XCD b % 8 (observed, used for
+// L2 locality only -- any placement is correct).  Bijective for every grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int total)
+{
+    const int q = total / kNumXcd, r = total % kNumXcd;
+    const int xcd = bid % kNumXcd, idx = bid / kNumXcd;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// max / sum across the two half-waves (lane l <-> lane l^32) with one v_permlane32_swap (VALU, no LDS trip):
+// swap(a, b) exchanges a[32..63] with b[0..31]; fed the same value twice it returns {lo, lo} and {hi, hi}.
+__device__ __forceinline__ float xhalf_max(float x)
+{
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float x)
+{
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+}  // namespace fa

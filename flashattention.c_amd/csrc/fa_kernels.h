@@ -1,0 +1,14 @@
+// fa_kernels.h -- launcher declarations shared by the C-ABI translation unit and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fa_common.h"
+
+namespace fa {
+
+// Each launcher enqueues one forward on `stream` and returns hipGetLastError().
+// `variant` selects among co-compiled tilings of the same kernel (0 = default); used by the ablation driver.
+hipError_t launch_naive_f32(const FwdParams& p, int d, int causal, hipStream_t stream);
+hipError_t launch_fwd_f32(const FwdParams& p, int d, int causal, int variant, hipStream_t stream);
+hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, int variant, hipStream_t stream);
+
+}  // namespace fa

@@ -1,0 +1,148 @@
+"""Host-side mirror of the reference's operator surface.
+
+The reference exposes exactly one call (``/root/reference/src/main.cpp:3-6``, used at
+``/root/reference/bench_flashattention.py:10,70``)::
+
+    minimal_flash = load(name='flash', sources=[...])
+    out = minimal_flash.forward(q, k, v, masking)        # q, k, v: (batch*heads, seq, head_dim) on the GPU
+
+This module provides the same call with the same positional meaning, backed by the C ABI in
+``include/flashattn_amd.h`` (hand-written HIP for gfx950).  PyTorch is used for device memory and the stream
+handle only.  Defaults reproduce the reference: ``scale = 1.0`` (``flashattention.cu:593,600``), fp32 in -> fp32 out.
+Differences, all deliberate (DESIGN.md "boundary"): the call is asynchronous on the current stream (the reference
+ends with ``cudaDeviceSynchronize``), invalid input raises ``ValueError``/``TypeError`` instead of tripping a device
+``assert`` (``flashattention.cu:606``), head dims 32/64/128 are all compiled in (the reference needs ``#define d``
+edited, ``:15``), any sequence length is exact (the reference needs N % 32 == 0), and bf16 tensors
+are accepted (bf16 MFMA path).
+"""
+from __future__ import annotations
+
+import ctypes
+from types import SimpleNamespace
+from typing import Optional, Tuple, Union
+
+import torch
+
+from . import _cabi
+
+__all__ = ["forward", "forward_packed_qkv", "load", "time_forward", "SUPPORTED_HEAD_DIMS"]
+
+SUPPORTED_HEAD_DIMS = (32, 64, 128)
+_DTYPES = {torch.float32: _cabi.FA_DTYPE_F32, torch.bfloat16: _cabi.FA_DTYPE_BF16}
+_KERNELS = {"auto": _cabi.FA_KERNEL_AUTO, "naive": _cabi.FA_KERNEL_NAIVE, "mfma": _cabi.FA_KERNEL_MFMA}
+
+
+def _kernel_id(kernel: Union[str, int]) -> int:
+    if isinstance(kernel, int):
+        return kernel
+    name, _, variant = kernel.partition(":")
+    if name not in _KERNELS:
+        raise ValueError(f"unknown kernel {kernel!r}; choose from {sorted(_KERNELS)}")
+    return _KERNELS[name] | (int(variant) << 8 if variant else 0)
+
+
+def _check_qkv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> Tuple[int, int, int]:
+    for name, t in (("q", q), ("k", k), ("v", v)):
+        if not isinstance(t, torch.Tensor):
+            raise TypeError(f"{name} must be a torch.Tensor")
+        if t.dim() != 3:
+            raise ValueError(f"{name} must be 3-D (batch*heads, seq_len, head_dim), got shape {tuple(t.shape)}")
+    if not (q.shape == k.shape == v.shape):
+        raise ValueError(f"q, k, v must have identical shapes, got {tuple(q.shape)}, {tuple(k.shape)}, {tuple(v.shape)}")
+    if not (q.dtype == k.dtype == v.dtype):
+        raise TypeError("q, k, v must share one dtype")
+    if q.dtype not in _DTYPES:
+        raise TypeError(f"dtype {q.dtype} not supported (float32 or bfloat16)")
+    if not (q.is_cuda and k.is_cuda and v.is_cuda):
+        raise ValueError("q, k, v must live on a GPU (there is no CPU implementation of this operator)")
+    if not (q.device == k.device == v.device):
+        raise ValueError("q, k, v must be on the same device")
+    bh, n, d = q.shape
+    if bh < 1 or n < 1:
+        raise ValueError("empty batch or sequence")
+    return bh, n, d
+
+
+def forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = False, *,
+            scale: float = 1.0, return_lse: bool = False, kernel: Union[str, int] = "auto",
+            out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None):
+    """``O = softmax(scale * q k^T [+ causal mask]) v`` per (batch*head); drop-in for ``flash.forward(q, k, v, causal)``.
+
+    Returns a new tensor shaped like ``q`` (the reference allocates with ``torch::zeros``; here ``torch.empty`` is
+    enough because every element is written).  ``return_lse=True`` additionally returns the (BH, N) fp32 row
+    log-sum-exp -- the quantity the reference's unused ``O_l`` buffer was reserved for.  ``out_dtype=torch.float32``
+    with bf16 inputs stores the fp32 accumulator unrounded (FA_DTYPE_BF16_OUT_F32).
+    """
+    bh, n, d = _check_qkv(q, k, v)
+    kid = _kernel_id(kernel)
+    if (kid & 0xff) != _cabi.FA_KERNEL_NAIVE and d not in SUPPORTED_HEAD_DIMS:
+        raise ValueError(f"head_dim {d} not supported by the MFMA kernels {SUPPORTED_HEAD_DIMS}")
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    if out_dtype is None:
+        out_dtype = out.dtype if out is not None else q.dtype
+    dt = _DTYPES[q.dtype]
+    if out_dtype != q.dtype:
+        if not (q.dtype == torch.bfloat16 and out_dtype == torch.float32):
+            raise TypeError(f"out_dtype {out_dtype} not supported for {q.dtype} inputs")
+        dt = _cabi.FA_DTYPE_BF16_OUT_F32
+    if out is None:
+        out = torch.empty(q.shape, dtype=out_dtype, device=q.device)
+    elif out.shape != q.shape or out.dtype != out_dtype or out.device != q.device or not out.is_contiguous():
+        raise ValueError("out must be a contiguous tensor shaped like q with dtype out_dtype")
+    lse = torch.empty((bh, n), dtype=torch.float32, device=q.device) if return_lse else None
+    L = _cabi.lib()
+    with torch.cuda.device(q.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = L.fa_forward_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                             lse.data_ptr() if lse is not None else None,
+                             bh, n, d, float(scale), int(bool(causal)), dt, kid, ctypes.c_void_p(stream))
+    _cabi.check(rc)
+    return (out, lse) if return_lse else out
+
+
+def forward_packed_qkv(inp: torch.Tensor, n_head: int) -> torch.Tensor:
+    """llm.c layout: ``inp`` (B, T, 3C) fp32 -> (B, T, C); causal, scale 1/sqrt(C/n_head).
+
+    Replaces ``attention_forward6`` (/root/reference/src/llm.c/attention_forward.cu:1106-1179) without its
+    permute / unpermute kernels or temporaries.
+    """
+    if inp.dim() != 3 or inp.shape[-1] % 3 != 0:
+        raise ValueError(f"inp must be (B, T, 3C), got {tuple(inp.shape)}")
+    if inp.dtype != torch.float32 or not inp.is_cuda:
+        raise TypeError("inp must be a float32 GPU tensor")
+    b, t, c3 = inp.shape
+    c = c3 // 3
+    if c % n_head != 0:
+        raise ValueError("C must be divisible by n_head")
+    inp = inp.contiguous()
+    out = torch.empty((b, t, c), dtype=torch.float32, device=inp.device)
+    with torch.cuda.device(inp.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = _cabi.lib().fa_forward_packed_qkv(inp.data_ptr(), out.data_ptr(), b, t, c, int(n_head), ctypes.c_void_p(stream))
+    _cabi.check(rc)
+    return out
+
+
+def time_forward(q, k, v, causal: bool = False, *, scale: float = 1.0, kernel: Union[str, int] = "auto",
+                 warmup: int = 3, iters: int = 20, out: Optional[torch.Tensor] = None) -> float:
+    """Mean milliseconds per forward, HIP events recorded on the launch stream inside the C ABI (fa_time_forward)."""
+    bh, n, d = _check_qkv(q, k, v)
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    if out is None:
+        out = torch.empty_like(q)
+    ms = ctypes.c_float(0.0)
+    with torch.cuda.device(q.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = _cabi.lib().fa_time_forward(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), bh, n, d, float(scale),
+                                         int(bool(causal)), _DTYPES[q.dtype], _kernel_id(kernel), ctypes.c_void_p(stream),
+                                         int(warmup), int(iters), ctypes.byref(ms))
+    _cabi.check(rc)
+    return float(ms.value)
+
+
+def load(name: str = "flash", sources=None, extra_cuda_cflags=None, **_ignored):
+    """Stand-in for ``torch.utils.cpp_extension.load(name='flash', sources=[...])`` as called at
+    /root/reference/bench_flashattention.py:10: returns an object whose ``.forward(q, k, v, causal)`` is this operator.
+    ``sources`` / flags are accepted and ignored -- the library is prebuilt by ``build.py``."""
+    _cabi.lib()  # fail loudly now if the extension is missing
+    return SimpleNamespace(forward=forward, forward_packed_qkv=forward_packed_qkv, __name__=name)

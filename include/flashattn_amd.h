@@ -1,0 +1,136 @@
+/*
+ * include/flashattn_amd.h -- C ABI of the MI355X-native fused flash-attention forward.
+ *
+ * This is the drop-in boundary for the one hot path of kilianhae/FlashAttention.C:
+ *
+ *     torch::Tensor forward(torch::Tensor Q, torch::Tensor K, torch::Tensor V, bool causal)
+ *         declared  /root/reference/src/main.cpp:3, bound to Python at :5-6
+ *         defined   /root/reference/src/flashattention.cu:603-617
+ *         launchers /root/reference/src/flashattention.cu:590-602 (run_flash_tiled_coarse{,_causal})
+ *
+ * Everything here is plain C: raw device pointers, sizes, an opaque HIP stream.  No torch types.
+ * The reference-side bindings a maintainer would add (pybind TU for main.cpp, ctypes for
+ * bench_flashattention.py, a direct call for test.cu) are shown in INTEGRATION.md.
+ *
+ * Semantics shared by every entry point
+ *   tensors     (BH, N, d) row-major contiguous, batch and head pre-flattened, exactly as the reference
+ *               addresses them: element (b, r, c) at b*N*d + r*d + c  (flashattention.cu:144,198,224,350)
+ *   math        O = softmax(scale * Q K^T  [causal: key index <= query index]) V, per (batch*head)
+ *   scale       explicit; the reference hard-wires 1.0 (flashattention.cu:593,600) -- pass 1.0f for parity
+ *   ragged N    any N >= 1 is handled exactly (tail keys are masked, not zero-filled as at
+ *               flashattention.cu:224-231)
+ *   ownership   the caller owns every buffer; nothing is allocated, freed or zero-filled here
+ *               (the reference allocates O and a dead O_l inside forward(), :608-609)
+ *   ordering    the kernel is enqueued on `stream` and the call returns without synchronising
+ *               (the reference launches on the legacy stream and calls cudaDeviceSynchronize, :593-594)
+ *   errors      every entry point returns FA_OK (0) or an fa_status code; fa_last_error() returns a
+ *               thread-local message.  Nothing asserts or exits (the reference asserts on d, :606).
+ *   threads     stateless and re-entrant; safe from any host thread for any (device, stream)
+ */
+#ifndef FLASHATTN_AMD_H
+#define FLASHATTN_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLASHATTN_AMD_ABI_VERSION 1
+
+typedef enum fa_status {
+    FA_OK = 0,
+    FA_ERR_INVALID_ARGUMENT = 1, /* null pointer, non-positive size, misaligned buffer              */
+    FA_ERR_UNSUPPORTED = 2,      /* head dim / dtype / kernel id not instantiated                    */
+    FA_ERR_HIP = 3,              /* a HIP runtime call or the launch itself failed                   */
+    FA_ERR_NO_DEVICE = 4         /* no gfx950 device visible                                         */
+} fa_status;
+
+typedef enum fa_dtype {
+    FA_DTYPE_F32 = 0, /* fp32 in, fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 out -- the reference's dtype */
+    FA_DTYPE_BF16 = 1,        /* bf16 in, bf16 MFMA with fp32 accumulate and fp32 softmax, bf16 out     */
+    FA_DTYPE_BF16_OUT_F32 = 2 /* same kernel, O written as fp32 (the accumulator precision)             */
+} fa_dtype;
+
+typedef enum fa_kernel {
+    FA_KERNEL_AUTO = 0,  /* fastest kernel instantiated for (dtype, d)                                  */
+    FA_KERNEL_NAIVE = 1, /* rung-0 scalar kernel: fp32 only, any d <= 256; on-device cross-check        */
+    FA_KERNEL_MFMA = 2   /* the tiled MFMA kernel for (dtype, d); d in {32, 64, 128}                     */
+} fa_kernel;
+
+/*
+ * fa_forward -- replaces forward() / run_flash_tiled_coarse{,_causal}
+ *               (/root/reference/src/flashattention.cu:590-617).
+ *   q, k, v   device pointers, (bh, n, d) elements of `dtype`, 16-byte aligned
+ *   o         device pointer, (bh, n, d) elements of `dtype` (fp32 for FA_DTYPE_BF16_OUT_F32); every element is written
+ *   d         head dim: 32, 64 or 128 (the reference compiles exactly one, `#define d 64`, :15)
+ *   causal    0 / non-zero: the `bool causal` of the reference signature
+ *   stream    hipStream_t (NULL = the null stream)
+ */
+int fa_forward(const void* q, const void* k, const void* v, void* o,
+               int64_t bh, int64_t n, int32_t d, float scale, int32_t causal,
+               int32_t dtype, void* stream);
+
+/*
+ * fa_forward_ex -- fa_forward plus the row log-sum-exp the reference reserves `O_l` for
+ *                  (/root/reference/src/flashattention.cu:609; filled only by the "lightning" kernels,
+ *                  flashattention_lightning.cu:124,234) and an explicit kernel choice.
+ *   lse       NULL, or device pointer to (bh, n) fp32: lse[b, r] = log(sum_c exp(scale * q_r . k_c))
+ *   kernel    an fa_kernel value
+ */
+int fa_forward_ex(const void* q, const void* k, const void* v, void* o, float* lse,
+                  int64_t bh, int64_t n, int32_t d, float scale, int32_t causal,
+                  int32_t dtype, int32_t kernel, void* stream);
+
+/*
+ * fa_forward_sharded -- the batch*head axis split across several devices of one node, no collective
+ *                       (every blockIdx.x of the reference grid is independent: flashattention.cu:144).
+ *   n_shards        number of shards
+ *   device_ids[i]   HIP device ordinal of shard i (buffers of shard i live there)
+ *   q/k/v/o[i]      device pointers of shard i, (bh[i], n, d)
+ *   streams[i]      hipStream_t on device_ids[i] (NULL entries / NULL array = null stream)
+ * Launches are enqueued shard by shard without synchronising; the caller's current device is restored.
+ */
+int fa_forward_sharded(int32_t n_shards, const int32_t* device_ids,
+                       const void* const* q, const void* const* k, const void* const* v, void* const* o,
+                       const int64_t* bh, int64_t n, int32_t d, float scale, int32_t causal,
+                       int32_t dtype, void* const* streams);
+
+/*
+ * fa_forward_packed_qkv -- llm.c layout entry, replaces attention_forward6
+ *                          (/root/reference/src/llm.c/attention_forward.cu:1106-1179): causal, scale
+ *                          1/sqrt(C/NH), fp32.  Reads the packed (B, T, 3C) activations directly and writes
+ *                          (B, T, C) -- the reference's permute_kernel / unpermute_kernel (:519-565) and
+ *                          their three temporaries are fused away.
+ */
+int fa_forward_packed_qkv(const float* inp, float* out, int32_t B, int32_t T, int32_t C, int32_t NH,
+                          void* stream);
+
+/*
+ * fa_time_forward -- enqueue `warmup` + `iters` forwards on `stream`, bracket the `iters` timed ones with
+ *                    HIP events recorded on that same stream, and return the mean milliseconds per forward.
+ *                    Synchronises the stream (this is the one blocking entry point; used by the C driver
+ *                    and bench.py's roofline leg, the counterpart of benchmark_kernel,
+ *                    /root/reference/src/llm.c/common.h:108-124).
+ */
+int fa_time_forward(const void* q, const void* k, const void* v, void* o,
+                    int64_t bh, int64_t n, int32_t d, float scale, int32_t causal,
+                    int32_t dtype, int32_t kernel, void* stream,
+                    int32_t warmup, int32_t iters, float* ms_per_forward);
+
+/* Thread-local description of the last failure on this thread ("" if none). */
+const char* fa_last_error(void);
+
+/* Number of visible HIP devices (0 on a machine without one; never fails). */
+int fa_device_count(void);
+
+/* "flashattn_amd <abi> gfx950 ..." build string. */
+const char* fa_version(void);
+
+/* Name of the kernel FA_KERNEL_AUTO resolves to for (dtype, d), or NULL if unsupported. */
+const char* fa_kernel_name(int32_t dtype, int32_t d, int32_t causal);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLASHATTN_AMD_H */

@@ -1,0 +1,284 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle and the committed golden vectors.
+
+Tolerances (max-abs, stated once here; BASELINE.md section 4 gives the arithmetic behind them):
+  fp32 kernel                          1e-3  (north_star bar; observed ~1e-5)
+  bf16 kernel, fp32 out, scale 1/8     1e-3  (north_star bar with 1/sqrt(d) scaling)
+  bf16 kernel, fp32 out, scale 1.0     8e-3  (unscaled scores: P is near one-hot, its bf16 rounding dominates)
+  bf16 kernel, bf16 out                + half a bf16 ulp of |O|: 2e-2 at scale 1.0 (|O| < 4), 6e-3 at scale 1/8
+The bf16 kernel is always compared with the oracle evaluated on the SAME bf16-valued inputs.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import flashattention_c_amd as fa
+from flashattention_c_amd import _cabi
+from oracle import oracle as orc
+from tests.conftest import GOLDEN_DIR, golden_cases
+
+pytestmark = pytest.mark.gpu
+
+TOL_F32 = 1e-3
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def to_dev(*arrs, dtype=torch.float32):
+    return [torch.from_numpy(np.ascontiguousarray(a)).to(dtype).to(dev()) for a in arrs]
+
+
+def max_err(t: torch.Tensor, ref: np.ndarray) -> float:
+    got = t.detach().float().cpu().numpy().astype(np.float64)
+    assert not np.isnan(got).any(), "NaN in output (unwritten or invalid element)"
+    return float(np.abs(got - ref).max())
+
+
+def bf16_tol(scale: float, out_f32: bool) -> float:
+    if out_f32:
+        return 8e-3 if scale >= 0.5 else 1e-3
+    return 2e-2 if scale >= 0.5 else 6e-3
+
+
+def randn(seed, *shape):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)).numpy()
+
+
+def test_extension_is_the_in_tree_library():
+    # the product path is the hipcc-built library next to the package, not a fallback
+    assert os.path.samefile(_cabi.LIB_PATH, os.path.join(ROOT, "flashattention.c_amd", "libflashattn_amd.so"))
+    assert _cabi.lib().fa_device_count() >= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# golden vectors (outputs of the reference's own oracle code, tests/golden)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernel", ["mfma", "naive"])
+@pytest.mark.parametrize("name", golden_cases())
+def test_fp32_against_golden(name, kernel):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    q, k, v = to_dev(z["q"], z["k"], z["v"])
+    o = fa.forward(q, k, v, bool(z["causal"]), scale=float(z["scale"]), kernel=kernel)
+    assert max_err(o, z["o"]) < TOL_F32
+
+
+@pytest.mark.parametrize("out_f32", [False, True])
+@pytest.mark.parametrize("name", [c for c in golden_cases() if "bf16vals" in c])
+def test_bf16_against_golden(name, out_f32):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    q, k, v = to_dev(z["q"], z["k"], z["v"], dtype=torch.bfloat16)  # exactly representable: no input rounding
+    scale = float(z["scale"])
+    o = fa.forward(q, k, v, bool(z["causal"]), scale=scale, out_dtype=torch.float32 if out_f32 else None)
+    assert o.dtype == (torch.float32 if out_f32 else torch.bfloat16)
+    assert max_err(o, z["o"]) < bf16_tol(scale, out_f32)
+
+
+def test_packed_qkv_against_golden():
+    z = np.load(os.path.join(GOLDEN_DIR, "llmc_packed_b2_t96_c128_nh2.npz"))
+    (inp,) = to_dev(z["inp"])
+    out = fa.forward_packed_qkv(inp, int(z["n_head"]))
+    # the reference validates this path at 1e-4 (src/llm.c/attention_forward.cu:1262)
+    assert max_err(out, z["out"].astype(np.float64)) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# seeded inputs vs the oracle: shapes, raggedness, causal, head dims
+# ---------------------------------------------------------------------------------------------------------------
+SHAPES = [
+    # bh, n, d
+    (4, 1024, 64),   # README shape family (c2), fewer slabs
+    (2, 1000, 64),   # ragged tail in the last tile
+    (3, 333, 32),    # d = 32 (README rows 2 and 4)
+    (2, 257, 128),   # d = 128, one row past a workgroup boundary
+    (1, 1, 64),      # single token
+    (5, 31, 64),     # shorter than one MFMA block
+    (2, 129, 64),    # one row past the 128-row q tile
+]
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("bh,n,d", SHAPES)
+def test_fp32_vs_oracle(bh, n, d, causal):
+    q, k, v = (randn(s, bh, n, d) for s in (1, 2, 3))
+    ref = orc.attention_f64(q, k, v, causal=causal, scale=1.0)
+    o = fa.forward(*to_dev(q, k, v), causal)
+    assert max_err(o, ref) < TOL_F32
+
+
+@pytest.mark.parametrize("scale", [1.0, 0.125])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("bh,n,d", SHAPES)
+def test_bf16_vs_oracle(bh, n, d, causal, scale):
+    q, k, v = (orc.round_to_bf16(randn(s, bh, n, d)) for s in (4, 5, 6))
+    ref = orc.attention_f64(q, k, v, causal=causal, scale=scale)
+    qd, kd, vd = to_dev(q, k, v, dtype=torch.bfloat16)
+    assert max_err(fa.forward(qd, kd, vd, causal, scale=scale, out_dtype=torch.float32), ref) < bf16_tol(scale, True)
+    assert max_err(fa.forward(qd, kd, vd, causal, scale=scale), ref) < bf16_tol(scale, False)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("causal", [False, True])
+def test_bf16_tiling_variants_agree(variant, causal):
+    q, k, v = (orc.round_to_bf16(randn(s, 3, 700, 64)) for s in (7, 8, 9))
+    ref = orc.attention_f64(q, k, v, causal=causal, scale=0.125)
+    qd, kd, vd = to_dev(q, k, v, dtype=torch.bfloat16)
+    o = fa.forward(qd, kd, vd, causal, scale=0.125, kernel=f"mfma:{variant}", out_dtype=torch.float32)
+    assert max_err(o, ref) < 1e-3
+
+
+def test_lse_output():
+    q, k, v = (randn(s, 2, 300, 64) for s in (10, 11, 12))
+    for causal in (False, True):
+        _, lse_ref = orc.attention_f64(q, k, v, causal=causal, scale=0.25, return_lse=True)
+        for kern in ("mfma", "naive"):
+            _, lse = fa.forward(*to_dev(q, k, v), causal, scale=0.25, return_lse=True, kernel=kern)
+            assert max_err(lse, lse_ref) < 1e-3
+        qb, kb, vb = (orc.round_to_bf16(t) for t in (q, k, v))
+        _, lse_ref_b = orc.attention_f64(qb, kb, vb, causal=causal, scale=0.25, return_lse=True)
+        _, lse_b = fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, scale=0.25, return_lse=True)
+        assert max_err(lse_b, lse_ref_b) < 1e-3
+
+
+def test_known_answer_iota_ones():
+    """test.cu:615-631 workload (Q = K = iota, V = 1): O must be exactly 1; scores reach ~1e12, exercising overflow safety."""
+    bh, n, d = 2, 512, 64
+    q = torch.arange(bh * n * d, dtype=torch.float32).reshape(bh, n, d).to(dev())
+    v = torch.ones_like(q)
+    for causal in (False, True):
+        assert torch.all(fa.forward(q, q, v, causal) == 1.0)
+        ob = fa.forward(q.bfloat16(), q.bfloat16(), v.bfloat16(), causal)
+        assert torch.all(ob.float() == 1.0)
+
+
+def test_forced_rescale_spike():
+    """A key that beats the running max by hundreds, late in the sequence, and one early (T13 / rule 26 input)."""
+    bh, n, d = 2, 2048, 64
+    q, k, v = (randn(s, bh, n, d) for s in (13, 14, 15))
+    k[0, 1900] = 6.0 * q[0, 37]
+    k[1, 5] = 4.0 * q[1, 1500]
+    for causal in (False, True):
+        ref = orc.attention_f64(q, k, v, causal=causal)
+        assert max_err(fa.forward(*to_dev(q, k, v), causal), ref) < TOL_F32
+        qb, kb, vb = (orc.round_to_bf16(t) for t in (q, k, v))
+        refb = orc.attention_f64(qb, kb, vb, causal=causal)
+        assert max_err(fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, out_dtype=torch.float32), refb) < 8e-3
+
+
+def test_transpose_detecting_structured_input():
+    """Asymmetric, structured Q/K/V: a swapped row/col map in any MFMA fragment or a transposed V changes the answer."""
+    bh, n, d = 1, 192, 64
+    r = np.arange(n, dtype=np.float32)[:, None]
+    c = np.arange(d, dtype=np.float32)[None, :]
+    q = (0.02 * r - 0.05 * c + 0.001 * r * c / d)[None].astype(np.float32) * 0.1
+    k = (0.03 * np.sin(0.1 * r) + 0.04 * np.cos(0.3 * c) + 0.002 * c)[None].astype(np.float32)
+    v = (r / n - 2.0 * c / d + 0.01 * r * c / (n * d) * 7)[None].astype(np.float32)
+    for causal in (False, True):
+        ref = orc.attention_f64(q, k, v, causal=causal)
+        assert max_err(fa.forward(*to_dev(q, k, v), causal), ref) < 1e-4
+        qb, kb, vb = (orc.round_to_bf16(t) for t in (q, k, v))
+        refb = orc.attention_f64(qb, kb, vb, causal=causal)
+        assert max_err(fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, out_dtype=torch.float32), refb) < 5e-3
+
+
+def test_packed_qkv_vs_oracle_random():
+    B, T, C, NH = 2, 300, 256, 4  # hs = 64, ragged T
+    inp = (np.random.default_rng(21).random((B, T, 3 * C), dtype=np.float32) * 2 - 1).astype(np.float32)
+    ref = orc.attention_packed_f32(inp, NH)
+    out = fa.forward_packed_qkv(torch.from_numpy(inp).to(dev()), NH)
+    assert max_err(out, ref.astype(np.float64)) < 1e-4
+
+
+def test_noncontiguous_and_out_argument():
+    q, k, v = (randn(s, 2, 130, 64) for s in (16, 17, 18))
+    ref = orc.attention_f64(q, k, v)
+    qd, kd, vd = to_dev(q, k, v)
+    qt = qd.transpose(0, 1).contiguous().transpose(0, 1)  # non-contiguous view of the same values
+    assert not qt.is_contiguous()
+    out = torch.full_like(qd, float("nan"))
+    res = fa.forward(qt, kd, vd, False, out=out)
+    assert res.data_ptr() == out.data_ptr()
+    assert max_err(out, ref) < TOL_F32
+
+
+def test_sharded_entry_point_on_one_device():
+    """fa_forward_sharded with two shards that both live on device 0 (a 1-GPU box can still exercise the entry point)."""
+    q, k, v = (randn(s, 5, 200, 64) for s in (19, 20, 21))
+    ref = orc.attention_f64(q, k, v, causal=True)
+    qd, kd, vd = to_dev(q, k, v)
+    (b0, e0), (b1, e1) = fa.shard_range(5, 2, 0), fa.shard_range(5, 2, 1)
+    outs = fa.forward_sharded([qd[b0:e0], qd[b1:e1]], [kd[b0:e0], kd[b1:e1]], [vd[b0:e0], vd[b1:e1]], True)
+    torch.cuda.synchronize()
+    assert max_err(torch.cat(outs), ref) < TOL_F32
+
+
+def test_runs_on_callers_stream_without_sync():
+    q, k, v = to_dev(*(randn(s, 4, 512, 64) for s in (22, 23, 24)))
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        o = fa.forward(q, k, v, False)
+    s.synchronize()
+    ref = orc.attention_f64(q.cpu().numpy(), k.cpu().numpy(), v.cpu().numpy())
+    assert max_err(o, ref) < TOL_F32
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: exact oracle on sampled slabs + size-independent properties on the whole tensor
+# ---------------------------------------------------------------------------------------------------------------
+FULL = [
+    ("c2", 128, 1024, 64, torch.float32),
+    ("c3", 16, 8192, 64, torch.float32),
+    ("c4", 16, 8192, 64, torch.bfloat16),
+]
+
+
+@pytest.mark.parametrize("name,bh,n,d,dtype", FULL)
+def test_full_size_configs(name, bh, n, d, dtype):
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn(bh, n, d, generator=g) for _ in range(3))
+    if dtype == torch.bfloat16:
+        q, k, v = (t.bfloat16() for t in (q, k, v))
+    qd, kd, vd = q.to(dev()), k.to(dev()), v.to(dev())
+    bf = dtype == torch.bfloat16
+    kw = dict(out_dtype=torch.float32) if bf else {}
+    tol = 8e-3 if bf else TOL_F32
+    o = fa.forward(qd, kd, vd, False, **kw)
+    # (a) exact oracle on two slabs (first and last)
+    for s in (0, bh - 1):
+        ref = orc.attention_f64(q[s:s + 1].float().numpy(), k[s:s + 1].float().numpy(), v[s:s + 1].float().numpy())
+        assert max_err(o[s:s + 1], ref) < tol, f"{name} slab {s}"
+    # (b) every slab against the rung-0 kernel on device (independent code path, fp32 on the same values)
+    o_naive = fa.forward(qd.float(), kd.float(), vd.float(), False, kernel="naive")
+    assert float((o.float() - o_naive).abs().max()) < tol
+    # (c) V == 1  =>  O == 1: every softmax row sums to 1 (checks l, m, masking and the whole write-out).  Not bitwise:
+    #     the numerator is summed by the matrix core (from bf16-rounded P on the bf16 path), the denominator by the VALU.
+    ones = torch.ones_like(vd)
+    assert float((fa.forward(qd, kd, ones, False, **kw) - 1.0).abs().max()) < (4e-3 if bf else 1e-5)
+    # (d) linearity in V: O(q, k, 2 v1 - v2) == 2 O(q, k, v1) - O(q, k, v2)  (fp32 only; bf16 V rounding breaks exactness)
+    if not bf:
+        v2 = torch.randn(bh, n, d, generator=g).to(dev())
+        lhs = fa.forward(qd, kd, 2.0 * vd - v2, False)
+        rhs = 2.0 * o - fa.forward(qd, kd, v2, False)
+        assert float((lhs - rhs).abs().max()) < 1e-4
+    # (e) causal: row 0 attends to key 0 only, so O[:, 0, :] == V[:, 0, :] exactly
+    oc = fa.forward(qd, kd, vd, True, **kw)
+    assert torch.equal(oc[:, 0, :].float(), vd[:, 0, :].float())
+    # (f) causal vs the oracle on one slab
+    refc = orc.attention_f64(q[:1].float().numpy(), k[:1].float().numpy(), v[:1].float().numpy(), causal=True)
+    assert max_err(oc[:1], refc) < tol
+
+
+def test_c_driver_known_answer():
+    """The torch-less driver (test.cu counterpart) on its iota/ones workload."""
+    drv = os.path.join(ROOT, "flashattention.c_amd", "fa_driver")
+    assert os.path.exists(drv), "fa_driver not built"
+    for dtype in ("f32", "bf16"):
+        r = subprocess.run([drv, "--mode", "kat", "--bh", "2", "--n", "1024", "--d", "64", "--dtype", dtype, "--causal", "1"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert '"pass": true' in r.stdout

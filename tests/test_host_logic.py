@@ -1,0 +1,99 @@
+"""CPU: host-side logic -- C-ABI exports, argument validation (no compute without a GPU), sharding arithmetic."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import flashattention_c_amd as fa
+from flashattention_c_amd import _cabi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "flashattn_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)   # prototypes only, not the prose
+    declared = set(re.findall(r"\b(fa_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_cabi.EXPORTED_SYMBOLS), declared ^ set(_cabi.EXPORTED_SYMBOLS)
+    L = _cabi.lib()
+    for sym in declared:
+        assert getattr(L, sym) is not None
+    assert b"gfx950" in L.fa_version()
+    assert L.fa_device_count() >= 0
+    assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16, 64, 0).startswith(b"fa_fwd_bf16")
+    assert L.fa_kernel_name(_cabi.FA_DTYPE_F32, 48, 0) is None
+
+
+def test_cabi_rejects_bad_arguments_without_touching_a_device():
+    L = _cabi.lib()
+    buf = ctypes.create_string_buffer(4096)
+    base = (ctypes.addressof(buf) + 15) & ~15
+    p = ctypes.c_void_p(base)
+    # null pointer
+    assert L.fa_forward(None, p, p, p, 1, 32, 64, 1.0, 0, 0, None) == 1
+    assert b"null" in L.fa_last_error()
+    # misaligned
+    assert L.fa_forward(ctypes.c_void_p(base + 4), p, p, p, 1, 32, 64, 1.0, 0, 0, None) == 1
+    # bad sizes / scale / dtype
+    assert L.fa_forward(p, p, p, p, 0, 32, 64, 1.0, 0, 0, None) == 1
+    assert L.fa_forward(p, p, p, p, 1, 0, 64, 1.0, 0, 0, None) == 1
+    assert L.fa_forward(p, p, p, p, 1, 32, 64, 0.0, 0, 0, None) == 1
+    assert L.fa_forward(p, p, p, p, 1, 32, 64, float("nan"), 0, 0, None) == 1
+    assert L.fa_forward(p, p, p, p, 1, 32, 64, 1.0, 0, 7, None) == 2
+    # unsupported head dim for the MFMA kernels, unknown kernel id
+    assert L.fa_forward(p, p, p, p, 1, 32, 48, 1.0, 0, 0, None) == 2
+    assert b"48" in L.fa_last_error()
+    assert L.fa_forward_ex(p, p, p, p, None, 1, 32, 64, 1.0, 0, 0, 9, None) == 2
+    assert L.fa_forward_packed_qkv(p, p, 1, 8, 96, 5, None) == 1      # C % NH != 0
+    assert L.fa_forward_packed_qkv(p, p, 1, 8, 96, 2, None) == 2      # hs = 48 not instantiated
+    ms = ctypes.c_float()
+    assert L.fa_time_forward(p, p, p, p, 1, 32, 64, 1.0, 0, 0, 0, None, 0, 0, ctypes.byref(ms)) == 1
+
+
+def test_python_surface_validates_like_the_reference_signature():
+    q = torch.randn(2, 32, 64)
+    with pytest.raises(ValueError, match="GPU"):
+        fa.forward(q, q, q, False)                      # CPU tensors: no CPU implementation, fail loudly
+    with pytest.raises(ValueError, match="3-D"):
+        fa.forward(q[0], q[0], q[0], False)
+    with pytest.raises(ValueError, match="identical shapes"):
+        fa.forward(q, q[:, :16], q, False)
+    with pytest.raises(TypeError):
+        fa.forward(q, q.double(), q, False)
+    with pytest.raises(TypeError, match="not supported"):
+        fa.forward(q.half(), q.half(), q.half(), False)
+    with pytest.raises(ValueError):
+        fa.forward_packed_qkv(torch.randn(2, 8, 100), 2)
+    mod = fa.load(name="flash", sources=["src/main.cpp", "src/flashattention.cu"], extra_cuda_cflags=["-O3"])
+    assert mod.forward is fa.forward
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_cabi, "_lib", None)
+    monkeypatch.setattr(_cabi, "LIB_PATH", "/nonexistent/libflashattn_amd.so")
+    with pytest.raises(_cabi.ExtensionMissing, match="no CPU/PyTorch fallback"):
+        _cabi.lib()
+
+
+@pytest.mark.parametrize("bh,world", [(1024, 8), (16, 1), (16, 2), (10, 4), (3, 8), (128, 3)])
+def test_shard_ranges_partition_the_slab_axis(bh, world):
+    ranges = [fa.shard_range(bh, world, r) for r in range(world)]
+    assert ranges[0][0] == 0 and ranges[-1][1] == bh
+    for (b0, e0), (b1, e1) in zip(ranges, ranges[1:]):
+        assert e0 == b1 and b0 <= e0
+    sizes = fa.shard_sizes(bh, world)
+    assert sum(sizes) == bh and max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        fa.shard_range(bh, world, world)
+
+
+def test_bench_flop_and_byte_model():
+    import bench
+    # c4 = 2.749e11 FLOP, 67.1 MB; c2 = 3.436e10 FLOP, 134.2 MB (fp32)
+    assert abs(bench.fwd_flop(16, 8192, 64, False) - 2.749e11) / 2.749e11 < 1e-3
+    assert abs(bench.algorithmic_bytes(16, 8192, 64, 2) - 67.1e6) / 67.1e6 < 1e-3
+    assert abs(bench.fwd_flop(128, 1024, 64, False) - 3.436e10) / 3.436e10 < 1e-3
+    assert abs(bench.algorithmic_bytes(128, 1024, 64, 4) - 134.2e6) / 134.2e6 < 1e-3
+    assert bench.fwd_flop(16, 8192, 64, True) * 2 == bench.fwd_flop(16, 8192, 64, False)
