@@ -59,6 +59,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int total)
     return base + idx;
 }
 
+// Drain this wave's outstanding LDS-DMA (global_load_lds) transfers.  LDS-DMA completion is tracked by vmcnt; a
+// barrier does not wait for it, and the compiler only inserts the wait in front of LDS reads it thinks may alias.
+__device__ __forceinline__ void wait_lds_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // max / sum across the two half-waves (lane l <-> lane l^32) with one v_permlane32_swap (VALU, no LDS trip):

@@ -171,7 +171,11 @@ __global__ __launch_bounds__(NWAVES* kWave, MINWAVES) void fa_fwd_bf16_kernel(Fw
     const float c = p.scale_log2e;
 
     for (int j = 0; j < nt; ++j) {
-        __syncthreads();  // tile j landed (own DMA drained, then barrier); everyone is done with tile j-1
+        // Tile j must have landed: hipcc only orders an LDS-DMA against LDS reads it cannot disambiguate, and a wave that
+        // skips a tile (causal) issues no such read -- so every wave drains its own DMA queue explicitly, THEN the
+        // barrier publishes all waves' pieces and proves everyone is done with the stage tile j+1 will overwrite.
+        wait_lds_dma();
+        __syncthreads();
         if (j + 1 < nt)
             issue_kv_tile<D, NWAVES>(kg, vg, (j + 1) * kKvBlk, n, p.kv_row_stride,
                                      smem + ((j + 1) & 1) * C::kStageBytes, wave, lane);

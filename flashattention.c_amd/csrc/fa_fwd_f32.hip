@@ -125,7 +125,8 @@ __global__ __launch_bounds__(NWAVES* kWave, MINWAVES) void fa_fwd_f32_kernel(Fwd
     const int v_lane_off = (4 * hi) * C::kRowBytes + lq * 4;
 
     for (int j = 0; j < nt; ++j) {
-        __syncthreads();
+        wait_lds_dma();   // own LDS-DMA pieces of tile j have landed (hipcc does not insert this wait itself) ...
+        __syncthreads();  // ... and so have everybody else's; all waves are done with the stage tile j+1 overwrites
         if (j + 1 < nt)
             issue_kv_tile_f32<D, NWAVES>(kg, vg, (j + 1) * kKvBlkF32, n, p.kv_row_stride,
                                          smem + ((j + 1) & 1) * C::kStageBytes, wave, lane);
