@@ -64,6 +64,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int total)
 __device__ __forceinline__ void wait_lds_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// min(2^x, 1): fmed3(., 0, 1) folds into the VOP3 clamp bit of v_exp_f32 -- one instruction
+__device__ __forceinline__ float exp2_clamp01(float x) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x), 0.0f, 1.0f); }
 
 // max / sum across the two half-waves (lane l <-> lane l^32) with one v_permlane32_swap (VALU, no LDS trip):
 // swap(a, b) exchanges a[32..63] with b[0..31]; fed the same value twice it returns {lo, lo} and {hi, hi}.

@@ -255,7 +255,7 @@ int main(int argc, char** argv)
         HIP_OK(hipMemcpy(ref.data(), b.of, ne * 4, hipMemcpyDeviceToHost));
     }
     if (a.mode == "sweep") {
-        const int nvar = a.dtype == "bf16" ? 2 : 1;
+        const int nvar = a.dtype == "bf16" ? 9 : 1;
         for (int v = 0; v < nvar; ++v) run_one(a, b, v, a.check ? &ref : nullptr);
     } else {
         run_one(a, b, a.variant, a.check ? &ref : nullptr);

@@ -39,7 +39,6 @@ typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 
 constexpr int kKvBlk = 64;  // keys per K/V tile
-constexpr float kFmaExpLimit = 1024.0f;  // |scale*log2e * rowmax| above which the exponent is formed subtract-first
 
 // XOR applied to the 16-byte slot index of K-image row `row` (see header comment).
 template <int D>
@@ -61,36 +60,50 @@ struct Bf16Cfg {
     static_assert(kChunks % NWAVES == 0, "tile must split evenly over the waves");
 };
 
-// Enqueue the LDS-DMA for K/V tile starting at key kv0 into `stage` (wave-uniform LDS address).
+// Enqueue the LDS-DMA of the K tile starting at key kv0 into `dst` (wave-uniform LDS address): row-major, slot-swizzled.
 template <int D, int NWAVES>
-__device__ __forceinline__ void issue_kv_tile(const __bf16* __restrict__ kg, const __bf16* __restrict__ vg,
-                                              int kv0, int n, int row_stride, char* stage, int wave, int lane)
+__device__ __forceinline__ void issue_k_tile(const __bf16* __restrict__ kg, int kv0, int n, int row_stride, char* dst, int wave,
+                                             int lane)
 {
     using C = Bf16Cfg<D, NWAVES>;
 #pragma unroll
     for (int i = 0; i < C::kChunksPerWave; ++i) {
         const int ch = wave + i * NWAVES;
-        // ---- K: row-major, slot-swizzled
-        {
-            const int off = ch * 1024 + lane * 16;
-            const int row = off / C::kRowBytes;
-            const int phys = (off % C::kRowBytes) / 16;
-            const int slot = phys ^ k_swizzle<D>(row);
-            const int grow = min(kv0 + row, n - 1);
-            const __bf16* src = kg + (int64_t)grow * row_stride + slot * 8;
-            __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)src, (lds_void_t*)(stage + ch * 1024), 16, 0, 0);
-        }
-        // ---- V: [key/4][col/16][4][16] sub-tiles (128 bytes each)
-        {
-            const int blk = ch * 8 + lane / 8;
-            const int kg4 = blk / (D / 16), cb = blk % (D / 16);
-            const int key = kg4 * 4 + (lane % 8) / 2;
-            const int col = cb * 16 + (lane & 1) * 8;
-            const int grow = min(kv0 + key, n - 1);
-            const __bf16* src = vg + (int64_t)grow * row_stride + col;
-            __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)src, (lds_void_t*)(stage + C::kTileBytes + ch * 1024), 16, 0, 0);
-        }
+        const int off = ch * 1024 + lane * 16;
+        const int row = off / C::kRowBytes;
+        const int phys = (off % C::kRowBytes) / 16;
+        const int slot = phys ^ k_swizzle<D>(row);
+        const int grow = min(kv0 + row, n - 1);
+        const __bf16* src = kg + (int64_t)grow * row_stride + slot * 8;
+        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)src, (lds_void_t*)(dst + ch * 1024), 16, 0, 0);
     }
+}
+
+// Same for the V tile: [key/4][col/16][4][16] sub-tiles (128 bytes each).
+template <int D, int NWAVES>
+__device__ __forceinline__ void issue_v_tile(const __bf16* __restrict__ vg, int kv0, int n, int row_stride, char* dst, int wave,
+                                             int lane)
+{
+    using C = Bf16Cfg<D, NWAVES>;
+#pragma unroll
+    for (int i = 0; i < C::kChunksPerWave; ++i) {
+        const int ch = wave + i * NWAVES;
+        const int blk = ch * 8 + lane / 8;
+        const int kg4 = blk / (D / 16), cb = blk % (D / 16);
+        const int key = kg4 * 4 + (lane % 8) / 2;
+        const int col = cb * 16 + (lane & 1) * 8;
+        const int grow = min(kv0 + key, n - 1);
+        const __bf16* src = vg + (int64_t)grow * row_stride + col;
+        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)src, (lds_void_t*)(dst + ch * 1024), 16, 0, 0);
+    }
+}
+
+template <int D, int NWAVES>
+__device__ __forceinline__ void issue_kv_tile(const __bf16* __restrict__ kg, const __bf16* __restrict__ vg,
+                                              int kv0, int n, int row_stride, char* stage, int wave, int lane)
+{
+    issue_k_tile<D, NWAVES>(kg, kv0, n, row_stride, stage, wave, lane);
+    issue_v_tile<D, NWAVES>(vg, kv0, n, row_stride, stage + Bf16Cfg<D, NWAVES>::kTileBytes, wave, lane);
 }
 
 __device__ __forceinline__ bf16x8 pack_bf16x8(const f32x16& s, int base)
@@ -226,35 +239,24 @@ __global__ __launch_bounds__(NWAVES* kWave, MINWAVES) void fa_fwd_bf16_kernel(Fw
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][kb][r]);
             mx = xhalf_max(mx);
-            // running max in the RAW score domain; exponent = c * (s - m)
-            const float m_new = fmaxf(m[qb], mx);
-            const float alpha = fast_exp2((m[qb] - m_new) * c);  // exp2(-inf) = 0 on the first tile
+            // running max kept in the scaled (exp2) domain, nudged DOWN by <= 2 ulp so that c*s_max - m >= 0 exactly;
+            // every p of the row carries the common factor 2^-m (cancels in O / l), and the hardware clamp on v_exp_f32
+            // caps the row maximum (and anything within those 2 ulp of it) at exactly 1 -- no overflow for any input
+            // magnitude (the iota known-answer workload of test.cu reaches |s| ~ 1e15) and no branch.
+            float mc = mx * c;
+            mc = fmaf(-fabsf(mc), 0x1p-23f, mc);
+            const float m_new = fmaxf(m[qb], mc);
+            const float alpha = fast_exp2(m[qb] - m_new);  // exp2(-inf) = 0 on the first tile
             m[qb] = m_new;
-            const float mc = m_new * c;
             float rs = 0.0f;
-            if (__builtin_expect(__any(fabsf(mc) > kFmaExpLimit), 0)) {
-                // enormous scores (e.g. the iota known-answer workload of test.cu): the rounding of c*m would no longer
-                // cancel inside fma(s, c, -c*m); subtract first, exactly
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb)
+            for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float pv = fast_exp2((s[qb][kb][r] - m_new) * c);
-                        s[qb][kb][r] = pv;
-                        rs += pv;
-                    }
-            } else {
-                // one fma + one exp per score; the single rounding of c*m perturbs the exponent by <= ulp(c*m)/2
-                // (<= 2^-14 at the branch limit, 2^-19 at |c*m| ~ 50): fp32-rounding class
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float pv = fast_exp2(fmaf(s[qb][kb][r], c, -mc));
-                        s[qb][kb][r] = pv;
-                        rs += pv;
-                    }
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = exp2_clamp01(fmaf(s[qb][kb][r], c, -m_new));
+                    s[qb][kb][r] = pv;
+                    rs += pv;
+                }
             l[qb] = fmaf(l[qb], alpha, rs);
 #pragma unroll
             for (int db = 0; db < DB; ++db)
@@ -310,9 +312,831 @@ __global__ __launch_bounds__(NWAVES* kWave, MINWAVES) void fa_fwd_bf16_kernel(Fw
                     }
                 }
             if (p.lse != nullptr && hi == 0)
-                p.lse[(int64_t)slab * n + qi] = m[qb] * p.scale + __builtin_amdgcn_logf(lt) * kLn2;
+                p.lse[(int64_t)slab * n + qi] = (m[qb] + __builtin_amdgcn_logf(lt)) * kLn2;
         }
     }
+}
+
+// =====================================================================================================================
+// Ping-pong kernel: two independent 32-row query blocks (A, B) per wave, half a tile period apart.
+//
+// Measured on MI355X (profiles/r01_ubench_issue.txt): a wave with a matrix instruction waiting for the matrix pipe holds
+// its SIMD's vector issue port, so a sibling wave's softmax cannot slide under it -- MFMA and VALU only overlap when they
+// alternate inside ONE instruction stream.  Each half-iteration below is therefore a single basic block holding the 16
+// MFMAs of one block (P.V of the previous tile, then K.Q^T of the current one) next to the ~185 softmax instructions of
+// the other block; the two are data-independent and sched_group_barrier pins the interleave.
+//
+//   iteration j:   half 1:  PV_A(j-1), QK_A(j)   ||  softmax_B(j-1)
+//                  half 2:  PV_B(j-1), QK_B(j)   ||  softmax_A(j)
+// Both halves read V(j-1) and K(j): the K and V rings are 2 deep each and one tile apart; K(j+1) and V(j) are in flight.
+// =====================================================================================================================
+template <int D>
+__device__ __forceinline__ void qk_block(const char* k_lds, int k_row_off, int k_g, const bf16x8 (&qf)[D / 16], f32x16 (&s)[2])
+{
+    constexpr int RB = 2 * D;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+        const int slot_off = ((2 * ks) ^ k_g) * 16;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const bf16x8 kf = *(const bf16x8*)(k_lds + k_row_off + kb * 32 * RB + slot_off);
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+        }
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void pv_block(const char* v_lds, int v_lane_off, const bf16x8 (&pf)[4], f32x16 (&o)[D / 32])
+{
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int db = 0; db < D / 32; ++db) {
+                const int off0 = ((kb * 8 + 4 * t + 0) * (D / 16) + 2 * db) * 128;
+                const int off1 = ((kb * 8 + 4 * t + 2) * (D / 16) + 2 * db) * 128;
+                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_lds + v_lane_off + off0));
+                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_lds + v_lane_off + off1));
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb * 2 + t], o[db], 0, 0, 0);
+            }
+}
+
+template <bool CAUSAL>
+__device__ __forceinline__ void mask_block(f32x16 (&s)[2], int kv0, int qi, int n, int hi)
+{
+    asm volatile("; mask_block" ::: "memory");  // not speculatable: keeps the caller's wave-uniform `if` a real branch
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kv0 + kb * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
+            if ((key >= n) || (CAUSAL && key > qi)) s[kb][r] = -INFINITY;
+        }
+}
+
+// online softmax of one 32x64 score block held in registers; leaves P packed as the four B-operand fragments of P.V
+template <int D>
+__device__ __forceinline__ void softmax_block(f32x16 (&s)[2], float& m, float& l, f32x16 (&o)[D / 32], bf16x8 (&pf)[4], float c)
+{
+    float mx = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    mx = xhalf_max(mx);
+    float mc = mx * c;
+    mc = fmaf(-fabsf(mc), 0x1p-23f, mc);  // nudge down: c*s_max - m >= 0 (see the comment in fa_fwd_bf16_kernel)
+    const float m_new = fmaxf(m, mc);
+    const float alpha = fast_exp2(m - m_new);
+    m = m_new;
+    float rs = 0.0f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = exp2_clamp01(fmaf(s[kb][r], c, -m_new));
+            s[kb][r] = pv;
+            rs += pv;
+        }
+    l = fmaf(l, alpha, rs);
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) pf[kb * 2 + t] = pack_bf16x8(s[kb], 8 * t);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Slot-scheduled half iteration.  The 4*DB P.V MFMAs and 2*KS K.Q^T MFMAs of block X are numbered 0..NSLOT-1; slot i holds
+// MFMA i, the LDS reads feeding MFMA i+2, and the i-th slice of block Y's softmax.  __builtin_amdgcn_sched_barrier(0) after
+// every slot pins that placement (the compiler still orders instructions inside a slot, allocates registers and inserts
+// the waits).  Softmax slices: [partial row maxima | combine, new running max, alpha | exp + row sum | l, O rescale, P pack].
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D>
+struct SlotPlan {
+    static constexpr int KS = D / 16, DB = D / 32;
+    static constexpr int NPV = 4 * DB, NQK = 2 * KS, NSLOT = NPV + NQK;
+    static constexpr int N_MAX = NSLOT / 8 > 0 ? NSLOT / 8 : 1;   // slots for the max phase
+    static constexpr int N_FIN = NSLOT / 4;                       // slots for l / rescale / pack
+    static constexpr int N_EXP = NSLOT - N_MAX - N_FIN;
+    static constexpr int N_FIN_ITEMS = 2 * DB + 4;                // 2*DB half-blocks of O to rescale + 4 P fragments to pack
+    static constexpr int max_slot(int e) { return e * N_MAX / 32; }
+    static constexpr int exp_slot(int e) { return N_MAX + e * N_EXP / 32; }
+    static constexpr int fin_slot(int i) { return N_MAX + N_EXP + i * N_FIN / N_FIN_ITEMS; }
+};
+
+struct SoftmaxCarry {
+    float pm[4];      // partial row maxima
+    float m_new, alpha;
+    float rs[2];      // two partial row sums (shorter dependency chains)
+};
+
+template <int D>
+__device__ __forceinline__ void softmax_slice(int slot, f32x16 (&s)[2], float& m, float& l, f32x16 (&o)[D / 32], bf16x8 (&pf)[4],
+                                              float c, SoftmaxCarry& cy)
+{
+    using P = SlotPlan<D>;
+    // ---- phase 1: partial maxima, two scores per step (v_max3_f32)
+#pragma unroll
+    for (int e = 0; e < 32; e += 2)
+        if (P::max_slot(e) == slot) {
+            const float a = s[e >> 4][e & 15], b2 = s[e >> 4][(e & 15) + 1];
+            const int k = (e >> 1) & 3;
+            cy.pm[k] = (e < 8) ? fmaxf(a, b2) : fmaxf(fmaxf(cy.pm[k], a), b2);
+        }
+    if (slot == P::N_MAX - 1) {
+        float mx = fmaxf(fmaxf(cy.pm[0], cy.pm[1]), fmaxf(cy.pm[2], cy.pm[3]));
+        mx = xhalf_max(mx);
+        float mc = mx * c;
+        mc = fmaf(-fabsf(mc), 0x1p-23f, mc);  // nudge down: c*s_max - m >= 0 (see fa_fwd_bf16_kernel)
+        cy.m_new = fmaxf(m, mc);
+        cy.alpha = fast_exp2(m - cy.m_new);
+        m = cy.m_new;
+        cy.rs[0] = cy.rs[1] = 0.0f;
+    }
+    // ---- phase 2: p = min(2^(c*s - m), 1), row sum
+#pragma unroll
+    for (int e = 0; e < 32; ++e)
+        if (P::exp_slot(e) == slot) {
+            const float pv = exp2_clamp01(fmaf(s[e >> 4][e & 15], c, -cy.m_new));
+            s[e >> 4][e & 15] = pv;
+            cy.rs[e & 1] += pv;
+        }
+    // ---- phase 3: l, O rescale, pack P
+#pragma unroll
+    for (int i = 0; i < P::N_FIN_ITEMS; ++i)
+        if (P::fin_slot(i) == slot) {
+            if (i == 0) l = fmaf(l, cy.alpha, cy.rs[0] + cy.rs[1]);
+            if (i < 2 * P::DB) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) o[i >> 1][(i & 1) * 8 + r] *= cy.alpha;
+            } else {
+                const int f = i - 2 * P::DB;  // fragment (kb, t) = (f >> 1, f & 1)
+                pf[f] = pack_bf16x8(s[f >> 1], 8 * (f & 1));
+            }
+        }
+}
+
+// LDS reads + MFMA of block X for one slot.  vfr / kfr are the fragment staging registers (indexed by MFMA number).
+template <int D>
+__device__ __forceinline__ void load_frag(int i, const char* k_lds, const char* v_lds, int k_row_off, int k_g, int v_lane_off,
+                                          bf16x8 (&fr)[SlotPlan<D>::NSLOT])
+{
+    using P = SlotPlan<D>;
+    constexpr int RB = 2 * D;
+    if (i < P::NPV) {
+        const int db = i % P::DB, kt = i / P::DB, kb = kt >> 1, t = kt & 1;
+        const int off0 = ((kb * 8 + 4 * t + 0) * (D / 16) + 2 * db) * 128;
+        const int off1 = ((kb * 8 + 4 * t + 2) * (D / 16) + 2 * db) * 128;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_lds + v_lane_off + off0));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_lds + v_lane_off + off1));
+        fr[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+    } else if (i < P::NSLOT) {
+        const int q = i - P::NPV, ks = q >> 1, kb = q & 1;
+        fr[i] = *(const bf16x8*)(k_lds + k_row_off + kb * 32 * RB + (((2 * ks) ^ k_g) * 16));
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void mfma_slot(int i, const bf16x8 (&fr)[SlotPlan<D>::NSLOT], const bf16x8 (&pf)[4],
+                                          const bf16x8 (&qf)[D / 16], f32x16 (&o)[D / 32], f32x16 (&s)[2])
+{
+    using P = SlotPlan<D>;
+    if (i < P::NPV) {
+        const int db = i % P::DB, kt = i / P::DB;
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], pf[kt], o[db], 0, 0, 0);
+    } else {
+        const int q = i - P::NPV, ks = q >> 1, kb = q & 1;
+        if (ks == 0) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], qf[ks], z, 0, 0, 0);
+        } else {
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], qf[ks], s[kb], 0, 0, 0);
+        }
+    }
+}
+
+// One half iteration: MFMAs of block X (P.V with pfx into ox, then K.Q^T into sx) beside the softmax of block Y.
+// FIRST_MFMA lets the prologue / epilogue run only the K.Q^T part (FIRST = NPV) or only the P.V part (LAST = NPV).
+template <int D, int FIRST, int LAST, bool DO_SOFTMAX>
+__device__ __forceinline__ void half_iteration(const char* k_lds, const char* v_lds, int k_row_off, int k_g, int v_lane_off,
+                                               const bf16x8 (&pfx)[4], const bf16x8 (&qfx)[D / 16], f32x16 (&ox)[D / 32],
+                                               f32x16 (&sx)[2], f32x16 (&sy)[2], float& my, float& ly, f32x16 (&oy)[D / 32],
+                                               bf16x8 (&pfy)[4], float c)
+{
+    using P = SlotPlan<D>;
+    constexpr int AHEAD = 2;  // LDS reads run this many MFMA slots ahead
+    bf16x8 fr[P::NSLOT];
+    SoftmaxCarry cy;
+#pragma unroll
+    for (int i = FIRST; i < FIRST + AHEAD && i < LAST; ++i) load_frag<D>(i, k_lds, v_lds, k_row_off, k_g, v_lane_off, fr);
+    // the softmax slices are spread over the slots that actually run
+#pragma unroll
+    for (int i = FIRST; i < LAST; ++i) {
+        if (i + AHEAD < LAST) load_frag<D>(i + AHEAD, k_lds, v_lds, k_row_off, k_g, v_lane_off, fr);
+        mfma_slot<D>(i, fr, pfx, qfx, ox, sx);
+        if (DO_SOFTMAX) {
+            // map the running slot onto the full NSLOT-slice plan (prologue/epilogue halves have fewer MFMA slots)
+            constexpr int NRUN = LAST - FIRST;
+            const int lo = (i - FIRST) * P::NSLOT / NRUN, hi_ = (i - FIRST + 1) * P::NSLOT / NRUN;
+#pragma unroll
+            for (int sl = 0; sl < P::NSLOT; ++sl)
+                if (sl >= lo && sl < hi_) softmax_slice<D>(sl, sy, my, ly, oy, pfy, c, cy);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Ask the scheduler for the interleave: per MFMA a couple of LDS reads and a slice of the other block's VALU work.
+template <int NMFMA, int VALU_PER_MFMA, int DS_PER_MFMA>
+__device__ __forceinline__ void interleave_hint()
+{
+#pragma unroll
+    for (int i = 0; i < NMFMA; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, DS_PER_MFMA, 0);    // DS reads feeding the next MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);  // VALU (incl. transcendental) of the other block
+    }
+}
+
+template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, int SCHED>
+__global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp_kernel(FwdParams p)
+{
+    using C = Bf16Cfg<D, NWAVES>;
+    constexpr int KS = D / 16, DB = D / 32;
+    constexpr int BM = NWAVES * 64;
+    constexpr int kVperM = SCHED;  // VALU instructions requested per MFMA slot (0 = leave it to the compiler)
+
+    __shared__ __attribute__((aligned(1024))) char smem[4 * C::kTileBytes];  // K ring [2], then V ring [2]
+    char* const k_ring = smem;
+    char* const v_ring = smem + 2 * C::kTileBytes;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lq = lane & 31, hi = lane >> 5;
+
+    const int total = p.bh * p.q_tiles;
+    const int w = xcd_remap(blockIdx.x, total);
+    const int slab = w / p.q_tiles;
+    int qt = w % p.q_tiles;
+    if (CAUSAL) qt = p.q_tiles - 1 - qt;
+    const int n = p.n;
+    const int q0a = qt * BM + wave * 64, q0b = q0a + 32;
+
+    const int b = slab / p.heads, h = slab % p.heads;
+    const __bf16* qg = (const __bf16*)p.q + b * p.q_batch_stride + h * p.q_head_stride;
+    const __bf16* kg = (const __bf16*)p.k + b * p.kv_batch_stride + h * p.kv_head_stride;
+    const __bf16* vg = (const __bf16*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
+    const int64_t o_slab_off = b * p.o_batch_stride + h * p.o_head_stride;
+
+    int kv_end = n;
+    if (CAUSAL) kv_end = min(n, qt * BM + BM);
+    const int nt = (kv_end + kKvBlk - 1) / kKvBlk;
+
+    issue_k_tile<D, NWAVES>(kg, 0, n, p.kv_row_stride, k_ring, wave, lane);
+
+    bf16x8 qfa[KS], qfb[KS];
+    {
+        const __bf16* qra = qg + (int64_t)min(q0a + lq, n - 1) * p.q_row_stride + hi * 8;
+        const __bf16* qrb = qg + (int64_t)min(q0b + lq, n - 1) * p.q_row_stride + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qfa[ks] = *(const bf16x8*)(qra + ks * 16);
+            qfb[ks] = *(const bf16x8*)(qrb + ks * 16);
+        }
+    }
+
+    f32x16 oa[DB], ob[DB], sa[2], sb[2];
+    bf16x8 pfa[4], pfb[4];
+    float ma = -INFINITY, mb = -INFINITY, la = 0.0f, lb = 0.0f;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oa[db][r] = ob[db][r] = 0.0f;
+
+    const int k_row_off = lq * C::kRowBytes;
+    const int k_g = hi ^ k_swizzle<D>(lq);
+    const int li = lane & 15;
+    const int v_lane_off = (hi * (D / 16) + ((lane >> 4) & 1)) * 128 + (li >> 2) * 32 + (li & 3) * 8;
+    const float c = p.scale_log2e;
+
+    auto needs_mask = [&](int tile, int q0) { return (tile * kKvBlk + kKvBlk > n) || (CAUSAL && (tile * kKvBlk + kKvBlk - 1 > q0)); };
+
+    // ---------------- prologue: tile 0 ----------------
+    wait_lds_dma();
+    __syncthreads();
+    if (nt > 1) issue_k_tile<D, NWAVES>(kg, kKvBlk, n, p.kv_row_stride, k_ring + C::kTileBytes, wave, lane);
+    issue_v_tile<D, NWAVES>(vg, 0, n, p.kv_row_stride, v_ring, wave, lane);
+    qk_block<D>(k_ring, k_row_off, k_g, qfa, sa);
+    if (needs_mask(0, q0a)) mask_block<CAUSAL>(sa, 0, q0a + lq, n, hi);
+    qk_block<D>(k_ring, k_row_off, k_g, qfb, sb);
+    softmax_block<D>(sa, ma, la, oa, pfa, c);
+    if (kVperM > 1) interleave_hint<2 * KS, kVperM, 1>();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---------------- steady state ----------------
+    // Masks are only ever needed on the LAST tiles of a workgroup (ragged tail; causal diagonal), so the tile loop is split
+    // in two instead of branching inside it: a mask-free loop whose body is ONE basic block (a branch between the halves
+    // would let LLVM sink the softmax out of the slots it was pinned to, and a diamond inside the loop doubles the live
+    // 16-register accumulator tuples), then a plain phase-structured loop for the few masked tiles.
+    int j_split = nt;
+    for (int j = 1; j < nt; ++j)
+        if (needs_mask(j - 1, q0b) || needs_mask(j, q0a)) {
+            j_split = j;
+            break;
+        }
+    if (SCHED != 1) j_split = 1;
+
+    auto stage_tiles = [&](int j) {
+        wait_lds_dma();   // K(j), V(j-1): own pieces landed
+        __syncthreads();  // everyone's pieces landed; everyone is done with K(j-1), V(j-2)
+        if (j + 1 < nt) issue_k_tile<D, NWAVES>(kg, (j + 1) * kKvBlk, n, p.kv_row_stride, k_ring + ((j + 1) & 1) * C::kTileBytes, wave, lane);
+        issue_v_tile<D, NWAVES>(vg, j * kKvBlk, n, p.kv_row_stride, v_ring + (j & 1) * C::kTileBytes, wave, lane);
+    };
+
+    for (int j = 1; j < j_split; ++j) {
+        stage_tiles(j);
+        const char* k_lds = k_ring + (j & 1) * C::kTileBytes;
+        const char* v_lds = v_ring + ((j - 1) & 1) * C::kTileBytes;
+        using P = SlotPlan<D>;
+        // half 1: MFMA stream of A beside the softmax of B; half 2: the mirror image
+        half_iteration<D, 0, P::NSLOT, true>(k_lds, v_lds, k_row_off, k_g, v_lane_off, pfa, qfa, oa, sa, sb, mb, lb, ob, pfb, c);
+        half_iteration<D, 0, P::NSLOT, true>(k_lds, v_lds, k_row_off, k_g, v_lane_off, pfb, qfb, ob, sb, sa, ma, la, oa, pfa, c);
+    }
+
+    for (int j = j_split; j < nt; ++j) {
+        stage_tiles(j);
+        const char* k_lds = k_ring + (j & 1) * C::kTileBytes;
+        const char* v_lds = v_ring + ((j - 1) & 1) * C::kTileBytes;
+        if (needs_mask(j - 1, q0b)) mask_block<CAUSAL>(sb, (j - 1) * kKvBlk, q0b + lq, n, hi);
+        pv_block<D>(v_lds, v_lane_off, pfa, oa);
+        qk_block<D>(k_lds, k_row_off, k_g, qfa, sa);
+        softmax_block<D>(sb, mb, lb, ob, pfb, c);
+        if (kVperM > 1) interleave_hint<2 * KS + 4 * DB, kVperM, 2>();
+        __builtin_amdgcn_sched_barrier(0);
+        if (needs_mask(j, q0a)) mask_block<CAUSAL>(sa, j * kKvBlk, q0a + lq, n, hi);
+        pv_block<D>(v_lds, v_lane_off, pfb, ob);
+        qk_block<D>(k_lds, k_row_off, k_g, qfb, sb);
+        softmax_block<D>(sa, ma, la, oa, pfa, c);
+        if (kVperM > 1) interleave_hint<2 * KS + 4 * DB, kVperM, 2>();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---------------- epilogue: P.V of the last tile ----------------
+    wait_lds_dma();
+    __syncthreads();
+    {
+        const char* v_lds = v_ring + ((nt - 1) & 1) * C::kTileBytes;
+        if (needs_mask(nt - 1, q0b)) mask_block<CAUSAL>(sb, (nt - 1) * kKvBlk, q0b + lq, n, hi);
+        pv_block<D>(v_lds, v_lane_off, pfa, oa);
+        softmax_block<D>(sb, mb, lb, ob, pfb, c);
+        if (kVperM > 1) interleave_hint<4 * DB, kVperM, 2>();
+        __builtin_amdgcn_sched_barrier(0);
+        pv_block<D>(v_lds, v_lane_off, pfb, ob);
+    }
+
+    // ---------------- store ----------------
+    auto store_block = [&](const f32x16 (&o)[DB], float l, float m, int q0) {
+        const float lt = xhalf_sum(l);
+        const float inv = 1.0f / lt;
+        const int qi = q0 + lq;
+        if (qi < n) {
+            const int64_t o_off = o_slab_off + (int64_t)qi * p.o_row_stride + 4 * hi;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (OUT_F32) {
+                        f32x4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = o[db][4 * g + e] * inv;
+                        *(f32x4*)((float*)p.o + o_off + db * 32 + 8 * g) = pk;
+                    } else {
+                        bf16x4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = (__bf16)(o[db][4 * g + e] * inv);
+                        *(bf16x4*)((__bf16*)p.o + o_off + db * 32 + 8 * g) = pk;
+                    }
+                }
+            if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (m + __builtin_amdgcn_logf(lt)) * kLn2;
+        }
+    };
+    store_block(oa, la, ma, q0a);
+    store_block(ob, lb, mb, q0b);
+}
+
+template <int D, int NWAVES, int SCHED>
+static hipError_t launch_pp(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
+{
+    FwdParams p = p0;
+    constexpr int BM = NWAVES * 64;
+    p.q_tiles = (p.n + BM - 1) / BM;
+    const int64_t total = (int64_t)p.bh * p.q_tiles;
+    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)total), block(NWAVES * kWave);
+    if (causal) {
+        if (out_f32)
+            hipLaunchKernelGGL((fa_fwd_bf16_pp_kernel<D, NWAVES, true, true, SCHED>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((fa_fwd_bf16_pp_kernel<D, NWAVES, true, false, SCHED>), grid, block, 0, stream, p);
+    } else {
+        if (out_f32)
+            hipLaunchKernelGGL((fa_fwd_bf16_pp_kernel<D, NWAVES, false, true, SCHED>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((fa_fwd_bf16_pp_kernel<D, NWAVES, false, false, SCHED>), grid, block, 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
+// =====================================================================================================================
+// Ping-pong kernel, second generation ("pp2"): the same two-block half-tile-skewed structure, with the softmax trimmed
+// to what the VALU cannot avoid (PMC + profiles/r01_ubench_issue.txt: the loop is bound by per-wave VALU issue, ~5.7
+// cycles per instruction, not by the matrix pipe):
+//   * row sums come from the matrix core: one v_mfma_f32_16x16x32_bf16 per P fragment against a constant 0/1 A operand
+//     built so that EVERY lane receives the full sum of its own query row (both half-waves) -- 4 small MFMAs replace 32
+//     adds per block-tile, and numerator and denominator now see the same bf16-rounded P;
+//   * the O accumulator is rescaled lazily: the running max used in the exponent only moves when some row of the wave
+//     outgrows it by more than 2^kLazyThr (wave-uniform, rare branch); the exponent carries a -kLazyThr bias so p <= 1
+//     still holds and the v_exp clamp keeps protecting against overflow for any input magnitude;
+//   * per MFMA slot the wave issues ~5 VALU + 1-2 LDS instructions: the issue time of a slot matches the 32 cycles its
+//     MFMA occupies the pipe.
+// =====================================================================================================================
+constexpr float kLazyThr = 8.0f;  // exp2-domain slack of the lazily updated running max (p spans 2^-8 .. 1 between rescales)
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+template <int D>
+struct Plan2 {
+    static constexpr int KS = D / 16, DB = D / 32;
+    static constexpr int NPV = 4 * DB, NSUM = 4, NQK = 2 * KS, NSLOT = NPV + NSUM + NQK;
+    static constexpr int N_MAX = NSLOT / 10 > 0 ? NSLOT / 10 : 1;  // slots for the max phase (before the rescale decision)
+    static constexpr int N_FIN = NSLOT / 5;                       // slots for packing P
+    static constexpr int N_EXP = NSLOT - N_MAX - N_FIN;
+    static constexpr int max_slot(int e) { return e * N_MAX / 32; }
+    static constexpr int exp_slot(int e) { return N_MAX + e * N_EXP / 32; }
+    static constexpr int fin_slot(int f) { return N_MAX + N_EXP + f * N_FIN / 4; }
+};
+
+// per-lane constant A operand of the row-sum MFMA: A[i][k] = ((i >> 2) & 1) == ((k >> 3) & 1)
+__device__ __forceinline__ bf16x8 rowsum_a_operand(int lane)
+{
+    const bool one = (((lane & 15) >> 2) & 1) == ((lane >> 4) & 1);
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = one ? (__bf16)1.0f : (__bf16)0.0f;
+    return a;
+}
+
+struct BlockState {   // running softmax state of one 32-row block (per lane: one query row, half of its keys)
+    float m;          // exponent reference: p = 2^(c*s - m - kLazyThr)
+    f32x4_t lacc;     // row sum of p (all four registers hold the same, complete, row sum)
+};
+
+// max phase result -> decision -> (rare) rescale.  Returns the exponent offset to use for this tile.
+template <int D>
+__device__ __forceinline__ float lazy_rescale(float mx_raw, float c, BlockState& st, f32x16 (&o)[D / 32])
+{
+    float mc = mx_raw * c;
+    mc = fmaf(-fabsf(mc), 0x1p-23f, mc);  // nudge down: c*s_max - mc >= 0 exactly (see fa_fwd_bf16_kernel)
+    if (__builtin_expect(__any(mc - st.m > kLazyThr), 0)) {
+        asm volatile("; lazy rescale" ::: "memory");  // keep this a real (non-speculated) branch
+        const float m_new = fmaxf(st.m, mc);
+        const float alpha = fast_exp2(st.m - m_new);  // 0 on the first tile (m = -inf)
+        st.m = m_new;
+#pragma unroll
+        for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st.lacc[r] *= alpha;
+    }
+    return st.m + kLazyThr;
+}
+
+__device__ __forceinline__ float block_rowmax(const f32x16 (&s)[2])
+{
+    float mx = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    return xhalf_max(mx);
+}
+
+// phase-structured softmax (prologue, masked tail tiles, epilogue)
+template <int D>
+__device__ __forceinline__ void softmax_block2(f32x16 (&s)[2], BlockState& st, f32x16 (&o)[D / 32], bf16x8 (&pf)[4], float c)
+{
+    const float off = lazy_rescale<D>(block_rowmax(s), c, st, o);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = exp2_clamp01(fmaf(s[kb][r], c, -off));
+#pragma unroll
+    for (int f = 0; f < 4; ++f) pf[f] = pack_bf16x8(s[f >> 1], 8 * (f & 1));
+}
+
+__device__ __forceinline__ void sum_block(const bf16x8& ones_a, const bf16x8 (&pf)[4], BlockState& st)
+{
+#pragma unroll
+    for (int f = 0; f < 4; ++f) st.lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pf[f], st.lacc, 0, 0, 0);
+}
+
+template <int D>
+__device__ __forceinline__ void load_frag2(int i, const char* k_lds, const char* v_lds, int k_row_off, int k_g, int v_lane_off,
+                                           bf16x8 (&fr)[Plan2<D>::NSLOT])
+{
+    using P = Plan2<D>;
+    constexpr int RB = 2 * D;
+    if (i < P::NPV) {
+        const int db = i % P::DB, kt = i / P::DB, kb = kt >> 1, t = kt & 1;
+        const int off0 = ((kb * 8 + 4 * t + 0) * (D / 16) + 2 * db) * 128;
+        const int off1 = ((kb * 8 + 4 * t + 2) * (D / 16) + 2 * db) * 128;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_lds + v_lane_off + off0));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_lds + v_lane_off + off1));
+        fr[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+    } else if (i >= P::NPV + P::NSUM && i < P::NSLOT) {
+        const int q = i - P::NPV - P::NSUM, ks = q >> 1, kb = q & 1;
+        fr[i] = *(const bf16x8*)(k_lds + k_row_off + kb * 32 * RB + (((2 * ks) ^ k_g) * 16));
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void mfma_slot2(int i, const bf16x8 (&fr)[Plan2<D>::NSLOT], const bf16x8& ones_a, const bf16x8 (&pf)[4],
+                                           const bf16x8 (&qf)[D / 16], f32x16 (&o)[D / 32], BlockState& st, f32x16 (&s)[2])
+{
+    using P = Plan2<D>;
+    if (i < P::NPV) {
+        const int db = i % P::DB, kt = i / P::DB;
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], pf[kt], o[db], 0, 0, 0);
+    } else if (i < P::NPV + P::NSUM) {
+        st.lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pf[i - P::NPV], st.lacc, 0, 0, 0);
+    } else {
+        const int q = i - P::NPV - P::NSUM, ks = q >> 1, kb = q & 1;
+        if (ks == 0) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], qf[ks], z, 0, 0, 0);
+        } else {
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], qf[ks], s[kb], 0, 0, 0);
+        }
+    }
+}
+
+// One half iteration of the mask-free main loop: the MFMA stream of block X (P.V, row sums, then K.Q^T of the next
+// tile) with the softmax of block Y sliced into its slots.
+template <int D, int AHEAD, int ABL>
+__device__ __forceinline__ void half_iteration2(const char* k_lds, const char* v_lds, int k_row_off, int k_g, int v_lane_off,
+                                                const bf16x8& ones_a, const bf16x8 (&pfx)[4], const bf16x8 (&qfx)[D / 16],
+                                                f32x16 (&ox)[D / 32], BlockState& stx, f32x16 (&sx)[2], f32x16 (&sy)[2],
+                                                BlockState& sty, f32x16 (&oy)[D / 32], bf16x8 (&pfy)[4], float c)
+{
+    using P = Plan2<D>;
+    bf16x8 fr[P::NSLOT];
+    float pm[4];
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) load_frag2<D>(i, k_lds, v_lds, k_row_off, k_g, v_lane_off, fr);
+    // ---- slots [0, N_MAX): MFMAs of X beside the partial row maxima of Y
+#pragma unroll
+    for (int i = 0; i < P::N_MAX; ++i) {
+        if (i + AHEAD < P::NSLOT) load_frag2<D>(i + AHEAD, k_lds, v_lds, k_row_off, k_g, v_lane_off, fr);
+        if (!(ABL & 2)) mfma_slot2<D>(i, fr, ones_a, pfx, qfx, ox, stx, sx);
+        else asm volatile("" ::"v"(fr[i]));
+#pragma unroll
+        for (int e = 0; e < 32; e += 2)
+            if (!(ABL & 1) && P::max_slot(e) == i) {
+                const float a = sy[e >> 4][e & 15], b2 = sy[e >> 4][(e & 15) + 1];
+                const int k = (e >> 1) & 3;
+                pm[k] = (e < 8) ? fmaxf(a, b2) : fmaxf(fmaxf(pm[k], a), b2);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float off = 0.0f;
+    if (!(ABL & 1)) {
+        const float mx = xhalf_max(fmaxf(fmaxf(pm[0], pm[1]), fmaxf(pm[2], pm[3])));
+        off = lazy_rescale<D>(mx, c, sty, oy);  // rare wave-uniform branch inside
+    }
+    // ---- slots [N_MAX, NSLOT): exp, then pack
+#pragma unroll
+    for (int i = P::N_MAX; i < P::NSLOT; ++i) {
+        if (i + AHEAD < P::NSLOT) load_frag2<D>(i + AHEAD, k_lds, v_lds, k_row_off, k_g, v_lane_off, fr);
+        if (!(ABL & 2)) mfma_slot2<D>(i, fr, ones_a, pfx, qfx, ox, stx, sx);
+        else asm volatile("" ::"v"(fr[i]));
+#pragma unroll
+        for (int e = 0; e < 32; ++e)
+            if (!(ABL & 1) && P::exp_slot(e) == i) sy[e >> 4][e & 15] = exp2_clamp01(fmaf(sy[e >> 4][e & 15], c, -off));
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            if (!(ABL & 1) && P::fin_slot(f) == i) {
+                pfy[f] = pack_bf16x8(sy[f >> 1], 8 * (f & 1));
+                asm volatile("" : "+v"(pfy[f]));  // pin the pack to this slot (its consumers live in the next basic block)
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, int AHEAD, int ABL = 0>
+__global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp2_kernel(FwdParams p)
+{
+    using C = Bf16Cfg<D, NWAVES>;
+    constexpr int KS = D / 16, DB = D / 32;
+    constexpr int BM = NWAVES * 64;
+
+    __shared__ __attribute__((aligned(1024))) char smem[4 * C::kTileBytes];  // K ring [2], then V ring [2]
+    char* const k_ring = smem;
+    char* const v_ring = smem + 2 * C::kTileBytes;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lq = lane & 31, hi = lane >> 5;
+
+    const int total = p.bh * p.q_tiles;
+    const int w = xcd_remap(blockIdx.x, total);
+    const int slab = w / p.q_tiles;
+    int qt = w % p.q_tiles;
+    if (CAUSAL) qt = p.q_tiles - 1 - qt;
+    const int n = p.n;
+    const int q0a = qt * BM + wave * 64, q0b = q0a + 32;
+
+    const int b = slab / p.heads, h = slab % p.heads;
+    const __bf16* qg = (const __bf16*)p.q + b * p.q_batch_stride + h * p.q_head_stride;
+    const __bf16* kg = (const __bf16*)p.k + b * p.kv_batch_stride + h * p.kv_head_stride;
+    const __bf16* vg = (const __bf16*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
+    const int64_t o_slab_off = b * p.o_batch_stride + h * p.o_head_stride;
+
+    int kv_end = n;
+    if (CAUSAL) kv_end = min(n, qt * BM + BM);
+    const int nt = (kv_end + kKvBlk - 1) / kKvBlk;
+
+    issue_k_tile<D, NWAVES>(kg, 0, n, p.kv_row_stride, k_ring, wave, lane);
+
+    bf16x8 qfa[KS], qfb[KS];
+    {
+        const __bf16* qra = qg + (int64_t)min(q0a + lq, n - 1) * p.q_row_stride + hi * 8;
+        const __bf16* qrb = qg + (int64_t)min(q0b + lq, n - 1) * p.q_row_stride + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qfa[ks] = *(const bf16x8*)(qra + ks * 16);
+            qfb[ks] = *(const bf16x8*)(qrb + ks * 16);
+        }
+    }
+    const bf16x8 ones_a = rowsum_a_operand(lane);
+
+    f32x16 oa[DB], ob[DB], sa[2], sb[2];
+    bf16x8 pfa[4], pfb[4];
+    BlockState sta, stb;
+    sta.m = stb.m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sta.lacc[r] = stb.lacc[r] = 0.0f;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oa[db][r] = ob[db][r] = 0.0f;
+
+    const int k_row_off = lq * C::kRowBytes;
+    const int k_g = hi ^ k_swizzle<D>(lq);
+    const int li = lane & 15;
+    const int v_lane_off = (hi * (D / 16) + ((lane >> 4) & 1)) * 128 + (li >> 2) * 32 + (li & 3) * 8;
+    const float c = p.scale_log2e;
+
+    auto needs_mask = [&](int tile, int q0) { return (tile * kKvBlk + kKvBlk > n) || (CAUSAL && (tile * kKvBlk + kKvBlk - 1 > q0)); };
+    auto stage_tiles = [&](int j) {
+        wait_lds_dma();   // K(j), V(j-1): own pieces landed
+        __syncthreads();  // everyone's pieces landed; everyone is done with K(j-1), V(j-2)
+        if (j + 1 < nt) issue_k_tile<D, NWAVES>(kg, (j + 1) * kKvBlk, n, p.kv_row_stride, k_ring + ((j + 1) & 1) * C::kTileBytes, wave, lane);
+        issue_v_tile<D, NWAVES>(vg, j * kKvBlk, n, p.kv_row_stride, v_ring + (j & 1) * C::kTileBytes, wave, lane);
+    };
+
+    // ---------------- prologue: tile 0 (phase-structured) ----------------
+    wait_lds_dma();
+    __syncthreads();
+    if (nt > 1) issue_k_tile<D, NWAVES>(kg, kKvBlk, n, p.kv_row_stride, k_ring + C::kTileBytes, wave, lane);
+    issue_v_tile<D, NWAVES>(vg, 0, n, p.kv_row_stride, v_ring, wave, lane);
+    qk_block<D>(k_ring, k_row_off, k_g, qfa, sa);
+    if (needs_mask(0, q0a)) mask_block<CAUSAL>(sa, 0, q0a + lq, n, hi);
+    qk_block<D>(k_ring, k_row_off, k_g, qfb, sb);
+    softmax_block2<D>(sa, sta, oa, pfa, c);
+
+    // Masks are only needed on the LAST tiles of a workgroup (ragged tail, causal diagonal): a mask-free loop whose halves
+    // are straight-line slot-pinned code, then a plain loop for the few masked tiles (see fa_fwd_bf16_pp_kernel).
+    int j_split = nt;
+    for (int j = 1; j < nt; ++j)
+        if (needs_mask(j - 1, q0b) || needs_mask(j, q0a)) {
+            j_split = j;
+            break;
+        }
+
+    for (int j = 1; j < j_split; ++j) {
+        if (!(ABL & 4)) stage_tiles(j);
+        const char* k_lds = k_ring + (j & 1) * C::kTileBytes;
+        const char* v_lds = v_ring + ((j - 1) & 1) * C::kTileBytes;
+        half_iteration2<D, AHEAD, ABL>(k_lds, v_lds, k_row_off, k_g, v_lane_off, ones_a, pfa, qfa, oa, sta, sa, sb, stb, ob, pfb, c);
+        half_iteration2<D, AHEAD, ABL>(k_lds, v_lds, k_row_off, k_g, v_lane_off, ones_a, pfb, qfb, ob, stb, sb, sa, sta, oa, pfa, c);
+    }
+
+    for (int j = j_split; j < nt; ++j) {
+        stage_tiles(j);
+        const char* k_lds = k_ring + (j & 1) * C::kTileBytes;
+        const char* v_lds = v_ring + ((j - 1) & 1) * C::kTileBytes;
+        if (needs_mask(j - 1, q0b)) mask_block<CAUSAL>(sb, (j - 1) * kKvBlk, q0b + lq, n, hi);
+        pv_block<D>(v_lds, v_lane_off, pfa, oa);
+        sum_block(ones_a, pfa, sta);
+        qk_block<D>(k_lds, k_row_off, k_g, qfa, sa);
+        softmax_block2<D>(sb, stb, ob, pfb, c);
+        if (needs_mask(j, q0a)) mask_block<CAUSAL>(sa, j * kKvBlk, q0a + lq, n, hi);
+        pv_block<D>(v_lds, v_lane_off, pfb, ob);
+        sum_block(ones_a, pfb, stb);
+        qk_block<D>(k_lds, k_row_off, k_g, qfb, sb);
+        softmax_block2<D>(sa, sta, oa, pfa, c);
+    }
+
+    // ---------------- epilogue: P.V of the last tile ----------------
+    wait_lds_dma();
+    __syncthreads();
+    {
+        const char* v_lds = v_ring + ((nt - 1) & 1) * C::kTileBytes;
+        if (needs_mask(nt - 1, q0b)) mask_block<CAUSAL>(sb, (nt - 1) * kKvBlk, q0b + lq, n, hi);
+        pv_block<D>(v_lds, v_lane_off, pfa, oa);
+        sum_block(ones_a, pfa, sta);
+        softmax_block2<D>(sb, stb, ob, pfb, c);
+        pv_block<D>(v_lds, v_lane_off, pfb, ob);
+        sum_block(ones_a, pfb, stb);
+    }
+
+    // ---------------- store ----------------
+    auto store_block = [&](const f32x16 (&o)[DB], const BlockState& st, int q0) {
+        const float lt = st.lacc[0];
+        const float inv = 1.0f / lt;
+        const int qi = q0 + lq;
+        if (qi < n) {
+            const int64_t o_off = o_slab_off + (int64_t)qi * p.o_row_stride + 4 * hi;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (OUT_F32) {
+                        f32x4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = o[db][4 * g + e] * inv;
+                        *(f32x4*)((float*)p.o + o_off + db * 32 + 8 * g) = pk;
+                    } else {
+                        bf16x4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = (__bf16)(o[db][4 * g + e] * inv);
+                        *(bf16x4*)((__bf16*)p.o + o_off + db * 32 + 8 * g) = pk;
+                    }
+                }
+            if (p.lse != nullptr && hi == 0)
+                p.lse[(int64_t)slab * n + qi] = (st.m + kLazyThr + __builtin_amdgcn_logf(lt)) * kLn2;
+        }
+    };
+    store_block(oa, sta, q0a);
+    store_block(ob, stb, q0b);
+}
+
+template <int D, int NWAVES, int AHEAD>
+static hipError_t launch_pp2(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
+{
+    FwdParams p = p0;
+    constexpr int BM = NWAVES * 64;
+    p.q_tiles = (p.n + BM - 1) / BM;
+    const int64_t total = (int64_t)p.bh * p.q_tiles;
+    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)total), block(NWAVES * kWave);
+    if (causal) {
+        if (out_f32)
+            hipLaunchKernelGGL((fa_fwd_bf16_pp2_kernel<D, NWAVES, true, true, AHEAD>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((fa_fwd_bf16_pp2_kernel<D, NWAVES, true, false, AHEAD>), grid, block, 0, stream, p);
+    } else {
+        if (out_f32)
+            hipLaunchKernelGGL((fa_fwd_bf16_pp2_kernel<D, NWAVES, false, true, AHEAD>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((fa_fwd_bf16_pp2_kernel<D, NWAVES, false, false, AHEAD>), grid, block, 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
+template <int ABL>
+static hipError_t launch_pp2_ablation(const FwdParams& p0, hipStream_t stream)
+{
+    FwdParams p = p0;
+    p.q_tiles = (p.n + 255) / 256;
+    dim3 grid((unsigned)(p.bh * p.q_tiles)), block(256);
+    hipLaunchKernelGGL((fa_fwd_bf16_pp2_kernel<64, 4, false, false, 2, ABL>), grid, block, 0, stream, p);
+    return hipGetLastError();
 }
 
 template <int D, int NWAVES, int QB, int MINWAVES>
@@ -343,8 +1167,23 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
     switch (d) {
         case 32: return launch_cfg<32, 4, 1, 4>(p, causal, out_f32, stream);
         case 64:
-            if (variant == 1) return launch_cfg<64, 4, 2, 2>(p, causal, out_f32, stream);
-            return launch_cfg<64, 4, 1, 4>(p, causal, out_f32, stream);
+            switch (variant) {
+                case 1: return launch_cfg<64, 4, 1, 4>(p, causal, out_f32, stream);   // phase-structured, 4 waves/SIMD
+                case 2: return launch_cfg<64, 4, 2, 2>(p, causal, out_f32, stream);   // phase-structured, 64 rows/wave
+                case 3: return launch_pp<64, 4, 0>(p, causal, out_f32, stream);       // ping-pong, compiler's own schedule
+                case 4: return launch_pp<64, 4, 12>(p, causal, out_f32, stream);      // ping-pong, sched_group_barrier hints
+                case 5: return launch_pp<64, 4, 1>(p, causal, out_f32, stream);       // ping-pong, slot-pinned interleave
+                case 6: return launch_pp2<64, 4, 4>(p, causal, out_f32, stream);
+                // ablations of the main loop (results are garbage; timing only): 1 = no softmax VALU, 2 = no MFMA,
+                // 4 = no barrier / DMA, and combinations
+                case 11: return launch_pp2_ablation<1>(p, stream);
+                case 12: return launch_pp2_ablation<2>(p, stream);
+                case 13: return launch_pp2_ablation<3>(p, stream);
+                case 14: return launch_pp2_ablation<4>(p, stream);
+                case 15: return launch_pp2_ablation<5>(p, stream);
+                case 16: return launch_pp2_ablation<6>(p, stream);
+                default: return launch_pp2<64, 4, 2>(p, causal, out_f32, stream);     // ping-pong 2: MFMA row sums, lazy rescale
+            }
         case 128: return launch_cfg<128, 4, 1, 2>(p, causal, out_f32, stream);
         default: return hipErrorInvalidValue;
     }

@@ -165,7 +165,9 @@ def test_lse_output():
         qb, kb, vb = (orc.round_to_bf16(t) for t in (q, k, v))
         _, lse_ref_b = orc.attention_f64(qb, kb, vb, causal=causal, scale=0.25, return_lse=True)
         _, lse_b = fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, scale=0.25, return_lse=True)
-        check(lse_b, lse_ref_b, 1e-3)
+        # the bf16 kernel sums the bf16-rounded P on the matrix core (same values as the numerator): each term carries
+        # 2^-9 relative rounding, so log(l) is good to a few 1e-3
+        check(lse_b, lse_ref_b, 5e-3)
 
 
 def test_known_answer_iota_ones():
