@@ -67,6 +67,15 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // min(2^x, 1): fmed3(., 0, 1) folds into the VOP3 clamp bit of v_exp_f32 -- one instruction
 __device__ __forceinline__ float exp2_clamp01(float x) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x), 0.0f, 1.0f); }
 
+// max(a, b, c) as ONE v_max3_f32.  Written as asm because hipcc puts a canonicalising v_max_f32 x, x, x in front of every fmaxf
+// whose operand comes straight out of an MFMA accumulator (24 extra VALU per tile pair in the attention loop).
+__device__ __forceinline__ float max3_raw(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // max / sum across the two half-waves (lane l <-> lane l^32) with one v_permlane32_swap (VALU, no LDS trip):
 // swap(a, b) exchanges a[32..63] with b[0..31]; fed the same value twice it returns {lo, lo} and {hi, hi}.
 __device__ __forceinline__ float xhalf_max(float x)
