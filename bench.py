@@ -176,6 +176,7 @@ def main():
     dist = init_dist(world, "nccl") if world > 1 else None
 
     import flashattention_c_amd as fa  # raises if libflashattn_amd.so is missing -- no fallback
+    from flashattention_c_amd import _cabi
 
     B, H, d, n, dtype, scaling = WORKLOADS[args.workload]
     total_bh = B * H
@@ -208,7 +209,7 @@ def main():
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_TFLOPS[dtype], 4),
                 "traffic": (pmc or {}).get(f"{args.workload}_hbm_bytes_per_launch"),
-                "kernel": "fa_fwd_bf16_kernel" if dtype == "bf16" else "fa_fwd_f32_kernel",
+                "kernel": _cabi.lib().fa_kernel_name(1 if dtype == "bf16" else 0, d, int(causal)).decode(),
                 "kernel_ms": round(kms, 4),
                 "algorithmic_flop_per_launch": fwd_flop(bh, n, d, causal),
                 "algorithmic_hbm_bytes_per_launch": algorithmic_bytes(bh, n, d, elem),

@@ -226,8 +226,12 @@ const char* fa_version(void) { return "flashattn_amd abi 1 gfx950 (hip, mfma f32
 const char* fa_kernel_name(int32_t dtype, int32_t d, int32_t causal)
 {
     if (!head_dim_supported(d)) return nullptr;
-    if (dtype == FA_DTYPE_F32) return causal ? "fa_fwd_f32_kernel<causal>" : "fa_fwd_f32_kernel";
-    if (dtype == FA_DTYPE_BF16 || dtype == FA_DTYPE_BF16_OUT_F32) return causal ? "fa_fwd_bf16_kernel<causal>" : "fa_fwd_bf16_kernel";
+    if (dtype == FA_DTYPE_F32) return "fa_fwd_f32_kernel";
+    if (dtype == FA_DTYPE_BF16 || dtype == FA_DTYPE_BF16_OUT_F32) {
+        // lockstep / software-pipelined kernel where it is instantiated, the phase-structured one elsewhere
+        if (d == 64 || (d == 32 && !causal)) return "fa_fwd_bf16_pp3_kernel";
+        return "fa_fwd_bf16_kernel";
+    }
     return nullptr;
 }
 
