@@ -63,18 +63,30 @@ __device__ __forceinline__ int xcd_remap(int bid, int total)
 // barrier does not wait for it, and the compiler only inserts the wait in front of LDS reads it thinks may alias.
 __device__ __forceinline__ void wait_lds_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Let every matrix-core instruction in flight retire before VALU code touches its destination registers.  hipcc pads
+// "MFMA write -> VALU read/write" hazards inside a basic block, but not across a branch or a loop exit (observed on
+// ROCm 7.2: an epilogue or a rarely taken branch that starts right after the last MFMA read the accumulator one MFMA
+// short).  64 idle states cover the longest (16-pass) instruction; use it only on cold paths.
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 // min(2^x, 1): fmed3(., 0, 1) folds into the VOP3 clamp bit of v_exp_f32 -- one instruction
 __device__ __forceinline__ float exp2_clamp01(float x) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x), 0.0f, 1.0f); }
 
 // max(a, b, c) as ONE v_max3_f32.  Written as asm because hipcc puts a canonicalising v_max_f32 x, x, x in front of every fmaxf
 // whose operand comes straight out of an MFMA accumulator (24 extra VALU per tile pair in the attention loop).
+// ONLY for operands whose producing MFMA retired long ago (a whole pipeline phase earlier): hipcc pads the
+// "MFMA write -> VALU read" hazard for its own instructions, never for the inside of an asm statement.  Reading the
+// scores with this helper right after K.Q^T returned partial sums (observed: wrong row maxima -> skipped rescale).
+// max3_safe() is the compiler-visible form for those places.
 __device__ __forceinline__ float max3_raw(float a, float b, float c)
 {
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+
+__device__ __forceinline__ float max3_safe(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
 // max / sum across the two half-waves (lane l <-> lane l^32) with one v_permlane32_swap (VALU, no LDS trip):
 // swap(a, b) exchanges a[32..63] with b[0..31]; fed the same value twice it returns {lo, lo} and {hi, hi}.

@@ -288,6 +288,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINWAVES) void fa_fwd_bf16_kernel(Fw
     }
 
     // ================= epilogue: O / l, pack, store =================
+    mfma_drain();  // the loop exit is a branch: the last P.V MFMAs may still be in flight
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const float lt = xhalf_sum(l[qb]);
@@ -707,6 +708,7 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp_kernel(FwdPar
     }
 
     // ---------------- store ----------------
+    mfma_drain();  // the loop exit is a branch: the last P.V / row-sum MFMAs may still be in flight
     auto store_block = [&](const f32x16 (&o)[DB], float l, float m, int q0) {
         const float lt = xhalf_sum(l);
         const float inv = 1.0f / lt;
@@ -811,6 +813,7 @@ __device__ __forceinline__ float lazy_rescale(float mx_raw, float c, BlockState&
     mc = fmaf(-fabsf(mc), 0x1p-23f, mc);  // nudge down: c*s_max - mc >= 0 exactly (see fa_fwd_bf16_kernel)
     if (__builtin_expect(__any(mc - st.m > kLazyThr), 0)) {
         asm volatile("; lazy rescale" ::: "memory");  // keep this a real (non-speculated) branch
+        mfma_drain();  // the accumulators rescaled below may have an MFMA in flight (hazard not padded across the branch)
         const float m_new = fmaxf(st.m, mc);
         const float alpha = fast_exp2(st.m - m_new);  // 0 on the first tile (m = -inf)
         st.m = m_new;
@@ -1080,6 +1083,7 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp2_kernel(FwdPa
     }
 
     // ---------------- store ----------------
+    mfma_drain();  // the loop exit is a branch: the last P.V / row-sum MFMAs may still be in flight
     auto store_block = [&](const f32x16 (&o)[DB], const BlockState& st, int q0) {
         const float lt = st.lacc[0];
         const float inv = 1.0f / lt;
@@ -1191,11 +1195,11 @@ __device__ __forceinline__ void load_v_frag_asm(unsigned v_addr, s16x4& lo, s16x
 
 __device__ __forceinline__ float rowmax16(const f32x16& s)
 {
-    float p0 = max3_raw(s[0], s[1], s[2]), p1 = max3_raw(s[3], s[4], s[5]);
-    float p2 = max3_raw(s[6], s[7], s[8]), p3 = max3_raw(s[9], s[10], s[11]);
-    p0 = max3_raw(p0, s[12], s[13]);
-    p1 = max3_raw(p1, s[14], s[15]);
-    return xhalf_max(fmaxf(max3_raw(p0, p1, p2), p3));
+    float p0 = max3_safe(s[0], s[1], s[2]), p1 = max3_safe(s[3], s[4], s[5]);
+    float p2 = max3_safe(s[6], s[7], s[8]), p3 = max3_safe(s[9], s[10], s[11]);
+    p0 = max3_safe(p0, s[12], s[13]);
+    p1 = max3_safe(p1, s[14], s[15]);
+    return xhalf_max(fmaxf(max3_safe(p0, p1, p2), p3));
 }
 
 // decision for both blocks at once (one rare wave-uniform branch per step)
@@ -1208,6 +1212,7 @@ __device__ __forceinline__ void lazy_rescale2(float mxa, float mxb, float c, Blo
     mcb = fmaf(-fabsf(mcb), 0x1p-23f, mcb);
     if (__builtin_expect(__any((mca - sta.m > kLazyThr) || (mcb - stb.m > kLazyThr)), 0)) {
         asm volatile("; lazy rescale (both blocks)" ::: "memory");
+        mfma_drain();  // the accumulators rescaled below may have an MFMA in flight (hazard not padded across the branch)
         const float na = fmaxf(sta.m, mca), nb = fmaxf(stb.m, mcb);
         const float aa = fast_exp2(sta.m - na), ab = fast_exp2(stb.m - nb);
         sta.m = na;
@@ -1378,7 +1383,10 @@ __device__ __forceinline__ void pp3_step(const char* k_lds, int kb_n, const char
         __builtin_amdgcn_sched_barrier(0);
     }
     if (PROF) t3 = stamp();
-    if (__builtin_expect(__any(need), 0)) lazy_rescale2<D>(xhalf_max(lma), xhalf_max(lmb), c, sta, stb, oa, ob, lz);
+    if (__builtin_expect(__any(need), 0)) {
+        mfma_drain();  // the last P.V / row-sum MFMAs of block B may still be in flight
+        lazy_rescale2<D>(xhalf_max(lma), xhalf_max(lmb), c, sta, stb, oa, ob, lz);
+    }
     if (PROF) {
         const unsigned long long t4 = stamp();
         tm[0] += t1 - t0;
@@ -1552,6 +1560,7 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
     }
 
     // ---------------- store ----------------
+    mfma_drain();  // the loop exit is a branch: the last P.V / row-sum MFMAs may still be in flight
     auto store_block = [&](const f32x16 (&o)[DB], const BlockState& st, int q0) {
         const float lt = st.lacc[0];
         const float inv = 1.0f / lt;
@@ -1624,6 +1633,178 @@ static hipError_t launch_pp3(const FwdParams& p0, int causal, int out_f32, hipSt
     return hipGetLastError();
 }
 
+// =====================================================================================================================
+// "w4": one 32-row block per wave, four waves per SIMD (<= 128 VGPRs), phase-structured like fa_fwd_bf16_kernel but on the
+// same VALU diet as pp2/pp3 (matrix-core row sums, lazily rescaled accumulator, lane-local rescale test, v_max3 without
+// canonicalisation).  Overlap of MFMA and VALU is left to the four co-resident waves.
+// =====================================================================================================================
+template <int D>
+__device__ __forceinline__ void softmax_block3(f32x16 (&s)[2], BlockState& st, f32x16 (&o)[D / 32], bf16x8 (&pf)[4], float c)
+{
+    // lane-local maximum of the 32 scores (no cross-half exchange unless the rare rescale fires)
+    float p0 = max3_safe(s[0][0], s[0][1], s[0][2]), p1 = max3_safe(s[0][3], s[0][4], s[0][5]);
+    float p2 = max3_safe(s[0][6], s[0][7], s[0][8]), p3 = max3_safe(s[0][9], s[0][10], s[0][11]);
+    p0 = max3_safe(p0, s[0][12], s[0][13]);
+    p1 = max3_safe(p1, s[0][14], s[0][15]);
+    p2 = max3_safe(p2, s[1][0], s[1][1]);
+    p3 = max3_safe(p3, s[1][2], s[1][3]);
+    p0 = max3_safe(p0, s[1][4], s[1][5]);
+    p1 = max3_safe(p1, s[1][6], s[1][7]);
+    p2 = max3_safe(p2, s[1][8], s[1][9]);
+    p3 = max3_safe(p3, s[1][10], s[1][11]);
+    p0 = max3_safe(p0, s[1][12], s[1][13]);
+    p1 = max3_safe(p1, s[1][14], s[1][15]);
+    const float lm = fmaxf(max3_safe(p0, p1, p2), p3);
+    if (__builtin_expect(__any(fmaf(lm, c, -st.m) > kLazyThr), 0)) {
+        asm volatile("; lazy rescale" ::: "memory");
+        mfma_drain();  // the accumulators rescaled below may have an MFMA in flight (hazard not padded across the branch)
+        float mc = xhalf_max(lm) * c;
+        mc = fmaf(-fabsf(mc), 0x1p-23f, mc);
+        const float m_new = fmaxf(st.m, mc);
+        const float alpha = fast_exp2(st.m - m_new);
+        st.m = m_new;
+#pragma unroll
+        for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st.lacc[r] *= alpha;
+    }
+    const float off = st.m + kLazyThr;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = exp2_clamp01(fmaf(s[kb][r], c, -off));
+        pf[2 * kb] = pack_bf16x8(s[kb], 0);
+        pf[2 * kb + 1] = pack_bf16x8(s[kb], 8);
+    }
+}
+
+template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, int MINWAVES>
+__global__ __launch_bounds__(NWAVES* kWave, MINWAVES) void fa_fwd_bf16_w4_kernel(FwdParams p)
+{
+    using C = Bf16Cfg<D, NWAVES>;
+    constexpr int KS = D / 16, DB = D / 32;
+    constexpr int BM = NWAVES * 32;
+
+    __shared__ __attribute__((aligned(1024))) char smem[2 * C::kStageBytes];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lq = lane & 31, hi = lane >> 5;
+
+    const int total = p.bh * p.q_tiles;
+    const int w = xcd_remap(blockIdx.x, total);
+    const int slab = w / p.q_tiles;
+    int qt = w % p.q_tiles;
+    if (CAUSAL) qt = p.q_tiles - 1 - qt;
+    const int n = p.n;
+    const int q0 = qt * BM + wave * 32;
+
+    const int b = slab / p.heads, h = slab % p.heads;
+    const __bf16* qg = (const __bf16*)p.q + b * p.q_batch_stride + h * p.q_head_stride;
+    const __bf16* kg = (const __bf16*)p.k + b * p.kv_batch_stride + h * p.kv_head_stride;
+    const __bf16* vg = (const __bf16*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
+    const int64_t o_slab_off = b * p.o_batch_stride + h * p.o_head_stride;
+
+    int kv_end = n;
+    if (CAUSAL) kv_end = min(n, qt * BM + BM);
+    const int nt = (kv_end + kKvBlk - 1) / kKvBlk;
+
+    issue_kv_tile<D, NWAVES>(kg, vg, 0, n, p.kv_row_stride, smem, wave, lane);
+
+    bf16x8 qf[KS];
+    {
+        const __bf16* qr = qg + (int64_t)min(q0 + lq, n - 1) * p.q_row_stride + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qr + ks * 16);
+    }
+    const bf16x8 ones_a = rowsum_a_operand(lane);
+
+    f32x16 o[DB];
+    BlockState st;
+    st.m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st.lacc[r] = 0.0f;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.0f;
+
+    const int k_row_off = lq * C::kRowBytes;
+    const int k_g = hi ^ k_swizzle<D>(lq);
+    const int li = lane & 15;
+    const int v_lane_off = (hi * (D / 16) + ((lane >> 4) & 1)) * 128 + (li >> 2) * 32 + (li & 3) * 8;
+    const float c = p.scale_log2e;
+
+    for (int j = 0; j < nt; ++j) {
+        wait_lds_dma();
+        __syncthreads();
+        if (j + 1 < nt)
+            issue_kv_tile<D, NWAVES>(kg, vg, (j + 1) * kKvBlk, n, p.kv_row_stride, smem + ((j + 1) & 1) * C::kStageBytes, wave, lane);
+        const int kv0 = j * kKvBlk;
+        if (CAUSAL && kv0 > q0 + 31) continue;  // tile entirely above this wave's diagonal
+        const char* k_lds = smem + (j & 1) * C::kStageBytes;
+        const char* v_lds = k_lds + C::kTileBytes;
+
+        f32x16 s[2];
+        bf16x8 pf[4];
+        qk_block<D>(k_lds, k_row_off, k_g, qf, s);
+        if ((kv0 + kKvBlk > n) || (CAUSAL && (kv0 + kKvBlk - 1 > q0))) mask_block<CAUSAL>(s, kv0, q0 + lq, n, hi);
+        softmax_block3<D>(s, st, o, pf, c);
+        pv_block<D>(v_lds, v_lane_off, pf, o);
+        sum_block(ones_a, pf, st);
+    }
+
+    mfma_drain();  // the loop exit is a branch: the last P.V / row-sum MFMAs may still be in flight
+    const float lt = st.lacc[0];
+    const float inv = 1.0f / lt;
+    const int qi = q0 + lq;
+    if (qi < n) {
+        const int64_t o_off = o_slab_off + (int64_t)qi * p.o_row_stride + 4 * hi;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (OUT_F32) {
+                    f32x4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = o[db][4 * g + e] * inv;
+                    *(f32x4*)((float*)p.o + o_off + db * 32 + 8 * g) = pk;
+                } else {
+                    bf16x4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (__bf16)(o[db][4 * g + e] * inv);
+                    *(bf16x4*)((__bf16*)p.o + o_off + db * 32 + 8 * g) = pk;
+                }
+            }
+        if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (st.m + kLazyThr + __builtin_amdgcn_logf(lt)) * kLn2;
+    }
+}
+
+template <int D, int NWAVES, int MINWAVES>
+static hipError_t launch_w4(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
+{
+    FwdParams p = p0;
+    constexpr int BM = NWAVES * 32;
+    p.q_tiles = (p.n + BM - 1) / BM;
+    const int64_t total = (int64_t)p.bh * p.q_tiles;
+    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)total), block(NWAVES * kWave);
+    if (causal) {
+        if (out_f32)
+            hipLaunchKernelGGL((fa_fwd_bf16_w4_kernel<D, NWAVES, true, true, MINWAVES>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((fa_fwd_bf16_w4_kernel<D, NWAVES, true, false, MINWAVES>), grid, block, 0, stream, p);
+    } else {
+        if (out_f32)
+            hipLaunchKernelGGL((fa_fwd_bf16_w4_kernel<D, NWAVES, false, true, MINWAVES>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((fa_fwd_bf16_w4_kernel<D, NWAVES, false, false, MINWAVES>), grid, block, 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
 template <int ABL>
 static hipError_t launch_pp2_ablation(const FwdParams& p0, hipStream_t stream)
 {
@@ -1689,6 +1870,8 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
                 case 20: return launch_pp2_ablation<12>(p, stream);   // half LDS, no sync
                 case 21: return launch_pp2_ablation<28>(p, stream);
                 case 9: return launch_pp2<64, 4, 2>(p, causal, out_f32, stream);      // ping-pong 2: MFMA row sums, lazy rescale
+                case 10: return launch_w4<64, 4, 4>(p, causal, out_f32, stream);       // 4 waves/SIMD on the VALU diet
+                case 23: return launch_w4<64, 4, 3>(p, causal, out_f32, stream);
                 default: return launch_pp3<64, 4>(p, causal, out_f32, stream);        // lockstep blocks, 32-key pipelined steps
             }
         case 128: return launch_cfg<128, 4, 1, 2>(p, causal, out_f32, stream);  // pp3 needs > 256 VGPRs at D = 128

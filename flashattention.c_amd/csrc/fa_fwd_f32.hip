@@ -189,6 +189,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINWAVES) void fa_fwd_f32_kernel(Fwd
     }
 
     // ---- epilogue
+    mfma_drain();  // the loop exit is a branch: the last P.V MFMAs may still be in flight
     const float lt = xhalf_sum(l);
     const float inv = 1.0f / lt;
     const int qi = q0 + lq;

@@ -196,6 +196,27 @@ def test_forced_rescale_spike():
         check(fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, out_dtype=torch.float32), refb, 1.2e-2)
 
 
+@pytest.mark.parametrize("out_f32", [False, True])
+@pytest.mark.parametrize("n", [512, 1024, 1000])
+def test_dominant_key_in_the_last_keys(n, out_f32):
+    """Rows whose maximum sits in the last few keys: the running-max update happens in the kernel's tail code, right
+    behind the final K.Q^T MFMAs (regression: an asm v_max3 there read the accumulator before the MFMA had retired, the
+    rescale was skipped and the dominant key was clamped -- one instantiation only, ~1 row in 65 000 on random data)."""
+    bh, d = 3, 64
+    q, k, v = (randn(s, bh, n, d) for s in (31, 32, 33))
+    for r, key, gain in ((5, n - 1, 1.2), (77, n - 2, 0.9), (300, n - 9, 1.5), (n - 1, n - 17, 1.0), (200, n - 33, 1.1)):
+        k[:, key] = gain * q[:, r] / np.linalg.norm(q[:, r], axis=-1, keepdims=True) * 8.0
+    qb, kb, vb = (orc.round_to_bf16(t) for t in (q, k, v))
+    for causal in (False, True):
+        check(fa.forward(*to_dev(q, k, v), causal), orc.attention_f64(q, k, v, causal=causal), TOL_F32, "fp32")
+        refb = orc.attention_f64(qb, kb, vb, causal=causal)
+        ob = fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, out_dtype=torch.float32 if out_f32 else None)
+        check(ob, refb, bf16_tol(1.0, out_f32), "bf16")
+        _, lse_ref = orc.attention_f64(qb, kb, vb, causal=causal, return_lse=True)
+        _, lse = fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, return_lse=True)
+        check(lse, lse_ref, 2e-2, "bf16 lse")
+
+
 def test_transpose_detecting_structured_input():
     """Asymmetric, structured Q/K/V: a swapped row/col map in any MFMA fragment or a transposed V changes the answer."""
     bh, n, d = 1, 192, 64
