@@ -335,3 +335,13 @@ def test_c_driver_known_answer():
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         assert '"pass": true' in r.stdout
+
+
+@pytest.mark.parametrize("extra", [[], ["--masking"], ["--dtype", "bf16"]])
+def test_bench_harness_reports_pass(extra):
+    """The bench_flashattention.py counterpart: README shape family, verdict line at the stated tolerance."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "flashattention.c_amd", "harness", "bench_flashattention.py"),
+                        "--batch_size", "2", "--seq_len", "1024", "--iters", "3"] + extra, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "[Correctness] attn values sanity check: PASSED" in r.stdout

@@ -98,3 +98,15 @@ def test_bench_flop_and_byte_model():
     assert abs(bench.fwd_flop(128, 1024, 64, False) - 3.436e10) / 3.436e10 < 1e-3
     assert abs(bench.algorithmic_bytes(128, 1024, 64, 4) - 134.2e6) / 134.2e6 < 1e-3
     assert bench.fwd_flop(16, 8192, 64, True) * 2 == bench.fwd_flop(16, 8192, 64, False)
+
+
+def test_harness_cpu_plumbing_config_c1():
+    """BASELINE.json configs[0]: B=2 H=8 d=32 N=1024 fp32 via PyTorch CPU SDPA in the bench harness (plumbing, no GPU)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "flashattention.c_amd", "harness", "bench_flashattention.py"),
+                        "--device", "cpu", "--batch_size", "2", "--seq_len", "1024", "--head_dim", "32"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PyTorch CPU SDPA" in r.stdout and "sanity check: PASSED" in r.stdout
+    assert "no CPU implementation" in r.stdout
