@@ -1,0 +1,172 @@
+// fa_bf16_common.h -- building blocks shared by the bf16 flash-attention kernels (gfx950 only).
+//
+// LDS images (both produced by LDS-DMA with permuted per-lane SOURCE addresses, the destination being lane-linear):
+//   K tile  row-major [key][D], 16-byte slots XOR-swizzled per row  -> conflict-free ds_read_b128 A fragments
+//   V tile  [key/4][col/16][4][16] sub-tiles                        -> ds_read_b64_tr_b16 hands out V^T fragments
+// Fragment conventions (v_mfma_f32_32x32x16_bf16, "swapped" product S^T = K Q^T): lane (q = lane&31, hi = lane>>5) owns
+// scores of keys 4*hi + (r&3) + 8*(r>>2), r = 0..15, of one query row; the same key permutation is applied to the V^T
+// fragment addresses, so P feeds the second MFMA straight from registers.
+#pragma once
+#include "fa_common.h"
+
+namespace fa {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+
+constexpr int kKvBlk = 64;  // keys per K/V tile
+
+// XOR applied to the 16-byte slot index of K-image row `row` (see header comment).
+template <int D>
+__device__ __forceinline__ int k_swizzle(int row)
+{
+    constexpr int S = D / 8;                       // 16-byte slots per row
+    constexpr int R = (S >= 16) ? 1 : 16 / S;      // rows per 256-byte LDS bank row
+    constexpr int M = (S >= 16) ? 15 : S - 1;
+    return (row / R) & M;
+}
+
+template <int D, int NWAVES>
+struct Bf16Cfg {
+    static constexpr int kRowBytes = 2 * D;
+    static constexpr int kTileBytes = kKvBlk * kRowBytes;       // one K (or V) tile
+    static constexpr int kStageBytes = 2 * kTileBytes;          // K + V
+    static constexpr int kChunks = kTileBytes / 1024;           // 1 KiB DMA pieces per tile
+    static constexpr int kChunksPerWave = kChunks / NWAVES;
+    static_assert(kChunks % NWAVES == 0, "tile must split evenly over the waves");
+};
+
+// Enqueue the LDS-DMA of the K tile starting at key kv0 into `dst` (wave-uniform LDS address): row-major, slot-swizzled.
+template <int D, int NWAVES>
+__device__ __forceinline__ void issue_k_tile(const __bf16* __restrict__ kg, int kv0, int n, int row_stride, char* dst, int wave,
+                                             int lane)
+{
+    using C = Bf16Cfg<D, NWAVES>;
+#pragma unroll
+    for (int i = 0; i < C::kChunksPerWave; ++i) {
+        const int ch = wave + i * NWAVES;
+        const int off = ch * 1024 + lane * 16;
+        const int row = off / C::kRowBytes;
+        const int phys = (off % C::kRowBytes) / 16;
+        const int slot = phys ^ k_swizzle<D>(row);
+        const int grow = min(kv0 + row, n - 1);
+        const __bf16* src = kg + (int64_t)grow * row_stride + slot * 8;
+        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)src, (lds_void_t*)(dst + ch * 1024), 16, 0, 0);
+    }
+}
+
+// Same for the V tile: [key/4][col/16][4][16] sub-tiles (128 bytes each).
+template <int D, int NWAVES>
+__device__ __forceinline__ void issue_v_tile(const __bf16* __restrict__ vg, int kv0, int n, int row_stride, char* dst, int wave,
+                                             int lane)
+{
+    using C = Bf16Cfg<D, NWAVES>;
+#pragma unroll
+    for (int i = 0; i < C::kChunksPerWave; ++i) {
+        const int ch = wave + i * NWAVES;
+        const int blk = ch * 8 + lane / 8;
+        const int kg4 = blk / (D / 16), cb = blk % (D / 16);
+        const int key = kg4 * 4 + (lane % 8) / 2;
+        const int col = cb * 16 + (lane & 1) * 8;
+        const int grow = min(kv0 + key, n - 1);
+        const __bf16* src = vg + (int64_t)grow * row_stride + col;
+        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)src, (lds_void_t*)(dst + ch * 1024), 16, 0, 0);
+    }
+}
+
+template <int D, int NWAVES>
+__device__ __forceinline__ void issue_kv_tile(const __bf16* __restrict__ kg, const __bf16* __restrict__ vg,
+                                              int kv0, int n, int row_stride, char* stage, int wave, int lane)
+{
+    issue_k_tile<D, NWAVES>(kg, kv0, n, row_stride, stage, wave, lane);
+    issue_v_tile<D, NWAVES>(vg, kv0, n, row_stride, stage + Bf16Cfg<D, NWAVES>::kTileBytes, wave, lane);
+}
+
+__device__ __forceinline__ bf16x8 pack_bf16x8(const f32x16& s, int base)
+{
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (__bf16)s[base + i];
+    return r;
+}
+
+template <int D>
+__device__ __forceinline__ void qk_block(const char* k_lds, int k_row_off, int k_g, const bf16x8 (&qf)[D / 16], f32x16 (&s)[2])
+{
+    constexpr int RB = 2 * D;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+        const int slot_off = ((2 * ks) ^ k_g) * 16;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const bf16x8 kf = *(const bf16x8*)(k_lds + k_row_off + kb * 32 * RB + slot_off);
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+        }
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void pv_block(const char* v_lds, int v_lane_off, const bf16x8 (&pf)[4], f32x16 (&o)[D / 32])
+{
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int db = 0; db < D / 32; ++db) {
+                const int off0 = ((kb * 8 + 4 * t + 0) * (D / 16) + 2 * db) * 128;
+                const int off1 = ((kb * 8 + 4 * t + 2) * (D / 16) + 2 * db) * 128;
+                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_lds + v_lane_off + off0));
+                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_lds + v_lane_off + off1));
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb * 2 + t], o[db], 0, 0, 0);
+            }
+}
+
+template <bool CAUSAL>
+__device__ __forceinline__ void mask_block(f32x16 (&s)[2], int kv0, int qi, int n, int hi)
+{
+    asm volatile("; mask_block" ::: "memory");  // not speculatable: keeps the caller's wave-uniform `if` a real branch
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kv0 + kb * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
+            if ((key >= n) || (CAUSAL && key > qi)) s[kb][r] = -INFINITY;
+        }
+}
+
+// online softmax of one 32x64 score block held in registers; leaves P packed as the four B-operand fragments of P.V
+
+constexpr float kLazyThr = 8.0f;  // exp2-domain slack of the lazily updated running max (p spans 2^-8 .. 1 between rescales)
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ bf16x8 rowsum_a_operand(int lane)
+{
+    const bool one = (((lane & 15) >> 2) & 1) == ((lane >> 4) & 1);
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = one ? (__bf16)1.0f : (__bf16)0.0f;
+    return a;
+}
+
+struct BlockState {   // running softmax state of one 32-row block (per lane: one query row, half of its keys)
+    float m;          // exponent reference: p = 2^(c*s - m - kLazyThr)
+    f32x4_t lacc;     // row sum of p (all four registers hold the same, complete, row sum)
+};
+
+// max phase result -> decision -> (rare) rescale.  Returns the exponent offset to use for this tile.
+__device__ __forceinline__ void sum_block(const bf16x8& ones_a, const bf16x8 (&pf)[4], BlockState& st)
+{
+#pragma unroll
+    for (int f = 0; f < 4; ++f) st.lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pf[f], st.lacc, 0, 0, 0);
+}
+
+
+}  // namespace fa

@@ -29,90 +29,14 @@
 //
 // Algorithmic cost per (32 query rows x 64 keys) at D = 64: 16 MFMA (32 cycles each on one SIMD),
 // 8 ds_read_b128 + 16 ds_read_b64_tr_b16, ~170 VALU/transcendental instructions.
-#include "fa_common.h"
+//
+// This file holds the phase-structured kernels (one 32/64-row block per wave, QK^T -> softmax -> PV per 64-key tile):
+// fa_fwd_bf16_kernel (D = 128, causal D = 32) and its leaner four-waves-per-SIMD sibling fa_fwd_bf16_w4_kernel, plus the
+// dispatcher.  The kernel used for D = 64 lives in fa_fwd_bf16_pipelined.hip.
+#include "fa_bf16_common.h"
 #include "fa_kernels.h"
 
 namespace fa {
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
-
-constexpr int kKvBlk = 64;  // keys per K/V tile
-
-// XOR applied to the 16-byte slot index of K-image row `row` (see header comment).
-template <int D>
-__device__ __forceinline__ int k_swizzle(int row)
-{
-    constexpr int S = D / 8;                       // 16-byte slots per row
-    constexpr int R = (S >= 16) ? 1 : 16 / S;      // rows per 256-byte LDS bank row
-    constexpr int M = (S >= 16) ? 15 : S - 1;
-    return (row / R) & M;
-}
-
-template <int D, int NWAVES>
-struct Bf16Cfg {
-    static constexpr int kRowBytes = 2 * D;
-    static constexpr int kTileBytes = kKvBlk * kRowBytes;       // one K (or V) tile
-    static constexpr int kStageBytes = 2 * kTileBytes;          // K + V
-    static constexpr int kChunks = kTileBytes / 1024;           // 1 KiB DMA pieces per tile
-    static constexpr int kChunksPerWave = kChunks / NWAVES;
-    static_assert(kChunks % NWAVES == 0, "tile must split evenly over the waves");
-};
-
-// Enqueue the LDS-DMA of the K tile starting at key kv0 into `dst` (wave-uniform LDS address): row-major, slot-swizzled.
-template <int D, int NWAVES>
-__device__ __forceinline__ void issue_k_tile(const __bf16* __restrict__ kg, int kv0, int n, int row_stride, char* dst, int wave,
-                                             int lane)
-{
-    using C = Bf16Cfg<D, NWAVES>;
-#pragma unroll
-    for (int i = 0; i < C::kChunksPerWave; ++i) {
-        const int ch = wave + i * NWAVES;
-        const int off = ch * 1024 + lane * 16;
-        const int row = off / C::kRowBytes;
-        const int phys = (off % C::kRowBytes) / 16;
-        const int slot = phys ^ k_swizzle<D>(row);
-        const int grow = min(kv0 + row, n - 1);
-        const __bf16* src = kg + (int64_t)grow * row_stride + slot * 8;
-        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)src, (lds_void_t*)(dst + ch * 1024), 16, 0, 0);
-    }
-}
-
-// Same for the V tile: [key/4][col/16][4][16] sub-tiles (128 bytes each).
-template <int D, int NWAVES>
-__device__ __forceinline__ void issue_v_tile(const __bf16* __restrict__ vg, int kv0, int n, int row_stride, char* dst, int wave,
-                                             int lane)
-{
-    using C = Bf16Cfg<D, NWAVES>;
-#pragma unroll
-    for (int i = 0; i < C::kChunksPerWave; ++i) {
-        const int ch = wave + i * NWAVES;
-        const int blk = ch * 8 + lane / 8;
-        const int kg4 = blk / (D / 16), cb = blk % (D / 16);
-        const int key = kg4 * 4 + (lane % 8) / 2;
-        const int col = cb * 16 + (lane & 1) * 8;
-        const int grow = min(kv0 + key, n - 1);
-        const __bf16* src = vg + (int64_t)grow * row_stride + col;
-        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)src, (lds_void_t*)(dst + ch * 1024), 16, 0, 0);
-    }
-}
-
-template <int D, int NWAVES>
-__device__ __forceinline__ void issue_kv_tile(const __bf16* __restrict__ kg, const __bf16* __restrict__ vg,
-                                              int kv0, int n, int row_stride, char* stage, int wave, int lane)
-{
-    issue_k_tile<D, NWAVES>(kg, kv0, n, row_stride, stage, wave, lane);
-    issue_v_tile<D, NWAVES>(vg, kv0, n, row_stride, stage + Bf16Cfg<D, NWAVES>::kTileBytes, wave, lane);
-}
-
-__device__ __forceinline__ bf16x8 pack_bf16x8(const f32x16& s, int base)
-{
-    bf16x8 r;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = (__bf16)s[base + i];
-    return r;
-}
 
 template <int D, int NWAVES, int QB, bool CAUSAL, bool OUT_F32, int MINWAVES>
 __global__ __launch_bounds__(NWAVES* kWave, MINWAVES) void fa_fwd_bf16_kernel(FwdParams p)
@@ -319,1321 +243,6 @@ __global__ __launch_bounds__(NWAVES* kWave, MINWAVES) void fa_fwd_bf16_kernel(Fw
 }
 
 // =====================================================================================================================
-// Ping-pong kernel: two independent 32-row query blocks (A, B) per wave, half a tile period apart.
-//
-// Measured on MI355X (profiles/r01_ubench_issue.txt): a wave with a matrix instruction waiting for the matrix pipe holds
-// its SIMD's vector issue port, so a sibling wave's softmax cannot slide under it -- MFMA and VALU only overlap when they
-// alternate inside ONE instruction stream.  Each half-iteration below is therefore a single basic block holding the 16
-// MFMAs of one block (P.V of the previous tile, then K.Q^T of the current one) next to the ~185 softmax instructions of
-// the other block; the two are data-independent and sched_group_barrier pins the interleave.
-//
-//   iteration j:   half 1:  PV_A(j-1), QK_A(j)   ||  softmax_B(j-1)
-//                  half 2:  PV_B(j-1), QK_B(j)   ||  softmax_A(j)
-// Both halves read V(j-1) and K(j): the K and V rings are 2 deep each and one tile apart; K(j+1) and V(j) are in flight.
-// =====================================================================================================================
-template <int D>
-__device__ __forceinline__ void qk_block(const char* k_lds, int k_row_off, int k_g, const bf16x8 (&qf)[D / 16], f32x16 (&s)[2])
-{
-    constexpr int RB = 2 * D;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
-#pragma unroll
-    for (int ks = 0; ks < D / 16; ++ks) {
-        const int slot_off = ((2 * ks) ^ k_g) * 16;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const bf16x8 kf = *(const bf16x8*)(k_lds + k_row_off + kb * 32 * RB + slot_off);
-            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
-        }
-    }
-}
-
-template <int D>
-__device__ __forceinline__ void pv_block(const char* v_lds, int v_lane_off, const bf16x8 (&pf)[4], f32x16 (&o)[D / 32])
-{
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int db = 0; db < D / 32; ++db) {
-                const int off0 = ((kb * 8 + 4 * t + 0) * (D / 16) + 2 * db) * 128;
-                const int off1 = ((kb * 8 + 4 * t + 2) * (D / 16) + 2 * db) * 128;
-                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_lds + v_lane_off + off0));
-                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_lds + v_lane_off + off1));
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb * 2 + t], o[db], 0, 0, 0);
-            }
-}
-
-template <bool CAUSAL>
-__device__ __forceinline__ void mask_block(f32x16 (&s)[2], int kv0, int qi, int n, int hi)
-{
-    asm volatile("; mask_block" ::: "memory");  // not speculatable: keeps the caller's wave-uniform `if` a real branch
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kv0 + kb * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
-            if ((key >= n) || (CAUSAL && key > qi)) s[kb][r] = -INFINITY;
-        }
-}
-
-// online softmax of one 32x64 score block held in registers; leaves P packed as the four B-operand fragments of P.V
-template <int D>
-__device__ __forceinline__ void softmax_block(f32x16 (&s)[2], float& m, float& l, f32x16 (&o)[D / 32], bf16x8 (&pf)[4], float c)
-{
-    float mx = s[0][0];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-    mx = xhalf_max(mx);
-    float mc = mx * c;
-    mc = fmaf(-fabsf(mc), 0x1p-23f, mc);  // nudge down: c*s_max - m >= 0 (see the comment in fa_fwd_bf16_kernel)
-    const float m_new = fmaxf(m, mc);
-    const float alpha = fast_exp2(m - m_new);
-    m = m_new;
-    float rs = 0.0f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float pv = exp2_clamp01(fmaf(s[kb][r], c, -m_new));
-            s[kb][r] = pv;
-            rs += pv;
-        }
-    l = fmaf(l, alpha, rs);
-#pragma unroll
-    for (int db = 0; db < D / 32; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) pf[kb * 2 + t] = pack_bf16x8(s[kb], 8 * t);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Slot-scheduled half iteration.  The 4*DB P.V MFMAs and 2*KS K.Q^T MFMAs of block X are numbered 0..NSLOT-1; slot i holds
-// MFMA i, the LDS reads feeding MFMA i+2, and the i-th slice of block Y's softmax.  __builtin_amdgcn_sched_barrier(0) after
-// every slot pins that placement (the compiler still orders instructions inside a slot, allocates registers and inserts
-// the waits).  Softmax slices: [partial row maxima | combine, new running max, alpha | exp + row sum | l, O rescale, P pack].
-// ---------------------------------------------------------------------------------------------------------------------
-template <int D>
-struct SlotPlan {
-    static constexpr int KS = D / 16, DB = D / 32;
-    static constexpr int NPV = 4 * DB, NQK = 2 * KS, NSLOT = NPV + NQK;
-    static constexpr int N_MAX = NSLOT / 8 > 0 ? NSLOT / 8 : 1;   // slots for the max phase
-    static constexpr int N_FIN = NSLOT / 4;                       // slots for l / rescale / pack
-    static constexpr int N_EXP = NSLOT - N_MAX - N_FIN;
-    static constexpr int N_FIN_ITEMS = 2 * DB + 4;                // 2*DB half-blocks of O to rescale + 4 P fragments to pack
-    static constexpr int max_slot(int e) { return e * N_MAX / 32; }
-    static constexpr int exp_slot(int e) { return N_MAX + e * N_EXP / 32; }
-    static constexpr int fin_slot(int i) { return N_MAX + N_EXP + i * N_FIN / N_FIN_ITEMS; }
-};
-
-struct SoftmaxCarry {
-    float pm[4];      // partial row maxima
-    float m_new, alpha;
-    float rs[2];      // two partial row sums (shorter dependency chains)
-};
-
-template <int D>
-__device__ __forceinline__ void softmax_slice(int slot, f32x16 (&s)[2], float& m, float& l, f32x16 (&o)[D / 32], bf16x8 (&pf)[4],
-                                              float c, SoftmaxCarry& cy)
-{
-    using P = SlotPlan<D>;
-    // ---- phase 1: partial maxima, two scores per step (v_max3_f32)
-#pragma unroll
-    for (int e = 0; e < 32; e += 2)
-        if (P::max_slot(e) == slot) {
-            const float a = s[e >> 4][e & 15], b2 = s[e >> 4][(e & 15) + 1];
-            const int k = (e >> 1) & 3;
-            cy.pm[k] = (e < 8) ? fmaxf(a, b2) : fmaxf(fmaxf(cy.pm[k], a), b2);
-        }
-    if (slot == P::N_MAX - 1) {
-        float mx = fmaxf(fmaxf(cy.pm[0], cy.pm[1]), fmaxf(cy.pm[2], cy.pm[3]));
-        mx = xhalf_max(mx);
-        float mc = mx * c;
-        mc = fmaf(-fabsf(mc), 0x1p-23f, mc);  // nudge down: c*s_max - m >= 0 (see fa_fwd_bf16_kernel)
-        cy.m_new = fmaxf(m, mc);
-        cy.alpha = fast_exp2(m - cy.m_new);
-        m = cy.m_new;
-        cy.rs[0] = cy.rs[1] = 0.0f;
-    }
-    // ---- phase 2: p = min(2^(c*s - m), 1), row sum
-#pragma unroll
-    for (int e = 0; e < 32; ++e)
-        if (P::exp_slot(e) == slot) {
-            const float pv = exp2_clamp01(fmaf(s[e >> 4][e & 15], c, -cy.m_new));
-            s[e >> 4][e & 15] = pv;
-            cy.rs[e & 1] += pv;
-        }
-    // ---- phase 3: l, O rescale, pack P
-#pragma unroll
-    for (int i = 0; i < P::N_FIN_ITEMS; ++i)
-        if (P::fin_slot(i) == slot) {
-            if (i == 0) l = fmaf(l, cy.alpha, cy.rs[0] + cy.rs[1]);
-            if (i < 2 * P::DB) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) o[i >> 1][(i & 1) * 8 + r] *= cy.alpha;
-            } else {
-                const int f = i - 2 * P::DB;  // fragment (kb, t) = (f >> 1, f & 1)
-                pf[f] = pack_bf16x8(s[f >> 1], 8 * (f & 1));
-            }
-        }
-}
-
-// LDS reads + MFMA of block X for one slot.  vfr / kfr are the fragment staging registers (indexed by MFMA number).
-template <int D>
-__device__ __forceinline__ void load_frag(int i, const char* k_lds, const char* v_lds, int k_row_off, int k_g, int v_lane_off,
-                                          bf16x8 (&fr)[SlotPlan<D>::NSLOT])
-{
-    using P = SlotPlan<D>;
-    constexpr int RB = 2 * D;
-    if (i < P::NPV) {
-        const int db = i % P::DB, kt = i / P::DB, kb = kt >> 1, t = kt & 1;
-        const int off0 = ((kb * 8 + 4 * t + 0) * (D / 16) + 2 * db) * 128;
-        const int off1 = ((kb * 8 + 4 * t + 2) * (D / 16) + 2 * db) * 128;
-        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_lds + v_lane_off + off0));
-        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_lds + v_lane_off + off1));
-        fr[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
-    } else if (i < P::NSLOT) {
-        const int q = i - P::NPV, ks = q >> 1, kb = q & 1;
-        fr[i] = *(const bf16x8*)(k_lds + k_row_off + kb * 32 * RB + (((2 * ks) ^ k_g) * 16));
-    }
-}
-
-template <int D>
-__device__ __forceinline__ void mfma_slot(int i, const bf16x8 (&fr)[SlotPlan<D>::NSLOT], const bf16x8 (&pf)[4],
-                                          const bf16x8 (&qf)[D / 16], f32x16 (&o)[D / 32], f32x16 (&s)[2])
-{
-    using P = SlotPlan<D>;
-    if (i < P::NPV) {
-        const int db = i % P::DB, kt = i / P::DB;
-        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], pf[kt], o[db], 0, 0, 0);
-    } else {
-        const int q = i - P::NPV, ks = q >> 1, kb = q & 1;
-        if (ks == 0) {
-            f32x16 z;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], qf[ks], z, 0, 0, 0);
-        } else {
-            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], qf[ks], s[kb], 0, 0, 0);
-        }
-    }
-}
-
-// One half iteration: MFMAs of block X (P.V with pfx into ox, then K.Q^T into sx) beside the softmax of block Y.
-// FIRST_MFMA lets the prologue / epilogue run only the K.Q^T part (FIRST = NPV) or only the P.V part (LAST = NPV).
-template <int D, int FIRST, int LAST, bool DO_SOFTMAX>
-__device__ __forceinline__ void half_iteration(const char* k_lds, const char* v_lds, int k_row_off, int k_g, int v_lane_off,
-                                               const bf16x8 (&pfx)[4], const bf16x8 (&qfx)[D / 16], f32x16 (&ox)[D / 32],
-                                               f32x16 (&sx)[2], f32x16 (&sy)[2], float& my, float& ly, f32x16 (&oy)[D / 32],
-                                               bf16x8 (&pfy)[4], float c)
-{
-    using P = SlotPlan<D>;
-    constexpr int AHEAD = 2;  // LDS reads run this many MFMA slots ahead
-    bf16x8 fr[P::NSLOT];
-    SoftmaxCarry cy;
-#pragma unroll
-    for (int i = FIRST; i < FIRST + AHEAD && i < LAST; ++i) load_frag<D>(i, k_lds, v_lds, k_row_off, k_g, v_lane_off, fr);
-    // the softmax slices are spread over the slots that actually run
-#pragma unroll
-    for (int i = FIRST; i < LAST; ++i) {
-        if (i + AHEAD < LAST) load_frag<D>(i + AHEAD, k_lds, v_lds, k_row_off, k_g, v_lane_off, fr);
-        mfma_slot<D>(i, fr, pfx, qfx, ox, sx);
-        if (DO_SOFTMAX) {
-            // map the running slot onto the full NSLOT-slice plan (prologue/epilogue halves have fewer MFMA slots)
-            constexpr int NRUN = LAST - FIRST;
-            const int lo = (i - FIRST) * P::NSLOT / NRUN, hi_ = (i - FIRST + 1) * P::NSLOT / NRUN;
-#pragma unroll
-            for (int sl = 0; sl < P::NSLOT; ++sl)
-                if (sl >= lo && sl < hi_) softmax_slice<D>(sl, sy, my, ly, oy, pfy, c, cy);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// Ask the scheduler for the interleave: per MFMA a couple of LDS reads and a slice of the other block's VALU work.
-template <int NMFMA, int VALU_PER_MFMA, int DS_PER_MFMA>
-__device__ __forceinline__ void interleave_hint()
-{
-#pragma unroll
-    for (int i = 0; i < NMFMA; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, DS_PER_MFMA, 0);    // DS reads feeding the next MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);  // VALU (incl. transcendental) of the other block
-    }
-}
-
-template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, int SCHED>
-__global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp_kernel(FwdParams p)
-{
-    using C = Bf16Cfg<D, NWAVES>;
-    constexpr int KS = D / 16, DB = D / 32;
-    constexpr int BM = NWAVES * 64;
-    constexpr int kVperM = SCHED;  // VALU instructions requested per MFMA slot (0 = leave it to the compiler)
-
-    __shared__ __attribute__((aligned(1024))) char smem[4 * C::kTileBytes];  // K ring [2], then V ring [2]
-    char* const k_ring = smem;
-    char* const v_ring = smem + 2 * C::kTileBytes;
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lq = lane & 31, hi = lane >> 5;
-
-    const int total = p.bh * p.q_tiles;
-    const int w = xcd_remap(blockIdx.x, total);
-    const int slab = w / p.q_tiles;
-    int qt = w % p.q_tiles;
-    if (CAUSAL) qt = p.q_tiles - 1 - qt;
-    const int n = p.n;
-    const int q0a = qt * BM + wave * 64, q0b = q0a + 32;
-
-    const int b = slab / p.heads, h = slab % p.heads;
-    const __bf16* qg = (const __bf16*)p.q + b * p.q_batch_stride + h * p.q_head_stride;
-    const __bf16* kg = (const __bf16*)p.k + b * p.kv_batch_stride + h * p.kv_head_stride;
-    const __bf16* vg = (const __bf16*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
-    const int64_t o_slab_off = b * p.o_batch_stride + h * p.o_head_stride;
-
-    int kv_end = n;
-    if (CAUSAL) kv_end = min(n, qt * BM + BM);
-    const int nt = (kv_end + kKvBlk - 1) / kKvBlk;
-
-    issue_k_tile<D, NWAVES>(kg, 0, n, p.kv_row_stride, k_ring, wave, lane);
-
-    bf16x8 qfa[KS], qfb[KS];
-    {
-        const __bf16* qra = qg + (int64_t)min(q0a + lq, n - 1) * p.q_row_stride + hi * 8;
-        const __bf16* qrb = qg + (int64_t)min(q0b + lq, n - 1) * p.q_row_stride + hi * 8;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            qfa[ks] = *(const bf16x8*)(qra + ks * 16);
-            qfb[ks] = *(const bf16x8*)(qrb + ks * 16);
-        }
-    }
-
-    f32x16 oa[DB], ob[DB], sa[2], sb[2];
-    bf16x8 pfa[4], pfb[4];
-    float ma = -INFINITY, mb = -INFINITY, la = 0.0f, lb = 0.0f;
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oa[db][r] = ob[db][r] = 0.0f;
-
-    const int k_row_off = lq * C::kRowBytes;
-    const int k_g = hi ^ k_swizzle<D>(lq);
-    const int li = lane & 15;
-    const int v_lane_off = (hi * (D / 16) + ((lane >> 4) & 1)) * 128 + (li >> 2) * 32 + (li & 3) * 8;
-    const float c = p.scale_log2e;
-
-    auto needs_mask = [&](int tile, int q0) { return (tile * kKvBlk + kKvBlk > n) || (CAUSAL && (tile * kKvBlk + kKvBlk - 1 > q0)); };
-
-    // ---------------- prologue: tile 0 ----------------
-    wait_lds_dma();
-    __syncthreads();
-    if (nt > 1) issue_k_tile<D, NWAVES>(kg, kKvBlk, n, p.kv_row_stride, k_ring + C::kTileBytes, wave, lane);
-    issue_v_tile<D, NWAVES>(vg, 0, n, p.kv_row_stride, v_ring, wave, lane);
-    qk_block<D>(k_ring, k_row_off, k_g, qfa, sa);
-    if (needs_mask(0, q0a)) mask_block<CAUSAL>(sa, 0, q0a + lq, n, hi);
-    qk_block<D>(k_ring, k_row_off, k_g, qfb, sb);
-    softmax_block<D>(sa, ma, la, oa, pfa, c);
-    if (kVperM > 1) interleave_hint<2 * KS, kVperM, 1>();
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---------------- steady state ----------------
-    // Masks are only ever needed on the LAST tiles of a workgroup (ragged tail; causal diagonal), so the tile loop is split
-    // in two instead of branching inside it: a mask-free loop whose body is ONE basic block (a branch between the halves
-    // would let LLVM sink the softmax out of the slots it was pinned to, and a diamond inside the loop doubles the live
-    // 16-register accumulator tuples), then a plain phase-structured loop for the few masked tiles.
-    int j_split = nt;
-    for (int j = 1; j < nt; ++j)
-        if (needs_mask(j - 1, q0b) || needs_mask(j, q0a)) {
-            j_split = j;
-            break;
-        }
-    if (SCHED != 1) j_split = 1;
-
-    auto stage_tiles = [&](int j) {
-        wait_lds_dma();   // K(j), V(j-1): own pieces landed
-        __syncthreads();  // everyone's pieces landed; everyone is done with K(j-1), V(j-2)
-        if (j + 1 < nt) issue_k_tile<D, NWAVES>(kg, (j + 1) * kKvBlk, n, p.kv_row_stride, k_ring + ((j + 1) & 1) * C::kTileBytes, wave, lane);
-        issue_v_tile<D, NWAVES>(vg, j * kKvBlk, n, p.kv_row_stride, v_ring + (j & 1) * C::kTileBytes, wave, lane);
-    };
-
-    for (int j = 1; j < j_split; ++j) {
-        stage_tiles(j);
-        const char* k_lds = k_ring + (j & 1) * C::kTileBytes;
-        const char* v_lds = v_ring + ((j - 1) & 1) * C::kTileBytes;
-        using P = SlotPlan<D>;
-        // half 1: MFMA stream of A beside the softmax of B; half 2: the mirror image
-        half_iteration<D, 0, P::NSLOT, true>(k_lds, v_lds, k_row_off, k_g, v_lane_off, pfa, qfa, oa, sa, sb, mb, lb, ob, pfb, c);
-        half_iteration<D, 0, P::NSLOT, true>(k_lds, v_lds, k_row_off, k_g, v_lane_off, pfb, qfb, ob, sb, sa, ma, la, oa, pfa, c);
-    }
-
-    for (int j = j_split; j < nt; ++j) {
-        stage_tiles(j);
-        const char* k_lds = k_ring + (j & 1) * C::kTileBytes;
-        const char* v_lds = v_ring + ((j - 1) & 1) * C::kTileBytes;
-        if (needs_mask(j - 1, q0b)) mask_block<CAUSAL>(sb, (j - 1) * kKvBlk, q0b + lq, n, hi);
-        pv_block<D>(v_lds, v_lane_off, pfa, oa);
-        qk_block<D>(k_lds, k_row_off, k_g, qfa, sa);
-        softmax_block<D>(sb, mb, lb, ob, pfb, c);
-        if (kVperM > 1) interleave_hint<2 * KS + 4 * DB, kVperM, 2>();
-        __builtin_amdgcn_sched_barrier(0);
-        if (needs_mask(j, q0a)) mask_block<CAUSAL>(sa, j * kKvBlk, q0a + lq, n, hi);
-        pv_block<D>(v_lds, v_lane_off, pfb, ob);
-        qk_block<D>(k_lds, k_row_off, k_g, qfb, sb);
-        softmax_block<D>(sa, ma, la, oa, pfa, c);
-        if (kVperM > 1) interleave_hint<2 * KS + 4 * DB, kVperM, 2>();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // ---------------- epilogue: P.V of the last tile ----------------
-    wait_lds_dma();
-    __syncthreads();
-    {
-        const char* v_lds = v_ring + ((nt - 1) & 1) * C::kTileBytes;
-        if (needs_mask(nt - 1, q0b)) mask_block<CAUSAL>(sb, (nt - 1) * kKvBlk, q0b + lq, n, hi);
-        pv_block<D>(v_lds, v_lane_off, pfa, oa);
-        softmax_block<D>(sb, mb, lb, ob, pfb, c);
-        if (kVperM > 1) interleave_hint<4 * DB, kVperM, 2>();
-        __builtin_amdgcn_sched_barrier(0);
-        pv_block<D>(v_lds, v_lane_off, pfb, ob);
-    }
-
-    // ---------------- store ----------------
-    mfma_drain();  // the loop exit is a branch: the last P.V / row-sum MFMAs may still be in flight
-    auto store_block = [&](const f32x16 (&o)[DB], float l, float m, int q0) {
-        const float lt = xhalf_sum(l);
-        const float inv = 1.0f / lt;
-        const int qi = q0 + lq;
-        if (qi < n) {
-            const int64_t o_off = o_slab_off + (int64_t)qi * p.o_row_stride + 4 * hi;
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (OUT_F32) {
-                        f32x4 pk;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) pk[e] = o[db][4 * g + e] * inv;
-                        *(f32x4*)((float*)p.o + o_off + db * 32 + 8 * g) = pk;
-                    } else {
-                        bf16x4 pk;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) pk[e] = (__bf16)(o[db][4 * g + e] * inv);
-                        *(bf16x4*)((__bf16*)p.o + o_off + db * 32 + 8 * g) = pk;
-                    }
-                }
-            if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (m + __builtin_amdgcn_logf(lt)) * kLn2;
-        }
-    };
-    store_block(oa, la, ma, q0a);
-    store_block(ob, lb, mb, q0b);
-}
-
-template <int D, int NWAVES, int SCHED>
-static hipError_t launch_pp(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
-{
-    FwdParams p = p0;
-    constexpr int BM = NWAVES * 64;
-    p.q_tiles = (p.n + BM - 1) / BM;
-    const int64_t total = (int64_t)p.bh * p.q_tiles;
-    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
-    dim3 grid((unsigned)total), block(NWAVES * kWave);
-    if (causal) {
-        if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_pp_kernel<D, NWAVES, true, true, SCHED>), grid, block, 0, stream, p);
-        else
-            hipLaunchKernelGGL((fa_fwd_bf16_pp_kernel<D, NWAVES, true, false, SCHED>), grid, block, 0, stream, p);
-    } else {
-        if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_pp_kernel<D, NWAVES, false, true, SCHED>), grid, block, 0, stream, p);
-        else
-            hipLaunchKernelGGL((fa_fwd_bf16_pp_kernel<D, NWAVES, false, false, SCHED>), grid, block, 0, stream, p);
-    }
-    return hipGetLastError();
-}
-
-// =====================================================================================================================
-// Ping-pong kernel, second generation ("pp2"): the same two-block half-tile-skewed structure, with the softmax trimmed
-// to what the VALU cannot avoid (PMC + profiles/r01_ubench_issue.txt: the loop is bound by per-wave VALU issue, ~5.7
-// cycles per instruction, not by the matrix pipe):
-//   * row sums come from the matrix core: one v_mfma_f32_16x16x32_bf16 per P fragment against a constant 0/1 A operand
-//     built so that EVERY lane receives the full sum of its own query row (both half-waves) -- 4 small MFMAs replace 32
-//     adds per block-tile, and numerator and denominator now see the same bf16-rounded P;
-//   * the O accumulator is rescaled lazily: the running max used in the exponent only moves when some row of the wave
-//     outgrows it by more than 2^kLazyThr (wave-uniform, rare branch); the exponent carries a -kLazyThr bias so p <= 1
-//     still holds and the v_exp clamp keeps protecting against overflow for any input magnitude;
-//   * per MFMA slot the wave issues ~5 VALU + 1-2 LDS instructions: the issue time of a slot matches the 32 cycles its
-//     MFMA occupies the pipe.
-// =====================================================================================================================
-constexpr float kLazyThr = 8.0f;  // exp2-domain slack of the lazily updated running max (p spans 2^-8 .. 1 between rescales)
-
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-
-template <int D>
-struct Plan2 {
-    static constexpr int KS = D / 16, DB = D / 32;
-    static constexpr int NPV = 4 * DB, NSUM = 4, NQK = 2 * KS, NSLOT = NPV + NSUM + NQK;
-    static constexpr int N_MAX = NSLOT / 10 > 0 ? NSLOT / 10 : 1;  // slots for the max phase (before the rescale decision)
-    static constexpr int N_FIN = NSLOT / 5;                       // slots for packing P
-    static constexpr int N_EXP = NSLOT - N_MAX - N_FIN;
-    static constexpr int max_slot(int e) { return e * N_MAX / 32; }
-    static constexpr int exp_slot(int e) { return N_MAX + e * N_EXP / 32; }
-    static constexpr int fin_slot(int f) { return N_MAX + N_EXP + f * N_FIN / 4; }
-};
-
-// per-lane constant A operand of the row-sum MFMA: A[i][k] = ((i >> 2) & 1) == ((k >> 3) & 1)
-__device__ __forceinline__ bf16x8 rowsum_a_operand(int lane)
-{
-    const bool one = (((lane & 15) >> 2) & 1) == ((lane >> 4) & 1);
-    bf16x8 a;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = one ? (__bf16)1.0f : (__bf16)0.0f;
-    return a;
-}
-
-struct BlockState {   // running softmax state of one 32-row block (per lane: one query row, half of its keys)
-    float m;          // exponent reference: p = 2^(c*s - m - kLazyThr)
-    f32x4_t lacc;     // row sum of p (all four registers hold the same, complete, row sum)
-};
-
-// max phase result -> decision -> (rare) rescale.  Returns the exponent offset to use for this tile.
-template <int D>
-__device__ __forceinline__ float lazy_rescale(float mx_raw, float c, BlockState& st, f32x16 (&o)[D / 32])
-{
-    float mc = mx_raw * c;
-    mc = fmaf(-fabsf(mc), 0x1p-23f, mc);  // nudge down: c*s_max - mc >= 0 exactly (see fa_fwd_bf16_kernel)
-    if (__builtin_expect(__any(mc - st.m > kLazyThr), 0)) {
-        asm volatile("; lazy rescale" ::: "memory");  // keep this a real (non-speculated) branch
-        mfma_drain();  // the accumulators rescaled below may have an MFMA in flight (hazard not padded across the branch)
-        const float m_new = fmaxf(st.m, mc);
-        const float alpha = fast_exp2(st.m - m_new);  // 0 on the first tile (m = -inf)
-        st.m = m_new;
-#pragma unroll
-        for (int db = 0; db < D / 32; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) st.lacc[r] *= alpha;
-    }
-    return st.m + kLazyThr;
-}
-
-__device__ __forceinline__ float block_rowmax(const f32x16 (&s)[2])
-{
-    float mx = s[0][0];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-    return xhalf_max(mx);
-}
-
-// phase-structured softmax (prologue, masked tail tiles, epilogue)
-template <int D>
-__device__ __forceinline__ void softmax_block2(f32x16 (&s)[2], BlockState& st, f32x16 (&o)[D / 32], bf16x8 (&pf)[4], float c)
-{
-    const float off = lazy_rescale<D>(block_rowmax(s), c, st, o);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] = exp2_clamp01(fmaf(s[kb][r], c, -off));
-#pragma unroll
-    for (int f = 0; f < 4; ++f) pf[f] = pack_bf16x8(s[f >> 1], 8 * (f & 1));
-}
-
-__device__ __forceinline__ void sum_block(const bf16x8& ones_a, const bf16x8 (&pf)[4], BlockState& st)
-{
-#pragma unroll
-    for (int f = 0; f < 4; ++f) st.lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pf[f], st.lacc, 0, 0, 0);
-}
-
-template <int D>
-__device__ __forceinline__ void load_frag2(int i, const char* k_lds, const char* v_lds, int k_row_off, int k_g, int v_lane_off,
-                                           bf16x8 (&fr)[Plan2<D>::NSLOT])
-{
-    using P = Plan2<D>;
-    constexpr int RB = 2 * D;
-    if (i < P::NPV) {
-        const int db = i % P::DB, kt = i / P::DB, kb = kt >> 1, t = kt & 1;
-        const int off0 = ((kb * 8 + 4 * t + 0) * (D / 16) + 2 * db) * 128;
-        const int off1 = ((kb * 8 + 4 * t + 2) * (D / 16) + 2 * db) * 128;
-        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_lds + v_lane_off + off0));
-        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_lds + v_lane_off + off1));
-        fr[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
-    } else if (i >= P::NPV + P::NSUM && i < P::NSLOT) {
-        const int q = i - P::NPV - P::NSUM, ks = q >> 1, kb = q & 1;
-        fr[i] = *(const bf16x8*)(k_lds + k_row_off + kb * 32 * RB + (((2 * ks) ^ k_g) * 16));
-    }
-}
-
-template <int D>
-__device__ __forceinline__ void mfma_slot2(int i, const bf16x8 (&fr)[Plan2<D>::NSLOT], const bf16x8& ones_a, const bf16x8 (&pf)[4],
-                                           const bf16x8 (&qf)[D / 16], f32x16 (&o)[D / 32], BlockState& st, f32x16 (&s)[2])
-{
-    using P = Plan2<D>;
-    if (i < P::NPV) {
-        const int db = i % P::DB, kt = i / P::DB;
-        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], pf[kt], o[db], 0, 0, 0);
-    } else if (i < P::NPV + P::NSUM) {
-        st.lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pf[i - P::NPV], st.lacc, 0, 0, 0);
-    } else {
-        const int q = i - P::NPV - P::NSUM, ks = q >> 1, kb = q & 1;
-        if (ks == 0) {
-            f32x16 z;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], qf[ks], z, 0, 0, 0);
-        } else {
-            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], qf[ks], s[kb], 0, 0, 0);
-        }
-    }
-}
-
-// One half iteration of the mask-free main loop: the MFMA stream of block X (P.V, row sums, then K.Q^T of the next
-// tile) with the softmax of block Y sliced into its slots.
-template <int D, int AHEAD, int ABL>
-__device__ __forceinline__ void half_iteration2(const char* k_lds, const char* v_lds, int k_row_off, int k_g, int v_lane_off,
-                                                const bf16x8& ones_a, const bf16x8 (&pfx)[4], const bf16x8 (&qfx)[D / 16],
-                                                f32x16 (&ox)[D / 32], BlockState& stx, f32x16 (&sx)[2], f32x16 (&sy)[2],
-                                                BlockState& sty, f32x16 (&oy)[D / 32], bf16x8 (&pfy)[4], float c)
-{
-    using P = Plan2<D>;
-    bf16x8 fr[P::NSLOT];
-    float pm[4];
-#pragma unroll
-    for (int i = 0; i < AHEAD; ++i)
-        if (!(ABL & 8) || !(i & 1)) load_frag2<D>(i, k_lds, v_lds, k_row_off, k_g, v_lane_off, fr);
-    // ---- slots [0, N_MAX): MFMAs of X beside the partial row maxima of Y
-#pragma unroll
-    for (int i = 0; i < P::N_MAX; ++i) {
-        if (i + AHEAD < P::NSLOT && (!(ABL & 8) || !((i + AHEAD) & 1))) load_frag2<D>(i + AHEAD, k_lds, v_lds, k_row_off, k_g, v_lane_off, fr);
-        if ((ABL & 8) && (i & 1)) fr[i] = fr[i - 1];
-        if (!(ABL & 2)) mfma_slot2<D>(i, fr, ones_a, pfx, qfx, ox, stx, sx);
-        else asm volatile("" ::"v"(fr[i]));
-#pragma unroll
-        for (int e = 0; e < 32; e += 2)
-            if (!(ABL & 1) && !(ABL & 16) && P::max_slot(e) == i) {
-                const float a = sy[e >> 4][e & 15], b2 = sy[e >> 4][(e & 15) + 1];
-                const int k = (e >> 1) & 3;
-                pm[k] = (e < 8) ? max3_raw(a, a, b2) : max3_raw(pm[k], a, b2);
-            }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    float off = 0.0f;
-    if (!(ABL & 1) && !(ABL & 16)) {
-        const float mx = xhalf_max(fmaxf(max3_raw(pm[0], pm[1], pm[2]), pm[3]));
-        off = lazy_rescale<D>(mx, c, sty, oy);  // rare wave-uniform branch inside
-    }
-    if (ABL & 16) off = sty.m + kLazyThr;
-    // ---- slots [N_MAX, NSLOT): exp, then pack
-#pragma unroll
-    for (int i = P::N_MAX; i < P::NSLOT; ++i) {
-        if (i + AHEAD < P::NSLOT && (!(ABL & 8) || !((i + AHEAD) & 1))) load_frag2<D>(i + AHEAD, k_lds, v_lds, k_row_off, k_g, v_lane_off, fr);
-        if ((ABL & 8) && (i & 1)) fr[i] = fr[i - 1];
-        if (!(ABL & 2)) mfma_slot2<D>(i, fr, ones_a, pfx, qfx, ox, stx, sx);
-        else asm volatile("" ::"v"(fr[i]));
-#pragma unroll
-        for (int e = 0; e < 32; ++e)
-            if (!(ABL & 1) && P::exp_slot(e) == i) sy[e >> 4][e & 15] = exp2_clamp01(fmaf(sy[e >> 4][e & 15], c, -off));
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-            if (!(ABL & 1) && P::fin_slot(f) == i) {
-                pfy[f] = pack_bf16x8(sy[f >> 1], 8 * (f & 1));
-                asm volatile("" : "+v"(pfy[f]));  // pin the pack to this slot (its consumers live in the next basic block)
-            }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, int AHEAD, int ABL = 0>
-__global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp2_kernel(FwdParams p)
-{
-    using C = Bf16Cfg<D, NWAVES>;
-    constexpr int KS = D / 16, DB = D / 32;
-    constexpr int BM = NWAVES * 64;
-
-    __shared__ __attribute__((aligned(1024))) char smem[4 * C::kTileBytes];  // K ring [2], then V ring [2]
-    char* const k_ring = smem;
-    char* const v_ring = smem + 2 * C::kTileBytes;
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lq = lane & 31, hi = lane >> 5;
-
-    const int total = p.bh * p.q_tiles;
-    const int w = xcd_remap(blockIdx.x, total);
-    const int slab = w / p.q_tiles;
-    int qt = w % p.q_tiles;
-    if (CAUSAL) qt = p.q_tiles - 1 - qt;
-    const int n = p.n;
-    const int q0a = qt * BM + wave * 64, q0b = q0a + 32;
-
-    const int b = slab / p.heads, h = slab % p.heads;
-    const __bf16* qg = (const __bf16*)p.q + b * p.q_batch_stride + h * p.q_head_stride;
-    const __bf16* kg = (const __bf16*)p.k + b * p.kv_batch_stride + h * p.kv_head_stride;
-    const __bf16* vg = (const __bf16*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
-    const int64_t o_slab_off = b * p.o_batch_stride + h * p.o_head_stride;
-
-    int kv_end = n;
-    if (CAUSAL) kv_end = min(n, qt * BM + BM);
-    const int nt = (kv_end + kKvBlk - 1) / kKvBlk;
-
-    issue_k_tile<D, NWAVES>(kg, 0, n, p.kv_row_stride, k_ring, wave, lane);
-
-    bf16x8 qfa[KS], qfb[KS];
-    {
-        const __bf16* qra = qg + (int64_t)min(q0a + lq, n - 1) * p.q_row_stride + hi * 8;
-        const __bf16* qrb = qg + (int64_t)min(q0b + lq, n - 1) * p.q_row_stride + hi * 8;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            qfa[ks] = *(const bf16x8*)(qra + ks * 16);
-            qfb[ks] = *(const bf16x8*)(qrb + ks * 16);
-        }
-    }
-    const bf16x8 ones_a = rowsum_a_operand(lane);
-
-    f32x16 oa[DB], ob[DB], sa[2], sb[2];
-    bf16x8 pfa[4], pfb[4];
-    BlockState sta, stb;
-    sta.m = stb.m = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sta.lacc[r] = stb.lacc[r] = 0.0f;
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oa[db][r] = ob[db][r] = 0.0f;
-
-    const int k_row_off = lq * C::kRowBytes;
-    const int k_g = hi ^ k_swizzle<D>(lq);
-    const int li = lane & 15;
-    const int v_lane_off = (hi * (D / 16) + ((lane >> 4) & 1)) * 128 + (li >> 2) * 32 + (li & 3) * 8;
-    const float c = p.scale_log2e;
-
-    auto needs_mask = [&](int tile, int q0) { return (tile * kKvBlk + kKvBlk > n) || (CAUSAL && (tile * kKvBlk + kKvBlk - 1 > q0)); };
-    auto stage_tiles = [&](int j) {
-        wait_lds_dma();   // K(j), V(j-1): own pieces landed
-        __syncthreads();  // everyone's pieces landed; everyone is done with K(j-1), V(j-2)
-        if (j + 1 < nt) issue_k_tile<D, NWAVES>(kg, (j + 1) * kKvBlk, n, p.kv_row_stride, k_ring + ((j + 1) & 1) * C::kTileBytes, wave, lane);
-        issue_v_tile<D, NWAVES>(vg, j * kKvBlk, n, p.kv_row_stride, v_ring + (j & 1) * C::kTileBytes, wave, lane);
-    };
-
-    // ---------------- prologue: tile 0 (phase-structured) ----------------
-    wait_lds_dma();
-    __syncthreads();
-    if (nt > 1) issue_k_tile<D, NWAVES>(kg, kKvBlk, n, p.kv_row_stride, k_ring + C::kTileBytes, wave, lane);
-    issue_v_tile<D, NWAVES>(vg, 0, n, p.kv_row_stride, v_ring, wave, lane);
-    qk_block<D>(k_ring, k_row_off, k_g, qfa, sa);
-    if (needs_mask(0, q0a)) mask_block<CAUSAL>(sa, 0, q0a + lq, n, hi);
-    qk_block<D>(k_ring, k_row_off, k_g, qfb, sb);
-    softmax_block2<D>(sa, sta, oa, pfa, c);
-
-    // Masks are only needed on the LAST tiles of a workgroup (ragged tail, causal diagonal): a mask-free loop whose halves
-    // are straight-line slot-pinned code, then a plain loop for the few masked tiles (see fa_fwd_bf16_pp_kernel).
-    int j_split = nt;
-    for (int j = 1; j < nt; ++j)
-        if (needs_mask(j - 1, q0b) || needs_mask(j, q0a)) {
-            j_split = j;
-            break;
-        }
-
-    for (int j = 1; j < j_split; ++j) {
-        if (!(ABL & 4)) stage_tiles(j);
-        const char* k_lds = k_ring + (j & 1) * C::kTileBytes;
-        const char* v_lds = v_ring + ((j - 1) & 1) * C::kTileBytes;
-        half_iteration2<D, AHEAD, ABL>(k_lds, v_lds, k_row_off, k_g, v_lane_off, ones_a, pfa, qfa, oa, sta, sa, sb, stb, ob, pfb, c);
-        half_iteration2<D, AHEAD, ABL>(k_lds, v_lds, k_row_off, k_g, v_lane_off, ones_a, pfb, qfb, ob, stb, sb, sa, sta, oa, pfa, c);
-    }
-
-    for (int j = j_split; j < nt; ++j) {
-        stage_tiles(j);
-        const char* k_lds = k_ring + (j & 1) * C::kTileBytes;
-        const char* v_lds = v_ring + ((j - 1) & 1) * C::kTileBytes;
-        if (needs_mask(j - 1, q0b)) mask_block<CAUSAL>(sb, (j - 1) * kKvBlk, q0b + lq, n, hi);
-        pv_block<D>(v_lds, v_lane_off, pfa, oa);
-        sum_block(ones_a, pfa, sta);
-        qk_block<D>(k_lds, k_row_off, k_g, qfa, sa);
-        softmax_block2<D>(sb, stb, ob, pfb, c);
-        if (needs_mask(j, q0a)) mask_block<CAUSAL>(sa, j * kKvBlk, q0a + lq, n, hi);
-        pv_block<D>(v_lds, v_lane_off, pfb, ob);
-        sum_block(ones_a, pfb, stb);
-        qk_block<D>(k_lds, k_row_off, k_g, qfb, sb);
-        softmax_block2<D>(sa, sta, oa, pfa, c);
-    }
-
-    // ---------------- epilogue: P.V of the last tile ----------------
-    wait_lds_dma();
-    __syncthreads();
-    {
-        const char* v_lds = v_ring + ((nt - 1) & 1) * C::kTileBytes;
-        if (needs_mask(nt - 1, q0b)) mask_block<CAUSAL>(sb, (nt - 1) * kKvBlk, q0b + lq, n, hi);
-        pv_block<D>(v_lds, v_lane_off, pfa, oa);
-        sum_block(ones_a, pfa, sta);
-        softmax_block2<D>(sb, stb, ob, pfb, c);
-        pv_block<D>(v_lds, v_lane_off, pfb, ob);
-        sum_block(ones_a, pfb, stb);
-    }
-
-    // ---------------- store ----------------
-    mfma_drain();  // the loop exit is a branch: the last P.V / row-sum MFMAs may still be in flight
-    auto store_block = [&](const f32x16 (&o)[DB], const BlockState& st, int q0) {
-        const float lt = st.lacc[0];
-        const float inv = 1.0f / lt;
-        const int qi = q0 + lq;
-        if (qi < n) {
-            const int64_t o_off = o_slab_off + (int64_t)qi * p.o_row_stride + 4 * hi;
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (OUT_F32) {
-                        f32x4 pk;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) pk[e] = o[db][4 * g + e] * inv;
-                        *(f32x4*)((float*)p.o + o_off + db * 32 + 8 * g) = pk;
-                    } else {
-                        bf16x4 pk;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) pk[e] = (__bf16)(o[db][4 * g + e] * inv);
-                        *(bf16x4*)((__bf16*)p.o + o_off + db * 32 + 8 * g) = pk;
-                    }
-                }
-            if (p.lse != nullptr && hi == 0)
-                p.lse[(int64_t)slab * n + qi] = (st.m + kLazyThr + __builtin_amdgcn_logf(lt)) * kLn2;
-        }
-    };
-    store_block(oa, sta, q0a);
-    store_block(ob, stb, q0b);
-}
-
-template <int D, int NWAVES, int AHEAD>
-static hipError_t launch_pp2(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
-{
-    FwdParams p = p0;
-    constexpr int BM = NWAVES * 64;
-    p.q_tiles = (p.n + BM - 1) / BM;
-    const int64_t total = (int64_t)p.bh * p.q_tiles;
-    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
-    dim3 grid((unsigned)total), block(NWAVES * kWave);
-    if (causal) {
-        if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_pp2_kernel<D, NWAVES, true, true, AHEAD>), grid, block, 0, stream, p);
-        else
-            hipLaunchKernelGGL((fa_fwd_bf16_pp2_kernel<D, NWAVES, true, false, AHEAD>), grid, block, 0, stream, p);
-    } else {
-        if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_pp2_kernel<D, NWAVES, false, true, AHEAD>), grid, block, 0, stream, p);
-        else
-            hipLaunchKernelGGL((fa_fwd_bf16_pp2_kernel<D, NWAVES, false, false, AHEAD>), grid, block, 0, stream, p);
-    }
-    return hipGetLastError();
-}
-
-// =====================================================================================================================
-// Third generation ("pp3"): the two 32-row blocks of a wave walk the keys in LOCKSTEP over 32-key sub-tiles, so every K
-// and V^T fragment fetched from LDS feeds two MFMAs (ablation on MI355X: halving the fragment reads of pp2 is worth 15 %).
-// MFMA/VALU overlap now comes from software pipelining across sub-tiles inside the single instruction stream:
-//
-//   step t:   Q  phase   K.Q^T of sub-tile t+1 for A and B (2*KS MFMAs)     ||  exp + pack of block A, sub-tile t
-//             P1 phase   P.V + row sums of block A, sub-tile t             ||  exp + pack of block B, sub-tile t
-//             P2 phase   P.V + row sums of block B (V^T fragments reused)  ||  row maxima of sub-tile t+1, rescale decision
-//
-// about 6 VALU instructions per MFMA in every phase.  Scores live in two register buffers per block (s0/s1, swapped every
-// step; a 64-key stage = two explicitly unrolled steps).  K ring 3 stages, V ring 2 stages, one barrier per 64 keys.
-// =====================================================================================================================
-template <int D>
-struct Plan3 {
-    static constexpr int KS = D / 16, DB = D / 32;
-    static constexpr int NV = 2 * DB;  // V^T fragments per 32-key sub-tile: (16-key step tt, 32-col block db)
-};
-
-struct Lazy2 {  // exponent offsets in use for the two blocks
-    float offa, offb;
-};
-
-// K fragment of sub-tile (stage-local 32-key block kb), k-step ks
-template <int D>
-__device__ __forceinline__ bf16x8 load_k_frag(const char* k_lds, int k_row_off, int k_g, int kb, int ks)
-{
-    return *(const bf16x8*)(k_lds + k_row_off + kb * 32 * (2 * D) + (((2 * ks) ^ k_g) * 16));
-}
-// V^T fragment v = tt * DB + db of stage-local 32-key block kb
-template <int D>
-__device__ __forceinline__ bf16x8 load_v_frag(const char* v_lds, int v_lane_off, int kb, int v)
-{
-    constexpr int DB = D / 32;
-    const int tt = v / DB, db = v % DB;
-    const int off0 = ((kb * 8 + 4 * tt + 0) * (D / 16) + 2 * db) * 128;
-    const int off1 = ((kb * 8 + 4 * tt + 2) * (D / 16) + 2 * db) * 128;
-    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_lds + v_lane_off + off0));
-    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_lds + v_lane_off + off1));
-    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
-}
-
-// The same fragment through inline asm.  hipcc orders every ds_read_b64_tr_b16 *builtin* behind all LDS-DMA in flight
-// (s_waitcnt vmcnt(0) in front of the first one after a global_load_lds), which would expose the whole latency of the
-// next stage's DMA once per stage; an asm read is invisible to that pass.  The caller owns the wait: wait_v_frags()
-// before the first MFMA that consumes them.  KB / V must be compile-time (immediate offsets).
-template <int D, int KB, int V>
-__device__ __forceinline__ void load_v_frag_asm(unsigned v_addr, s16x4& lo, s16x4& hi)
-{
-    constexpr int DB = D / 32;
-    constexpr int tt = V / DB, db = V % DB;
-    constexpr int off0 = ((KB * 8 + 4 * tt + 0) * (D / 16) + 2 * db) * 128;
-    constexpr int off1 = ((KB * 8 + 4 * tt + 2) * (D / 16) + 2 * db) * 128;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(v_addr), "i"(off0));
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(v_addr), "i"(off1));
-}
-
-__device__ __forceinline__ float rowmax16(const f32x16& s)
-{
-    float p0 = max3_safe(s[0], s[1], s[2]), p1 = max3_safe(s[3], s[4], s[5]);
-    float p2 = max3_safe(s[6], s[7], s[8]), p3 = max3_safe(s[9], s[10], s[11]);
-    p0 = max3_safe(p0, s[12], s[13]);
-    p1 = max3_safe(p1, s[14], s[15]);
-    return xhalf_max(fmaxf(max3_safe(p0, p1, p2), p3));
-}
-
-// decision for both blocks at once (one rare wave-uniform branch per step)
-template <int D>
-__device__ __forceinline__ void lazy_rescale2(float mxa, float mxb, float c, BlockState& sta, BlockState& stb, f32x16 (&oa)[D / 32],
-                                              f32x16 (&ob)[D / 32], Lazy2& lz)
-{
-    float mca = mxa * c, mcb = mxb * c;
-    mca = fmaf(-fabsf(mca), 0x1p-23f, mca);
-    mcb = fmaf(-fabsf(mcb), 0x1p-23f, mcb);
-    if (__builtin_expect(__any((mca - sta.m > kLazyThr) || (mcb - stb.m > kLazyThr)), 0)) {
-        asm volatile("; lazy rescale (both blocks)" ::: "memory");
-        mfma_drain();  // the accumulators rescaled below may have an MFMA in flight (hazard not padded across the branch)
-        const float na = fmaxf(sta.m, mca), nb = fmaxf(stb.m, mcb);
-        const float aa = fast_exp2(sta.m - na), ab = fast_exp2(stb.m - nb);
-        sta.m = na;
-        stb.m = nb;
-#pragma unroll
-        for (int db = 0; db < D / 32; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                oa[db][r] *= aa;
-                ob[db][r] *= ab;
-            }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            sta.lacc[r] *= aa;
-            stb.lacc[r] *= ab;
-        }
-    }
-    lz.offa = sta.m + kLazyThr;
-    lz.offb = stb.m + kLazyThr;
-}
-
-__device__ __forceinline__ void mask16(f32x16& s, int key0, int qi, int n, int hi, bool causal)
-{
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int key = key0 + 4 * hi + (r & 3) + 8 * (r >> 2);
-        if ((key >= n) || (causal && key > qi)) s[r] = -INFINITY;
-    }
-}
-
-// exp + pack of one block's 16 scores, element range [e0, e1) and pack of fragment(s) whose elements are complete
-__device__ __forceinline__ void exp_range(f32x16& s, bf16x8 (&pf)[2], float c, float off, int e0, int e1)
-{
-#pragma unroll
-    for (int e = 0; e < 16; ++e)
-        if (e >= e0 && e < e1) s[e] = exp2_clamp01(fmaf(s[e], c, -off));
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-        if (e1 == 8 * (f + 1) || (e0 < 8 * (f + 1) && e1 > 8 * (f + 1) && false)) {
-            pf[f] = pack_bf16x8(s, 8 * f);
-            asm volatile("" : "+v"(pf[f]));
-        }
-}
-
-// One pipelined step.  CUR/NXT score buffers are passed by reference (the caller swaps them every step).
-//   k_lds/kb_n : LDS address / 32-key block of the K sub-tile t+1;   v_lds/kb_c : same for the V sub-tile t
-// cycle stamps for the in-kernel phase profile (PROF builds only)
-__device__ __forceinline__ unsigned long long stamp() { return __builtin_readcyclecounter(); }
-
-// lane-local (no cross-half exchange) maximum of 16 scores: three micro-steps u = 0, 1, 2
-__device__ __forceinline__ void lanemax_step(int u, const f32x16& sx, float (&pm)[4], float& out)
-{
-    if (u == 0) {
-        pm[0] = max3_raw(sx[0], sx[1], sx[2]);
-        pm[1] = max3_raw(sx[3], sx[4], sx[5]);
-        pm[2] = max3_raw(sx[6], sx[7], sx[8]);
-    } else if (u == 1) {
-        pm[3] = max3_raw(sx[9], sx[10], sx[11]);
-        pm[0] = max3_raw(pm[0], sx[12], sx[13]);
-        pm[1] = max3_raw(pm[1], sx[14], sx[15]);
-    } else {
-        out = fmaxf(max3_raw(pm[0], pm[1], pm[2]), pm[3]);
-    }
-}
-
-// One pipelined step.  CUR/NXT score buffers are passed by reference (the caller swaps them every step).
-//   k_lds/kb_n   : LDS address / 32-key block of the K sub-tile t+1 (scores computed in this step)
-//   v_lds/kb_c   : same for the V sub-tile t (accumulated in this step)
-//   k_lds2/kb_n2 : K sub-tile t+2 -- its first fragment is fetched at the end of this step (kf0 carries it over)
-template <int D, int KB_C, bool PROF = false>
-__device__ __forceinline__ void pp3_step(const char* k_lds, int kb_n, const char* v_lds, const char* k_lds2, int kb_n2,
-                                         int k_row_off, int k_g, int v_lane_off, const bf16x8& ones_a, const bf16x8 (&qfa)[D / 16],
-                                         const bf16x8 (&qfb)[D / 16], f32x16& sa_cur, f32x16& sb_cur, f32x16& sa_nxt, f32x16& sb_nxt,
-                                         f32x16 (&oa)[D / 32], f32x16 (&ob)[D / 32], bf16x8 (&pfa)[2], bf16x8 (&pfb)[2], BlockState& sta,
-                                         BlockState& stb, float c, Lazy2& lz, bf16x8& kf0, unsigned long long* tm = nullptr)
-{
-    using P = Plan3<D>;
-    constexpr int KS = P::KS, DB = P::DB, NV = P::NV;
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-    if (PROF) t0 = stamp();
-    s16x4 vlo[NV], vhi[NV];
-    const unsigned v_addr = (unsigned)(size_t)(lds_s16x4_t*)(v_lds + v_lane_off);
-    // ---------------- Q phase: K.Q^T of sub-tile t+1 (A and B share each K fragment)  ||  exp + pack of A.
-    // Every MFMA gets its own slot (two matrix instructions back to back park the in-order wave on the matrix pipe);
-    // the V^T fragments of the P phases are fetched here, a whole phase ahead of their first use.
-    {
-        bf16x8 kf[KS];
-        kf[0] = kf0;
-        if (KS > 1) kf[1] = load_k_frag<D>(k_lds, k_row_off, k_g, kb_n, 1);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 2 < KS) kf[ks + 2] = load_k_frag<D>(k_lds, k_row_off, k_g, kb_n, ks + 2);
-            if (ks == 0 * KS / NV) load_v_frag_asm<D, KB_C, 0>(v_addr, vlo[0], vhi[0]);
-            if (NV > 1 && ks == 1 * KS / NV) load_v_frag_asm<D, KB_C, 1 % NV>(v_addr, vlo[1 % NV], vhi[1 % NV]);
-            if (NV > 2 && ks == 2 * KS / NV) load_v_frag_asm<D, KB_C, 2 % NV>(v_addr, vlo[2 % NV], vhi[2 % NV]);
-            if (NV > 3 && ks == 3 * KS / NV) load_v_frag_asm<D, KB_C, 3 % NV>(v_addr, vlo[3 % NV], vhi[3 % NV]);
-            if (NV > 4 && ks == 4 * KS / NV) load_v_frag_asm<D, KB_C, 4 % NV>(v_addr, vlo[4 % NV], vhi[4 % NV]);
-            if (NV > 5 && ks == 5 * KS / NV) load_v_frag_asm<D, KB_C, 5 % NV>(v_addr, vlo[5 % NV], vhi[5 % NV]);
-            if (NV > 6 && ks == 6 * KS / NV) load_v_frag_asm<D, KB_C, 6 % NV>(v_addr, vlo[6 % NV], vhi[6 % NV]);
-            if (NV > 7 && ks == 7 * KS / NV) load_v_frag_asm<D, KB_C, 7 % NV>(v_addr, vlo[7 % NV], vhi[7 % NV]);
-            if (ks == 0) {
-                f32x16 z;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-                sa_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qfa[ks], z, 0, 0, 0);
-            } else {
-                sa_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qfa[ks], sa_nxt, 0, 0, 0);
-            }
-            exp_range(sa_cur, pfa, c, lz.offa, 16 * (2 * ks) / (2 * KS), 16 * (2 * ks + 1) / (2 * KS));
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks == 0) {
-                f32x16 z;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-                sb_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qfb[ks], z, 0, 0, 0);
-            } else {
-                sb_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qfb[ks], sb_nxt, 0, 0, 0);
-            }
-            exp_range(sa_cur, pfa, c, lz.offa, 16 * (2 * ks + 1) / (2 * KS), 16 * (2 * ks + 2) / (2 * KS));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    if (PROF) t1 = stamp();
-    // the asm-issued V^T reads were started a whole phase ago; this wait is the one that orders them before the MFMAs
-    // (the "+v" operands stop the compiler from touching the destination registers earlier)
-    static_assert(NV <= 8, "V^T fragment staging written for NV <= 8");
-#pragma unroll
-    for (int v = 0; v < NV; ++v) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[v]), "+v"(vhi[v]));
-    __builtin_amdgcn_sched_barrier(0);
-    bf16x8 vf[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) vf[v] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(vlo[v], vhi[v], 0, 1, 2, 3, 4, 5, 6, 7));
-    // ---------------- P1 phase: P.V + row sums of A  ||  exp + pack of B
-#pragma unroll
-    for (int v = 0; v < NV + 2; ++v) {
-        if (v < NV) {
-            oa[v % DB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[v], pfa[v / DB], oa[v % DB], 0, 0, 0);
-        } else {
-            sta.lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pfa[v - NV], sta.lacc, 0, 0, 0);
-        }
-        exp_range(sb_cur, pfb, c, lz.offb, 16 * v / (NV + 2), 16 * (v + 1) / (NV + 2));
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (PROF) t2 = stamp();
-    // ---------------- P2 phase: P.V + row sums of B  ||  lane-local maxima of sub-tile t+1 and the rescale test.
-    // The test only needs each lane's own partial maximum: a row outgrows its reference iff one of its two lanes does,
-    // so the cross-half exchange happens inside the rare rescale branch, not here.
-    float lma = 0.0f, lmb = 0.0f, pm[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    bool need = false;
-#pragma unroll
-    for (int v = 0; v < NV + 2; ++v) {
-        if (v < NV) {
-            ob[v % DB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[v], pfb[v / DB], ob[v % DB], 0, 0, 0);
-        } else {
-            stb.lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pfb[v - NV], stb.lacc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < 6; ++u)
-            if (u * (NV + 1) / 6 == v) {
-                if (u < 3) lanemax_step(u, sa_nxt, pm, lma);
-                else lanemax_step(u - 3, sb_nxt, pm, lmb);
-            }
-        if (v == NV + 1) {
-            // c > 0: compare in the scaled domain with a one-sided safety margin instead of the exact nudge
-            need = (fmaf(lma, c, -sta.m) > kLazyThr) || (fmaf(lmb, c, -stb.m) > kLazyThr);
-            kf0 = load_k_frag<D>(k_lds2, k_row_off, k_g, kb_n2, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (PROF) t3 = stamp();
-    if (__builtin_expect(__any(need), 0)) {
-        mfma_drain();  // the last P.V / row-sum MFMAs of block B may still be in flight
-        lazy_rescale2<D>(xhalf_max(lma), xhalf_max(lmb), c, sta, stb, oa, ob, lz);
-    }
-    if (PROF) {
-        const unsigned long long t4 = stamp();
-        tm[0] += t1 - t0;
-        tm[1] += t2 - t1;
-        tm[2] += t3 - t2;
-        tm[3] += t4 - t3;
-    }
-}
-
-template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, bool PROF = false>
-__global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdParams p)
-{
-    using C = Bf16Cfg<D, NWAVES>;
-    constexpr int KS = D / 16, DB = D / 32;
-    constexpr int BM = NWAVES * 64;
-
-    const unsigned long long t_entry = PROF ? stamp() : 0;
-    __shared__ __attribute__((aligned(1024))) char smem[5 * C::kTileBytes];  // K ring [3], then V ring [2]
-    char* const k_ring = smem;
-    char* const v_ring = smem + 3 * C::kTileBytes;
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lq = lane & 31, hi = lane >> 5;
-
-    const int total = p.bh * p.q_tiles;
-    const int w = xcd_remap(blockIdx.x, total);
-    const int slab = w / p.q_tiles;
-    int qt = w % p.q_tiles;
-    if (CAUSAL) qt = p.q_tiles - 1 - qt;
-    const int n = p.n;
-    const int q0a = qt * BM + wave * 64, q0b = q0a + 32;
-
-    const int b = slab / p.heads, h = slab % p.heads;
-    const __bf16* qg = (const __bf16*)p.q + b * p.q_batch_stride + h * p.q_head_stride;
-    const __bf16* kg = (const __bf16*)p.k + b * p.kv_batch_stride + h * p.kv_head_stride;
-    const __bf16* vg = (const __bf16*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
-    const int64_t o_slab_off = b * p.o_batch_stride + h * p.o_head_stride;
-
-    int kv_end = n;
-    if (CAUSAL) kv_end = min(n, qt * BM + BM);
-    const int nst = (kv_end + kKvBlk - 1) / kKvBlk;  // 64-key stages
-    const int nsub = (kv_end + 31) / 32;             // 32-key sub-tiles
-
-    issue_k_tile<D, NWAVES>(kg, 0, n, p.kv_row_stride, k_ring, wave, lane);
-
-    bf16x8 qfa[KS], qfb[KS];
-    {
-        const __bf16* qra = qg + (int64_t)min(q0a + lq, n - 1) * p.q_row_stride + hi * 8;
-        const __bf16* qrb = qg + (int64_t)min(q0b + lq, n - 1) * p.q_row_stride + hi * 8;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            qfa[ks] = *(const bf16x8*)(qra + ks * 16);
-            qfb[ks] = *(const bf16x8*)(qrb + ks * 16);
-        }
-    }
-    const bf16x8 ones_a = rowsum_a_operand(lane);
-
-    f32x16 oa[DB], ob[DB], sa0, sb0, sa1, sb1;
-    bf16x8 pfa[2], pfb[2];
-    BlockState sta, stb;
-    Lazy2 lz;
-    sta.m = stb.m = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sta.lacc[r] = stb.lacc[r] = 0.0f;
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oa[db][r] = ob[db][r] = 0.0f;
-
-    const int k_row_off = lq * C::kRowBytes;
-    const int k_g = hi ^ k_swizzle<D>(lq);
-    const int li = lane & 15;
-    const int v_lane_off = (hi * (D / 16) + ((lane >> 4) & 1)) * 128 + (li >> 2) * 32 + (li & 3) * 8;
-    const float c = p.scale_log2e;
-
-    // sub-tile t needs a mask for the block whose first row is q0?
-    auto needs_mask = [&](int t, int q0) { return (t * 32 + 32 > n) || (CAUSAL && (t * 32 + 31 > q0)); };
-    auto k_stage = [&](int j) { return k_ring + (j % 3) * C::kTileBytes; };
-    auto v_stage = [&](int j) { return v_ring + (j & 1) * C::kTileBytes; };
-    auto stage_top = [&](int j) {
-        wait_lds_dma();   // K(j+1), V(j): own pieces landed
-        __syncthreads();  // everyone's landed; everyone is done with K(j-1), V(j-1)
-        if (j + 2 < nst) issue_k_tile<D, NWAVES>(kg, (j + 2) * kKvBlk, n, p.kv_row_stride, k_stage(j + 2), wave, lane);
-        if (j + 1 < nst) issue_v_tile<D, NWAVES>(vg, (j + 1) * kKvBlk, n, p.kv_row_stride, v_stage(j + 1), wave, lane);
-    };
-    // scores of sub-tile t for both blocks, phase-structured (prologue and tail)
-    auto qk_sub = [&](int t, f32x16& sa, f32x16& sb) {
-        const char* k_lds = k_stage(t >> 1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sa[r] = sb[r] = 0.0f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 kf = load_k_frag<D>(k_lds, k_row_off, k_g, t & 1, ks);
-            sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfa[ks], sa, 0, 0, 0);
-            sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfb[ks], sb, 0, 0, 0);
-        }
-        if (needs_mask(t, q0a)) mask16(sa, t * 32, q0a + lq, n, hi, CAUSAL);
-        if (needs_mask(t, q0b)) mask16(sb, t * 32, q0b + lq, n, hi, CAUSAL);
-        lazy_rescale2<D>(rowmax16(sa), rowmax16(sb), c, sta, stb, oa, ob, lz);
-    };
-    // exp, pack, P.V and row sums of sub-tile t for both blocks, phase-structured (tail)
-    auto finish_sub = [&](int t, f32x16& sa, f32x16& sb) {
-        exp_range(sa, pfa, c, lz.offa, 0, 8);
-        exp_range(sa, pfa, c, lz.offa, 8, 16);
-        exp_range(sb, pfb, c, lz.offb, 0, 8);
-        exp_range(sb, pfb, c, lz.offb, 8, 16);
-        const char* v_lds = v_stage(t >> 1);
-#pragma unroll
-        for (int v = 0; v < 2 * DB; ++v) {
-            const bf16x8 vf = load_v_frag<D>(v_lds, v_lane_off, t & 1, v);
-            oa[v % DB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfa[v / DB], oa[v % DB], 0, 0, 0);
-            ob[v % DB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfb[v / DB], ob[v % DB], 0, 0, 0);
-        }
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            sta.lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pfa[f], sta.lacc, 0, 0, 0);
-            stb.lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pfb[f], stb.lacc, 0, 0, 0);
-        }
-    };
-
-    // ---------------- prologue: K(0) landed -> scores of sub-tile 0 ----------------
-    wait_lds_dma();
-    __syncthreads();
-    if (nst > 1) issue_k_tile<D, NWAVES>(kg, kKvBlk, n, p.kv_row_stride, k_stage(1), wave, lane);
-    issue_v_tile<D, NWAVES>(vg, 0, n, p.kv_row_stride, v_stage(0), wave, lane);
-    qk_sub(0, sa0, sb0);
-
-    // ---------------- fast loop: whole stages whose sub-tiles 2j .. 2j+2 are in range and mask-free ----------------
-    int jf = 0;
-    while ((2 * jf + 3) * 32 <= kv_end && !needs_mask(2 * jf + 2, q0a) && !needs_mask(2 * jf + 2, q0b) && !needs_mask(0, q0a)) ++jf;
-    unsigned long long tm[6] = {0, 0, 0, 0, 0, 0};
-    const unsigned long long t_begin = PROF ? stamp() : 0;
-    bf16x8 kf0 = load_k_frag<D>(k_stage(0), k_row_off, k_g, 1, 0);  // first K fragment of sub-tile 1 (K(0) has landed)
-    for (int j = 0; j < jf; ++j) {
-        const unsigned long long ts0 = PROF ? stamp() : 0;
-        stage_top(j);
-        if (PROF) tm[4] += stamp() - ts0;
-        // step 2j: scores(2j+1) from K(j) block 1; P.V(2j) from V(j) block 0; prefetch for scores(2j+2): K(j+1) block 0
-        pp3_step<D, 0, PROF>(k_stage(j), 1, v_stage(j), k_stage(j + 1), 0, k_row_off, k_g, v_lane_off, ones_a, qfa, qfb, sa0, sb0, sa1, sb1,
-                          oa, ob, pfa, pfb, sta, stb, c, lz, kf0, tm);
-        // step 2j+1: scores(2j+2) from K(j+1) block 0; P.V(2j+1) from V(j) block 1; prefetch for scores(2j+3): K(j+1) block 1
-        pp3_step<D, 1, PROF>(k_stage(j + 1), 0, v_stage(j), k_stage(j + 1), 1, k_row_off, k_g, v_lane_off, ones_a, qfa, qfb, sa1, sb1, sa0,
-                          sb0, oa, ob, pfa, pfb, sta, stb, c, lz, kf0, tm);
-    }
-    if (PROF) {
-        tm[5] = stamp() - t_begin;
-        if (lane == 0 && p.lse != nullptr) {
-            float* dst = p.lse + ((int64_t)blockIdx.x * NWAVES + wave) * 8;
-            for (int i = 0; i < 6; ++i) dst[i] = (float)tm[i];
-            dst[6] = (float)jf;
-            dst[7] = 0.0f;
-        }
-    }
-
-    // ---------------- tail: remaining sub-tiles, phase-structured, masks applied where needed ----------------
-    // Every wave keeps taking part in the stage barriers / DMA, but only computes the sub-tiles its own rows can see
-    // (causal: the sub-tiles up to the diagonal of its last row).
-    const int nsub_w = CAUSAL ? min(nsub, (q0b + 31) / 32 + 1) : nsub;
-    for (int j = jf; j < nst; ++j) {
-        stage_top(j);
-        const int t0 = 2 * j, t1 = 2 * j + 1;
-        if (t0 < nsub_w) {
-            finish_sub(t0, sa0, sb0);        // scores(t0) are already in s0 with the rescale decision taken
-            if (t1 < nsub_w) {
-                qk_sub(t1, sa1, sb1);
-                finish_sub(t1, sa1, sb1);
-                if (t1 + 1 < nsub_w) qk_sub(t1 + 1, sa0, sb0);  // K(j+1) landed at this stage's barrier
-            }
-        }
-    }
-
-    // ---------------- store ----------------
-    mfma_drain();  // the loop exit is a branch: the last P.V / row-sum MFMAs may still be in flight
-    auto store_block = [&](const f32x16 (&o)[DB], const BlockState& st, int q0) {
-        const float lt = st.lacc[0];
-        const float inv = 1.0f / lt;
-        const int qi = q0 + lq;
-        if (qi < n) {
-            const int64_t o_off = o_slab_off + (int64_t)qi * p.o_row_stride + 4 * hi;
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (OUT_F32) {
-                        f32x4 pk;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) pk[e] = o[db][4 * g + e] * inv;
-                        *(f32x4*)((float*)p.o + o_off + db * 32 + 8 * g) = pk;
-                    } else {
-                        bf16x4 pk;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) pk[e] = (__bf16)(o[db][4 * g + e] * inv);
-                        *(bf16x4*)((__bf16*)p.o + o_off + db * 32 + 8 * g) = pk;
-                    }
-                }
-            if (!PROF && p.lse != nullptr && hi == 0)
-                p.lse[(int64_t)slab * n + qi] = (st.m + kLazyThr + __builtin_amdgcn_logf(lt)) * kLn2;
-        }
-    };
-    store_block(oa, sta, q0a);
-    store_block(ob, stb, q0b);
-    if (PROF && lane == 0 && p.lse != nullptr) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        p.lse[((int64_t)blockIdx.x * NWAVES + wave) * 8 + 7] = (float)(stamp() - t_entry);  // whole kernel
-        unsigned hwid, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        float* aux = p.lse + (int64_t)gridDim.x * NWAVES * 8 + ((int64_t)blockIdx.x * NWAVES + wave) * 2;
-        aux[0] = (float)(((xcc & 0xf) << 16) | (((hwid >> 13) & 7) << 8) | (((hwid >> 8) & 0xf) << 4) | ((hwid >> 4) & 3));
-        aux[1] = (float)(t_entry & 0xffffff);
-    }
-}
-
-static hipError_t launch_pp3_prof(const FwdParams& p0, hipStream_t stream)
-{
-    FwdParams p = p0;
-    p.q_tiles = (p.n + 255) / 256;
-    dim3 grid((unsigned)(p.bh * p.q_tiles)), block(256);
-    hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<64, 4, false, false, true>), grid, block, 0, stream, p);
-    return hipGetLastError();
-}
-
-template <int D, int NWAVES>
-static hipError_t launch_pp3(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
-{
-    FwdParams p = p0;
-    constexpr int BM = NWAVES * 64;
-    p.q_tiles = (p.n + BM - 1) / BM;
-    const int64_t total = (int64_t)p.bh * p.q_tiles;
-    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
-    dim3 grid((unsigned)total), block(NWAVES * kWave);
-    if (causal) {
-        if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, true, true>), grid, block, 0, stream, p);
-        else
-            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, true, false>), grid, block, 0, stream, p);
-    } else {
-        if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, false, true>), grid, block, 0, stream, p);
-        else
-            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, false, false>), grid, block, 0, stream, p);
-    }
-    return hipGetLastError();
-}
-
-// =====================================================================================================================
 // "w4": one 32-row block per wave, four waves per SIMD (<= 128 VGPRs), phase-structured like fa_fwd_bf16_kernel but on the
 // same VALU diet as pp2/pp3 (matrix-core row sums, lazily rescaled accumulator, lane-local rescale test, v_max3 without
 // canonicalisation).  Overlap of MFMA and VALU is left to the four co-resident waves.
@@ -1805,16 +414,6 @@ static hipError_t launch_w4(const FwdParams& p0, int causal, int out_f32, hipStr
     return hipGetLastError();
 }
 
-template <int ABL>
-static hipError_t launch_pp2_ablation(const FwdParams& p0, hipStream_t stream)
-{
-    FwdParams p = p0;
-    p.q_tiles = (p.n + 255) / 256;
-    dim3 grid((unsigned)(p.bh * p.q_tiles)), block(256);
-    hipLaunchKernelGGL((fa_fwd_bf16_pp2_kernel<64, 4, false, false, 2, ABL>), grid, block, 0, stream, p);
-    return hipGetLastError();
-}
-
 template <int D, int NWAVES, int QB, int MINWAVES>
 static hipError_t launch_cfg(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
 {
@@ -1840,41 +439,29 @@ static hipError_t launch_cfg(const FwdParams& p0, int causal, int out_f32, hipSt
 
 hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, int variant, hipStream_t stream)
 {
+    // 256-row work items of the pipelined kernel; few of them + causal imbalance -> 128-row workgroups pack better
+    const int64_t items256 = (int64_t)p.bh * ((p.n + 255) / 256);
     switch (d) {
         case 32:
+            if (variant == 24) return launch_bf16_pipelined(p, 32, 2, causal, out_f32, 0, stream);
             // lockstep/pipelined kernel for the non-causal case; its 256-row workgroups waste more of the causal
             // triangle than the 128-row phase-structured kernel recovers at D = 32
-            if (variant == 7 || (variant == 0 && !causal)) return launch_pp3<32, 4>(p, causal, out_f32, stream);
+            if (variant == 7 || (variant == 0 && !causal)) return launch_bf16_pipelined(p, 32, 4, causal, out_f32, 0, stream);
             return launch_cfg<32, 4, 1, 4>(p, causal, out_f32, stream);
         case 64:
             switch (variant) {
+                case 0:  // product path
+                    return launch_bf16_pipelined(p, 64, (causal && items256 <= 1024) ? 2 : 4, causal, out_f32, 0, stream);
                 case 1: return launch_cfg<64, 4, 1, 4>(p, causal, out_f32, stream);   // phase-structured, 4 waves/SIMD
                 case 2: return launch_cfg<64, 4, 2, 2>(p, causal, out_f32, stream);   // phase-structured, 64 rows/wave
-                case 3: return launch_pp<64, 4, 0>(p, causal, out_f32, stream);       // ping-pong, compiler's own schedule
-                case 4: return launch_pp<64, 4, 12>(p, causal, out_f32, stream);      // ping-pong, sched_group_barrier hints
-                case 5: return launch_pp<64, 4, 1>(p, causal, out_f32, stream);       // ping-pong, slot-pinned interleave
-                case 6: return launch_pp2<64, 4, 4>(p, causal, out_f32, stream);
-                case 7: return launch_pp3<64, 4>(p, causal, out_f32, stream);          // lockstep blocks, 32-key pipelined steps
-                case 22: return launch_pp3_prof(p, stream);                            // + in-kernel phase timers (written to lse)
-                // ablations of the main loop (results are garbage; timing only): 1 = no softmax VALU, 2 = no MFMA,
-                // 4 = no barrier / DMA, and combinations
-                case 11: return launch_pp2_ablation<1>(p, stream);
-                case 12: return launch_pp2_ablation<2>(p, stream);
-                case 13: return launch_pp2_ablation<3>(p, stream);
-                case 14: return launch_pp2_ablation<4>(p, stream);
-                case 15: return launch_pp2_ablation<5>(p, stream);
-                case 16: return launch_pp2_ablation<6>(p, stream);
-                case 17: return launch_pp2_ablation<8>(p, stream);    // half the LDS fragment reads
-                case 18: return launch_pp2_ablation<16>(p, stream);   // no max phase / rescale decision
-                case 19: return launch_pp2_ablation<24>(p, stream);
-                case 20: return launch_pp2_ablation<12>(p, stream);   // half LDS, no sync
-                case 21: return launch_pp2_ablation<28>(p, stream);
-                case 9: return launch_pp2<64, 4, 2>(p, causal, out_f32, stream);      // ping-pong 2: MFMA row sums, lazy rescale
+                case 7: return launch_bf16_pipelined(p, 64, 4, causal, out_f32, 0, stream);
+                case 24: return launch_bf16_pipelined(p, 64, 2, causal, out_f32, 0, stream);
+                case 22: return launch_bf16_pipelined(p, 64, 4, 0, 0, 1, stream);
+                case 25: return launch_bf16_pipelined(p, 64, 4, 0, 0, 2, stream);
                 case 10: return launch_w4<64, 4, 4>(p, causal, out_f32, stream);       // 4 waves/SIMD on the VALU diet
-                case 23: return launch_w4<64, 4, 3>(p, causal, out_f32, stream);
-                default: return launch_pp3<64, 4>(p, causal, out_f32, stream);        // lockstep blocks, 32-key pipelined steps
+                default: return launch_bf16_pp2(p, causal, out_f32, variant, stream);  // 9 = pp2, 6, 11..21 = its ablations
             }
-        case 128: return launch_cfg<128, 4, 1, 2>(p, causal, out_f32, stream);  // pp3 needs > 256 VGPRs at D = 128
+        case 128: return launch_cfg<128, 4, 1, 2>(p, causal, out_f32, stream);  // the pipelined kernel needs > 256 VGPRs at D = 128
         default: return hipErrorInvalidValue;
     }
 }

@@ -1,0 +1,530 @@
+// fa_fwd_bf16_pipelined.hip -- the bf16 kernel that ships for D = 64 (and non-causal D = 32): two 32-row blocks per wave in
+// lockstep over 32-key sub-tiles, software-pipelined inside one instruction stream ("pp3").  Design notes in the block
+// comment below and in DESIGN.md section 3.
+#include "fa_bf16_common.h"
+#include "fa_kernels.h"
+
+namespace fa {
+
+// =====================================================================================================================
+// Third generation ("pp3"): the two 32-row blocks of a wave walk the keys in LOCKSTEP over 32-key sub-tiles, so every K
+// and V^T fragment fetched from LDS feeds two MFMAs (ablation on MI355X: halving the fragment reads of pp2 is worth 15 %).
+// MFMA/VALU overlap now comes from software pipelining across sub-tiles inside the single instruction stream:
+//
+//   step t:   Q  phase   K.Q^T of sub-tile t+1 for A and B (2*KS MFMAs)     ||  exp + pack of block A, sub-tile t
+//             P1 phase   P.V + row sums of block A, sub-tile t             ||  exp + pack of block B, sub-tile t
+//             P2 phase   P.V + row sums of block B (V^T fragments reused)  ||  row maxima of sub-tile t+1, rescale decision
+//
+// about 6 VALU instructions per MFMA in every phase.  Scores live in two register buffers per block (s0/s1, swapped every
+// step; a 64-key stage = two explicitly unrolled steps).  K ring 3 stages, V ring 2 stages, one barrier per 64 keys.
+// =====================================================================================================================
+template <int D>
+struct Plan3 {
+    static constexpr int KS = D / 16, DB = D / 32;
+    static constexpr int NV = 2 * DB;  // V^T fragments per 32-key sub-tile: (16-key step tt, 32-col block db)
+};
+
+struct Lazy2 {  // exponent offsets in use for the two blocks
+    float offa, offb;
+};
+
+// K fragment of sub-tile (stage-local 32-key block kb), k-step ks
+template <int D>
+__device__ __forceinline__ bf16x8 load_k_frag(const char* k_lds, int k_row_off, int k_g, int kb, int ks)
+{
+    return *(const bf16x8*)(k_lds + k_row_off + kb * 32 * (2 * D) + (((2 * ks) ^ k_g) * 16));
+}
+// V^T fragment v = tt * DB + db of stage-local 32-key block kb
+template <int D>
+__device__ __forceinline__ bf16x8 load_v_frag(const char* v_lds, int v_lane_off, int kb, int v)
+{
+    constexpr int DB = D / 32;
+    const int tt = v / DB, db = v % DB;
+    const int off0 = ((kb * 8 + 4 * tt + 0) * (D / 16) + 2 * db) * 128;
+    const int off1 = ((kb * 8 + 4 * tt + 2) * (D / 16) + 2 * db) * 128;
+    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_lds + v_lane_off + off0));
+    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_lds + v_lane_off + off1));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// The same fragment through inline asm.  hipcc orders every ds_read_b64_tr_b16 *builtin* behind all LDS-DMA in flight
+// (s_waitcnt vmcnt(0) in front of the first one after a global_load_lds), which would expose the whole latency of the
+// next stage's DMA once per stage; an asm read is invisible to that pass.  The caller owns the wait: wait_v_frags()
+// before the first MFMA that consumes them.  KB / V must be compile-time (immediate offsets).
+template <int D, int KB, int V>
+__device__ __forceinline__ void load_v_frag_asm(unsigned v_addr, s16x4& lo, s16x4& hi)
+{
+    constexpr int DB = D / 32;
+    constexpr int tt = V / DB, db = V % DB;
+    constexpr int off0 = ((KB * 8 + 4 * tt + 0) * (D / 16) + 2 * db) * 128;
+    constexpr int off1 = ((KB * 8 + 4 * tt + 2) * (D / 16) + 2 * db) * 128;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(v_addr), "i"(off0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(v_addr), "i"(off1));
+}
+
+__device__ __forceinline__ float rowmax16(const f32x16& s)
+{
+    float p0 = max3_safe(s[0], s[1], s[2]), p1 = max3_safe(s[3], s[4], s[5]);
+    float p2 = max3_safe(s[6], s[7], s[8]), p3 = max3_safe(s[9], s[10], s[11]);
+    p0 = max3_safe(p0, s[12], s[13]);
+    p1 = max3_safe(p1, s[14], s[15]);
+    return xhalf_max(fmaxf(max3_safe(p0, p1, p2), p3));
+}
+
+// decision for both blocks at once (one rare wave-uniform branch per step)
+template <int D>
+__device__ __forceinline__ void lazy_rescale2(float mxa, float mxb, float c, BlockState& sta, BlockState& stb, f32x16 (&oa)[D / 32],
+                                              f32x16 (&ob)[D / 32], Lazy2& lz)
+{
+    float mca = mxa * c, mcb = mxb * c;
+    mca = fmaf(-fabsf(mca), 0x1p-23f, mca);
+    mcb = fmaf(-fabsf(mcb), 0x1p-23f, mcb);
+    if (__builtin_expect(__any((mca - sta.m > kLazyThr) || (mcb - stb.m > kLazyThr)), 0)) {
+        asm volatile("; lazy rescale (both blocks)" ::: "memory");
+        mfma_drain();  // the accumulators rescaled below may have an MFMA in flight (hazard not padded across the branch)
+        const float na = fmaxf(sta.m, mca), nb = fmaxf(stb.m, mcb);
+        const float aa = fast_exp2(sta.m - na), ab = fast_exp2(stb.m - nb);
+        sta.m = na;
+        stb.m = nb;
+#pragma unroll
+        for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                oa[db][r] *= aa;
+                ob[db][r] *= ab;
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sta.lacc[r] *= aa;
+            stb.lacc[r] *= ab;
+        }
+    }
+    lz.offa = sta.m + kLazyThr;
+    lz.offb = stb.m + kLazyThr;
+}
+
+__device__ __forceinline__ void mask16(f32x16& s, int key0, int qi, int n, int hi, bool causal)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int key = key0 + 4 * hi + (r & 3) + 8 * (r >> 2);
+        if ((key >= n) || (causal && key > qi)) s[r] = -INFINITY;
+    }
+}
+
+// exp + pack of one block's 16 scores, element range [e0, e1) and pack of fragment(s) whose elements are complete
+__device__ __forceinline__ void exp_range(f32x16& s, bf16x8 (&pf)[2], float c, float off, int e0, int e1)
+{
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+        if (e >= e0 && e < e1) s[e] = exp2_clamp01(fmaf(s[e], c, -off));
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+        if (e1 == 8 * (f + 1) || (e0 < 8 * (f + 1) && e1 > 8 * (f + 1) && false)) {
+            pf[f] = pack_bf16x8(s, 8 * f);
+            asm volatile("" : "+v"(pf[f]));
+        }
+}
+
+// One pipelined step.  CUR/NXT score buffers are passed by reference (the caller swaps them every step).
+//   k_lds/kb_n : LDS address / 32-key block of the K sub-tile t+1;   v_lds/kb_c : same for the V sub-tile t
+// cycle stamps for the in-kernel phase profile (PROF builds only)
+__device__ __forceinline__ unsigned long long stamp() { return __builtin_readcyclecounter(); }
+
+// lane-local (no cross-half exchange) maximum of 16 scores: three micro-steps u = 0, 1, 2
+__device__ __forceinline__ void lanemax_step(int u, const f32x16& sx, float (&pm)[4], float& out)
+{
+    if (u == 0) {
+        pm[0] = max3_raw(sx[0], sx[1], sx[2]);
+        pm[1] = max3_raw(sx[3], sx[4], sx[5]);
+        pm[2] = max3_raw(sx[6], sx[7], sx[8]);
+    } else if (u == 1) {
+        pm[3] = max3_raw(sx[9], sx[10], sx[11]);
+        pm[0] = max3_raw(pm[0], sx[12], sx[13]);
+        pm[1] = max3_raw(pm[1], sx[14], sx[15]);
+    } else {
+        out = fmaxf(max3_raw(pm[0], pm[1], pm[2]), pm[3]);
+    }
+}
+
+// One pipelined step.  CUR/NXT score buffers are passed by reference (the caller swaps them every step).
+//   k_lds/kb_n   : LDS address / 32-key block of the K sub-tile t+1 (scores computed in this step)
+//   v_lds/kb_c   : same for the V sub-tile t (accumulated in this step)
+//   k_lds2/kb_n2 : K sub-tile t+2 -- its first fragment is fetched at the end of this step (kf0 carries it over)
+template <int D, int KB_C, bool PROF = false>
+__device__ __forceinline__ void pp3_step(const char* k_lds, int kb_n, const char* v_lds, const char* k_lds2, int kb_n2,
+                                         int k_row_off, int k_g, int v_lane_off, const bf16x8& ones_a, const bf16x8 (&qfa)[D / 16],
+                                         const bf16x8 (&qfb)[D / 16], f32x16& sa_cur, f32x16& sb_cur, f32x16& sa_nxt, f32x16& sb_nxt,
+                                         f32x16 (&oa)[D / 32], f32x16 (&ob)[D / 32], bf16x8 (&pfa)[2], bf16x8 (&pfb)[2], BlockState& sta,
+                                         BlockState& stb, float c, Lazy2& lz, bf16x8& kf0, unsigned long long* tm = nullptr)
+{
+    using P = Plan3<D>;
+    constexpr int KS = P::KS, DB = P::DB, NV = P::NV;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (PROF) t0 = stamp();
+    s16x4 vlo[NV], vhi[NV];
+    const unsigned v_addr = (unsigned)(size_t)(lds_s16x4_t*)(v_lds + v_lane_off);
+    // ---------------- Q phase: K.Q^T of sub-tile t+1 (A and B share each K fragment)  ||  exp + pack of A.
+    // Every MFMA gets its own slot (two matrix instructions back to back park the in-order wave on the matrix pipe);
+    // the V^T fragments of the P phases are fetched here, a whole phase ahead of their first use.
+    {
+        bf16x8 kf[KS];
+        kf[0] = kf0;
+        if (KS > 1) kf[1] = load_k_frag<D>(k_lds, k_row_off, k_g, kb_n, 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 2 < KS) kf[ks + 2] = load_k_frag<D>(k_lds, k_row_off, k_g, kb_n, ks + 2);
+            if (ks == 0 * KS / NV) load_v_frag_asm<D, KB_C, 0>(v_addr, vlo[0], vhi[0]);
+            if (NV > 1 && ks == 1 * KS / NV) load_v_frag_asm<D, KB_C, 1 % NV>(v_addr, vlo[1 % NV], vhi[1 % NV]);
+            if (NV > 2 && ks == 2 * KS / NV) load_v_frag_asm<D, KB_C, 2 % NV>(v_addr, vlo[2 % NV], vhi[2 % NV]);
+            if (NV > 3 && ks == 3 * KS / NV) load_v_frag_asm<D, KB_C, 3 % NV>(v_addr, vlo[3 % NV], vhi[3 % NV]);
+            if (NV > 4 && ks == 4 * KS / NV) load_v_frag_asm<D, KB_C, 4 % NV>(v_addr, vlo[4 % NV], vhi[4 % NV]);
+            if (NV > 5 && ks == 5 * KS / NV) load_v_frag_asm<D, KB_C, 5 % NV>(v_addr, vlo[5 % NV], vhi[5 % NV]);
+            if (NV > 6 && ks == 6 * KS / NV) load_v_frag_asm<D, KB_C, 6 % NV>(v_addr, vlo[6 % NV], vhi[6 % NV]);
+            if (NV > 7 && ks == 7 * KS / NV) load_v_frag_asm<D, KB_C, 7 % NV>(v_addr, vlo[7 % NV], vhi[7 % NV]);
+            if (ks == 0) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                sa_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qfa[ks], z, 0, 0, 0);
+            } else {
+                sa_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qfa[ks], sa_nxt, 0, 0, 0);
+            }
+            exp_range(sa_cur, pfa, c, lz.offa, 16 * (2 * ks) / (2 * KS), 16 * (2 * ks + 1) / (2 * KS));
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == 0) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                sb_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qfb[ks], z, 0, 0, 0);
+            } else {
+                sb_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qfb[ks], sb_nxt, 0, 0, 0);
+            }
+            exp_range(sa_cur, pfa, c, lz.offa, 16 * (2 * ks + 1) / (2 * KS), 16 * (2 * ks + 2) / (2 * KS));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (PROF) t1 = stamp();
+    // the asm-issued V^T reads were started a whole phase ago; this wait is the one that orders them before the MFMAs
+    // (the "+v" operands stop the compiler from touching the destination registers earlier)
+    static_assert(NV <= 8, "V^T fragment staging written for NV <= 8");
+#pragma unroll
+    for (int v = 0; v < NV; ++v) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[v]), "+v"(vhi[v]));
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 vf[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) vf[v] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(vlo[v], vhi[v], 0, 1, 2, 3, 4, 5, 6, 7));
+    // ---------------- P1 phase: P.V + row sums of A  ||  exp + pack of B
+#pragma unroll
+    for (int v = 0; v < NV + 2; ++v) {
+        if (v < NV) {
+            oa[v % DB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[v], pfa[v / DB], oa[v % DB], 0, 0, 0);
+        } else {
+            sta.lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pfa[v - NV], sta.lacc, 0, 0, 0);
+        }
+        exp_range(sb_cur, pfb, c, lz.offb, 16 * v / (NV + 2), 16 * (v + 1) / (NV + 2));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (PROF) t2 = stamp();
+    // ---------------- P2 phase: P.V + row sums of B  ||  lane-local maxima of sub-tile t+1 and the rescale test.
+    // The test only needs each lane's own partial maximum: a row outgrows its reference iff one of its two lanes does,
+    // so the cross-half exchange happens inside the rare rescale branch, not here.
+    float lma = 0.0f, lmb = 0.0f, pm[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    bool need = false;
+#pragma unroll
+    for (int v = 0; v < NV + 2; ++v) {
+        if (v < NV) {
+            ob[v % DB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[v], pfb[v / DB], ob[v % DB], 0, 0, 0);
+        } else {
+            stb.lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pfb[v - NV], stb.lacc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            if (u * NV / 6 == v) {
+                if (u < 3) lanemax_step(u, sa_nxt, pm, lma);
+                else lanemax_step(u - 3, sb_nxt, pm, lmb);
+            }
+        // the test is evaluated one MFMA slot before the branch that consumes it (VALU compare -> scalar branch latency)
+        if (v == NV) need = (fmaf(lma, c, -sta.m) > kLazyThr) || (fmaf(lmb, c, -stb.m) > kLazyThr);
+        if (v == NV + 1) kf0 = load_k_frag<D>(k_lds2, k_row_off, k_g, kb_n2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (PROF) t3 = stamp();
+    if (__builtin_expect(__any(need), 0)) {
+        mfma_drain();  // the last P.V / row-sum MFMAs of block B may still be in flight
+        lazy_rescale2<D>(xhalf_max(lma), xhalf_max(lmb), c, sta, stb, oa, ob, lz);
+    }
+    if (PROF) {
+        const unsigned long long t4 = stamp();
+        tm[0] += t1 - t0;
+        tm[1] += t2 - t1;
+        tm[2] += t3 - t2;
+        tm[3] += t4 - t3;
+    }
+}
+
+template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, bool PROF = false, bool FAIR = false>
+__global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdParams p)
+{
+    using C = Bf16Cfg<D, NWAVES>;
+    constexpr int KS = D / 16, DB = D / 32;
+    constexpr int BM = NWAVES * 64;
+
+    const unsigned long long t_entry = PROF ? stamp() : 0;
+    __shared__ __attribute__((aligned(1024))) char smem[5 * C::kTileBytes];  // K ring [3], then V ring [2]
+    char* const k_ring = smem;
+    char* const v_ring = smem + 3 * C::kTileBytes;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lq = lane & 31, hi = lane >> 5;
+
+    const int total = p.bh * p.q_tiles;
+    const int w = xcd_remap(blockIdx.x, total);
+    const int slab = w / p.q_tiles;
+    int qt = w % p.q_tiles;
+    if (CAUSAL) qt = p.q_tiles - 1 - qt;
+    const int n = p.n;
+    const int q0a = qt * BM + wave * 64, q0b = q0a + 32;
+
+    const int b = slab / p.heads, h = slab % p.heads;
+    const __bf16* qg = (const __bf16*)p.q + b * p.q_batch_stride + h * p.q_head_stride;
+    const __bf16* kg = (const __bf16*)p.k + b * p.kv_batch_stride + h * p.kv_head_stride;
+    const __bf16* vg = (const __bf16*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
+    const int64_t o_slab_off = b * p.o_batch_stride + h * p.o_head_stride;
+
+    int kv_end = n;
+    if (CAUSAL) kv_end = min(n, qt * BM + BM);
+    const int nst = (kv_end + kKvBlk - 1) / kKvBlk;  // 64-key stages
+    const int nsub = (kv_end + 31) / 32;             // 32-key sub-tiles
+
+    issue_k_tile<D, NWAVES>(kg, 0, n, p.kv_row_stride, k_ring, wave, lane);
+
+    bf16x8 qfa[KS], qfb[KS];
+    {
+        const __bf16* qra = qg + (int64_t)min(q0a + lq, n - 1) * p.q_row_stride + hi * 8;
+        const __bf16* qrb = qg + (int64_t)min(q0b + lq, n - 1) * p.q_row_stride + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qfa[ks] = *(const bf16x8*)(qra + ks * 16);
+            qfb[ks] = *(const bf16x8*)(qrb + ks * 16);
+        }
+    }
+    const bf16x8 ones_a = rowsum_a_operand(lane);
+
+    f32x16 oa[DB], ob[DB], sa0, sb0, sa1, sb1;
+    bf16x8 pfa[2], pfb[2];
+    BlockState sta, stb;
+    Lazy2 lz;
+    sta.m = stb.m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sta.lacc[r] = stb.lacc[r] = 0.0f;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oa[db][r] = ob[db][r] = 0.0f;
+
+    const int k_row_off = lq * C::kRowBytes;
+    const int k_g = hi ^ k_swizzle<D>(lq);
+    const int li = lane & 15;
+    const int v_lane_off = (hi * (D / 16) + ((lane >> 4) & 1)) * 128 + (li >> 2) * 32 + (li & 3) * 8;
+    const float c = p.scale_log2e;
+
+    // sub-tile t needs a mask for the block whose first row is q0?
+    auto needs_mask = [&](int t, int q0) { return (t * 32 + 32 > n) || (CAUSAL && (t * 32 + 31 > q0)); };
+    auto k_stage = [&](int j) { return k_ring + (j % 3) * C::kTileBytes; };
+    auto v_stage = [&](int j) { return v_ring + (j & 1) * C::kTileBytes; };
+    auto stage_top = [&](int j) {
+        wait_lds_dma();   // K(j+1), V(j): own pieces landed
+        __syncthreads();  // everyone's landed; everyone is done with K(j-1), V(j-1)
+        if (j + 2 < nst) issue_k_tile<D, NWAVES>(kg, (j + 2) * kKvBlk, n, p.kv_row_stride, k_stage(j + 2), wave, lane);
+        if (j + 1 < nst) issue_v_tile<D, NWAVES>(vg, (j + 1) * kKvBlk, n, p.kv_row_stride, v_stage(j + 1), wave, lane);
+    };
+    // scores of sub-tile t for both blocks, phase-structured (prologue and tail)
+    auto qk_sub = [&](int t, f32x16& sa, f32x16& sb) {
+        const char* k_lds = k_stage(t >> 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sa[r] = sb[r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 kf = load_k_frag<D>(k_lds, k_row_off, k_g, t & 1, ks);
+            sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfa[ks], sa, 0, 0, 0);
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfb[ks], sb, 0, 0, 0);
+        }
+        if (needs_mask(t, q0a)) mask16(sa, t * 32, q0a + lq, n, hi, CAUSAL);
+        if (needs_mask(t, q0b)) mask16(sb, t * 32, q0b + lq, n, hi, CAUSAL);
+        lazy_rescale2<D>(rowmax16(sa), rowmax16(sb), c, sta, stb, oa, ob, lz);
+    };
+    // exp, pack, P.V and row sums of sub-tile t for both blocks, phase-structured (tail)
+    auto finish_sub = [&](int t, f32x16& sa, f32x16& sb) {
+        exp_range(sa, pfa, c, lz.offa, 0, 8);
+        exp_range(sa, pfa, c, lz.offa, 8, 16);
+        exp_range(sb, pfb, c, lz.offb, 0, 8);
+        exp_range(sb, pfb, c, lz.offb, 8, 16);
+        const char* v_lds = v_stage(t >> 1);
+#pragma unroll
+        for (int v = 0; v < 2 * DB; ++v) {
+            const bf16x8 vf = load_v_frag<D>(v_lds, v_lane_off, t & 1, v);
+            oa[v % DB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfa[v / DB], oa[v % DB], 0, 0, 0);
+            ob[v % DB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfb[v / DB], ob[v % DB], 0, 0, 0);
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            sta.lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pfa[f], sta.lacc, 0, 0, 0);
+            stb.lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pfb[f], stb.lacc, 0, 0, 0);
+        }
+    };
+
+    // ---------------- prologue: K(0) landed -> scores of sub-tile 0 ----------------
+    wait_lds_dma();
+    __syncthreads();
+    if (nst > 1) issue_k_tile<D, NWAVES>(kg, kKvBlk, n, p.kv_row_stride, k_stage(1), wave, lane);
+    issue_v_tile<D, NWAVES>(vg, 0, n, p.kv_row_stride, v_stage(0), wave, lane);
+    qk_sub(0, sa0, sb0);
+
+    // ---------------- fast loop: whole stages whose sub-tiles 2j .. 2j+2 are in range and mask-free ----------------
+    int jf = 0;
+    while ((2 * jf + 3) * 32 <= kv_end && !needs_mask(2 * jf + 2, q0a) && !needs_mask(2 * jf + 2, q0b) && !needs_mask(0, q0a)) ++jf;
+    unsigned long long tm[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = PROF ? stamp() : 0;
+    bf16x8 kf0 = load_k_frag<D>(k_stage(0), k_row_off, k_g, 1, 0);  // first K fragment of sub-tile 1 (K(0) has landed)
+    // The two workgroups sharing a CU are arbitrated by age: left alone, the older one runs at nearly single-workgroup speed
+    // and the younger one finishes ~45 % later on an otherwise idle CU.  Alternating a raised priority between them every
+    // stage (which workgroup is which is only a guess from the dispatch order -- it affects speed, never results) keeps
+    // them level, so both use the shared phase to the end.
+    const int prio_phase = (int)((blockIdx.x / (gridDim.x > 1 ? (gridDim.x + 1) / 2 : 1)) & 1);
+    for (int j = 0; j < jf; ++j) {
+        const unsigned long long ts0 = PROF ? stamp() : 0;
+        if (FAIR) {
+            if ((j ^ prio_phase) & 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        stage_top(j);
+        if (PROF) tm[4] += stamp() - ts0;
+        // step 2j: scores(2j+1) from K(j) block 1; P.V(2j) from V(j) block 0; prefetch for scores(2j+2): K(j+1) block 0
+        pp3_step<D, 0, PROF>(k_stage(j), 1, v_stage(j), k_stage(j + 1), 0, k_row_off, k_g, v_lane_off, ones_a, qfa, qfb, sa0, sb0, sa1, sb1,
+                          oa, ob, pfa, pfb, sta, stb, c, lz, kf0, tm);
+        // step 2j+1: scores(2j+2) from K(j+1) block 0; P.V(2j+1) from V(j) block 1; prefetch for scores(2j+3): K(j+1) block 1
+        pp3_step<D, 1, PROF>(k_stage(j + 1), 0, v_stage(j), k_stage(j + 1), 1, k_row_off, k_g, v_lane_off, ones_a, qfa, qfb, sa1, sb1, sa0,
+                          sb0, oa, ob, pfa, pfb, sta, stb, c, lz, kf0, tm);
+    }
+    if (PROF) {
+        tm[5] = stamp() - t_begin;
+        if (lane == 0 && p.lse != nullptr) {
+            float* dst = p.lse + ((int64_t)blockIdx.x * NWAVES + wave) * 8;
+            for (int i = 0; i < 6; ++i) dst[i] = (float)tm[i];
+            dst[6] = (float)jf;
+            dst[7] = 0.0f;
+        }
+    }
+
+    // ---------------- tail: remaining sub-tiles, phase-structured, masks applied where needed ----------------
+    // Every wave keeps taking part in the stage barriers / DMA, but only computes the sub-tiles its own rows can see
+    // (causal: the sub-tiles up to the diagonal of its last row).
+    const int nsub_w = CAUSAL ? min(nsub, (q0b + 31) / 32 + 1) : nsub;
+    for (int j = jf; j < nst; ++j) {
+        stage_top(j);
+        const int t0 = 2 * j, t1 = 2 * j + 1;
+        if (t0 < nsub_w) {
+            finish_sub(t0, sa0, sb0);        // scores(t0) are already in s0 with the rescale decision taken
+            if (t1 < nsub_w) {
+                qk_sub(t1, sa1, sb1);
+                finish_sub(t1, sa1, sb1);
+                if (t1 + 1 < nsub_w) qk_sub(t1 + 1, sa0, sb0);  // K(j+1) landed at this stage's barrier
+            }
+        }
+    }
+
+    // ---------------- store ----------------
+    mfma_drain();  // the loop exit is a branch: the last P.V / row-sum MFMAs may still be in flight
+    auto store_block = [&](const f32x16 (&o)[DB], const BlockState& st, int q0) {
+        const float lt = st.lacc[0];
+        const float inv = 1.0f / lt;
+        const int qi = q0 + lq;
+        if (qi < n) {
+            const int64_t o_off = o_slab_off + (int64_t)qi * p.o_row_stride + 4 * hi;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (OUT_F32) {
+                        f32x4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = o[db][4 * g + e] * inv;
+                        *(f32x4*)((float*)p.o + o_off + db * 32 + 8 * g) = pk;
+                    } else {
+                        bf16x4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = (__bf16)(o[db][4 * g + e] * inv);
+                        *(bf16x4*)((__bf16*)p.o + o_off + db * 32 + 8 * g) = pk;
+                    }
+                }
+            if (!PROF && p.lse != nullptr && hi == 0)
+                p.lse[(int64_t)slab * n + qi] = (st.m + kLazyThr + __builtin_amdgcn_logf(lt)) * kLn2;
+        }
+    };
+    store_block(oa, sta, q0a);
+    store_block(ob, stb, q0b);
+    if (PROF && lane == 0 && p.lse != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p.lse[((int64_t)blockIdx.x * NWAVES + wave) * 8 + 7] = (float)(stamp() - t_entry);  // whole kernel
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        float* aux = p.lse + (int64_t)gridDim.x * NWAVES * 8 + ((int64_t)blockIdx.x * NWAVES + wave) * 2;
+        aux[0] = (float)(((xcc & 0xf) << 16) | (((hwid >> 13) & 7) << 8) | (((hwid >> 8) & 0xf) << 4) | ((hwid >> 4) & 3));
+        aux[1] = (float)(t_entry & 0xffffff);
+    }
+}
+
+static hipError_t launch_pp3_fair(const FwdParams& p0, hipStream_t stream)
+{
+    FwdParams p = p0;
+    p.q_tiles = (p.n + 255) / 256;
+    dim3 grid((unsigned)(p.bh * p.q_tiles)), block(256);
+    hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<64, 4, false, false, false, true>), grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+static hipError_t launch_pp3_prof(const FwdParams& p0, hipStream_t stream)
+{
+    FwdParams p = p0;
+    p.q_tiles = (p.n + 255) / 256;
+    dim3 grid((unsigned)(p.bh * p.q_tiles)), block(256);
+    hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<64, 4, false, false, true>), grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+template <int D, int NWAVES>
+static hipError_t launch_pp3(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
+{
+    FwdParams p = p0;
+    constexpr int BM = NWAVES * 64;
+    p.q_tiles = (p.n + BM - 1) / BM;
+    const int64_t total = (int64_t)p.bh * p.q_tiles;
+    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)total), block(NWAVES * kWave);
+    if (causal) {
+        if (out_f32)
+            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, true, true>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, true, false>), grid, block, 0, stream, p);
+    } else {
+        if (out_f32)
+            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, false, true>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, false, false>), grid, block, 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_bf16_pipelined(const FwdParams& p, int d, int nwaves, int causal, int out_f32, int mode, hipStream_t stream)
+{
+    if (mode == 1) return launch_pp3_prof(p, stream);   // D = 64 only: in-kernel phase timers (written to lse)
+    if (mode == 2) return launch_pp3_fair(p, stream);   // D = 64 only: alternating priority between co-resident workgroups
+    if (d == 64) return nwaves == 2 ? launch_pp3<64, 2>(p, causal, out_f32, stream) : launch_pp3<64, 4>(p, causal, out_f32, stream);
+    if (d == 32) return nwaves == 2 ? launch_pp3<32, 2>(p, causal, out_f32, stream) : launch_pp3<32, 4>(p, causal, out_f32, stream);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace fa
