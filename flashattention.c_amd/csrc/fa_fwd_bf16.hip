@@ -461,7 +461,10 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
                 case 10: return launch_w4<64, 4, 4>(p, causal, out_f32, stream);       // 4 waves/SIMD on the VALU diet
                 default: return launch_bf16_pp2(p, causal, out_f32, variant, stream);  // 9 = pp2, 6, 11..21 = its ablations
             }
-        case 128: return launch_cfg<128, 4, 1, 2>(p, causal, out_f32, stream);  // the pipelined kernel needs > 256 VGPRs at D = 128
+        case 128:
+            if (variant == 10) return launch_w4<128, 4, 2>(p, causal, out_f32, stream);
+            if (variant == 23) return launch_w4<128, 4, 3>(p, causal, out_f32, stream);
+            return launch_cfg<128, 4, 1, 2>(p, causal, out_f32, stream);  // the pipelined kernel needs > 256 VGPRs at D = 128
         default: return hipErrorInvalidValue;
     }
 }
