@@ -75,6 +75,63 @@ __device__ __forceinline__ void issue_v_tile(const __bf16* __restrict__ vg, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same two LDS images through BUFFER loads (buffer_load_dwordx4 ... lds): the per-lane source permutation is computed
+// once per kernel (a 32-bit byte offset per lane), the tile / chunk position travels in the scalar offset, and rows past
+// the end of the slab are answered with zeros by the bounds check of the descriptor -- so a stage costs one SALU add and
+// one DMA instruction per 1 KiB piece instead of ~5 VALU of 64-bit address arithmetic per piece.
+// Requires (n - 1) * row_stride * 2 + 2 * D < 2^32 (checked by the launcher).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D, int NWAVES>
+struct TileDma {
+    using C = Bf16Cfg<D, NWAVES>;
+    __amdgpu_buffer_rsrc_t k_rsrc, v_rsrc;
+    unsigned k_voff, v_voff;   // per-lane byte offset of this wave's chunk 0 within a tile (source permutation included)
+    unsigned chunk_step;       // byte distance between the sources of two consecutive chunks of this wave
+    unsigned stage_step;       // byte distance between two tiles (kKvBlk rows)
+
+    __device__ __forceinline__ void init(const __bf16* kg, const __bf16* vg, int n, int row_stride, int wave, int lane)
+    {
+        const unsigned bytes = ((unsigned)(n - 1) * (unsigned)row_stride + D) * 2u;
+        k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kg, 0, bytes, 0x00020000);
+        v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vg, 0, bytes, 0x00020000);
+        {   // K image: row-major, 16-byte slots XOR-swizzled (same mapping as issue_k_tile)
+            const int off = wave * 1024 + lane * 16;
+            const int row = off / C::kRowBytes;
+            const int slot = ((off % C::kRowBytes) / 16) ^ k_swizzle<D>(row);
+            k_voff = (unsigned)(row * row_stride + slot * 8) * 2u;
+        }
+        {   // V image: [key/4][col/16][4][16] sub-tiles (same mapping as issue_v_tile)
+            const int blk = wave * 8 + lane / 8;
+            const int kg4 = blk / (D / 16), cb = blk % (D / 16);
+            const int key = kg4 * 4 + (lane % 8) / 2;
+            const int col = cb * 16 + (lane & 1) * 8;
+            v_voff = (unsigned)(key * row_stride + col) * 2u;
+        }
+        // chunk i of a wave is chunk (wave + i * NWAVES) of the tile: NWAVES * 512 / D rows further down in both images,
+        // and both permutations are periodic in that distance (see the static_asserts)
+        static_assert(((NWAVES * 512 / D) / ((D / 8 >= 16) ? 1 : 16 / (D / 8))) % (D / 8 >= 16 ? 16 : D / 8) == 0, "K swizzle period");
+        static_assert((NWAVES * 8) % (D / 16) == 0, "V sub-tile period");
+        chunk_step = (unsigned)(NWAVES * 512 / D) * (unsigned)row_stride * 2u;
+        stage_step = (unsigned)kKvBlk * (unsigned)row_stride * 2u;
+    }
+    // enqueue the K (V) tile of stage j into the LDS tile at dst (wave-uniform)
+    __device__ __forceinline__ void issue_k(unsigned stage_off, char* dst, int wave) const
+    {
+#pragma unroll
+        for (int i = 0; i < C::kChunksPerWave; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void_t*)(dst + (wave + i * NWAVES) * 1024), 16, k_voff,
+                                                     stage_off + i * chunk_step, 0, 0);
+    }
+    __device__ __forceinline__ void issue_v(unsigned stage_off, char* dst, int wave) const
+    {
+#pragma unroll
+        for (int i = 0; i < C::kChunksPerWave; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void_t*)(dst + (wave + i * NWAVES) * 1024), 16, v_voff,
+                                                     stage_off + i * chunk_step, 0, 0);
+    }
+};
+
 template <int D, int NWAVES>
 __device__ __forceinline__ void issue_kv_tile(const __bf16* __restrict__ kg, const __bf16* __restrict__ vg,
                                               int kv0, int n, int row_stride, char* stage, int wave, int lane)

@@ -262,19 +262,19 @@ int main(int argc, char** argv)
         fa_ok(fa_forward_ex(b.q, b.k, b.v, b.o, lse, a.bh, a.n, a.d, a.scale, 0, FA_DTYPE_BF16, FA_KERNEL_MFMA | (22 << 8), nullptr), "prof");
         HIP_OK(hipDeviceSynchronize());
         const size_t nw = (size_t)a.bh * ((a.n + 255) / 256) * 4;
-        std::vector<float> h(nw * 8);
+        std::vector<float> h(nw * 16);
         HIP_OK(hipMemcpy(h.data(), lse, h.size() * 4, hipMemcpyDeviceToHost));
-        double acc[7] = {0};
+        double acc[9] = {0};
         for (size_t w = 0; w < nw; ++w)
-            for (int i = 0; i < 7; ++i) acc[i] += h[w * 8 + i];
-        const double steps = acc[6] / nw * 2.0;
+            for (int i = 0; i < 9; ++i) acc[i] += h[w * 16 + i];
+        const double steps = acc[8] / nw * 2.0;
         printf("pp3 phase profile (mean cycles per wave; %zu waves, %.0f steps each)\n", nw, steps);
-        const char* nm[6] = {"Q  phase (QK MFMAs || exp A)", "P1 phase (PV A || exp B)", "P2 phase (PV B || max)", "rescale decision",
-                             "stage top (wait+barrier+DMA issue)", "whole fast loop"};
-        for (int i = 0; i < 6; ++i)
-            printf("  %-38s total %10.0f   per step %8.1f\n", nm[i], acc[i] / nw, acc[i] / nw / (i == 4 ? steps / 2 : steps));
+        const char* nm[8] = {"Q  phase (QK MFMAs || exp A)", "P1 phase (PV A || exp B)", "P2 phase (PV B || max)", "rescale decision",
+                             "stage top: wait for own DMA", "stage top: barrier", "stage top: DMA issue", "whole fast loop"};
+        for (int i = 0; i < 8; ++i)
+            printf("  %-38s total %10.0f   per step %8.1f\n", nm[i], acc[i] / nw, acc[i] / nw / steps);
         double mn = 1e30, mx = 0, av = 0;
-        for (size_t w = 0; w < nw; ++w) { const double x = h[w * 8 + 7]; mn = x < mn ? x : mn; mx = x > mx ? x : mx; av += x / nw; }
+        for (size_t w = 0; w < nw; ++w) { const double x = h[w * 16 + 9]; mn = x < mn ? x : mn; mx = x > mx ? x : mx; av += x / nw; }
         printf("  whole kernel per wave: min %.0f mean %.0f max %.0f cycles\n", mn, av, mx);
         return 0;
     }

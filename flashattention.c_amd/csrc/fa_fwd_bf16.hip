@@ -441,6 +441,8 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
 {
     // 256-row work items of the pipelined kernel; few of them + causal imbalance -> 128-row workgroups pack better
     const int64_t items256 = (int64_t)p.bh * ((p.n + 255) / 256);
+    if (!bf16_pipelined_supported(p, d) && d != 128) return d == 64 ? launch_cfg<64, 4, 1, 4>(p, causal, out_f32, stream)
+                                                                     : launch_cfg<32, 4, 1, 4>(p, causal, out_f32, stream);
     switch (d) {
         case 32:
             if (variant == 24) return launch_bf16_pipelined(p, 32, 2, causal, out_f32, 0, stream);
@@ -457,7 +459,7 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
                 case 7: return launch_bf16_pipelined(p, 64, 4, causal, out_f32, 0, stream);
                 case 24: return launch_bf16_pipelined(p, 64, 2, causal, out_f32, 0, stream);
                 case 22: return launch_bf16_pipelined(p, 64, 4, 0, 0, 1, stream);
-                case 25: return launch_bf16_pipelined(p, 64, 4, 0, 0, 2, stream);
+                case 25: return launch_bf16_pipelined(p, 64, 4, causal, out_f32, 3, stream);  // barrier every stage
                 case 10: return launch_w4<64, 4, 4>(p, causal, out_f32, stream);       // 4 waves/SIMD on the VALU diet
                 default: return launch_bf16_pp2(p, causal, out_f32, variant, stream);  // 9 = pp2, 6, 11..21 = its ablations
             }

@@ -126,8 +126,6 @@ __device__ __forceinline__ void exp_range(f32x16& s, bf16x8 (&pf)[2], float c, f
         }
 }
 
-// One pipelined step.  CUR/NXT score buffers are passed by reference (the caller swaps them every step).
-//   k_lds/kb_n : LDS address / 32-key block of the K sub-tile t+1;   v_lds/kb_c : same for the V sub-tile t
 // cycle stamps for the in-kernel phase profile (PROF builds only)
 __device__ __forceinline__ unsigned long long stamp() { return __builtin_readcyclecounter(); }
 
@@ -143,20 +141,21 @@ __device__ __forceinline__ void lanemax_step(int u, const f32x16& sx, float (&pm
         pm[0] = max3_raw(pm[0], sx[12], sx[13]);
         pm[1] = max3_raw(pm[1], sx[14], sx[15]);
     } else {
-        out = fmaxf(max3_raw(pm[0], pm[1], pm[2]), pm[3]);
+        out = max3_raw(max3_raw(pm[0], pm[1], pm[2]), pm[3], pm[3]);  // (asm outputs: an fmaxf here costs two canonicalising v_max)
     }
 }
 
 // One pipelined step.  CUR/NXT score buffers are passed by reference (the caller swaps them every step).
-//   k_lds/kb_n   : LDS address / 32-key block of the K sub-tile t+1 (scores computed in this step)
-//   v_lds/kb_c   : same for the V sub-tile t (accumulated in this step)
-//   k_lds2/kb_n2 : K sub-tile t+2 -- its first fragment is fetched at the end of this step (kf0 carries it over)
+//   kf           : K fragments of sub-tile t+1 (scores computed in this step), fetched during the previous step
+//   v_lds/KB_C   : LDS address / 32-key block of the V sub-tile t (accumulated in this step)
+//   k_lds2/kb_n2 : K sub-tile t+2 -- its fragments are fetched during the P1 phase of this step (kf carries them over), so
+//                  that every LDS read is issued a whole phase before its first use (under load the LDS latency is several
+//                  MFMA slots; a read issued two slots ahead stalls the in-order wave and drains the matrix pipe)
 template <int D, int KB_C, bool PROF = false>
-__device__ __forceinline__ void pp3_step(const char* k_lds, int kb_n, const char* v_lds, const char* k_lds2, int kb_n2,
-                                         int k_row_off, int k_g, int v_lane_off, const bf16x8& ones_a, const bf16x8 (&qfa)[D / 16],
+__device__ __forceinline__ void pp3_step(const char* v_lds, const char* k_lds2, int kb_n2, int k_row_off, int k_g, int v_lane_off, const bf16x8& ones_a, const bf16x8 (&qfa)[D / 16],
                                          const bf16x8 (&qfb)[D / 16], f32x16& sa_cur, f32x16& sb_cur, f32x16& sa_nxt, f32x16& sb_nxt,
                                          f32x16 (&oa)[D / 32], f32x16 (&ob)[D / 32], bf16x8 (&pfa)[2], bf16x8 (&pfb)[2], BlockState& sta,
-                                         BlockState& stb, float c, Lazy2& lz, bf16x8& kf0, unsigned long long* tm = nullptr)
+                                         BlockState& stb, float c, Lazy2& lz, bf16x8 (&kf)[D / 16], unsigned long long* tm = nullptr)
 {
     using P = Plan3<D>;
     constexpr int KS = P::KS, DB = P::DB, NV = P::NV;
@@ -168,20 +167,13 @@ __device__ __forceinline__ void pp3_step(const char* k_lds, int kb_n, const char
     // Every MFMA gets its own slot (two matrix instructions back to back park the in-order wave on the matrix pipe);
     // the V^T fragments of the P phases are fetched here, a whole phase ahead of their first use.
     {
-        bf16x8 kf[KS];
-        kf[0] = kf0;
-        if (KS > 1) kf[1] = load_k_frag<D>(k_lds, k_row_off, k_g, kb_n, 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 2 < KS) kf[ks + 2] = load_k_frag<D>(k_lds, k_row_off, k_g, kb_n, ks + 2);
-            if (ks == 0 * KS / NV) load_v_frag_asm<D, KB_C, 0>(v_addr, vlo[0], vhi[0]);
-            if (NV > 1 && ks == 1 * KS / NV) load_v_frag_asm<D, KB_C, 1 % NV>(v_addr, vlo[1 % NV], vhi[1 % NV]);
-            if (NV > 2 && ks == 2 * KS / NV) load_v_frag_asm<D, KB_C, 2 % NV>(v_addr, vlo[2 % NV], vhi[2 % NV]);
-            if (NV > 3 && ks == 3 * KS / NV) load_v_frag_asm<D, KB_C, 3 % NV>(v_addr, vlo[3 % NV], vhi[3 % NV]);
-            if (NV > 4 && ks == 4 * KS / NV) load_v_frag_asm<D, KB_C, 4 % NV>(v_addr, vlo[4 % NV], vhi[4 % NV]);
-            if (NV > 5 && ks == 5 * KS / NV) load_v_frag_asm<D, KB_C, 5 % NV>(v_addr, vlo[5 % NV], vhi[5 % NV]);
-            if (NV > 6 && ks == 6 * KS / NV) load_v_frag_asm<D, KB_C, 6 % NV>(v_addr, vlo[6 % NV], vhi[6 % NV]);
-            if (NV > 7 && ks == 7 * KS / NV) load_v_frag_asm<D, KB_C, 7 % NV>(v_addr, vlo[7 % NV], vhi[7 % NV]);
+            // V^T fragment reads of this step: all issued in the first NV slots, >= KS slots before the P1 phase
+            if (2 * ks + 0 == 0) load_v_frag_asm<D, KB_C, 0>(v_addr, vlo[0], vhi[0]);
+            if (NV > 2 && 2 * ks + 0 == 2) load_v_frag_asm<D, KB_C, 2 % NV>(v_addr, vlo[2 % NV], vhi[2 % NV]);
+            if (NV > 4 && 2 * ks + 0 == 4) load_v_frag_asm<D, KB_C, 4 % NV>(v_addr, vlo[4 % NV], vhi[4 % NV]);
+            if (NV > 6 && 2 * ks + 0 == 6) load_v_frag_asm<D, KB_C, 6 % NV>(v_addr, vlo[6 % NV], vhi[6 % NV]);
             if (ks == 0) {
                 f32x16 z;
 #pragma unroll
@@ -192,6 +184,10 @@ __device__ __forceinline__ void pp3_step(const char* k_lds, int kb_n, const char
             }
             exp_range(sa_cur, pfa, c, lz.offa, 16 * (2 * ks) / (2 * KS), 16 * (2 * ks + 1) / (2 * KS));
             __builtin_amdgcn_sched_barrier(0);
+            if (NV > 1 && 2 * ks + 1 == 1) load_v_frag_asm<D, KB_C, 1 % NV>(v_addr, vlo[1 % NV], vhi[1 % NV]);
+            if (NV > 3 && 2 * ks + 1 == 3) load_v_frag_asm<D, KB_C, 3 % NV>(v_addr, vlo[3 % NV], vhi[3 % NV]);
+            if (NV > 5 && 2 * ks + 1 == 5) load_v_frag_asm<D, KB_C, 5 % NV>(v_addr, vlo[5 % NV], vhi[5 % NV]);
+            if (NV > 7 && 2 * ks + 1 == 7) load_v_frag_asm<D, KB_C, 7 % NV>(v_addr, vlo[7 % NV], vhi[7 % NV]);
             if (ks == 0) {
                 f32x16 z;
 #pragma unroll
@@ -222,6 +218,7 @@ __device__ __forceinline__ void pp3_step(const char* k_lds, int kb_n, const char
         } else {
             sta.lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pfa[v - NV], sta.lacc, 0, 0, 0);
         }
+        if (v < KS) kf[v] = load_k_frag<D>(k_lds2, k_row_off, k_g, kb_n2, v);   // scores of the NEXT step (kf is free: Q phase done)
         exp_range(sb_cur, pfb, c, lz.offb, 16 * v / (NV + 2), 16 * (v + 1) / (NV + 2));
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -245,8 +242,7 @@ __device__ __forceinline__ void pp3_step(const char* k_lds, int kb_n, const char
                 else lanemax_step(u - 3, sb_nxt, pm, lmb);
             }
         // the test is evaluated one MFMA slot before the branch that consumes it (VALU compare -> scalar branch latency)
-        if (v == NV) need = (fmaf(lma, c, -sta.m) > kLazyThr) || (fmaf(lmb, c, -stb.m) > kLazyThr);
-        if (v == NV + 1) kf0 = load_k_frag<D>(k_lds2, k_row_off, k_g, kb_n2, 0);
+        if (v == NV) need = fmaxf(fmaf(lma, c, -lz.offa), fmaf(lmb, c, -lz.offb)) > 0.0f;  // off = m + kLazyThr
         __builtin_amdgcn_sched_barrier(0);
     }
     if (PROF) t3 = stamp();
@@ -263,17 +259,23 @@ __device__ __forceinline__ void pp3_step(const char* k_lds, int kb_n, const char
     }
 }
 
-template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, bool PROF = false, bool FAIR = false>
+// G = stages (64 keys each) between two workgroup barriers.  A barrier costs the skew between the four waves, not a data
+// wait (measured: ~600 cycles per barrier, DMA wait ~0), so it is paid once per G stages; the price is LDS: rings of 2G tiles
+// for K and for V (G = 2: 64 KiB per workgroup, two workgroups per CU; G = 1: 32 KiB, used by the 2-wave workgroups).
+template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, bool PROF = false, int G = 2>
 __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdParams p)
 {
     using C = Bf16Cfg<D, NWAVES>;
     constexpr int KS = D / 16, DB = D / 32;
     constexpr int BM = NWAVES * 64;
+    constexpr int KR = 2 * G, VR = 2 * G;  // ring depths in tiles (powers of two)
+    static_assert(G == 1 || G == 2, "ring index arithmetic written for G = 1, 2");
+    constexpr int T = C::kTileBytes;
 
     const unsigned long long t_entry = PROF ? stamp() : 0;
-    __shared__ __attribute__((aligned(1024))) char smem[5 * C::kTileBytes];  // K ring [3], then V ring [2]
+    __shared__ __attribute__((aligned(1024))) char smem[(KR + VR) * T];  // K ring, then V ring
     char* const k_ring = smem;
-    char* const v_ring = smem + 3 * C::kTileBytes;
+    char* const v_ring = smem + KR * T;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -298,7 +300,12 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
     const int nst = (kv_end + kKvBlk - 1) / kKvBlk;  // 64-key stages
     const int nsub = (kv_end + 31) / 32;             // 32-key sub-tiles
 
-    issue_k_tile<D, NWAVES>(kg, 0, n, p.kv_row_stride, k_ring, wave, lane);
+    auto k_slot = [&](int j) { return k_ring + (j & (KR - 1)) * T; };
+    auto v_slot = [&](int j) { return v_ring + (j & (VR - 1)) * T; };
+
+    TileDma<D, NWAVES> dma;
+    dma.init(kg, vg, n, p.kv_row_stride, wave, lane);
+    dma.issue_k(0u, k_slot(0), wave);
 
     bf16x8 qfa[KS], qfb[KS];
     {
@@ -332,24 +339,44 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
 
     // sub-tile t needs a mask for the block whose first row is q0?
     auto needs_mask = [&](int t, int q0) { return (t * 32 + 32 > n) || (CAUSAL && (t * 32 + 31 > q0)); };
-    auto k_stage = [&](int j) { return k_ring + (j % 3) * C::kTileBytes; };
-    auto v_stage = [&](int j) { return v_ring + (j & 1) * C::kTileBytes; };
-    auto stage_top = [&](int j) {
-        wait_lds_dma();   // K(j+1), V(j): own pieces landed
-        __syncthreads();  // everyone's landed; everyone is done with K(j-1), V(j-1)
-        if (j + 2 < nst) issue_k_tile<D, NWAVES>(kg, (j + 2) * kKvBlk, n, p.kv_row_stride, k_stage(j + 2), wave, lane);
-        if (j + 1 < nst) issue_v_tile<D, NWAVES>(vg, (j + 1) * kKvBlk, n, p.kv_row_stride, v_stage(j + 1), wave, lane);
+
+    unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // Top of stage j, j a multiple of G.  Afterwards K(j+1 .. j+G) and V(j .. j+G-1) are visible to every wave and
+    // K(j+G+1 .. j+2G), V(j+G .. j+2G-1) are on their way into the ring slots of K(j-G+1 .. j), V(j-G .. j-1), which
+    // nobody reads any more: K tiles are only ever read into the fragment registers kf one step ahead of their use, and
+    // every LDS read of a wave has returned before it arrives at the barrier.
+    auto sync_top = [&](int j) {
+        const unsigned long long s0 = PROF ? stamp() : 0;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // own DMA pieces landed, own LDS reads returned
+        const unsigned long long s1 = PROF ? stamp() : 0;
+        __syncthreads();
+        const unsigned long long s2 = PROF ? stamp() : 0;
+#pragma unroll
+        for (int g = 1; g <= G; ++g)
+            if (j + G + g < nst) dma.issue_k((unsigned)(j + G + g) * dma.stage_step, k_slot(j + G + g), wave);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (j + G + g < nst) dma.issue_v((unsigned)(j + G + g) * dma.stage_step, v_slot(j + G + g), wave);
+        if (PROF) {
+            tm[4] += s1 - s0;
+            tm[5] += s2 - s1;
+            tm[6] += stamp() - s2;
+        }
     };
-    // scores of sub-tile t for both blocks, phase-structured (prologue and tail)
-    auto qk_sub = [&](int t, f32x16& sa, f32x16& sb) {
-        const char* k_lds = k_stage(t >> 1);
+    bf16x8 kf[KS];  // K fragments of the sub-tile whose scores are computed next
+    auto load_kf = [&](int t) {
+        const char* k_lds = k_slot(t >> 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[ks] = load_k_frag<D>(k_lds, k_row_off, k_g, t & 1, ks);
+    };
+    // scores of sub-tile t for both blocks from the fragments in kf, phase-structured (prologue and tail)
+    auto qk_regs = [&](int t, f32x16& sa, f32x16& sb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sa[r] = sb[r] = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 kf = load_k_frag<D>(k_lds, k_row_off, k_g, t & 1, ks);
-            sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfa[ks], sa, 0, 0, 0);
-            sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfb[ks], sb, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qfa[ks], sa, 0, 0, 0);
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qfb[ks], sb, 0, 0, 0);
         }
         if (needs_mask(t, q0a)) mask16(sa, t * 32, q0a + lq, n, hi, CAUSAL);
         if (needs_mask(t, q0b)) mask16(sb, t * 32, q0b + lq, n, hi, CAUSAL);
@@ -361,7 +388,7 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
         exp_range(sa, pfa, c, lz.offa, 8, 16);
         exp_range(sb, pfb, c, lz.offb, 0, 8);
         exp_range(sb, pfb, c, lz.offb, 8, 16);
-        const char* v_lds = v_stage(t >> 1);
+        const char* v_lds = v_slot(t >> 1);
 #pragma unroll
         for (int v = 0; v < 2 * DB; ++v) {
             const bf16x8 vf = load_v_frag<D>(v_lds, v_lane_off, t & 1, v);
@@ -375,62 +402,65 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
         }
     };
 
-    // ---------------- prologue: K(0) landed -> scores of sub-tile 0 ----------------
+    // ---------------- prologue: K(0) landed -> scores of sub-tile 0, fragments of sub-tile 1 ----------------
     wait_lds_dma();
     __syncthreads();
-    if (nst > 1) issue_k_tile<D, NWAVES>(kg, kKvBlk, n, p.kv_row_stride, k_stage(1), wave, lane);
-    issue_v_tile<D, NWAVES>(vg, 0, n, p.kv_row_stride, v_stage(0), wave, lane);
-    qk_sub(0, sa0, sb0);
+#pragma unroll
+    for (int g = 1; g <= G; ++g)
+        if (g < nst) dma.issue_k((unsigned)g * dma.stage_step, k_slot(g), wave);
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+        if (g < nst) dma.issue_v((unsigned)g * dma.stage_step, v_slot(g), wave);
+    load_kf(0);
+    qk_regs(0, sa0, sb0);
+    load_kf(1);
 
-    // ---------------- fast loop: whole stages whose sub-tiles 2j .. 2j+2 are in range and mask-free ----------------
+    // ---------------- fast loop: groups of G whole stages whose sub-tiles 2j .. 2j+2 are in range and mask-free ----------------
     int jf = 0;
     while ((2 * jf + 3) * 32 <= kv_end && !needs_mask(2 * jf + 2, q0a) && !needs_mask(2 * jf + 2, q0b) && !needs_mask(0, q0a)) ++jf;
-    unsigned long long tm[6] = {0, 0, 0, 0, 0, 0};
+    jf -= jf % G;
     const unsigned long long t_begin = PROF ? stamp() : 0;
-    bf16x8 kf0 = load_k_frag<D>(k_stage(0), k_row_off, k_g, 1, 0);  // first K fragment of sub-tile 1 (K(0) has landed)
-    // The two workgroups sharing a CU are arbitrated by age: left alone, the older one runs at nearly single-workgroup speed
-    // and the younger one finishes ~45 % later on an otherwise idle CU.  Alternating a raised priority between them every
-    // stage (which workgroup is which is only a guess from the dispatch order -- it affects speed, never results) keeps
-    // them level, so both use the shared phase to the end.
-    const int prio_phase = (int)((blockIdx.x / (gridDim.x > 1 ? (gridDim.x + 1) / 2 : 1)) & 1);
-    for (int j = 0; j < jf; ++j) {
-        const unsigned long long ts0 = PROF ? stamp() : 0;
-        if (FAIR) {
-            if ((j ^ prio_phase) & 1) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
+    for (int j = 0; j < jf; j += G) {
+        sync_top(j);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const char* v_lds = v_slot(j + g);
+            const char* k_nxt = k_slot(j + g + 1);
+            // step 2(j+g): scores(2(j+g)+1) from kf; P.V(2(j+g)) from V block 0; fetch for scores(2(j+g)+2): K(j+g+1) block 0
+            pp3_step<D, 0, PROF>(v_lds, k_nxt, 0, k_row_off, k_g, v_lane_off, ones_a, qfa, qfb, sa0, sb0, sa1, sb1, oa, ob, pfa, pfb, sta,
+                                 stb, c, lz, kf, tm);
+            // step 2(j+g)+1: scores(2(j+g)+2) from kf; P.V(2(j+g)+1) from V block 1; fetch for scores(2(j+g)+3): K(j+g+1) block 1
+            pp3_step<D, 1, PROF>(v_lds, k_nxt, 1, k_row_off, k_g, v_lane_off, ones_a, qfa, qfb, sa1, sb1, sa0, sb0, oa, ob, pfa, pfb, sta,
+                                 stb, c, lz, kf, tm);
         }
-        stage_top(j);
-        if (PROF) tm[4] += stamp() - ts0;
-        // step 2j: scores(2j+1) from K(j) block 1; P.V(2j) from V(j) block 0; prefetch for scores(2j+2): K(j+1) block 0
-        pp3_step<D, 0, PROF>(k_stage(j), 1, v_stage(j), k_stage(j + 1), 0, k_row_off, k_g, v_lane_off, ones_a, qfa, qfb, sa0, sb0, sa1, sb1,
-                          oa, ob, pfa, pfb, sta, stb, c, lz, kf0, tm);
-        // step 2j+1: scores(2j+2) from K(j+1) block 0; P.V(2j+1) from V(j) block 1; prefetch for scores(2j+3): K(j+1) block 1
-        pp3_step<D, 1, PROF>(k_stage(j + 1), 0, v_stage(j), k_stage(j + 1), 1, k_row_off, k_g, v_lane_off, ones_a, qfa, qfb, sa1, sb1, sa0,
-                          sb0, oa, ob, pfa, pfb, sta, stb, c, lz, kf0, tm);
     }
     if (PROF) {
-        tm[5] = stamp() - t_begin;
+        tm[7] = stamp() - t_begin;
         if (lane == 0 && p.lse != nullptr) {
-            float* dst = p.lse + ((int64_t)blockIdx.x * NWAVES + wave) * 8;
-            for (int i = 0; i < 6; ++i) dst[i] = (float)tm[i];
-            dst[6] = (float)jf;
-            dst[7] = 0.0f;
+            float* dst = p.lse + ((int64_t)blockIdx.x * NWAVES + wave) * 16;
+            for (int i = 0; i < 8; ++i) dst[i] = (float)tm[i];
+            dst[8] = (float)jf;
         }
     }
 
-    // ---------------- tail: remaining sub-tiles, phase-structured, masks applied where needed ----------------
-    // Every wave keeps taking part in the stage barriers / DMA, but only computes the sub-tiles its own rows can see
-    // (causal: the sub-tiles up to the diagonal of its last row).
+    // ---------------- tail: remaining stages, phase-structured, masks applied where needed ----------------
+    // Invariant at the top of stage j: the scores of sub-tile 2j are in s0 with the rescale decision taken, and kf holds the
+    // K fragments of sub-tile 2j+1.  Every wave keeps taking part in the barriers / DMA, but only computes the sub-tiles
+    // its own rows can see (causal: the sub-tiles up to the diagonal of its last row).
     const int nsub_w = CAUSAL ? min(nsub, (q0b + 31) / 32 + 1) : nsub;
     for (int j = jf; j < nst; ++j) {
-        stage_top(j);
+        if (j % G == 0) sync_top(j);
         const int t0 = 2 * j, t1 = 2 * j + 1;
         if (t0 < nsub_w) {
-            finish_sub(t0, sa0, sb0);        // scores(t0) are already in s0 with the rescale decision taken
+            finish_sub(t0, sa0, sb0);
             if (t1 < nsub_w) {
-                qk_sub(t1, sa1, sb1);
+                qk_regs(t1, sa1, sb1);
+                load_kf(t1 + 1);  // K(j+1) block 0: visible since the last barrier
                 finish_sub(t1, sa1, sb1);
-                if (t1 + 1 < nsub_w) qk_sub(t1 + 1, sa0, sb0);  // K(j+1) landed at this stage's barrier
+                if (t1 + 1 < nsub_w) {
+                    qk_regs(t1 + 1, sa0, sb0);
+                    load_kf(t1 + 2);
+                }
             }
         }
     }
@@ -467,23 +497,20 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
     store_block(ob, stb, q0b);
     if (PROF && lane == 0 && p.lse != nullptr) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        p.lse[((int64_t)blockIdx.x * NWAVES + wave) * 8 + 7] = (float)(stamp() - t_entry);  // whole kernel
+        float* dst = p.lse + ((int64_t)blockIdx.x * NWAVES + wave) * 16;
+        dst[9] = (float)(stamp() - t_entry);  // whole kernel
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        float* aux = p.lse + (int64_t)gridDim.x * NWAVES * 8 + ((int64_t)blockIdx.x * NWAVES + wave) * 2;
-        aux[0] = (float)(((xcc & 0xf) << 16) | (((hwid >> 13) & 7) << 8) | (((hwid >> 8) & 0xf) << 4) | ((hwid >> 4) & 3));
-        aux[1] = (float)(t_entry & 0xffffff);
+        dst[10] = (float)(((xcc & 0xf) << 16) | (((hwid >> 13) & 7) << 8) | (((hwid >> 8) & 0xf) << 4) | ((hwid >> 4) & 3));
+        dst[11] = (float)(t_entry & 0xffffff);
     }
 }
 
-static hipError_t launch_pp3_fair(const FwdParams& p0, hipStream_t stream)
+// the buffer-form LDS-DMA addresses a slab with 32-bit byte offsets
+static bool pp3_addressable(const FwdParams& p, int d)
 {
-    FwdParams p = p0;
-    p.q_tiles = (p.n + 255) / 256;
-    dim3 grid((unsigned)(p.bh * p.q_tiles)), block(256);
-    hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<64, 4, false, false, false, true>), grid, block, 0, stream, p);
-    return hipGetLastError();
+    return ((int64_t)(p.n - 1) * p.kv_row_stride + d) * 2 < (int64_t)0xffffffffLL;
 }
 
 static hipError_t launch_pp3_prof(const FwdParams& p0, hipStream_t stream)
@@ -491,11 +518,11 @@ static hipError_t launch_pp3_prof(const FwdParams& p0, hipStream_t stream)
     FwdParams p = p0;
     p.q_tiles = (p.n + 255) / 256;
     dim3 grid((unsigned)(p.bh * p.q_tiles)), block(256);
-    hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<64, 4, false, false, true>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<64, 4, false, false, true, 2>), grid, block, 0, stream, p);
     return hipGetLastError();
 }
 
-template <int D, int NWAVES>
+template <int D, int NWAVES, int G>
 static hipError_t launch_pp3(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
 {
     FwdParams p = p0;
@@ -506,25 +533,32 @@ static hipError_t launch_pp3(const FwdParams& p0, int causal, int out_f32, hipSt
     dim3 grid((unsigned)total), block(NWAVES * kWave);
     if (causal) {
         if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, true, true>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, true, true, false, G>), grid, block, 0, stream, p);
         else
-            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, true, false>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, true, false, false, G>), grid, block, 0, stream, p);
     } else {
         if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, false, true>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, false, true, false, G>), grid, block, 0, stream, p);
         else
-            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, false, false>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, false, false, false, G>), grid, block, 0, stream, p);
     }
     return hipGetLastError();
 }
 
+bool bf16_pipelined_supported(const FwdParams& p, int d) { return (d == 64 || d == 32) && pp3_addressable(p, d); }
+
+// mode: 0 = product configuration (4-wave workgroups: barrier every 2 stages; 2-wave workgroups: every stage),
+//       1 = in-kernel phase timers (D = 64, non-causal; written to lse), 3 = 4-wave workgroups with a barrier every stage
 hipError_t launch_bf16_pipelined(const FwdParams& p, int d, int nwaves, int causal, int out_f32, int mode, hipStream_t stream)
 {
-    if (mode == 1) return launch_pp3_prof(p, stream);   // D = 64 only: in-kernel phase timers (written to lse)
-    if (mode == 2) return launch_pp3_fair(p, stream);   // D = 64 only: alternating priority between co-resident workgroups
-    if (d == 64) return nwaves == 2 ? launch_pp3<64, 2>(p, causal, out_f32, stream) : launch_pp3<64, 4>(p, causal, out_f32, stream);
-    if (d == 32) return nwaves == 2 ? launch_pp3<32, 2>(p, causal, out_f32, stream) : launch_pp3<32, 4>(p, causal, out_f32, stream);
-    return hipErrorInvalidValue;
+    if (!bf16_pipelined_supported(p, d)) return hipErrorInvalidValue;
+    if (mode == 1) return d == 64 ? launch_pp3_prof(p, stream) : hipErrorInvalidValue;
+    if (d == 64) {
+        if (nwaves == 2) return launch_pp3<64, 2, 1>(p, causal, out_f32, stream);
+        return mode == 3 ? launch_pp3<64, 4, 1>(p, causal, out_f32, stream) : launch_pp3<64, 4, 2>(p, causal, out_f32, stream);
+    }
+    if (nwaves == 2) return launch_pp3<32, 2, 1>(p, causal, out_f32, stream);
+    return mode == 3 ? launch_pp3<32, 4, 1>(p, causal, out_f32, stream) : launch_pp3<32, 4, 2>(p, causal, out_f32, stream);
 }
 
 }  // namespace fa
