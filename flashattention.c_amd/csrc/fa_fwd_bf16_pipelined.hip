@@ -120,7 +120,7 @@ __device__ __forceinline__ void exp_range(f32x16& s, bf16x8 (&pf)[2], float c, f
         if (e >= e0 && e < e1) s[e] = exp2_clamp01(fmaf(s[e], c, -off));
 #pragma unroll
     for (int f = 0; f < 2; ++f)
-        if (e1 == 8 * (f + 1) || (e0 < 8 * (f + 1) && e1 > 8 * (f + 1) && false)) {
+        if (e0 < 8 * (f + 1) && e1 >= 8 * (f + 1)) {  // this range completes fragment f
             pf[f] = pack_bf16x8(s, 8 * f);
             asm volatile("" : "+v"(pf[f]));
         }
@@ -129,19 +129,21 @@ __device__ __forceinline__ void exp_range(f32x16& s, bf16x8 (&pf)[2], float c, f
 // cycle stamps for the in-kernel phase profile (PROF builds only)
 __device__ __forceinline__ unsigned long long stamp() { return __builtin_readcyclecounter(); }
 
-// lane-local (no cross-half exchange) maximum of 16 scores: three micro-steps u = 0, 1, 2
+// lane-local (no cross-half exchange) maximum of 16 scores: three micro-steps u = 0, 1, 2.  One asm statement per
+// micro-step (hipcc pads a conservative s_nop between two asm statements that touch the same register).  The operands are
+// accumulators of MFMAs that retired a phase ago (see max3_raw).
 __device__ __forceinline__ void lanemax_step(int u, const f32x16& sx, float (&pm)[4], float& out)
 {
     if (u == 0) {
-        pm[0] = max3_raw(sx[0], sx[1], sx[2]);
-        pm[1] = max3_raw(sx[3], sx[4], sx[5]);
-        pm[2] = max3_raw(sx[6], sx[7], sx[8]);
+        asm volatile("v_max3_f32 %0, %3, %4, %5\n\tv_max3_f32 %1, %6, %7, %8\n\tv_max3_f32 %2, %9, %10, %11"
+                     : "=&v"(pm[0]), "=&v"(pm[1]), "=&v"(pm[2])
+                     : "v"(sx[0]), "v"(sx[1]), "v"(sx[2]), "v"(sx[3]), "v"(sx[4]), "v"(sx[5]), "v"(sx[6]), "v"(sx[7]), "v"(sx[8]));
     } else if (u == 1) {
-        pm[3] = max3_raw(sx[9], sx[10], sx[11]);
-        pm[0] = max3_raw(pm[0], sx[12], sx[13]);
-        pm[1] = max3_raw(pm[1], sx[14], sx[15]);
+        asm volatile("v_max3_f32 %0, %3, %4, %5\n\tv_max3_f32 %1, %1, %6, %7\n\tv_max3_f32 %2, %2, %8, %9"
+                     : "=&v"(pm[3]), "+v"(pm[0]), "+v"(pm[1])
+                     : "v"(sx[9]), "v"(sx[10]), "v"(sx[11]), "v"(sx[12]), "v"(sx[13]), "v"(sx[14]), "v"(sx[15]));
     } else {
-        out = max3_raw(max3_raw(pm[0], pm[1], pm[2]), pm[3], pm[3]);  // (asm outputs: an fmaxf here costs two canonicalising v_max)
+        asm volatile("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %4" : "=&v"(out) : "v"(pm[0]), "v"(pm[1]), "v"(pm[2]), "v"(pm[3]));
     }
 }
 
@@ -210,7 +212,9 @@ __device__ __forceinline__ void pp3_step(const char* v_lds, const char* k_lds2, 
     bf16x8 vf[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) vf[v] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(vlo[v], vhi[v], 0, 1, 2, 3, 4, 5, 6, 7));
-    // ---------------- P1 phase: P.V + row sums of A  ||  exp + pack of B
+    // ---------------- P1 phase: P.V + row sums of A  ||  exp + pack of B (its first E1 elements: the k-step-1 operand of
+    // block B is only needed by the third MFMA of the P2 phase, and P2 has VALU slots to spare)
+    constexpr int E1 = (D == 64) ? 12 : 16;
 #pragma unroll
     for (int v = 0; v < NV + 2; ++v) {
         if (v < NV) {
@@ -219,7 +223,7 @@ __device__ __forceinline__ void pp3_step(const char* v_lds, const char* k_lds2, 
             sta.lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pfa[v - NV], sta.lacc, 0, 0, 0);
         }
         if (v < KS) kf[v] = load_k_frag<D>(k_lds2, k_row_off, k_g, kb_n2, v);   // scores of the NEXT step (kf is free: Q phase done)
-        exp_range(sb_cur, pfb, c, lz.offb, 16 * v / (NV + 2), 16 * (v + 1) / (NV + 2));
+        exp_range(sb_cur, pfb, c, lz.offb, E1 * v / (NV + 2), E1 * (v + 1) / (NV + 2));
         __builtin_amdgcn_sched_barrier(0);
     }
     if (PROF) t2 = stamp();
@@ -235,9 +239,10 @@ __device__ __forceinline__ void pp3_step(const char* v_lds, const char* k_lds2, 
         } else {
             stb.lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pfb[v - NV], stb.lacc, 0, 0, 0);
         }
+        if (E1 < 16 && v < 2) exp_range(sb_cur, pfb, c, lz.offb, E1 + (16 - E1) * v / 2, E1 + (16 - E1) * (v + 1) / 2);
 #pragma unroll
         for (int u = 0; u < 6; ++u)
-            if (u * NV / 6 == v) {
+            if ((E1 < 16 ? 2 + u / 2 : u * NV / 6) == v) {
                 if (u < 3) lanemax_step(u, sa_nxt, pm, lma);
                 else lanemax_step(u - 3, sb_nxt, pm, lmb);
             }
@@ -353,10 +358,10 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
         const unsigned long long s2 = PROF ? stamp() : 0;
 #pragma unroll
         for (int g = 1; g <= G; ++g)
-            if (j + G + g < nst) dma.issue_k((unsigned)(j + G + g) * dma.stage_step, k_slot(j + G + g), wave);
+            if (__builtin_expect(j + G + g < nst, 1)) dma.issue_k((unsigned)(j + G + g) * dma.stage_step, k_slot(j + G + g), wave);
 #pragma unroll
         for (int g = 0; g < G; ++g)
-            if (j + G + g < nst) dma.issue_v((unsigned)(j + G + g) * dma.stage_step, v_slot(j + G + g), wave);
+            if (__builtin_expect(j + G + g < nst, 1)) dma.issue_v((unsigned)(j + G + g) * dma.stage_step, v_slot(j + G + g), wave);
         if (PROF) {
             tm[4] += s1 - s0;
             tm[5] += s2 - s1;
