@@ -460,6 +460,9 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
                 case 24: return launch_bf16_pipelined(p, 64, 2, causal, out_f32, 0, stream);
                 case 22: return launch_bf16_pipelined(p, 64, 4, 0, 0, 1, stream);
                 case 25: return launch_bf16_pipelined(p, 64, 4, causal, out_f32, 3, stream);  // barrier every stage
+                case 30: return launch_bf16_x4(p, causal, out_f32, 2, stream);
+                case 31: return launch_bf16_x4(p, causal, out_f32, 1, stream);
+                case 32: return launch_bf16_x4(p, causal, out_f32, 4, stream);
                 case 10: return launch_w4<64, 4, 4>(p, causal, out_f32, stream);       // 4 waves/SIMD on the VALU diet
                 default: return launch_bf16_pp2(p, causal, out_f32, variant, stream);  // 9 = pp2, 6, 11..21 = its ablations
             }

@@ -1,7 +1,7 @@
 // fa_fwd_bf16_pipelined.hip -- the bf16 kernel that ships for D = 64 (and non-causal D = 32): two 32-row blocks per wave in
 // lockstep over 32-key sub-tiles, software-pipelined inside one instruction stream ("pp3").  Design notes in the block
 // comment below and in DESIGN.md section 3.
-#include "fa_bf16_common.h"
+#include "fa_bf16_step.h"
 #include "fa_kernels.h"
 
 namespace fa {
@@ -27,49 +27,6 @@ struct Plan3 {
 struct Lazy2 {  // exponent offsets in use for the two blocks
     float offa, offb;
 };
-
-// K fragment of sub-tile (stage-local 32-key block kb), k-step ks
-template <int D>
-__device__ __forceinline__ bf16x8 load_k_frag(const char* k_lds, int k_row_off, int k_g, int kb, int ks)
-{
-    return *(const bf16x8*)(k_lds + k_row_off + kb * 32 * (2 * D) + (((2 * ks) ^ k_g) * 16));
-}
-// V^T fragment v = tt * DB + db of stage-local 32-key block kb
-template <int D>
-__device__ __forceinline__ bf16x8 load_v_frag(const char* v_lds, int v_lane_off, int kb, int v)
-{
-    constexpr int DB = D / 32;
-    const int tt = v / DB, db = v % DB;
-    const int off0 = ((kb * 8 + 4 * tt + 0) * (D / 16) + 2 * db) * 128;
-    const int off1 = ((kb * 8 + 4 * tt + 2) * (D / 16) + 2 * db) * 128;
-    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_lds + v_lane_off + off0));
-    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_lds + v_lane_off + off1));
-    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
-}
-
-// The same fragment through inline asm.  hipcc orders every ds_read_b64_tr_b16 *builtin* behind all LDS-DMA in flight
-// (s_waitcnt vmcnt(0) in front of the first one after a global_load_lds), which would expose the whole latency of the
-// next stage's DMA once per stage; an asm read is invisible to that pass.  The caller owns the wait: wait_v_frags()
-// before the first MFMA that consumes them.  KB / V must be compile-time (immediate offsets).
-template <int D, int KB, int V>
-__device__ __forceinline__ void load_v_frag_asm(unsigned v_addr, s16x4& lo, s16x4& hi)
-{
-    constexpr int DB = D / 32;
-    constexpr int tt = V / DB, db = V % DB;
-    constexpr int off0 = ((KB * 8 + 4 * tt + 0) * (D / 16) + 2 * db) * 128;
-    constexpr int off1 = ((KB * 8 + 4 * tt + 2) * (D / 16) + 2 * db) * 128;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(v_addr), "i"(off0));
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(v_addr), "i"(off1));
-}
-
-__device__ __forceinline__ float rowmax16(const f32x16& s)
-{
-    float p0 = max3_safe(s[0], s[1], s[2]), p1 = max3_safe(s[3], s[4], s[5]);
-    float p2 = max3_safe(s[6], s[7], s[8]), p3 = max3_safe(s[9], s[10], s[11]);
-    p0 = max3_safe(p0, s[12], s[13]);
-    p1 = max3_safe(p1, s[14], s[15]);
-    return xhalf_max(fmaxf(max3_safe(p0, p1, p2), p3));
-}
 
 // decision for both blocks at once (one rare wave-uniform branch per step)
 template <int D>
@@ -102,51 +59,6 @@ __device__ __forceinline__ void lazy_rescale2(float mxa, float mxb, float c, Blo
     lz.offa = sta.m + kLazyThr;
     lz.offb = stb.m + kLazyThr;
 }
-
-__device__ __forceinline__ void mask16(f32x16& s, int key0, int qi, int n, int hi, bool causal)
-{
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int key = key0 + 4 * hi + (r & 3) + 8 * (r >> 2);
-        if ((key >= n) || (causal && key > qi)) s[r] = -INFINITY;
-    }
-}
-
-// exp + pack of one block's 16 scores, element range [e0, e1) and pack of fragment(s) whose elements are complete
-__device__ __forceinline__ void exp_range(f32x16& s, bf16x8 (&pf)[2], float c, float off, int e0, int e1)
-{
-#pragma unroll
-    for (int e = 0; e < 16; ++e)
-        if (e >= e0 && e < e1) s[e] = exp2_clamp01(fmaf(s[e], c, -off));
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-        if (e0 < 8 * (f + 1) && e1 >= 8 * (f + 1)) {  // this range completes fragment f
-            pf[f] = pack_bf16x8(s, 8 * f);
-            asm volatile("" : "+v"(pf[f]));
-        }
-}
-
-// cycle stamps for the in-kernel phase profile (PROF builds only)
-__device__ __forceinline__ unsigned long long stamp() { return __builtin_readcyclecounter(); }
-
-// lane-local (no cross-half exchange) maximum of 16 scores: three micro-steps u = 0, 1, 2.  One asm statement per
-// micro-step (hipcc pads a conservative s_nop between two asm statements that touch the same register).  The operands are
-// accumulators of MFMAs that retired a phase ago (see max3_raw).
-__device__ __forceinline__ void lanemax_step(int u, const f32x16& sx, float (&pm)[4], float& out)
-{
-    if (u == 0) {
-        asm volatile("v_max3_f32 %0, %3, %4, %5\n\tv_max3_f32 %1, %6, %7, %8\n\tv_max3_f32 %2, %9, %10, %11"
-                     : "=&v"(pm[0]), "=&v"(pm[1]), "=&v"(pm[2])
-                     : "v"(sx[0]), "v"(sx[1]), "v"(sx[2]), "v"(sx[3]), "v"(sx[4]), "v"(sx[5]), "v"(sx[6]), "v"(sx[7]), "v"(sx[8]));
-    } else if (u == 1) {
-        asm volatile("v_max3_f32 %0, %3, %4, %5\n\tv_max3_f32 %1, %1, %6, %7\n\tv_max3_f32 %2, %2, %8, %9"
-                     : "=&v"(pm[3]), "+v"(pm[0]), "+v"(pm[1])
-                     : "v"(sx[9]), "v"(sx[10]), "v"(sx[11]), "v"(sx[12]), "v"(sx[13]), "v"(sx[14]), "v"(sx[15]));
-    } else {
-        asm volatile("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %4" : "=&v"(out) : "v"(pm[0]), "v"(pm[1]), "v"(pm[2]), "v"(pm[3]));
-    }
-}
-
 // One pipelined step.  CUR/NXT score buffers are passed by reference (the caller swaps them every step).
 //   kf           : K fragments of sub-tile t+1 (scores computed in this step), fetched during the previous step
 //   v_lds/KB_C   : LDS address / 32-key block of the V sub-tile t (accumulated in this step)

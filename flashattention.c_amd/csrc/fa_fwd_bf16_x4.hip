@@ -1,0 +1,481 @@
+// fa_fwd_bf16_x4.hip -- bf16 kernel for large grids at D = 64: ONE wave per SIMD, four 32-row blocks per wave (128 query rows),
+// the whole 512-entry register file of the SIMD for that wave.
+//
+// Why: on gfx950 two waves of a SIMD do not issue VALU work side by side once matrix instructions are in their streams
+// (a wave parked on the busy matrix pipe holds the vector issue port; measured in profiles/ubench), so the loop is bound
+// by the number of instructions issued per MFMA, and both the chip's power budget and that issue budget are spent best
+// by the stream with the fewest instructions per FLOP.  Four blocks per wave halve the LDS fragment reads, barriers, DMA
+// and per-step bookkeeping per FLOP compared with the two-block kernel (fa_fwd_bf16_pipelined.hip); the single resident
+// wave needs every latency hidden by the software pipeline itself:
+//
+//   step t (32 keys, 40 MFMA slots):   K.Q^T of sub-tile t+1 for blocks A,B | P.V + row sums of A | K.Q^T (t+1) for C,D, first half
+//                                      | P.V B | K.Q^T C,D second half | P.V C | P.V D
+//   VALU work (exp + pack of A, B, C, D for sub-tile t, then the lane maxima of sub-tile t+1 and the rescale test) is cut
+//   into ~4-instruction units and dealt out over the MFMA slots in proportion to their length, which by construction
+//   finishes exp(X) before P.V(X) and starts max(X) only after K.Q^T(X) has retired.
+//   V^T fragments of the step are read in its first four slots, the K fragments of the next step in slots 28..31.
+#include <utility>
+#include "fa_bf16_step.h"
+#include "fa_kernels.h"
+
+namespace fa {
+
+constexpr int kNB = 4;  // 32-row blocks per wave
+
+// ---- matrix instructions with explicit register files ------------------------------------------------------------------
+// With one wave per SIMD the wave owns 256 architectural VGPRs and 256 accumulation registers (AGPRs).  VALU instructions
+// only reach the former, MFMA operands may sit in either.  hipcc picks ONE form for every MFMA of a function (all
+// accumulators in AGPRs: the scores then need a v_accvgpr_read per element; or all in VGPRs: the Q fragments and
+// output accumulators are shuttled through v_accvgpr copies) -- either way hundreds of extra issue slots per step.  So
+// the placement is stated per instruction:   scores S -> VGPRs (the softmax reads them),   O, row sums -> AGPRs
+// (only MFMAs touch them in the loop),   Q fragments -> AGPRs (B operand),   K / V^T / P fragments -> VGPRs.
+// The price: hipcc does not see an MFMA inside an asm statement, so the hazards are ours --
+//   * MFMA result -> VALU read: the static schedule reads scores >= 7 slots after their last MFMA; every cold path
+//     (tail, rescale branch, epilogue) calls mfma_drain() first;
+//   * MFMA -> dependent MFMA (same accumulator): at least one independent 32x32x16 MFMA (32 cycles) sits between them;
+//   * LDS / VALU results -> MFMA operands are ordinary register dependencies (interlocked; waits counted by hipcc or by
+//     the explicit lgkmcnt wait in front of the first P.V slot).
+__device__ __forceinline__ void mfma_s_first(f32x16& s, const bf16x8& kf, const bf16x8& q)
+{
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s) : "v"(kf), "a"(q));
+}
+__device__ __forceinline__ void mfma_s(f32x16& s, const bf16x8& kf, const bf16x8& q)
+{
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(kf), "a"(q));
+}
+__device__ __forceinline__ void mfma_o(f32x16& o, const bf16x8& vf, const bf16x8& pfrag)
+{
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(vf), "v"(pfrag));
+}
+__device__ __forceinline__ void mfma_l(f32x4_t& l, const bf16x8& ones, const bf16x8& pfrag)
+{
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(pfrag));
+}
+
+// (rare, wave-uniform) move the exponent references of all blocks; everything still at the old reference is scaled once
+__device__ __forceinline__ void x4_rescale(const float (&mx)[kNB], float c, BlockState (&st)[kNB], f32x16 (&o)[kNB][2], float (&off)[kNB])
+{
+    bool any = false;
+    float mc[kNB];
+#pragma unroll
+    for (int b = 0; b < kNB; ++b) {
+        mc[b] = mx[b] * c;
+        mc[b] = fmaf(-fabsf(mc[b]), 0x1p-23f, mc[b]);
+        any = any || (mc[b] - st[b].m > kLazyThr);
+    }
+    if (__builtin_expect(__any(any), 0)) {
+        asm volatile("; lazy rescale (four blocks)" ::: "memory");
+        mfma_drain();  // the accumulators rescaled below may have an MFMA in flight (hazard not padded across the branch)
+#pragma unroll
+        for (int b = 0; b < kNB; ++b) {
+            const float nm = fmaxf(st[b].m, mc[b]);
+            const float a = fast_exp2(st[b].m - nm);
+            st[b].m = nm;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[b][db][r] *= a;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[b].lacc[r] *= a;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < kNB; ++b) off[b] = st[b].m + kLazyThr;
+}
+
+// ---- static schedule of one step -------------------------------------------------------------------------------------
+// MFMA slot i -> what it is
+struct X4Slot {
+    int kind;  // 0 = K.Q^T, 1 = P.V, 2 = row sum
+    int blk, idx;
+};
+__device__ __host__ constexpr X4Slot x4_pv_group(int blk, int j)  // six slots: no two dependent MFMAs adjacent
+{
+    if (j == 2) return {2, blk, 0};
+    if (j == 5) return {2, blk, 1};
+    return {1, blk, j < 2 ? j : j - 1};
+}
+__device__ __host__ constexpr X4Slot x4_slot(int i)
+{
+    if (i < 8) return {0, i % 2, i / 2};                              // K.Q^T A,B   k-step i/2
+    if (i < 14) return x4_pv_group(0, i - 8);                         // P.V + row sums A
+    if (i < 18) return {0, 2 + (i - 14) % 2, (i - 14) / 2};           // K.Q^T C,D   k-steps 0,1
+    if (i < 24) return x4_pv_group(1, i - 18);                        // P.V + row sums B
+    if (i < 28) return {0, 2 + (i - 24) % 2, 2 + (i - 24) / 2};       // K.Q^T C,D   k-steps 2,3
+    if (i < 34) return x4_pv_group(2, i - 28);                        // P.V + row sums C
+    return x4_pv_group(3, i - 34);                                    // P.V + row sums D
+}
+constexpr int kX4Slots = 40;
+constexpr int kX4Units = 53;  // 4 blocks x (8 exp pairs + 2 packs) + 4 x 3 max micro-steps + 1 test
+__device__ __host__ constexpr int x4_weight_before(int i)  // in half-slots: a 32x32x16 slot = 2, a 16x16x32 slot = 1
+{
+    int w = 0;
+    for (int k = 0; k < i; ++k) w += (x4_slot(k).kind == 2) ? 1 : 2;
+    return w;
+}
+constexpr int kX4Weight = x4_weight_before(kX4Slots);  // 72
+struct X4Table {
+    int ub[kX4Slots + 1];  // VALU units dealt out before slot i
+};
+__device__ __host__ constexpr X4Table x4_make_table()
+{
+    X4Table t{};
+    for (int i = 0; i <= kX4Slots; ++i) t.ub[i] = kX4Units * x4_weight_before(i) / kX4Weight;
+    return t;
+}
+
+// One step.  sc: scores of sub-tile t (consumed), sn: scores of sub-tile t+1 (produced); kf: K fragments of sub-tile t+1 on
+// entry, of sub-tile t+2 (read from k_nxt / block kb_n2) on exit.  Returns the lane's rescale test for sub-tile t+1.
+// Every slot / unit index is a template parameter (fold expressions over integer sequences): nothing here relies on the
+// optimiser unrolling a 40 x 53 loop nest to resolve the register arrays.
+struct X4Ctx {
+    const bf16x8& ones_a;
+    const bf16x8 (&qf)[kNB][4];
+    f32x16 (&sc)[kNB];
+    f32x16 (&sn)[kNB];
+    f32x16 (&o)[kNB][2];
+    BlockState (&st)[kNB];
+    const float (&off)[kNB];
+    bf16x8 (&kf)[4];
+    float (&lm)[kNB];
+    float c;
+    const char* k_nxt;
+    int kb_n2, k_row_off, k_g;
+    unsigned v_addr;
+    s16x4 vlo[4], vhi[4];
+    bf16x8 vf[4];
+    bf16x8 pf[kNB][2];
+    float pm[4];
+    bool need;
+};
+
+template <int U>
+__device__ __forceinline__ void x4_unit(X4Ctx& x)
+{
+    if constexpr (U < 40) {
+        constexpr int b = U / 10, k = U % 10;
+        if constexpr (k == 4 || k == 9) {
+            x.pf[b][k / 5] = pack_bf16x8(x.sc[b], 8 * (k / 5));
+            asm volatile("" : "+v"(x.pf[b][k / 5]));
+        } else {
+            constexpr int e = 2 * (k < 4 ? k : k - 1);
+            x.sc[b][e] = exp2_clamp01(fmaf(x.sc[b][e], x.c, -x.off[b]));
+            x.sc[b][e + 1] = exp2_clamp01(fmaf(x.sc[b][e + 1], x.c, -x.off[b]));
+        }
+    } else if constexpr (U < 52) {
+        constexpr int b = (U - 40) / 3, m = (U - 40) % 3;
+        lanemax_step(m, x.sn[b], x.pm, x.lm[b]);
+    } else {
+        float t = fmaf(x.lm[0], x.c, -x.off[0]);
+#pragma unroll
+        for (int b = 1; b < kNB; ++b) t = fmaxf(t, fmaf(x.lm[b], x.c, -x.off[b]));
+        x.need = t > 0.0f;  // off = m + kLazyThr
+    }
+}
+template <int U0, int... Us>
+__device__ __forceinline__ void x4_units(X4Ctx& x, std::integer_sequence<int, Us...>)
+{
+    (x4_unit<U0 + Us>(x), ...);
+}
+
+template <int KB_C, int I>
+__device__ __forceinline__ void x4_slot_body(X4Ctx& x)
+{
+    constexpr int D = 64;
+    constexpr X4Slot sl = x4_slot(I);
+    constexpr X4Table tab = x4_make_table();
+    if constexpr (I == 8) {
+        // the asm-issued V^T reads were started in slots 0..3; this wait orders them before the first P.V MFMA
+#pragma unroll
+        for (int v = 0; v < 4; ++v) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x.vlo[v]), "+v"(x.vhi[v]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) x.vf[v] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(x.vlo[v], x.vhi[v], 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+    if constexpr (I < 4) load_v_frag_asm<D, KB_C, I>(x.v_addr, x.vlo[I], x.vhi[I]);
+    if constexpr (sl.kind == 0) {
+        if constexpr (sl.idx == 0) mfma_s_first(x.sn[sl.blk], x.kf[sl.idx], x.qf[sl.blk][sl.idx]);
+        else mfma_s(x.sn[sl.blk], x.kf[sl.idx], x.qf[sl.blk][sl.idx]);
+    } else if constexpr (sl.kind == 1) {
+        mfma_o(x.o[sl.blk][sl.idx % 2], x.vf[sl.idx], x.pf[sl.blk][sl.idx / 2]);
+    } else {
+        mfma_l(x.st[sl.blk].lacc, x.ones_a, x.pf[sl.blk][sl.idx]);
+    }
+    if constexpr (I >= 28 && I < 32) x.kf[I - 28] = load_k_frag<D>(x.k_nxt, x.k_row_off, x.k_g, x.kb_n2, I - 28);  // last K.Q^T: slot 27
+    x4_units<tab.ub[I]>(x, std::make_integer_sequence<int, tab.ub[I + 1] - tab.ub[I]>{});
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int KB_C, int... Is>
+__device__ __forceinline__ void x4_slots(X4Ctx& x, std::integer_sequence<int, Is...>)
+{
+    (x4_slot_body<KB_C, Is>(x), ...);
+}
+
+template <int KB_C>
+__device__ __forceinline__ bool x4_step(const char* v_lds, const char* k_nxt, int kb_n2, int k_row_off, int k_g, int v_lane_off,
+                                        const bf16x8& ones_a, const bf16x8 (&qf)[kNB][4], f32x16 (&sc)[kNB], f32x16 (&sn)[kNB],
+                                        f32x16 (&o)[kNB][2], BlockState (&st)[kNB], float c, const float (&off)[kNB], bf16x8 (&kf)[4],
+                                        float (&lm)[kNB])
+{
+    X4Ctx x{ones_a, qf, sc, sn, o, st, off, kf, lm, c, k_nxt, kb_n2, k_row_off, k_g, (unsigned)(size_t)(lds_s16x4_t*)(v_lds + v_lane_off)};
+    x.need = false;
+    x4_slots<KB_C>(x, std::make_integer_sequence<int, kX4Slots>{});
+    return x.need;
+}
+
+template <int NWAVES, bool CAUSAL, bool OUT_F32, int G>
+__global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdParams p)
+{
+    constexpr int D = 64, KS = 4, DB = 2;
+    using C = Bf16Cfg<D, NWAVES>;
+    constexpr int BM = NWAVES * 32 * kNB;
+    constexpr int KR = 2 * G, VR = 2 * G;
+    static_assert(G == 1 || G == 2 || G == 4, "ring index arithmetic needs a power of two");
+    constexpr int T = C::kTileBytes;
+
+    __shared__ __attribute__((aligned(1024))) char smem[(KR + VR) * T];  // K ring, then V ring
+    char* const k_ring = smem;
+    char* const v_ring = smem + KR * T;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lq = lane & 31, hi = lane >> 5;
+
+    const int total = p.bh * p.q_tiles;
+    const int w = xcd_remap(blockIdx.x, total);
+    const int slab = w / p.q_tiles;
+    int qt = w % p.q_tiles;
+    if (CAUSAL) qt = p.q_tiles - 1 - qt;
+    const int n = p.n;
+    const int q0 = qt * BM + wave * 32 * kNB;  // first row of block 0; block b starts at q0 + 32 b
+
+    const int b = slab / p.heads, h = slab % p.heads;
+    const __bf16* qg = (const __bf16*)p.q + b * p.q_batch_stride + h * p.q_head_stride;
+    const __bf16* kg = (const __bf16*)p.k + b * p.kv_batch_stride + h * p.kv_head_stride;
+    const __bf16* vg = (const __bf16*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
+    const int64_t o_slab_off = b * p.o_batch_stride + h * p.o_head_stride;
+
+    int kv_end = n;
+    if (CAUSAL) kv_end = min(n, qt * BM + BM);
+    const int nst = (kv_end + kKvBlk - 1) / kKvBlk;  // 64-key stages
+    const int nsub = (kv_end + 31) / 32;             // 32-key sub-tiles
+
+    auto k_slot = [&](int j) { return k_ring + (j & (KR - 1)) * T; };
+    auto v_slot = [&](int j) { return v_ring + (j & (VR - 1)) * T; };
+
+    TileDma<D, NWAVES> dma;
+    dma.init(kg, vg, n, p.kv_row_stride, wave, lane);
+    dma.issue_k(0u, k_slot(0), wave);
+
+    bf16x8 qf[kNB][KS];
+#pragma unroll
+    for (int blk = 0; blk < kNB; ++blk) {
+        const __bf16* qr = qg + (int64_t)min(q0 + 32 * blk + lq, n - 1) * p.q_row_stride + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[blk][ks] = *(const bf16x8*)(qr + ks * 16);
+    }
+    const bf16x8 ones_a = rowsum_a_operand(lane);
+
+    f32x16 o[kNB][DB], s0[kNB], s1[kNB];
+    BlockState st[kNB];
+    float off[kNB], lm[kNB];
+#pragma unroll
+    for (int blk = 0; blk < kNB; ++blk) {
+        st[blk].m = -INFINITY;
+        lm[blk] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[blk].lacc[r] = 0.0f;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[blk][db][r] = 0.0f;
+    }
+
+    const int k_row_off = lq * C::kRowBytes;
+    const int k_g = hi ^ k_swizzle<D>(lq);
+    const int li = lane & 15;
+    const int v_lane_off = (hi * (D / 16) + ((lane >> 4) & 1)) * 128 + (li >> 2) * 32 + (li & 3) * 8;
+    const float c = p.scale_log2e;
+
+    // sub-tile t needs a mask for the block whose first row is qb?
+    auto needs_mask = [&](int t, int qb) { return (t * 32 + 32 > n) || (CAUSAL && (t * 32 + 31 > qb)); };
+
+    // Top of stage j, j a multiple of G: K(j+1 .. j+G), V(j .. j+G-1) visible; K(j+G+1 .. j+2G), V(j+G .. j+2G-1) enqueued into the
+    // ring slots nobody reads any more (K tiles are only read into kf one step ahead of their use, and every LDS read of
+    // a wave has returned before it arrives at the barrier).
+    auto sync_top = [&](int j) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int g = 1; g <= G; ++g)
+            if (__builtin_expect(j + G + g < nst, 1)) dma.issue_k((unsigned)(j + G + g) * dma.stage_step, k_slot(j + G + g), wave);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (__builtin_expect(j + G + g < nst, 1)) dma.issue_v((unsigned)(j + G + g) * dma.stage_step, v_slot(j + G + g), wave);
+    };
+    bf16x8 kf[KS];
+    auto load_kf = [&](int t) {
+        const char* k_lds = k_slot(t >> 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[ks] = load_k_frag<D>(k_lds, k_row_off, k_g, t & 1, ks);
+    };
+    // scores of sub-tile t for all blocks from the fragments in kf, phase-structured (prologue and tail)
+    auto qk_regs = [&](int t, f32x16 (&s)[kNB]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int blk = 0; blk < kNB; ++blk) {
+                if (ks == 0) mfma_s_first(s[blk], kf[ks], qf[blk][ks]);
+                else mfma_s(s[blk], kf[ks], qf[blk][ks]);
+            }
+        mfma_drain();  // cold path: let the scores retire before the VALU reads them
+        float mx[kNB];
+#pragma unroll
+        for (int blk = 0; blk < kNB; ++blk) {
+            if (needs_mask(t, q0 + 32 * blk)) mask16(s[blk], t * 32, q0 + 32 * blk + lq, n, hi, CAUSAL);
+            mx[blk] = rowmax16(s[blk]);
+        }
+        x4_rescale(mx, c, st, o, off);
+    };
+    // exp, pack, P.V and row sums of sub-tile t for all blocks, phase-structured (tail)
+    auto finish_sub = [&](int t, f32x16 (&s)[kNB]) {
+        const char* v_lds = v_slot(t >> 1);
+        bf16x8 vf[2 * DB];
+#pragma unroll
+        for (int v = 0; v < 2 * DB; ++v) vf[v] = load_v_frag<D>(v_lds, v_lane_off, t & 1, v);
+#pragma unroll
+        for (int blk = 0; blk < kNB; ++blk) {
+            bf16x8 pf[2];
+            exp_range(s[blk], pf, c, off[blk], 0, 8);
+            exp_range(s[blk], pf, c, off[blk], 8, 16);
+#pragma unroll
+            for (int v = 0; v < 2 * DB; ++v) mfma_o(o[blk][v % DB], vf[v], pf[v / DB]);
+            mfma_l(st[blk].lacc, ones_a, pf[0]);
+            asm volatile("s_nop 7");  // dependent row-sum MFMAs back to back: the hazard is ours
+            mfma_l(st[blk].lacc, ones_a, pf[1]);
+        }
+    };
+
+    // ---------------- prologue: K(0) landed -> scores of sub-tile 0, fragments of sub-tile 1 ----------------
+    wait_lds_dma();
+    __syncthreads();
+#pragma unroll
+    for (int g = 1; g <= G; ++g)
+        if (g < nst) dma.issue_k((unsigned)g * dma.stage_step, k_slot(g), wave);
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+        if (g < nst) dma.issue_v((unsigned)g * dma.stage_step, v_slot(g), wave);
+    load_kf(0);
+    qk_regs(0, s0);
+    load_kf(1);
+
+    // ---------------- fast loop: groups of G whole stages whose sub-tiles 2j .. 2j+2 are in range and mask-free ----------------
+    int jf = 0;
+    while ((2 * jf + 3) * 32 <= kv_end && !needs_mask(2 * jf + 2, q0) && !needs_mask(0, q0)) ++jf;
+    jf -= jf % G;
+    for (int j = 0; j < jf; j += G) {
+        sync_top(j);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const char* v_lds = v_slot(j + g);
+            const char* k_nxt = k_slot(j + g + 1);
+            bool need = x4_step<0>(v_lds, k_nxt, 0, k_row_off, k_g, v_lane_off, ones_a, qf, s0, s1, o, st, c, off, kf, lm);
+            if (__builtin_expect(__any(need), 0)) {
+                float mx[kNB];
+#pragma unroll
+                for (int blk = 0; blk < kNB; ++blk) mx[blk] = xhalf_max(lm[blk]);
+                x4_rescale(mx, c, st, o, off);
+            }
+            need = x4_step<1>(v_lds, k_nxt, 1, k_row_off, k_g, v_lane_off, ones_a, qf, s1, s0, o, st, c, off, kf, lm);
+            if (__builtin_expect(__any(need), 0)) {
+                float mx[kNB];
+#pragma unroll
+                for (int blk = 0; blk < kNB; ++blk) mx[blk] = xhalf_max(lm[blk]);
+                x4_rescale(mx, c, st, o, off);
+            }
+        }
+    }
+
+    // ---------------- tail: remaining stages, phase-structured, masks applied where needed ----------------
+    // Invariant at the top of stage j: scores of sub-tile 2j in s0 with the rescale decision taken, kf = fragments of sub-tile 2j+1.
+    const int nsub_w = CAUSAL ? min(nsub, (q0 + 32 * (kNB - 1) + 31) / 32 + 1) : nsub;
+    for (int j = jf; j < nst; ++j) {
+        if (j % G == 0) sync_top(j);
+        const int t0 = 2 * j, t1 = 2 * j + 1;
+        if (t0 < nsub_w) {
+            finish_sub(t0, s0);
+            if (t1 < nsub_w) {
+                qk_regs(t1, s1);
+                load_kf(t1 + 1);
+                finish_sub(t1, s1);
+                if (t1 + 1 < nsub_w) {
+                    qk_regs(t1 + 1, s0);
+                    load_kf(t1 + 2);
+                }
+            }
+        }
+    }
+
+    // ---------------- store ----------------
+    mfma_drain();
+#pragma unroll
+    for (int blk = 0; blk < kNB; ++blk) {
+        const float lt = st[blk].lacc[0];
+        const float inv = 1.0f / lt;
+        const int qi = q0 + 32 * blk + lq;
+        if (qi < n) {
+            const int64_t o_off = o_slab_off + (int64_t)qi * p.o_row_stride + 4 * hi;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (OUT_F32) {
+                        f32x4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = o[blk][db][4 * g + e] * inv;
+                        *(f32x4*)((float*)p.o + o_off + db * 32 + 8 * g) = pk;
+                    } else {
+                        bf16x4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = (__bf16)(o[blk][db][4 * g + e] * inv);
+                        *(bf16x4*)((__bf16*)p.o + o_off + db * 32 + 8 * g) = pk;
+                    }
+                }
+            if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (st[blk].m + kLazyThr + __builtin_amdgcn_logf(lt)) * kLn2;
+        }
+    }
+}
+
+template <int G>
+static hipError_t launch_x4(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
+{
+    FwdParams p = p0;
+    constexpr int NWAVES = 4, BM = NWAVES * 32 * kNB;
+    p.q_tiles = (p.n + BM - 1) / BM;
+    const int64_t total = (int64_t)p.bh * p.q_tiles;
+    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)total), block(NWAVES * kWave);
+    if (causal) {
+        if (out_f32)
+            hipLaunchKernelGGL((fa_fwd_bf16_x4_kernel<NWAVES, true, true, G>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((fa_fwd_bf16_x4_kernel<NWAVES, true, false, G>), grid, block, 0, stream, p);
+    } else {
+        if (out_f32)
+            hipLaunchKernelGGL((fa_fwd_bf16_x4_kernel<NWAVES, false, true, G>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((fa_fwd_bf16_x4_kernel<NWAVES, false, false, G>), grid, block, 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
+// D = 64 only; mode selects the barrier period (stages)
+hipError_t launch_bf16_x4(const FwdParams& p, int causal, int out_f32, int mode, hipStream_t stream)
+{
+    if (!bf16_pipelined_supported(p, 64)) return hipErrorInvalidValue;
+    if (mode == 1) return launch_x4<1>(p, causal, out_f32, stream);
+    if (mode == 4) return launch_x4<4>(p, causal, out_f32, stream);
+    return launch_x4<2>(p, causal, out_f32, stream);
+}
+
+}  // namespace fa
