@@ -214,6 +214,16 @@ def main():
                 "algorithmic_flop_per_launch": fwd_flop(bh, n, d, causal),
                 "algorithmic_hbm_bytes_per_launch": algorithmic_bytes(bh, n, d, elem),
                 "hbm_gbps_at_algorithmic_bytes": round(algorithmic_bytes(bh, n, d, elem) / (kms * 1e-3) / 1e9, 1)}
+        if not args.no_extras:
+            # the same launches captured into one hipGraph and replayed (no stream-launch gap between kernels); reported
+            # beside the stream-launch figures above, never instead of them
+            try:
+                gms = fa.time_forward(q, k, v, causal, scale=args.scale, warmup=3, iters=max(10, min(args.steps, 50)), out=out, graph=True)
+                gtf = fwd_flop(bh, n, d, causal) / (gms * 1e-3) / 1e12
+                extras["graph_replay"] = {"kernel_ms": round(gms, 4), "tflops": round(gtf, 2),
+                                          "frac_mfma_peak": round(gtf / PEAK_TFLOPS[dtype], 4)}
+            except Exception as e:  # pragma: no cover - informational only
+                extras["graph_replay"] = {"error": repr(e)}
         if not args.no_extras and world == 1 and args.workload == "c4":
             # the same shape in exact fp32 (config c3) and the README shape (c2), a few launches each
             for name in ("c3", "c2"):

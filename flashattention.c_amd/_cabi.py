@@ -13,7 +13,7 @@ FA_KERNEL_AUTO, FA_KERNEL_NAIVE, FA_KERNEL_MFMA = 0, 1, 2
 
 # every symbol include/flashattn_amd.h declares
 EXPORTED_SYMBOLS = (
-    "fa_forward", "fa_forward_ex", "fa_forward_sharded", "fa_forward_packed_qkv", "fa_time_forward",
+    "fa_forward", "fa_forward_ex", "fa_forward_sharded", "fa_forward_packed_qkv", "fa_time_forward", "fa_time_forward_graph",
     "fa_last_error", "fa_device_count", "fa_version", "fa_kernel_name",
 )
 
@@ -46,6 +46,8 @@ def lib() -> ctypes.CDLL:
     L.fa_forward_packed_qkv.restype = ctypes.c_int
     L.fa_time_forward.argtypes = [vp, vp, vp, vp, i64, i64, i32, f32, i32, i32, i32, vp, i32, i32, ctypes.POINTER(f32)]
     L.fa_time_forward.restype = ctypes.c_int
+    L.fa_time_forward_graph.argtypes = [vp, vp, vp, vp, i64, i64, i32, f32, i32, i32, i32, i32, i32, ctypes.POINTER(f32)]
+    L.fa_time_forward_graph.restype = ctypes.c_int
     L.fa_last_error.argtypes = []
     L.fa_last_error.restype = ctypes.c_char_p
     L.fa_device_count.argtypes = []

@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 #include "fa_kernels.h"
 
@@ -180,8 +181,9 @@ int fa_forward_packed_qkv(const float* inp, float* out, int32_t B, int32_t T, in
     return launch(p, hs, /*causal=*/1, FA_DTYPE_F32, FA_KERNEL_AUTO, static_cast<hipStream_t>(stream));
 }
 
-int fa_time_forward(const void* q, const void* k, const void* v, void* o, int64_t bh, int64_t n, int32_t d, float scale,
-                    int32_t causal, int32_t dtype, int32_t kernel, void* stream, int32_t warmup, int32_t iters, float* ms_per_forward)
+static int time_forward_impl(const void* q, const void* k, const void* v, void* o, int64_t bh, int64_t n, int32_t d, float scale,
+                             int32_t causal, int32_t dtype, int32_t kernel, void* stream, int32_t warmup, int32_t iters,
+                             float* ms_per_forward, bool graph_replay)
 {
     g_err[0] = 0;
     if (!ms_per_forward || iters < 1 || warmup < 0) return fail(FA_ERR_INVALID_ARGUMENT, "bad timing arguments");
@@ -195,7 +197,33 @@ int fa_time_forward(const void* q, const void* k, const void* v, void* o, int64_
     }
     int rc = FA_OK;
     for (int i = 0; i < warmup && rc == FA_OK; ++i) rc = launch(p, d, causal, dtype, kernel, s);
-    if (rc == FA_OK) {
+    if (rc == FA_OK && graph_replay) {  // the `iters` launches captured into one hipGraph, one replay timed
+        hipStream_t cs = nullptr;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        if (hipStreamCreate(&cs) != hipSuccess) rc = fail(FA_ERR_HIP, "hipStreamCreate failed");
+        if (rc == FA_OK && hipStreamBeginCapture(cs, hipStreamCaptureModeGlobal) != hipSuccess) rc = fail(FA_ERR_HIP, "begin capture failed");
+        for (int i = 0; i < iters && rc == FA_OK; ++i) rc = launch(p, d, causal, dtype, kernel, cs);
+        if (rc == FA_OK && hipStreamEndCapture(cs, &graph) != hipSuccess) rc = fail(FA_ERR_HIP, "end capture failed");
+        if (rc == FA_OK && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) rc = fail(FA_ERR_HIP, "graph instantiate failed");
+        if (rc == FA_OK) {
+            (void)hipGraphLaunch(exec, cs);   // warm replay
+            (void)hipStreamSynchronize(cs);
+            (void)hipEventRecord(e0, cs);
+            (void)hipGraphLaunch(exec, cs);
+            (void)hipEventRecord(e1, cs);
+            const hipError_t e = hipEventSynchronize(e1);
+            if (e != hipSuccess) rc = fail(FA_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(e));
+            if (rc == FA_OK) {
+                float ms = 0.0f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                *ms_per_forward = ms / (float)iters;
+            }
+        }
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (cs) (void)hipStreamDestroy(cs);
+    } else if (rc == FA_OK) {
         (void)hipEventRecord(e0, s);
         for (int i = 0; i < iters && rc == FA_OK; ++i) rc = launch(p, d, causal, dtype, kernel, s);
         (void)hipEventRecord(e1, s);
@@ -210,6 +238,20 @@ int fa_time_forward(const void* q, const void* k, const void* v, void* o, int64_
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return rc;
+}
+
+int fa_time_forward(const void* q, const void* k, const void* v, void* o, int64_t bh, int64_t n, int32_t d, float scale,
+                    int32_t causal, int32_t dtype, int32_t kernel, void* stream, int32_t warmup, int32_t iters, float* ms_per_forward)
+{
+    const char* env = getenv("FA_TIME_GRAPH");  // experiment switch of the C driver
+    return time_forward_impl(q, k, v, o, bh, n, d, scale, causal, dtype, kernel, stream, warmup, iters, ms_per_forward,
+                             env && env[0] == '1');
+}
+
+int fa_time_forward_graph(const void* q, const void* k, const void* v, void* o, int64_t bh, int64_t n, int32_t d, float scale,
+                          int32_t causal, int32_t dtype, int32_t kernel, int32_t warmup, int32_t iters, float* ms_per_forward)
+{
+    return time_forward_impl(q, k, v, o, bh, n, d, scale, causal, dtype, kernel, nullptr, warmup, iters, ms_per_forward, true);
 }
 
 const char* fa_last_error(void) { return g_err; }

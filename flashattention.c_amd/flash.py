@@ -124,14 +124,22 @@ def forward_packed_qkv(inp: torch.Tensor, n_head: int) -> torch.Tensor:
 
 
 def time_forward(q, k, v, causal: bool = False, *, scale: float = 1.0, kernel: Union[str, int] = "auto",
-                 warmup: int = 3, iters: int = 20, out: Optional[torch.Tensor] = None) -> float:
-    """Mean milliseconds per forward, HIP events recorded on the launch stream inside the C ABI (fa_time_forward)."""
+                 warmup: int = 3, iters: int = 20, out: Optional[torch.Tensor] = None, graph: bool = False) -> float:
+    """Mean milliseconds per forward, HIP events recorded on the launch stream inside the C ABI (fa_time_forward).
+    ``graph=True``: the ``iters`` launches are captured into one hipGraph and one replay is timed (fa_time_forward_graph)."""
     bh, n, d = _check_qkv(q, k, v)
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     if out is None:
         out = torch.empty_like(q)
     ms = ctypes.c_float(0.0)
     with torch.cuda.device(q.device):
+        if graph:
+            torch.cuda.current_stream().synchronize()
+            rc = _cabi.lib().fa_time_forward_graph(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), bh, n, d, float(scale),
+                                                   int(bool(causal)), _DTYPES[q.dtype], _kernel_id(kernel), int(warmup), int(iters),
+                                                   ctypes.byref(ms))
+            _cabi.check(rc)
+            return float(ms.value)
         stream = torch.cuda.current_stream().cuda_stream
         rc = _cabi.lib().fa_time_forward(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), bh, n, d, float(scale),
                                          int(bool(causal)), _DTYPES[q.dtype], _kernel_id(kernel), ctypes.c_void_p(stream),

@@ -118,6 +118,16 @@ int fa_time_forward(const void* q, const void* k, const void* v, void* o,
                     int32_t dtype, int32_t kernel, void* stream,
                     int32_t warmup, int32_t iters, float* ms_per_forward);
 
+/*
+ * fa_time_forward_graph -- the same measurement with the `iters` launches captured into one hipGraph on a private
+ *                          stream and ONE replay of that graph timed (after a warm replay).  Back-to-back stream
+ *                          launches of a ~0.3 ms forward leave ~25 us between kernels on MI355X; a graph-captured
+ *                          pipeline does not.  Reported beside the stream-launch figure, never instead of it.
+ */
+int fa_time_forward_graph(const void* q, const void* k, const void* v, void* o,
+                          int64_t bh, int64_t n, int32_t d, float scale, int32_t causal, int32_t dtype,
+                          int32_t kernel, int32_t warmup, int32_t iters, float* ms_per_forward);
+
 /* Thread-local description of the last failure on this thread ("" if none). */
 const char* fa_last_error(void);
 
