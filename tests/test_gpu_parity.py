@@ -146,7 +146,9 @@ def test_bf16_vs_oracle(bh, n, d, causal, scale):
     check(fa.forward(qd, kd, vd, causal, scale=scale), ref, bf16_tol(scale, False), "bf16-out")
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+# 0 = product dispatch, 1 = phase-structured kernel, 7/25 = pipelined kernel (barrier every 2 / every stage), 24 = its 2-wave
+# workgroups, 30/31 = one-wave-per-SIMD 128-rows-per-wave kernel (barrier every 2 / every stage)
+@pytest.mark.parametrize("variant", [0, 1, 7, 24, 25, 30, 31])
 @pytest.mark.parametrize("causal", [False, True])
 def test_bf16_tiling_variants_agree(variant, causal):
     q, k, v = (orc.round_to_bf16(randn(s, 3, 700, 64)) for s in (7, 8, 9))
@@ -215,6 +217,35 @@ def test_dominant_key_in_the_last_keys(n, out_f32):
         _, lse_ref = orc.attention_f64(qb, kb, vb, causal=causal, return_lse=True)
         _, lse = fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, return_lse=True)
         check(lse, lse_ref, 2e-2, "bf16 lse")
+
+
+@pytest.mark.parametrize("variant", [0, 24, 25, 30])
+@pytest.mark.parametrize("causal", [False, True])
+def test_rescale_inside_the_pipelined_loop(variant, causal):
+    """Keys that outgrow a row's running maximum by far more than the lazy-rescale slack (2^64), placed in the middle of
+    the sequence: the rare rescale branch of the software-pipelined main loop (not the prologue / tail) has to fire, for
+    single rows, for a whole 32-row block and for neighbouring blocks of one wave, and everything already accumulated
+    at the old reference has to be scaled exactly once."""
+    bh, n, d = 2, 1536, 64
+    q, k, v = (randn(s, bh, n, d) for s in (41, 42, 43))
+    unit = lambda x: x / np.linalg.norm(x, axis=-1, keepdims=True)
+    for r, key, gain in ((3, 700, 14.0), (40, 701, 16.0), (200, 1100, 12.0), (1300, 900, 15.0), (1301, 650, 18.0), (1535, 333, 13.0)):
+        k[:, key] = gain * unit(q[:, r])           # score ~ gain * |q| ~ 8 gain  ->  > 64 / log2(e) above the crowd
+    k[0, 800] = 20.0 * unit(q[0, 64:96].mean(axis=0))  # one key that lifts a whole 32-row block at once
+    qb, kb, vb = (orc.round_to_bf16(t) for t in (q, k, v))
+    ref = orc.attention_f64(qb, kb, vb, causal=causal)
+    o = fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, kernel=f"mfma:{variant}", out_dtype=torch.float32)
+    check(o, ref, bf16_tol(1.0, True), f"variant {variant}")
+    _, lse_ref = orc.attention_f64(qb, kb, vb, causal=causal, return_lse=True)
+    _, lse = fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, kernel=f"mfma:{variant}", return_lse=True)
+    check(lse, lse_ref, 2e-2, f"lse variant {variant}")
+
+
+def test_graph_replay_timing_entry():
+    q, k, v = (torch.randn(4, 512, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
+    ms_stream = fa.time_forward(q, k, v, False, warmup=1, iters=5)
+    ms_graph = fa.time_forward(q, k, v, False, warmup=1, iters=5, graph=True)
+    assert 0.0 < ms_graph < 50.0 and 0.0 < ms_stream < 50.0
 
 
 def test_transpose_detecting_structured_input():
