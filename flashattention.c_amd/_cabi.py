@@ -14,7 +14,7 @@ FA_KERNEL_AUTO, FA_KERNEL_NAIVE, FA_KERNEL_MFMA = 0, 1, 2
 # every symbol include/flashattn_amd.h declares
 EXPORTED_SYMBOLS = (
     "fa_forward", "fa_forward_ex", "fa_forward_sharded", "fa_forward_packed_qkv", "fa_time_forward", "fa_time_forward_graph",
-    "fa_last_error", "fa_device_count", "fa_version", "fa_kernel_name",
+    "fa_last_error", "fa_device_count", "fa_version", "fa_kernel_name", "fa_kernel_name_for",
 )
 
 
@@ -56,6 +56,8 @@ def lib() -> ctypes.CDLL:
     L.fa_version.restype = ctypes.c_char_p
     L.fa_kernel_name.argtypes = [i32, i32, i32]
     L.fa_kernel_name.restype = ctypes.c_char_p
+    L.fa_kernel_name_for.argtypes = [i32, i32, i32, i64, i64]
+    L.fa_kernel_name_for.restype = ctypes.c_char_p
     _lib = L
     return L
 

@@ -265,16 +265,14 @@ int fa_device_count(void)
 
 const char* fa_version(void) { return "flashattn_amd abi 1 gfx950 (hip, mfma f32 32x32x2 / bf16 32x32x16, lds-dma)"; }
 
-const char* fa_kernel_name(int32_t dtype, int32_t d, int32_t causal)
+const char* fa_kernel_name_for(int32_t dtype, int32_t d, int32_t causal, int64_t bh, int64_t n)
 {
-    if (!head_dim_supported(d)) return nullptr;
+    if (!head_dim_supported(d) || bh < 1 || n < 1) return nullptr;
     if (dtype == FA_DTYPE_F32) return "fa_fwd_f32_kernel";
-    if (dtype == FA_DTYPE_BF16 || dtype == FA_DTYPE_BF16_OUT_F32) {
-        // lockstep / software-pipelined kernel where it is instantiated, the phase-structured one elsewhere
-        if (d == 64 || (d == 32 && !causal)) return "fa_fwd_bf16_pp3_kernel";
-        return "fa_fwd_bf16_kernel";
-    }
+    if (dtype == FA_DTYPE_BF16 || dtype == FA_DTYPE_BF16_OUT_F32) return fa::bf16_kernel_name(bh, n, d, causal);
     return nullptr;
 }
+
+const char* fa_kernel_name(int32_t dtype, int32_t d, int32_t causal) { return fa_kernel_name_for(dtype, d, causal, 16, 8192); }
 
 }  // extern "C"

@@ -437,23 +437,63 @@ static hipError_t launch_cfg(const FwdParams& p0, int causal, int out_f32, hipSt
     return hipGetLastError();
 }
 
+// ---- product dispatch (variant 0) --------------------------------------------------------------------------------------
+// Measured on MI355X, steady clocks, TFLOP/s at bh = 16, n = 8192 (profiles/): d = 64 non-causal  x4 1044 / pipelined 1022;
+// d = 64 causal  pipelined 2-wave 712 / 4-wave 642 / x4 594;  d = 128  w4 1012 / phase-structured 950;  d = 32  pipelined 735.
+enum Bf16Choice { kChoosePhase, kChoosePipelined4, kChoosePipelined2, kChooseX4, kChooseW4 };
+
+static Bf16Choice choose_bf16(int64_t bh, int64_t n, int d, int causal, bool addressable)
+{
+    if (d == 128) return causal ? kChoosePhase : kChooseW4;
+    if (!addressable) return kChoosePhase;
+    if (d == 32) return causal ? kChoosePhase : kChoosePipelined4;  // 256-row workgroups waste too much of the causal triangle at d = 32
+    // d == 64
+    const int64_t items256 = bh * ((n + 255) / 256), items512 = bh * ((n + 511) / 512);
+    if (causal) return items256 <= 1024 ? kChoosePipelined2 : kChoosePipelined4;  // few items + causal imbalance: 128-row workgroups pack better
+    // one wave per SIMD, 512-row workgroups, one workgroup per CU: worth it when those workgroups fill whole rounds of the
+    // 256 CUs at least as well as 256-row workgroups fill the 512 slots of the two-wave kernel
+    const double eff512 = (double)items512 / (double)(((items512 + 255) / 256) * 256);
+    const double eff256 = (double)items256 / (double)(((items256 + 511) / 512) * 512);
+    const double pad512 = (double)n / (double)(((n + 511) / 512) * 512), pad256 = (double)n / (double)(((n + 255) / 256) * 256);
+    if (n >= 2048 && eff512 * pad512 >= 0.98 * eff256 * pad256) return kChooseX4;
+    return kChoosePipelined4;
+}
+
+const char* bf16_kernel_name(int64_t bh, int64_t n, int d, int causal)
+{
+    switch (choose_bf16(bh, n, d, causal, true)) {
+        case kChooseX4: return "fa_fwd_bf16_x4_kernel";
+        case kChoosePipelined4:
+        case kChoosePipelined2: return "fa_fwd_bf16_pp3_kernel";
+        case kChooseW4: return "fa_fwd_bf16_w4_kernel";
+        default: return "fa_fwd_bf16_kernel";
+    }
+}
+
 hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, int variant, hipStream_t stream)
 {
-    // 256-row work items of the pipelined kernel; few of them + causal imbalance -> 128-row workgroups pack better
-    const int64_t items256 = (int64_t)p.bh * ((p.n + 255) / 256);
-    if (!bf16_pipelined_supported(p, d) && d != 128) return d == 64 ? launch_cfg<64, 4, 1, 4>(p, causal, out_f32, stream)
-                                                                     : launch_cfg<32, 4, 1, 4>(p, causal, out_f32, stream);
+    if (variant == 0) {
+        switch (choose_bf16(p.bh, p.n, d, causal, bf16_pipelined_supported(p, d))) {
+            case kChooseX4: return launch_bf16_x4(p, causal, out_f32, 2, stream);
+            case kChoosePipelined4: return launch_bf16_pipelined(p, d, 4, causal, out_f32, 0, stream);
+            case kChoosePipelined2: return launch_bf16_pipelined(p, d, 2, causal, out_f32, 0, stream);
+            case kChooseW4: return launch_w4<128, 4, 2>(p, causal, out_f32, stream);
+            default:
+                if (d == 32) return launch_cfg<32, 4, 1, 4>(p, causal, out_f32, stream);
+                if (d == 64) return launch_cfg<64, 4, 1, 4>(p, causal, out_f32, stream);
+                return launch_cfg<128, 4, 1, 2>(p, causal, out_f32, stream);
+        }
+    }
+    if (!bf16_pipelined_supported(p, d) && d != 128) return hipErrorInvalidValue;  // the ablation variants assume 32-bit slab offsets
     switch (d) {
         case 32:
             if (variant == 24) return launch_bf16_pipelined(p, 32, 2, causal, out_f32, 0, stream);
             // lockstep/pipelined kernel for the non-causal case; its 256-row workgroups waste more of the causal
             // triangle than the 128-row phase-structured kernel recovers at D = 32
-            if (variant == 7 || (variant == 0 && !causal)) return launch_bf16_pipelined(p, 32, 4, causal, out_f32, 0, stream);
+            if (variant == 7) return launch_bf16_pipelined(p, 32, 4, causal, out_f32, 0, stream);
             return launch_cfg<32, 4, 1, 4>(p, causal, out_f32, stream);
         case 64:
             switch (variant) {
-                case 0:  // product path
-                    return launch_bf16_pipelined(p, 64, (causal && items256 <= 1024) ? 2 : 4, causal, out_f32, 0, stream);
                 case 1: return launch_cfg<64, 4, 1, 4>(p, causal, out_f32, stream);   // phase-structured, 4 waves/SIMD
                 case 2: return launch_cfg<64, 4, 2, 2>(p, causal, out_f32, stream);   // phase-structured, 64 rows/wave
                 case 7: return launch_bf16_pipelined(p, 64, 4, causal, out_f32, 0, stream);
@@ -462,7 +502,6 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
                 case 25: return launch_bf16_pipelined(p, 64, 4, causal, out_f32, 3, stream);  // barrier every stage
                 case 30: return launch_bf16_x4(p, causal, out_f32, 2, stream);
                 case 31: return launch_bf16_x4(p, causal, out_f32, 1, stream);
-                case 32: return launch_bf16_x4(p, causal, out_f32, 4, stream);
                 case 10: return launch_w4<64, 4, 4>(p, causal, out_f32, stream);       // 4 waves/SIMD on the VALU diet
                 default: return launch_bf16_pp2(p, causal, out_f32, variant, stream);  // 9 = pp2, 6, 11..21 = its ablations
             }

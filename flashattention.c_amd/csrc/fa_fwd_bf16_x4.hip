@@ -230,7 +230,7 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdPar
     using C = Bf16Cfg<D, NWAVES>;
     constexpr int BM = NWAVES * 32 * kNB;
     constexpr int KR = 2 * G, VR = 2 * G;
-    static_assert(G == 1 || G == 2 || G == 4, "ring index arithmetic needs a power of two");
+    static_assert(G == 1 || G == 2, "ring index arithmetic written for G = 1, 2");
     constexpr int T = C::kTileBytes;
 
     __shared__ __attribute__((aligned(1024))) char smem[(KR + VR) * T];  // K ring, then V ring
@@ -474,7 +474,6 @@ hipError_t launch_bf16_x4(const FwdParams& p, int causal, int out_f32, int mode,
 {
     if (!bf16_pipelined_supported(p, 64)) return hipErrorInvalidValue;
     if (mode == 1) return launch_x4<1>(p, causal, out_f32, stream);
-    if (mode == 4) return launch_x4<4>(p, causal, out_f32, stream);
     return launch_x4<2>(p, causal, out_f32, stream);
 }
 

@@ -13,6 +13,7 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
 
 // bf16 kernels living in their own translation units (called by launch_fwd_bf16)
 hipError_t launch_bf16_pipelined(const FwdParams& p, int d, int nwaves, int causal, int out_f32, int mode, hipStream_t stream);
+const char* bf16_kernel_name(int64_t bh, int64_t n, int d, int causal);  // the kernel the product dispatch picks
 bool bf16_pipelined_supported(const FwdParams& p, int d);  // d in {32, 64} and the slab addressable with 32-bit byte offsets
 hipError_t launch_bf16_x4(const FwdParams& p, int causal, int out_f32, int mode, hipStream_t stream);  // D = 64, 128 rows/wave
 hipError_t launch_bf16_pp2(const FwdParams& p, int causal, int out_f32, int variant, hipStream_t stream);

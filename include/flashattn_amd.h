@@ -138,7 +138,9 @@ int fa_device_count(void);
 const char* fa_version(void);
 
 /* Name of the kernel FA_KERNEL_AUTO resolves to for (dtype, d), or NULL if unsupported. */
-const char* fa_kernel_name(int32_t dtype, int32_t d, int32_t causal);
+const char* fa_kernel_name(int32_t dtype, int32_t d, int32_t causal);   /* at the headline shape bh = 16, n = 8192 */
+/* the dispatch is shape dependent (tile sizes follow the grid): the kernel fa_forward picks for this very call */
+const char* fa_kernel_name_for(int32_t dtype, int32_t d, int32_t causal, int64_t bh, int64_t n);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,22 @@
+#!/bin/bash
+# profiles/collect.sh TAG -- run on the GPU box (gpurun -- 'bash profiles/collect.sh r01c'): rocprofv3 kernel-trace + stats
+# and the PMC passes (counters in their own runs) over the default bench.py command, then the text/json summaries that are
+# committed under profiles/.  Everything is written under gpurun_out/ (scratch); copy the summaries into profiles/ afterwards.
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+OUT=$R/gpurun_out/prof_$TAG
+rm -rf $OUT && mkdir -p $OUT
+BENCH="$R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras"
+rocprofv3 --kernel-trace --stats -d $OUT/stats -- python3 $BENCH > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -- python3 $BENCH > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -- python3 $BENCH > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES \
+    --kernel-trace -d $OUT/pmc_sq1 -- python3 $BENCH > $OUT/pmc_sq1.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_SALU \
+    --kernel-trace -d $OUT/pmc_sq2 -- python3 $BENCH > $OUT/pmc_sq2.log 2>&1
+cd $R
+python3 bench.py > $OUT/bench_line.json 2> $OUT/bench.err
+python3 profiles/summarize_rocpd.py $OUT $TAG --out $OUT
+grep -h '"metric"' $OUT/*.log | head -3
+cat $OUT/bench_line.json

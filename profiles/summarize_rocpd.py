@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Turn rocprofv3's rocpd SQLite outputs (gpurun_out/prof/<pass>/*_results.db) into the small text summaries that are
-committed under profiles/.  Usage: python profiles/summarize_rocpd.py gpurun_out/prof r01"""
+"""Turn rocprofv3's rocpd SQLite outputs (<src>/<pass>/**/*_results.db) into the small text summaries that are
+committed under profiles/.  Usage: python profiles/summarize_rocpd.py <src dir> <tag> [--out <dir>]  (default: profiles/)"""
 import glob
 import json
 import os
@@ -8,12 +8,12 @@ import sqlite3
 import sys
 
 
-def main(src: str, tag: str):
-    here = os.path.dirname(os.path.abspath(__file__))
+def main(src: str, tag: str, out: str = None):
+    here = out or os.path.dirname(os.path.abspath(__file__))
     lines = []
     pmc = {}
     for d in sorted(os.listdir(src)):
-        dbs = glob.glob(os.path.join(src, d, "*_results.db"))
+        dbs = glob.glob(os.path.join(src, d, "**", "*_results.db"), recursive=True)
         if not dbs:
             continue
         c = sqlite3.connect(dbs[0])
@@ -42,4 +42,4 @@ def main(src: str, tag: str):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None)
