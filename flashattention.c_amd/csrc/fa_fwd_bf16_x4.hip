@@ -184,13 +184,16 @@ __device__ __forceinline__ void x4_slot_body(X4Ctx& x)
     constexpr int D = 64;
     constexpr X4Slot sl = x4_slot(I);
     constexpr X4Table tab = x4_make_table();
-    if constexpr (I == 8) {
-        // the asm-issued V^T reads were started in slots 0..3; this wait orders them before the first P.V MFMA
-#pragma unroll
-        for (int v = 0; v < 4; ++v) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x.vlo[v]), "+v"(x.vhi[v]));
+    // The asm-issued V^T reads were started in slots 0..3 (two ds_read per fragment, LDS returns in order): each P.V slot of
+    // block A waits only for the fragment it consumes, so the youngest read gets nine slots instead of five to land.
+    if constexpr (I == 8 || I == 9 || I == 11 || I == 12) {
+        constexpr int v = I == 8 ? 0 : I == 9 ? 1 : I == 11 ? 2 : 3;
+        if constexpr (v == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(x.vlo[0]), "+v"(x.vhi[0]));
+        if constexpr (v == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x.vlo[1]), "+v"(x.vhi[1]));
+        if constexpr (v == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(x.vlo[2]), "+v"(x.vhi[2]));
+        if constexpr (v == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x.vlo[3]), "+v"(x.vhi[3]));
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) x.vf[v] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(x.vlo[v], x.vhi[v], 0, 1, 2, 3, 4, 5, 6, 7));
+        x.vf[v] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(x.vlo[v], x.vhi[v], 0, 1, 2, 3, 4, 5, 6, 7));
     }
     if constexpr (I < 4) load_v_frag_asm<D, KB_C, I>(x.v_addr, x.vlo[I], x.vhi[I]);
     if constexpr (sl.kind == 0) {
@@ -201,7 +204,13 @@ __device__ __forceinline__ void x4_slot_body(X4Ctx& x)
     } else {
         mfma_l(x.st[sl.blk].lacc, x.ones_a, x.pf[sl.blk][sl.idx]);
     }
-    if constexpr (I >= 28 && I < 32) x.kf[I - 28] = load_k_frag<D>(x.k_nxt, x.k_row_off, x.k_g, x.kb_n2, I - 28);  // last K.Q^T: slot 27
+    if constexpr (I >= 28 && I < 32) {  // K fragments of the next step (the last K.Q^T of this one was slot 27)
+        // asm, like the V^T reads: a compiler-visible LDS load would make hipcc put its own lgkmcnt waits in front of the
+        // next step's K.Q^T MFMAs, and those waits -- counted without the asm reads in flight -- drain the V^T reads too
+        constexpr int ks = I - 28;
+        const unsigned a = (unsigned)(size_t)(lds_s16x4_t*)(x.k_nxt + x.k_row_off + x.kb_n2 * 32 * (2 * D) + (((2 * ks) ^ x.k_g) * 16));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(x.kf[ks]) : "v"(a));
+    }
     x4_units<tab.ub[I]>(x, std::make_integer_sequence<int, tab.ub[I + 1] - tab.ub[I]>{});
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -220,6 +229,9 @@ __device__ __forceinline__ bool x4_step(const char* v_lds, const char* k_nxt, in
     X4Ctx x{ones_a, qf, sc, sn, o, st, off, kf, lm, c, k_nxt, kb_n2, k_row_off, k_g, (unsigned)(size_t)(lds_s16x4_t*)(v_lds + v_lane_off)};
     x.need = false;
     x4_slots<KB_C>(x, std::make_integer_sequence<int, kX4Slots>{});
+    // the K reads of slots 28..31 are eight MFMA slots old: this wait is free, and it keeps every asm-issued load inside the
+    // basic block that issued it (hipcc may move or spill a register across a branch without knowing a load is in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]));
     return x.need;
 }
 
