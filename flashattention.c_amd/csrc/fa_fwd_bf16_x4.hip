@@ -332,7 +332,7 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdPar
         for (int ks = 0; ks < KS; ++ks) kf[ks] = load_k_frag<D>(k_lds, k_row_off, k_g, t & 1, ks);
     };
     // scores of sub-tile t for all blocks from the fragments in kf, phase-structured (prologue and tail)
-    auto qk_regs = [&](int t, f32x16 (&s)[kNB]) {
+    auto qk_regs = [&](int t, f32x16 (&s)[kNB], bool first = false) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -347,7 +347,16 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdPar
             if (needs_mask(t, q0 + 32 * blk)) mask16(s[blk], t * 32, q0 + 32 * blk + lq, n, hi, CAUSAL);
             mx[blk] = rowmax16(s[blk]);
         }
-        x4_rescale(mx, c, st, o, off);
+        if (first) {  // nothing accumulated yet: set the references, leave the (zero) accumulators alone
+#pragma unroll
+            for (int blk = 0; blk < kNB; ++blk) {
+                const float mc = mx[blk] * c;
+                st[blk].m = fmaf(-fabsf(mc), 0x1p-23f, mc);
+                off[blk] = st[blk].m + kLazyThr;
+            }
+        } else {
+            x4_rescale(mx, c, st, o, off);
+        }
     };
     // exp, pack, P.V and row sums of sub-tile t for all blocks, phase-structured (tail)
     auto finish_sub = [&](int t, f32x16 (&s)[kNB]) {
@@ -378,7 +387,7 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdPar
     for (int g = 0; g < G; ++g)
         if (g < nst) dma.issue_v((unsigned)g * dma.stage_step, v_slot(g), wave);
     load_kf(0);
-    qk_regs(0, s0);
+    qk_regs(0, s0, true);
     load_kf(1);
 
     // ---------------- fast loop: groups of G whole stages whose sub-tiles 2j .. 2j+2 are in range and mask-free ----------------
