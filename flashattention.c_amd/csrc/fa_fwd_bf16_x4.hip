@@ -106,7 +106,7 @@ __device__ __host__ constexpr X4Slot x4_slot(int i)
     return x4_pv_group(3, i - 34);                                    // P.V + row sums D
 }
 constexpr int kX4Slots = 40;
-constexpr int kX4Units = 53;  // 4 blocks x (8 exp pairs + 2 packs) + 4 x 3 max micro-steps + 1 test
+constexpr int kX4Units = 85;  // 4 blocks x (16 exp elements + 2 packs) + 4 x 3 max micro-steps + 1 test
 __device__ __host__ constexpr int x4_weight_before(int i)  // in half-slots: a 32x32x16 slot = 2, a 16x16x32 slot = 1
 {
     int w = 0;
@@ -114,13 +114,34 @@ __device__ __host__ constexpr int x4_weight_before(int i)  // in half-slots: a 3
     return w;
 }
 constexpr int kX4Weight = x4_weight_before(kX4Slots);  // 72
+// VALU units are dealt out by ISSUE COST, not by count: measured beside MFMAs (profiles/ubench/ubench_clock.hip) a plain
+// VALU instruction occupies the wave's issue for 4 cycles and a v_exp_f32 for 8, so an exp element (fma + exp) costs 12, a
+// pack (4 cvt) 16, the max micro-steps 12 / 12 / 8, the test ~20 -- 1044 cycles per step.  Slot i receives the units whose
+// cumulative cost fits its share of the step's 72 half-slots (table computed by that rule; 24..36 cycles per full slot).
 struct X4Table {
     int ub[kX4Slots + 1];  // VALU units dealt out before slot i
 };
+__device__ __host__ constexpr int x4_unit_cost(int u)
+{
+    if (u < 72) return (u % 18 == 8 || u % 18 == 17) ? 16 : 12;
+    if (u < 84) return (u - 72) % 3 == 2 ? 8 : 12;
+    return 20;
+}
 __device__ __host__ constexpr X4Table x4_make_table()
 {
     X4Table t{};
-    for (int i = 0; i <= kX4Slots; ++i) t.ub[i] = kX4Units * x4_weight_before(i) / kX4Weight;
+    int total = 0;
+    for (int u = 0; u < kX4Units; ++u) total += x4_unit_cost(u);
+    int n = 0, cum_next = x4_unit_cost(0);  // cum_next: cost of units 0..n inclusive
+    for (int i = 0; i <= kX4Slots; ++i) {
+        const int target = total * x4_weight_before(i) / kX4Weight + 6;
+        while (n < kX4Units && cum_next <= target) {
+            ++n;
+            if (n < kX4Units) cum_next += x4_unit_cost(n);
+        }
+        t.ub[i] = n;
+    }
+    t.ub[kX4Slots] = kX4Units;
     return t;
 }
 
@@ -149,21 +170,22 @@ struct X4Ctx {
     bool need;
 };
 
+// unit U:  0 .. 71  block U/18, k = U%18:  k in 0..7 -> exp of element k;  8 -> pack fragment 0;  9..16 -> exp of element
+//          k-1;  17 -> pack fragment 1.   72 .. 83  lane maxima of sub-tile t+1 (three micro-steps per block).   84  rescale test
 template <int U>
 __device__ __forceinline__ void x4_unit(X4Ctx& x)
 {
-    if constexpr (U < 40) {
-        constexpr int b = U / 10, k = U % 10;
-        if constexpr (k == 4 || k == 9) {
-            x.pf[b][k / 5] = pack_bf16x8(x.sc[b], 8 * (k / 5));
-            asm volatile("" : "+v"(x.pf[b][k / 5]));
+    if constexpr (U < 72) {
+        constexpr int b = U / 18, k = U % 18;
+        if constexpr (k == 8 || k == 17) {
+            x.pf[b][k / 9] = pack_bf16x8(x.sc[b], 8 * (k / 9));
+            asm volatile("" : "+v"(x.pf[b][k / 9]));
         } else {
-            constexpr int e = 2 * (k < 4 ? k : k - 1);
+            constexpr int e = k < 8 ? k : k - 1;
             x.sc[b][e] = exp2_clamp01(fmaf(x.sc[b][e], x.c, -x.off[b]));
-            x.sc[b][e + 1] = exp2_clamp01(fmaf(x.sc[b][e + 1], x.c, -x.off[b]));
         }
-    } else if constexpr (U < 52) {
-        constexpr int b = (U - 40) / 3, m = (U - 40) % 3;
+    } else if constexpr (U < 84) {
+        constexpr int b = (U - 72) / 3, m = (U - 72) % 3;
         lanemax_step(m, x.sn[b], x.pm, x.lm[b]);
     } else {
         float t = fmaf(x.lm[0], x.c, -x.off[0]);
