@@ -121,12 +121,45 @@ constexpr int kX4Weight = x4_weight_before(kX4Slots);  // 72
 struct X4Table {
     int ub[kX4Slots + 1];  // VALU units dealt out before slot i
 };
-__device__ __host__ constexpr int x4_unit_cost(int u)
+// The unit sequence.  A pack (v_cvt_pk) is scheduled two exp units after the last exponential it consumes: a VALU
+// instruction that reads the result of a transcendental issued just before it costs a wait state (hipcc pads an s_nop).
+struct X4Unit {
+    int kind;  // 0 = exp of one element, 1 = pack of one fragment, 2 = lane-max micro-step, 3 = rescale test
+    int blk, idx, cost;
+};
+struct X4UnitList {
+    X4Unit u[kX4Units];
+};
+__device__ __host__ constexpr X4UnitList x4_make_units()
 {
-    if (u < 72) return (u % 18 == 8 || u % 18 == 17) ? 16 : 12;
-    if (u < 84) return (u - 72) % 3 == 2 ? 8 : 12;
-    return 20;
+    X4UnitList l{};
+    int n = 0;
+    bool pending = false;
+    X4Unit pend{};
+    for (int b = 0; b < kNB; ++b) {
+        for (int e = 0; e < 16; ++e) {
+            l.u[n++] = {0, b, e, 12};
+            if (e == 1 && pending) {
+                l.u[n++] = pend;
+                pending = false;
+            }
+            if (e == 9) l.u[n++] = {1, b, 0, 16};
+        }
+        pend = {1, b, 1, 16};
+        pending = true;
+    }
+    for (int b = 0; b < kNB; ++b)
+        for (int m = 0; m < 3; ++m) {
+            l.u[n++] = {2, b, m, m == 2 ? 8 : 12};
+            if (b == 0 && m == 1 && pending) {
+                l.u[n++] = pend;
+                pending = false;
+            }
+        }
+    l.u[n++] = {3, 0, 0, 20};
+    return l;
 }
+__device__ __host__ constexpr int x4_unit_cost(int u) { return x4_make_units().u[u].cost; }
 __device__ __host__ constexpr X4Table x4_make_table()
 {
     X4Table t{};
@@ -170,23 +203,17 @@ struct X4Ctx {
     bool need;
 };
 
-// unit U:  0 .. 71  block U/18, k = U%18:  k in 0..7 -> exp of element k;  8 -> pack fragment 0;  9..16 -> exp of element
-//          k-1;  17 -> pack fragment 1.   72 .. 83  lane maxima of sub-tile t+1 (three micro-steps per block).   84  rescale test
 template <int U>
 __device__ __forceinline__ void x4_unit(X4Ctx& x)
 {
-    if constexpr (U < 72) {
-        constexpr int b = U / 18, k = U % 18;
-        if constexpr (k == 8 || k == 17) {
-            x.pf[b][k / 9] = pack_bf16x8(x.sc[b], 8 * (k / 9));
-            asm volatile("" : "+v"(x.pf[b][k / 9]));
-        } else {
-            constexpr int e = k < 8 ? k : k - 1;
-            x.sc[b][e] = exp2_clamp01(fmaf(x.sc[b][e], x.c, -x.off[b]));
-        }
-    } else if constexpr (U < 84) {
-        constexpr int b = (U - 72) / 3, m = (U - 72) % 3;
-        lanemax_step(m, x.sn[b], x.pm, x.lm[b]);
+    constexpr X4Unit un = x4_make_units().u[U];
+    if constexpr (un.kind == 0) {
+        x.sc[un.blk][un.idx] = exp2_clamp01(fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]));
+    } else if constexpr (un.kind == 1) {
+        x.pf[un.blk][un.idx] = pack_bf16x8(x.sc[un.blk], 8 * un.idx);
+        asm volatile("" : "+v"(x.pf[un.blk][un.idx]));
+    } else if constexpr (un.kind == 2) {
+        lanemax_step(un.idx, x.sn[un.blk], x.pm, x.lm[un.blk]);
     } else {
         float t = fmaf(x.lm[0], x.c, -x.off[0]);
 #pragma unroll
