@@ -502,6 +502,12 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
                 case 25: return launch_bf16_pipelined(p, 64, 4, causal, out_f32, 3, stream);  // barrier every stage
                 case 30: return launch_bf16_x4(p, causal, out_f32, 2, stream);
                 case 31: return launch_bf16_x4(p, causal, out_f32, 1, stream);
+                case 33: return launch_bf16_x4(p, causal, out_f32, 11, stream);  // x4 timing ablations
+                case 34: return launch_bf16_x4(p, causal, out_f32, 12, stream);
+                case 35: return launch_bf16_x4(p, causal, out_f32, 13, stream);
+                case 36: return launch_bf16_x4(p, causal, out_f32, 14, stream);
+                case 37: return launch_bf16_x4(p, causal, out_f32, 15, stream);
+                case 38: return launch_bf16_x4(p, causal, out_f32, 16, stream);
                 case 10: return launch_w4<64, 4, 4>(p, causal, out_f32, stream);       // 4 waves/SIMD on the VALU diet
                 default: return launch_bf16_pp2(p, causal, out_f32, variant, stream);  // 9 = pp2, 6, 11..21 = its ablations
             }

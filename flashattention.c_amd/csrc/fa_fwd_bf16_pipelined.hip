@@ -69,7 +69,7 @@ template <int D, int KB_C, bool PROF = false>
 __device__ __forceinline__ void pp3_step(const char* v_lds, const char* k_lds2, int kb_n2, int k_row_off, int k_g, int v_lane_off, const bf16x8& ones_a, const bf16x8 (&qfa)[D / 16],
                                          const bf16x8 (&qfb)[D / 16], f32x16& sa_cur, f32x16& sb_cur, f32x16& sa_nxt, f32x16& sb_nxt,
                                          f32x16 (&oa)[D / 32], f32x16 (&ob)[D / 32], bf16x8 (&pfa)[2], bf16x8 (&pfb)[2], BlockState& sta,
-                                         BlockState& stb, float c, Lazy2& lz, bf16x8 (&kf)[D / 16], unsigned long long* tm = nullptr)
+                                         BlockState& stb, float c, Lazy2& lz, bf16x8 (&kf)[D / 16], bool honor_test, unsigned long long* tm = nullptr)
 {
     using P = Plan3<D>;
     constexpr int KS = P::KS, DB = P::DB, NV = P::NV;
@@ -163,7 +163,7 @@ __device__ __forceinline__ void pp3_step(const char* v_lds, const char* k_lds2, 
         __builtin_amdgcn_sched_barrier(0);
     }
     if (PROF) t3 = stamp();
-    if (__builtin_expect(__any(need), 0)) {
+    if (__builtin_expect(__any(need) && honor_test, 0)) {  // honor_test is false when sub-tile t+1 does not exist
         mfma_drain();  // the last P.V / row-sum MFMAs of block B may still be in flight
         lazy_rescale2<D>(xhalf_max(lma), xhalf_max(lmb), c, sta, stb, oa, ob, lz);
     }
@@ -223,6 +223,13 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
     TileDma<D, NWAVES> dma;
     dma.init(kg, vg, n, p.kv_row_stride, wave, lane);
     dma.issue_k(0u, k_slot(0), wave);
+    // every tile the first barrier group needs is requested before anything is waited for: one memory round trip, not two
+#pragma unroll
+    for (int g = 1; g <= G; ++g)
+        if (g < nst) dma.issue_k((unsigned)g * dma.stage_step, k_slot(g), wave);
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+        if (g < nst) dma.issue_v((unsigned)g * dma.stage_step, v_slot(g), wave);
 
     bf16x8 qfa[KS], qfb[KS];
     {
@@ -322,12 +329,6 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
     // ---------------- prologue: K(0) landed -> scores of sub-tile 0, fragments of sub-tile 1 ----------------
     wait_lds_dma();
     __syncthreads();
-#pragma unroll
-    for (int g = 1; g <= G; ++g)
-        if (g < nst) dma.issue_k((unsigned)g * dma.stage_step, k_slot(g), wave);
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-        if (g < nst) dma.issue_v((unsigned)g * dma.stage_step, v_slot(g), wave);
     load_kf(0);
     qk_regs(0, sa0, sb0);
     load_kf(1);
@@ -335,6 +336,11 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
     // ---------------- fast loop: groups of G whole stages whose sub-tiles 2j .. 2j+2 are in range and mask-free ----------------
     int jf = 0;
     while ((2 * jf + 3) * 32 <= kv_end && !needs_mask(2 * jf + 2, q0a) && !needs_mask(2 * jf + 2, q0b) && !needs_mask(0, q0a)) ++jf;
+    // The last stage may run in the fast loop too when its own two sub-tiles are whole and mask-free: its second step then
+    // computes scores of a sub-tile that does not exist (from whatever the ring slot holds) and nobody consumes them --
+    // the rescale test of that step is ignored.  Without this the final 128 keys of every slab took the slow tail path.
+    if (jf == nst - 1 && (2 * jf + 2) * 32 <= kv_end && !needs_mask(2 * jf + 1, q0a) && !needs_mask(2 * jf + 1, q0b) && !needs_mask(0, q0a))
+        jf = nst;
     jf -= jf % G;
     const unsigned long long t_begin = PROF ? stamp() : 0;
     for (int j = 0; j < jf; j += G) {
@@ -345,10 +351,10 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
             const char* k_nxt = k_slot(j + g + 1);
             // step 2(j+g): scores(2(j+g)+1) from kf; P.V(2(j+g)) from V block 0; fetch for scores(2(j+g)+2): K(j+g+1) block 0
             pp3_step<D, 0, PROF>(v_lds, k_nxt, 0, k_row_off, k_g, v_lane_off, ones_a, qfa, qfb, sa0, sb0, sa1, sb1, oa, ob, pfa, pfb, sta,
-                                 stb, c, lz, kf, tm);
+                                 stb, c, lz, kf, true, tm);
             // step 2(j+g)+1: scores(2(j+g)+2) from kf; P.V(2(j+g)+1) from V block 1; fetch for scores(2(j+g)+3): K(j+g+1) block 1
             pp3_step<D, 1, PROF>(v_lds, k_nxt, 1, k_row_off, k_g, v_lane_off, ones_a, qfa, qfb, sa1, sb1, sa0, sb0, oa, ob, pfa, pfb, sta,
-                                 stb, c, lz, kf, tm);
+                                 stb, c, lz, kf, 2 * (j + g) + 2 < nsub, tm);
         }
     }
     if (PROF) {

@@ -227,7 +227,7 @@ __device__ __forceinline__ void x4_units(X4Ctx& x, std::integer_sequence<int, Us
     (x4_unit<U0 + Us>(x), ...);
 }
 
-template <int KB_C, int I>
+template <int KB_C, int I, int ABL>
 __device__ __forceinline__ void x4_slot_body(X4Ctx& x)
 {
     constexpr int D = 64;
@@ -237,15 +237,18 @@ __device__ __forceinline__ void x4_slot_body(X4Ctx& x)
     // block A waits only for the fragment it consumes, so the youngest read gets nine slots instead of five to land.
     if constexpr (I == 8 || I == 9 || I == 11 || I == 12) {
         constexpr int v = I == 8 ? 0 : I == 9 ? 1 : I == 11 ? 2 : 3;
-        if constexpr (v == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(x.vlo[0]), "+v"(x.vhi[0]));
-        if constexpr (v == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x.vlo[1]), "+v"(x.vhi[1]));
-        if constexpr (v == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(x.vlo[2]), "+v"(x.vhi[2]));
-        if constexpr (v == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x.vlo[3]), "+v"(x.vhi[3]));
+        if constexpr (ABL & 4) asm volatile("" : "+v"(x.vlo[v]), "+v"(x.vhi[v]));  // timing-only ablation: no wait
+        else if constexpr (v == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(x.vlo[0]), "+v"(x.vhi[0]));
+        else if constexpr (v == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x.vlo[1]), "+v"(x.vhi[1]));
+        else if constexpr (v == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(x.vlo[2]), "+v"(x.vhi[2]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x.vlo[3]), "+v"(x.vhi[3]));
         __builtin_amdgcn_sched_barrier(0);
         x.vf[v] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(x.vlo[v], x.vhi[v], 0, 1, 2, 3, 4, 5, 6, 7));
     }
     if constexpr (I < 4) load_v_frag_asm<D, KB_C, I>(x.v_addr, x.vlo[I], x.vhi[I]);
-    if constexpr (sl.kind == 0) {
+    if constexpr (ABL & 1) {
+        // timing-only ablation: no matrix instructions
+    } else if constexpr (sl.kind == 0) {
         if constexpr (sl.idx == 0) mfma_s_first(x.sn[sl.blk], x.kf[sl.idx], x.qf[sl.blk][sl.idx]);
         else mfma_s(x.sn[sl.blk], x.kf[sl.idx], x.qf[sl.blk][sl.idx]);
     } else if constexpr (sl.kind == 1) {
@@ -260,16 +263,16 @@ __device__ __forceinline__ void x4_slot_body(X4Ctx& x)
         const unsigned a = (unsigned)(size_t)(lds_s16x4_t*)(x.k_nxt + x.k_row_off + x.kb_n2 * 32 * (2 * D) + (((2 * ks) ^ x.k_g) * 16));
         asm volatile("ds_read_b128 %0, %1" : "=v"(x.kf[ks]) : "v"(a));
     }
-    x4_units<tab.ub[I]>(x, std::make_integer_sequence<int, tab.ub[I + 1] - tab.ub[I]>{});
+    if constexpr (!(ABL & 2)) x4_units<tab.ub[I]>(x, std::make_integer_sequence<int, tab.ub[I + 1] - tab.ub[I]>{});  // ABL & 2: no VALU work
     __builtin_amdgcn_sched_barrier(0);
 }
-template <int KB_C, int... Is>
+template <int KB_C, int ABL, int... Is>
 __device__ __forceinline__ void x4_slots(X4Ctx& x, std::integer_sequence<int, Is...>)
 {
-    (x4_slot_body<KB_C, Is>(x), ...);
+    (x4_slot_body<KB_C, Is, ABL>(x), ...);
 }
 
-template <int KB_C>
+template <int KB_C, int ABL = 0>
 __device__ __forceinline__ bool x4_step(const char* v_lds, const char* k_nxt, int kb_n2, int k_row_off, int k_g, int v_lane_off,
                                         const bf16x8& ones_a, const bf16x8 (&qf)[kNB][4], f32x16 (&sc)[kNB], f32x16 (&sn)[kNB],
                                         f32x16 (&o)[kNB][2], BlockState (&st)[kNB], float c, const float (&off)[kNB], bf16x8 (&kf)[4],
@@ -277,14 +280,14 @@ __device__ __forceinline__ bool x4_step(const char* v_lds, const char* k_nxt, in
 {
     X4Ctx x{ones_a, qf, sc, sn, o, st, off, kf, lm, c, k_nxt, kb_n2, k_row_off, k_g, (unsigned)(size_t)(lds_s16x4_t*)(v_lds + v_lane_off)};
     x.need = false;
-    x4_slots<KB_C>(x, std::make_integer_sequence<int, kX4Slots>{});
+    x4_slots<KB_C, ABL>(x, std::make_integer_sequence<int, kX4Slots>{});
     // the K reads of slots 28..31 are eight MFMA slots old: this wait is free, and it keeps every asm-issued load inside the
     // basic block that issued it (hipcc may move or spill a register across a branch without knowing a load is in flight)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]));
     return x.need;
 }
 
-template <int NWAVES, bool CAUSAL, bool OUT_F32, int G>
+template <int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL = 0>
 __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdParams p)
 {
     constexpr int D = 64, KS = 4, DB = 2;
@@ -327,6 +330,13 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdPar
     TileDma<D, NWAVES> dma;
     dma.init(kg, vg, n, p.kv_row_stride, wave, lane);
     dma.issue_k(0u, k_slot(0), wave);
+    // every tile the first barrier group needs is requested before anything is waited for: one memory round trip, not two
+#pragma unroll
+    for (int g = 1; g <= G; ++g)
+        if (g < nst) dma.issue_k((unsigned)g * dma.stage_step, k_slot(g), wave);
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+        if (g < nst) dma.issue_v((unsigned)g * dma.stage_step, v_slot(g), wave);
 
     bf16x8 qf[kNB][KS];
 #pragma unroll
@@ -365,8 +375,10 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdPar
     // ring slots nobody reads any more (K tiles are only read into kf one step ahead of their use, and every LDS read of
     // a wave has returned before it arrives at the barrier).
     auto sync_top = [&](int j) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (!(ABL & 8)) {  // ABL & 8: timing-only ablation without the wait + barrier
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
 #pragma unroll
         for (int g = 1; g <= G; ++g)
             if (__builtin_expect(j + G + g < nst, 1)) dma.issue_k((unsigned)(j + G + g) * dma.stage_step, k_slot(j + G + g), wave);
@@ -429,12 +441,6 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdPar
     // ---------------- prologue: K(0) landed -> scores of sub-tile 0, fragments of sub-tile 1 ----------------
     wait_lds_dma();
     __syncthreads();
-#pragma unroll
-    for (int g = 1; g <= G; ++g)
-        if (g < nst) dma.issue_k((unsigned)g * dma.stage_step, k_slot(g), wave);
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-        if (g < nst) dma.issue_v((unsigned)g * dma.stage_step, v_slot(g), wave);
     load_kf(0);
     qk_regs(0, s0, true);
     load_kf(1);
@@ -442,6 +448,10 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdPar
     // ---------------- fast loop: groups of G whole stages whose sub-tiles 2j .. 2j+2 are in range and mask-free ----------------
     int jf = 0;
     while ((2 * jf + 3) * 32 <= kv_end && !needs_mask(2 * jf + 2, q0) && !needs_mask(0, q0)) ++jf;
+    // The last stage may run in the fast loop too when its own two sub-tiles are whole and mask-free: its second step then
+    // computes scores of a sub-tile that does not exist (from whatever the ring slot holds) and nobody consumes them --
+    // the rescale test of that step is ignored.  Without this the final 128 keys of every slab took the slow tail path.
+    if (jf == nst - 1 && (2 * jf + 2) * 32 <= kv_end && !needs_mask(2 * jf + 1, q0) && !needs_mask(0, q0)) jf = nst;
     jf -= jf % G;
     for (int j = 0; j < jf; j += G) {
         sync_top(j);
@@ -449,15 +459,15 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdPar
         for (int g = 0; g < G; ++g) {
             const char* v_lds = v_slot(j + g);
             const char* k_nxt = k_slot(j + g + 1);
-            bool need = x4_step<0>(v_lds, k_nxt, 0, k_row_off, k_g, v_lane_off, ones_a, qf, s0, s1, o, st, c, off, kf, lm);
+            bool need = x4_step<0, ABL>(v_lds, k_nxt, 0, k_row_off, k_g, v_lane_off, ones_a, qf, s0, s1, o, st, c, off, kf, lm);
             if (__builtin_expect(__any(need), 0)) {
                 float mx[kNB];
 #pragma unroll
                 for (int blk = 0; blk < kNB; ++blk) mx[blk] = xhalf_max(lm[blk]);
                 x4_rescale(mx, c, st, o, off);
             }
-            need = x4_step<1>(v_lds, k_nxt, 1, k_row_off, k_g, v_lane_off, ones_a, qf, s1, s0, o, st, c, off, kf, lm);
-            if (__builtin_expect(__any(need), 0)) {
+            need = x4_step<1, ABL>(v_lds, k_nxt, 1, k_row_off, k_g, v_lane_off, ones_a, qf, s1, s0, o, st, c, off, kf, lm);
+            if (__builtin_expect(__any(need) && 2 * (j + g) + 2 < nsub, 0)) {
                 float mx[kNB];
 #pragma unroll
                 for (int blk = 0; blk < kNB; ++blk) mx[blk] = xhalf_max(lm[blk]);
@@ -539,11 +549,27 @@ static hipError_t launch_x4(const FwdParams& p0, int causal, int out_f32, hipStr
     return hipGetLastError();
 }
 
-// D = 64 only; mode selects the barrier period (stages)
+template <int ABL>
+static hipError_t launch_x4_ablation(const FwdParams& p0, hipStream_t stream)
+{
+    FwdParams p = p0;
+    p.q_tiles = (p.n + 511) / 512;
+    dim3 grid((unsigned)(p.bh * p.q_tiles)), block(256);
+    hipLaunchKernelGGL((fa_fwd_bf16_x4_kernel<4, false, false, 2, ABL>), grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+// D = 64 only; mode selects the barrier period (stages); modes 11..13: timing-only ablations (results are garbage)
 hipError_t launch_bf16_x4(const FwdParams& p, int causal, int out_f32, int mode, hipStream_t stream)
 {
     if (!bf16_pipelined_supported(p, 64)) return hipErrorInvalidValue;
     if (mode == 1) return launch_x4<1>(p, causal, out_f32, stream);
+    if (mode == 11) return launch_x4_ablation<1>(p, stream);  // no MFMA
+    if (mode == 12) return launch_x4_ablation<2>(p, stream);  // no VALU units
+    if (mode == 13) return launch_x4_ablation<3>(p, stream);  // neither: LDS reads, waits, barriers, DMA only
+    if (mode == 14) return launch_x4_ablation<4>(p, stream);  // no waits for the V^T fragments
+    if (mode == 15) return launch_x4_ablation<8>(p, stream);  // no DMA wait + barrier
+    if (mode == 16) return launch_x4_ablation<12>(p, stream); // neither wait
     return launch_x4<2>(p, causal, out_f32, stream);
 }
 
