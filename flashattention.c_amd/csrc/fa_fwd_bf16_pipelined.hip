@@ -65,11 +65,14 @@ __device__ __forceinline__ void lazy_rescale2(float mxa, float mxb, float c, Blo
 //   k_lds2/kb_n2 : K sub-tile t+2 -- its fragments are fetched during the P1 phase of this step (kf carries them over), so
 //                  that every LDS read is issued a whole phase before its first use (under load the LDS latency is several
 //                  MFMA slots; a read issued two slots ahead stalls the in-order wave and drains the matrix pipe)
-template <int D, int KB_C, bool PROF = false>
+//   MASKED       : the scores of sub-tile t+1 (first key key0_next) get the causal / sequence-end mask before their maxima
+//                  are taken -- the same pipelined step serves the diagonal and ragged tiles, no slow path
+template <int D, int KB_C, bool PROF = false, bool MASKED = false, bool CAUSAL = false>
 __device__ __forceinline__ void pp3_step(const char* v_lds, const char* k_lds2, int kb_n2, int k_row_off, int k_g, int v_lane_off, const bf16x8& ones_a, const bf16x8 (&qfa)[D / 16],
                                          const bf16x8 (&qfb)[D / 16], f32x16& sa_cur, f32x16& sb_cur, f32x16& sa_nxt, f32x16& sb_nxt,
                                          f32x16 (&oa)[D / 32], f32x16 (&ob)[D / 32], bf16x8 (&pfa)[2], bf16x8 (&pfb)[2], BlockState& sta,
-                                         BlockState& stb, float c, Lazy2& lz, bf16x8 (&kf)[D / 16], bool honor_test, unsigned long long* tm = nullptr)
+                                         BlockState& stb, float c, Lazy2& lz, bf16x8 (&kf)[D / 16], bool honor_test, unsigned long long* tm = nullptr,
+                                         int key0_next = 0, int qia = 0, int qib = 0, int n = 0, int hi = 0)
 {
     using P = Plan3<D>;
     constexpr int KS = P::KS, DB = P::DB, NV = P::NV;
@@ -136,6 +139,10 @@ __device__ __forceinline__ void pp3_step(const char* v_lds, const char* k_lds2, 
         }
         if (v < KS) kf[v] = load_k_frag<D>(k_lds2, k_row_off, k_g, kb_n2, v);   // scores of the NEXT step (kf is free: Q phase done)
         exp_range(sb_cur, pfb, c, lz.offb, E1 * v / (NV + 2), E1 * (v + 1) / (NV + 2));
+        if (MASKED && v == NV + 1) {  // K.Q^T of sub-tile t+1 finished a phase ago
+            mask16(sa_nxt, key0_next, qia, n, hi, CAUSAL);
+            mask16(sb_nxt, key0_next, qib, n, hi, CAUSAL);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     if (PROF) t2 = stamp();
@@ -306,26 +313,6 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
         if (needs_mask(t, q0b)) mask16(sb, t * 32, q0b + lq, n, hi, CAUSAL);
         lazy_rescale2<D>(rowmax16(sa), rowmax16(sb), c, sta, stb, oa, ob, lz);
     };
-    // exp, pack, P.V and row sums of sub-tile t for both blocks, phase-structured (tail)
-    auto finish_sub = [&](int t, f32x16& sa, f32x16& sb) {
-        exp_range(sa, pfa, c, lz.offa, 0, 8);
-        exp_range(sa, pfa, c, lz.offa, 8, 16);
-        exp_range(sb, pfb, c, lz.offb, 0, 8);
-        exp_range(sb, pfb, c, lz.offb, 8, 16);
-        const char* v_lds = v_slot(t >> 1);
-#pragma unroll
-        for (int v = 0; v < 2 * DB; ++v) {
-            const bf16x8 vf = load_v_frag<D>(v_lds, v_lane_off, t & 1, v);
-            oa[v % DB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfa[v / DB], oa[v % DB], 0, 0, 0);
-            ob[v % DB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfb[v / DB], ob[v % DB], 0, 0, 0);
-        }
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            sta.lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pfa[f], sta.lacc, 0, 0, 0);
-            stb.lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pfb[f], stb.lacc, 0, 0, 0);
-        }
-    };
-
     // ---------------- prologue: K(0) landed -> scores of sub-tile 0, fragments of sub-tile 1 ----------------
     wait_lds_dma();
     __syncthreads();
@@ -366,25 +353,20 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
         }
     }
 
-    // ---------------- tail: remaining stages, phase-structured, masks applied where needed ----------------
-    // Invariant at the top of stage j: the scores of sub-tile 2j are in s0 with the rescale decision taken, and kf holds the
-    // K fragments of sub-tile 2j+1.  Every wave keeps taking part in the barriers / DMA, but only computes the sub-tiles
-    // its own rows can see (causal: the sub-tiles up to the diagonal of its last row).
+    // ---------------- tail: the remaining stages through the same pipelined step with masks applied ----------------
+    // Sub-tiles past the end of the keys (their ring slots hold stale or zero data) are masked out entirely, so the step
+    // after the last real sub-tile is harmless.  Every wave keeps taking part in the barriers / DMA, but only computes
+    // the stages its own rows can see (causal: up to the diagonal of its last row).
     const int nsub_w = CAUSAL ? min(nsub, (q0b + 31) / 32 + 1) : nsub;
     for (int j = jf; j < nst; ++j) {
         if (j % G == 0) sync_top(j);
-        const int t0 = 2 * j, t1 = 2 * j + 1;
-        if (t0 < nsub_w) {
-            finish_sub(t0, sa0, sb0);
-            if (t1 < nsub_w) {
-                qk_regs(t1, sa1, sb1);
-                load_kf(t1 + 1);  // K(j+1) block 0: visible since the last barrier
-                finish_sub(t1, sa1, sb1);
-                if (t1 + 1 < nsub_w) {
-                    qk_regs(t1 + 1, sa0, sb0);
-                    load_kf(t1 + 2);
-                }
-            }
+        if (2 * j < nsub_w) {
+            const char* v_lds = v_slot(j);
+            const char* k_nxt = k_slot(j + 1);
+            pp3_step<D, 0, false, true, CAUSAL>(v_lds, k_nxt, 0, k_row_off, k_g, v_lane_off, ones_a, qfa, qfb, sa0, sb0, sa1, sb1, oa, ob, pfa,
+                                                pfb, sta, stb, c, lz, kf, true, nullptr, (2 * j + 1) * 32, q0a + lq, q0b + lq, n, hi);
+            pp3_step<D, 1, false, true, CAUSAL>(v_lds, k_nxt, 1, k_row_off, k_g, v_lane_off, ones_a, qfa, qfb, sa1, sb1, sa0, sb0, oa, ob, pfa,
+                                                pfb, sta, stb, c, lz, kf, true, nullptr, (2 * j + 2) * 32, q0a + lq, q0b + lq, n, hi);
         }
     }
 

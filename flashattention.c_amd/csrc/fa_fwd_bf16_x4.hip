@@ -237,7 +237,8 @@ __device__ __forceinline__ void x4_slot_body(X4Ctx& x)
     // block A waits only for the fragment it consumes, so the youngest read gets nine slots instead of five to land.
     if constexpr (I == 8 || I == 9 || I == 11 || I == 12) {
         constexpr int v = I == 8 ? 0 : I == 9 ? 1 : I == 11 ? 2 : 3;
-        if constexpr (ABL & 4) asm volatile("" : "+v"(x.vlo[v]), "+v"(x.vhi[v]));  // timing-only ablation: no wait
+        if constexpr (ABL & 32) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x.vlo[v]), "+v"(x.vhi[v]));
+        else if constexpr (ABL & 4) asm volatile("" : "+v"(x.vlo[v]), "+v"(x.vhi[v]));  // timing-only ablation: no wait
         else if constexpr (v == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(x.vlo[0]), "+v"(x.vhi[0]));
         else if constexpr (v == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x.vlo[1]), "+v"(x.vhi[1]));
         else if constexpr (v == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(x.vlo[2]), "+v"(x.vhi[2]));
@@ -245,7 +246,9 @@ __device__ __forceinline__ void x4_slot_body(X4Ctx& x)
         __builtin_amdgcn_sched_barrier(0);
         x.vf[v] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(x.vlo[v], x.vhi[v], 0, 1, 2, 3, 4, 5, 6, 7));
     }
-    if constexpr (I < 4) load_v_frag_asm<D, KB_C, I>(x.v_addr, x.vlo[I], x.vhi[I]);
+    if constexpr (I < 4 && !(ABL & 16)) load_v_frag_asm<D, KB_C, I>(x.v_addr, x.vlo[I], x.vhi[I]);  // ABL & 16: no LDS fragment reads
+    if constexpr (I < 4 && (ABL & 16)) asm volatile("" : "=v"(x.vlo[I]), "=v"(x.vhi[I]));
+    if constexpr (I < 4 && (ABL & 32)) load_v_frag_asm<D, KB_C, I>(x.v_addr, x.vlo[I], x.vhi[I]);  // ABL & 32: every fragment read issued twice
     if constexpr (ABL & 1) {
         // timing-only ablation: no matrix instructions
     } else if constexpr (sl.kind == 0) {
@@ -261,7 +264,9 @@ __device__ __forceinline__ void x4_slot_body(X4Ctx& x)
         // next step's K.Q^T MFMAs, and those waits -- counted without the asm reads in flight -- drain the V^T reads too
         constexpr int ks = I - 28;
         const unsigned a = (unsigned)(size_t)(lds_s16x4_t*)(x.k_nxt + x.k_row_off + x.kb_n2 * 32 * (2 * D) + (((2 * ks) ^ x.k_g) * 16));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(x.kf[ks]) : "v"(a));
+        if constexpr (ABL & 16) asm volatile("" : "=v"(x.kf[ks]) : "v"(a));
+        else asm volatile("ds_read_b128 %0, %1" : "=v"(x.kf[ks]) : "v"(a));
+        if constexpr (ABL & 32) asm volatile("ds_read_b128 %0, %1" : "=v"(x.kf[ks]) : "v"(a));
     }
     if constexpr (!(ABL & 2)) x4_units<tab.ub[I]>(x, std::make_integer_sequence<int, tab.ub[I + 1] - tab.ub[I]>{});  // ABL & 2: no VALU work
     __builtin_amdgcn_sched_barrier(0);
@@ -570,6 +575,9 @@ hipError_t launch_bf16_x4(const FwdParams& p, int causal, int out_f32, int mode,
     if (mode == 14) return launch_x4_ablation<4>(p, stream);  // no waits for the V^T fragments
     if (mode == 15) return launch_x4_ablation<8>(p, stream);  // no DMA wait + barrier
     if (mode == 16) return launch_x4_ablation<12>(p, stream); // neither wait
+    if (mode == 17) return launch_x4_ablation<16>(p, stream); // no LDS fragment reads
+    if (mode == 18) return launch_x4_ablation<17>(p, stream); // no LDS fragment reads, no MFMA
+    if (mode == 19) return launch_x4_ablation<32>(p, stream); // every LDS fragment read issued twice (results stay valid)
     return launch_x4<2>(p, causal, out_f32, stream);
 }
 
