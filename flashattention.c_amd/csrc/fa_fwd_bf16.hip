@@ -502,6 +502,7 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
                 case 25: return launch_bf16_pipelined(p, 64, 4, causal, out_f32, 3, stream);  // barrier every stage
                 case 30: return launch_bf16_x4(p, causal, out_f32, 2, stream);
                 case 31: return launch_bf16_x4(p, causal, out_f32, 1, stream);
+                case 42: return launch_bf16_x4(p, causal, out_f32, 3, stream);   // x4, rescaling mix only
                 case 33: return launch_bf16_x4(p, causal, out_f32, 11, stream);  // x4 timing ablations
                 case 34: return launch_bf16_x4(p, causal, out_f32, 12, stream);
                 case 35: return launch_bf16_x4(p, causal, out_f32, 13, stream);

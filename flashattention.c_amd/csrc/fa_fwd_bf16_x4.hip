@@ -31,10 +31,10 @@ constexpr int kNB = 4;  // 32-row blocks per wave
 // (only MFMAs touch them in the loop),   Q fragments -> AGPRs (B operand),   K / V^T / P fragments -> VGPRs.
 // The price: hipcc does not see an MFMA inside an asm statement, so the hazards are ours --
 //   * MFMA result -> VALU read: the static schedule reads scores >= 7 slots after their last MFMA; every cold path
-//     (tail, rescale branch, epilogue) calls mfma_drain() first;
+//     (tail, rescale branch, epilogue) drains the matrix pipe first, with the registers concerned tied to the drain;
 //   * MFMA -> dependent MFMA (same accumulator): at least one independent 32x32x16 MFMA (32 cycles) sits between them;
-//   * LDS / VALU results -> MFMA operands are ordinary register dependencies (interlocked; waits counted by hipcc or by
-//     the explicit lgkmcnt wait in front of the first P.V slot).
+//   * VALU result -> MFMA operand: two wait states, ours as well (the loop packs P a whole slot ahead; the tail pads);
+//     LDS result -> MFMA operand: the explicit lgkmcnt waits.
 __device__ __forceinline__ void mfma_s_first(f32x16& s, const bf16x8& kf, const bf16x8& q)
 {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s) : "v"(kf), "a"(q));
@@ -52,6 +52,20 @@ __device__ __forceinline__ void mfma_l(f32x4_t& l, const bf16x8& ones, const bf1
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(pfrag));
 }
 
+// mfma_drain() with the registers it protects as operands: the drain is an asm statement without a data dependence of its
+// own, and hipcc is free to schedule the VALU consumers of an asm MFMA's result in front of it (it did: the optimistic
+// mix has no branch between the tail's K.Q^T and the exponentials, and they were hoisted above the bare drain).
+__device__ __forceinline__ void drain_scores(f32x16 (&s)[kNB])
+{
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]));
+}
+__device__ __forceinline__ void drain_accumulators(f32x16 (&o)[kNB][2], BlockState (&st)[kNB])
+{
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+                 : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[2][0]), "+a"(o[2][1]), "+a"(o[3][0]), "+a"(o[3][1]),
+                   "+a"(st[0].lacc), "+a"(st[1].lacc), "+a"(st[2].lacc), "+a"(st[3].lacc));
+}
+
 // (rare, wave-uniform) move the exponent references of all blocks; everything still at the old reference is scaled once
 __device__ __forceinline__ void x4_rescale(const float (&mx)[kNB], float c, BlockState (&st)[kNB], f32x16 (&o)[kNB][2], float (&off)[kNB])
 {
@@ -65,7 +79,7 @@ __device__ __forceinline__ void x4_rescale(const float (&mx)[kNB], float c, Bloc
     }
     if (__builtin_expect(__any(any), 0)) {
         asm volatile("; lazy rescale (four blocks)" ::: "memory");
-        mfma_drain();  // the accumulators rescaled below may have an MFMA in flight (hazard not padded across the branch)
+        drain_accumulators(o, st);  // the accumulators rescaled below may have an MFMA in flight (hazard not padded across the branch)
 #pragma unroll
         for (int b = 0; b < kNB; ++b) {
             const float nm = fmaxf(st[b].m, mc[b]);
@@ -106,7 +120,12 @@ __device__ __host__ constexpr X4Slot x4_slot(int i)
     return x4_pv_group(3, i - 34);                                    // P.V + row sums D
 }
 constexpr int kX4Slots = 40;
-constexpr int kX4Units = 85;  // 4 blocks x (16 exp elements + 2 packs) + 4 x 3 max micro-steps + 1 test
+// Two instruction mixes share the slot sequence:
+//   OPT = false  the lazily rescaled softmax: exp + pack of sub-tile t, lane maxima of sub-tile t+1, rescale test (85 units)
+//   OPT = true   the optimistic softmax: the exponent reference of a row is fixed after its first sub-tile (with 2^100 of
+//                headroom either way, see kOptBias), so the loop has no maxima, no test and no branch (72 units); the tile
+//                is verified at the end and redone with OPT = false if any row left the safe range.
+constexpr int x4_num_units(bool opt) { return opt ? 72 : 85; }
 __device__ __host__ constexpr int x4_weight_before(int i)  // in half-slots: a 32x32x16 slot = 2, a 16x16x32 slot = 1
 {
     int w = 0;
@@ -114,10 +133,12 @@ __device__ __host__ constexpr int x4_weight_before(int i)  // in half-slots: a 3
     return w;
 }
 constexpr int kX4Weight = x4_weight_before(kX4Slots);  // 72
+// all VALU work of the optimistic mix has to be finished before P.V of block D starts (slot 34)
+constexpr int x4_weight_end(bool opt) { return opt ? x4_weight_before(34) : kX4Weight; }
 // VALU units are dealt out by ISSUE COST, not by count: measured beside MFMAs (profiles/ubench/ubench_clock.hip) a plain
 // VALU instruction occupies the wave's issue for 4 cycles and a v_exp_f32 for 8, so an exp element (fma + exp) costs 12, a
-// pack (4 cvt) 16, the max micro-steps 12 / 12 / 8, the test ~20 -- 1044 cycles per step.  Slot i receives the units whose
-// cumulative cost fits its share of the step's 72 half-slots (table computed by that rule; 24..36 cycles per full slot).
+// pack (4 cvt) 16, the max micro-steps 12 / 12 / 8, the test ~20 -- 1044 (896) cycles per step.  Slot i receives the units
+// whose cumulative cost fits its share of the step's half-slots (24..36 cycles per full slot).
 struct X4Table {
     int ub[kX4Slots + 1];  // VALU units dealt out before slot i
 };
@@ -128,9 +149,9 @@ struct X4Unit {
     int blk, idx, cost;
 };
 struct X4UnitList {
-    X4Unit u[kX4Units];
+    X4Unit u[85];
 };
-__device__ __host__ constexpr X4UnitList x4_make_units()
+__device__ __host__ constexpr X4UnitList x4_make_units(bool opt)
 {
     X4UnitList l{};
     int n = 0;
@@ -148,6 +169,10 @@ __device__ __host__ constexpr X4UnitList x4_make_units()
         pend = {1, b, 1, 16};
         pending = true;
     }
+    if (opt) {
+        l.u[n++] = pend;
+        return l;
+    }
     for (int b = 0; b < kNB; ++b)
         for (int m = 0; m < 3; ++m) {
             l.u[n++] = {2, b, m, m == 2 ? 8 : 12};
@@ -159,22 +184,24 @@ __device__ __host__ constexpr X4UnitList x4_make_units()
     l.u[n++] = {3, 0, 0, 20};
     return l;
 }
-__device__ __host__ constexpr int x4_unit_cost(int u) { return x4_make_units().u[u].cost; }
-__device__ __host__ constexpr X4Table x4_make_table()
+__device__ __host__ constexpr X4Table x4_make_table(bool opt)
 {
+    const X4UnitList l = x4_make_units(opt);
+    const int nu = x4_num_units(opt), wend = x4_weight_end(opt);
     X4Table t{};
     int total = 0;
-    for (int u = 0; u < kX4Units; ++u) total += x4_unit_cost(u);
-    int n = 0, cum_next = x4_unit_cost(0);  // cum_next: cost of units 0..n inclusive
+    for (int u = 0; u < nu; ++u) total += l.u[u].cost;
+    int n = 0, cum_next = l.u[0].cost;  // cum_next: cost of units 0..n inclusive
     for (int i = 0; i <= kX4Slots; ++i) {
-        const int target = total * x4_weight_before(i) / kX4Weight + 6;
-        while (n < kX4Units && cum_next <= target) {
+        const int wb = x4_weight_before(i) < wend ? x4_weight_before(i) : wend;
+        const int target = total * wb / wend + 6;
+        while (n < nu && cum_next <= target) {
             ++n;
-            if (n < kX4Units) cum_next += x4_unit_cost(n);
+            if (n < nu) cum_next += l.u[n].cost;
         }
         t.ub[i] = n;
     }
-    t.ub[kX4Slots] = kX4Units;
+    t.ub[kX4Slots] = nu;
     return t;
 }
 
@@ -203,12 +230,15 @@ struct X4Ctx {
     bool need;
 };
 
-template <int U>
+template <bool OPT, int U>
 __device__ __forceinline__ void x4_unit(X4Ctx& x)
 {
-    constexpr X4Unit un = x4_make_units().u[U];
+    constexpr X4Unit un = x4_make_units(OPT).u[U];
     if constexpr (un.kind == 0) {
-        x.sc[un.blk][un.idx] = exp2_clamp01(fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]));
+        // optimistic mix: no clamp -- an overflow has to reach the row sum (as a huge value or +inf): that is what the final
+        // check reads
+        if constexpr (OPT) x.sc[un.blk][un.idx] = fast_exp2(fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]));
+        else x.sc[un.blk][un.idx] = exp2_clamp01(fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]));
     } else if constexpr (un.kind == 1) {
         x.pf[un.blk][un.idx] = pack_bf16x8(x.sc[un.blk], 8 * un.idx);
         asm volatile("" : "+v"(x.pf[un.blk][un.idx]));
@@ -221,18 +251,18 @@ __device__ __forceinline__ void x4_unit(X4Ctx& x)
         x.need = t > 0.0f;  // off = m + kLazyThr
     }
 }
-template <int U0, int... Us>
+template <bool OPT, int U0, int... Us>
 __device__ __forceinline__ void x4_units(X4Ctx& x, std::integer_sequence<int, Us...>)
 {
-    (x4_unit<U0 + Us>(x), ...);
+    (x4_unit<OPT, U0 + Us>(x), ...);
 }
 
-template <int KB_C, int I, int ABL>
+template <int KB_C, int I, int ABL, bool OPT>
 __device__ __forceinline__ void x4_slot_body(X4Ctx& x)
 {
     constexpr int D = 64;
     constexpr X4Slot sl = x4_slot(I);
-    constexpr X4Table tab = x4_make_table();
+    constexpr X4Table tab = x4_make_table(OPT);
     // The asm-issued V^T reads were started in slots 0..3 (two ds_read per fragment, LDS returns in order): each P.V slot of
     // block A waits only for the fragment it consumes, so the youngest read gets nine slots instead of five to land.
     if constexpr (I == 8 || I == 9 || I == 11 || I == 12) {
@@ -268,16 +298,16 @@ __device__ __forceinline__ void x4_slot_body(X4Ctx& x)
         else asm volatile("ds_read_b128 %0, %1" : "=v"(x.kf[ks]) : "v"(a));
         if constexpr (ABL & 32) asm volatile("ds_read_b128 %0, %1" : "=v"(x.kf[ks]) : "v"(a));
     }
-    if constexpr (!(ABL & 2)) x4_units<tab.ub[I]>(x, std::make_integer_sequence<int, tab.ub[I + 1] - tab.ub[I]>{});  // ABL & 2: no VALU work
+    if constexpr (!(ABL & 2)) x4_units<OPT, tab.ub[I]>(x, std::make_integer_sequence<int, tab.ub[I + 1] - tab.ub[I]>{});  // ABL & 2: no VALU work
     __builtin_amdgcn_sched_barrier(0);
 }
-template <int KB_C, int ABL, int... Is>
+template <int KB_C, int ABL, bool OPT, int... Is>
 __device__ __forceinline__ void x4_slots(X4Ctx& x, std::integer_sequence<int, Is...>)
 {
-    (x4_slot_body<KB_C, Is, ABL>(x), ...);
+    (x4_slot_body<KB_C, Is, ABL, OPT>(x), ...);
 }
 
-template <int KB_C, int ABL = 0>
+template <int KB_C, int ABL = 0, bool OPT = false>
 __device__ __forceinline__ bool x4_step(const char* v_lds, const char* k_nxt, int kb_n2, int k_row_off, int k_g, int v_lane_off,
                                         const bf16x8& ones_a, const bf16x8 (&qf)[kNB][4], f32x16 (&sc)[kNB], f32x16 (&sn)[kNB],
                                         f32x16 (&o)[kNB][2], BlockState (&st)[kNB], float c, const float (&off)[kNB], bf16x8 (&kf)[4],
@@ -285,25 +315,35 @@ __device__ __forceinline__ bool x4_step(const char* v_lds, const char* k_nxt, in
 {
     X4Ctx x{ones_a, qf, sc, sn, o, st, off, kf, lm, c, k_nxt, kb_n2, k_row_off, k_g, (unsigned)(size_t)(lds_s16x4_t*)(v_lds + v_lane_off)};
     x.need = false;
-    x4_slots<KB_C, ABL>(x, std::make_integer_sequence<int, kX4Slots>{});
+    x4_slots<KB_C, ABL, OPT>(x, std::make_integer_sequence<int, kX4Slots>{});
     // the K reads of slots 28..31 are eight MFMA slots old: this wait is free, and it keeps every asm-issued load inside the
     // basic block that issued it (hipcc may move or spill a register across a branch without knowing a load is in flight)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]));
     return x.need;
 }
 
-template <int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL = 0>
-__global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdParams p)
+// Exponent bias of the optimistic mix: p = 2^(c*s - m0 - kOptBias) with m0 the row maximum of the FIRST sub-tile, fixed for
+// the whole row.  The shift is an exact power of two in P (bf16, 8 exponent bits), O and the row sum (fp32) and cancels in
+// O / l, so the only requirement is range: the largest term of a row is >= 2^-100, and everything within 2^-24 of it stays
+// above the smallest normal bf16 (2^-126); the row sum l = sum p < 2^100 at the end proves that no term exceeded 2^100
+// (fp32 accumulators hold N * 2^100 * |v| comfortably), i.e. a row may outgrow its first 32 keys by a factor 2^200 before
+// the tile is redone with the rescaling mix.
+constexpr float kOptBias = 100.0f;
+constexpr float kOptLimit = 0x1p100f;
+
+// One 512-row tile.  OPT: optimistic mix; returns false (nothing stored) when some row of the workgroup left the safe range.
+template <int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL, bool OPT>
+__device__ __forceinline__ bool x4_tile(const FwdParams& p, char* smem)
 {
     constexpr int D = 64, KS = 4, DB = 2;
+    constexpr float kBias = OPT ? kOptBias : kLazyThr;
     using C = Bf16Cfg<D, NWAVES>;
     constexpr int BM = NWAVES * 32 * kNB;
     constexpr int KR = 2 * G, VR = 2 * G;
     static_assert(G == 1 || G == 2, "ring index arithmetic written for G = 1, 2");
     constexpr int T = C::kTileBytes;
 
-    __shared__ __attribute__((aligned(1024))) char smem[(KR + VR) * T];  // K ring, then V ring
-    char* const k_ring = smem;
+    char* const k_ring = smem;  // K ring, then V ring
     char* const v_ring = smem + KR * T;
 
     const int lane = threadIdx.x & 63;
@@ -406,7 +446,7 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdPar
                 if (ks == 0) mfma_s_first(s[blk], kf[ks], qf[blk][ks]);
                 else mfma_s(s[blk], kf[ks], qf[blk][ks]);
             }
-        mfma_drain();  // cold path: let the scores retire before the VALU reads them
+        drain_scores(s);  // cold path: let the scores retire before the VALU reads them
         float mx[kNB];
 #pragma unroll
         for (int blk = 0; blk < kNB; ++blk) {
@@ -418,9 +458,9 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdPar
             for (int blk = 0; blk < kNB; ++blk) {
                 const float mc = mx[blk] * c;
                 st[blk].m = fmaf(-fabsf(mc), 0x1p-23f, mc);
-                off[blk] = st[blk].m + kLazyThr;
+                off[blk] = st[blk].m + kBias;
             }
-        } else {
+        } else if (!OPT) {
             x4_rescale(mx, c, st, o, off);
         }
     };
@@ -433,8 +473,18 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdPar
 #pragma unroll
         for (int blk = 0; blk < kNB; ++blk) {
             bf16x8 pf[2];
-            exp_range(s[blk], pf, c, off[blk], 0, 8);
-            exp_range(s[blk], pf, c, off[blk], 8, 16);
+            if (OPT) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[blk][e] = fast_exp2(fmaf(s[blk][e], c, -off[blk]));
+                pf[0] = pack_bf16x8(s[blk], 0);
+                pf[1] = pack_bf16x8(s[blk], 8);
+            } else {
+                exp_range(s[blk], pf, c, off[blk], 0, 8);
+                exp_range(s[blk], pf, c, off[blk], 8, 16);
+            }
+            // a VALU result needs two wait states before an MFMA may read it; hipcc counts them for its own MFMAs, not
+            // for an asm one (the pipelined loop packs P at least one whole slot ahead of its first use)
+            asm volatile("s_nop 1" : "+v"(pf[0]), "+v"(pf[1]));
 #pragma unroll
             for (int v = 0; v < 2 * DB; ++v) mfma_o(o[blk][v % DB], vf[v], pf[v / DB]);
             mfma_l(st[blk].lacc, ones_a, pf[0]);
@@ -464,15 +514,15 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdPar
         for (int g = 0; g < G; ++g) {
             const char* v_lds = v_slot(j + g);
             const char* k_nxt = k_slot(j + g + 1);
-            bool need = x4_step<0, ABL>(v_lds, k_nxt, 0, k_row_off, k_g, v_lane_off, ones_a, qf, s0, s1, o, st, c, off, kf, lm);
-            if (__builtin_expect(__any(need), 0)) {
+            bool need = x4_step<0, ABL, OPT>(v_lds, k_nxt, 0, k_row_off, k_g, v_lane_off, ones_a, qf, s0, s1, o, st, c, off, kf, lm);
+            if (!OPT && __builtin_expect(__any(need), 0)) {
                 float mx[kNB];
 #pragma unroll
                 for (int blk = 0; blk < kNB; ++blk) mx[blk] = xhalf_max(lm[blk]);
                 x4_rescale(mx, c, st, o, off);
             }
-            need = x4_step<1, ABL>(v_lds, k_nxt, 1, k_row_off, k_g, v_lane_off, ones_a, qf, s1, s0, o, st, c, off, kf, lm);
-            if (__builtin_expect(__any(need) && 2 * (j + g) + 2 < nsub, 0)) {
+            need = x4_step<1, ABL, OPT>(v_lds, k_nxt, 1, k_row_off, k_g, v_lane_off, ones_a, qf, s1, s0, o, st, c, off, kf, lm);
+            if (!OPT && __builtin_expect(__any(need) && 2 * (j + g) + 2 < nsub, 0)) {
                 float mx[kNB];
 #pragma unroll
                 for (int blk = 0; blk < kNB; ++blk) mx[blk] = xhalf_max(lm[blk]);
@@ -501,8 +551,17 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdPar
         }
     }
 
-    // ---------------- store ----------------
-    mfma_drain();
+    // ---------------- verify (optimistic mix), store ----------------
+    drain_accumulators(o, st);
+    if (OPT) {
+        // every P was exponentiated against the first sub-tile's maximum: the tile stands iff no term left the safe range,
+        // which the row sums prove (a term > 2^100, +inf or NaN makes its row sum fail this test)
+        bool bad = false;
+#pragma unroll
+        for (int blk = 0; blk < kNB; ++blk) bad = bad || !(st[blk].lacc[0] < kOptLimit);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // no DMA of this attempt may land after the vote
+        if (__syncthreads_or(bad ? 1 : 0)) return false;             // workgroup-wide: the redo shares tiles and barriers
+    }
 #pragma unroll
     for (int blk = 0; blk < kNB; ++blk) {
         const float lt = st[blk].lacc[0];
@@ -526,12 +585,25 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdPar
                         *(bf16x4*)((__bf16*)p.o + o_off + db * 32 + 8 * g) = pk;
                     }
                 }
-            if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (st[blk].m + kLazyThr + __builtin_amdgcn_logf(lt)) * kLn2;
+            if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (st[blk].m + kBias + __builtin_amdgcn_logf(lt)) * kLn2;
         }
     }
+    return true;
 }
 
-template <int G>
+// OPTIMISTIC: try the fixed-reference mix first, redo the tile with the rescaling mix if its verification fails
+template <int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL = 0, bool OPTIMISTIC = true>
+__global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdParams p)
+{
+    using C = Bf16Cfg<64, NWAVES>;
+    __shared__ __attribute__((aligned(1024))) char smem[4 * G * C::kTileBytes];
+    if (OPTIMISTIC && ABL == 0) {
+        if (x4_tile<NWAVES, CAUSAL, OUT_F32, G, 0, true>(p, smem)) return;
+    }
+    (void)x4_tile<NWAVES, CAUSAL, OUT_F32, G, ABL, false>(p, smem);
+}
+
+template <int G, bool OPTIMISTIC = true>
 static hipError_t launch_x4(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
 {
     FwdParams p = p0;
@@ -542,14 +614,14 @@ static hipError_t launch_x4(const FwdParams& p0, int causal, int out_f32, hipStr
     dim3 grid((unsigned)total), block(NWAVES * kWave);
     if (causal) {
         if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_x4_kernel<NWAVES, true, true, G>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_x4_kernel<NWAVES, true, true, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
         else
-            hipLaunchKernelGGL((fa_fwd_bf16_x4_kernel<NWAVES, true, false, G>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_x4_kernel<NWAVES, true, false, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
     } else {
         if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_x4_kernel<NWAVES, false, true, G>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_x4_kernel<NWAVES, false, true, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
         else
-            hipLaunchKernelGGL((fa_fwd_bf16_x4_kernel<NWAVES, false, false, G>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_x4_kernel<NWAVES, false, false, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
     }
     return hipGetLastError();
 }
@@ -569,6 +641,7 @@ hipError_t launch_bf16_x4(const FwdParams& p, int causal, int out_f32, int mode,
 {
     if (!bf16_pipelined_supported(p, 64)) return hipErrorInvalidValue;
     if (mode == 1) return launch_x4<1>(p, causal, out_f32, stream);
+    if (mode == 3) return launch_x4<2, false>(p, causal, out_f32, stream);  // rescaling mix only (no optimistic attempt)
     if (mode == 11) return launch_x4_ablation<1>(p, stream);  // no MFMA
     if (mode == 12) return launch_x4_ablation<2>(p, stream);  // no VALU units
     if (mode == 13) return launch_x4_ablation<3>(p, stream);  // neither: LDS reads, waits, barriers, DMA only
