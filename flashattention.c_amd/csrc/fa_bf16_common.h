@@ -207,6 +207,16 @@ __device__ __forceinline__ void mask_block(f32x16 (&s)[2], int kv0, int qi, int 
 // event on real data: with 8 it fired in a quarter of all steps of a 64-row wave on unit-variance data at scale 1.
 constexpr float kLazyThr = 64.0f;
 
+// Optimistic softmax (used by the software-pipelined kernels): p = 2^(c*s - m0 - kOptBias) with m0 the row maximum of the
+// FIRST sub-tile, fixed for the whole row -- no running maximum, no rescale test, no branch in the main loop.  The shift is
+// an exact power of two in P (bf16, 8 exponent bits), O and the row sum (fp32) and cancels in O / l, so the only requirement
+// is range: the largest term of a row is >= 2^-100, and everything within 2^-24 of it stays above the smallest normal bf16
+// (2^-126); the row sum l = sum p < 2^100 at the end of the tile proves that no term exceeded 2^100 (a larger term, +inf or
+// NaN fails the test; fp32 accumulators hold N * 2^100 * |v| comfortably).  A row may thus outgrow the maximum of its first
+// 32 keys by a factor 2^200 before its tile is redone with the lazily rescaled softmax -- which keeps every input correct.
+constexpr float kOptBias = 100.0f;
+constexpr float kOptLimit = 0x1p100f;
+
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 __device__ __forceinline__ bf16x8 rowsum_a_operand(int lane)

@@ -59,11 +59,12 @@ __device__ __forceinline__ void mask16(f32x16& s, int key0, int qi, int n, int h
 }
 
 // exp + pack of one block's 16 scores, element range [e0, e1) and pack of fragment(s) whose elements are complete
-__device__ __forceinline__ void exp_range(f32x16& s, bf16x8 (&pf)[2], float c, float off, int e0, int e1)
+// (clamp = false: the optimistic mix, where an overflow has to reach the row sum instead of being clamped away)
+__device__ __forceinline__ void exp_range(f32x16& s, bf16x8 (&pf)[2], float c, float off, int e0, int e1, bool clamp = true)
 {
 #pragma unroll
     for (int e = 0; e < 16; ++e)
-        if (e >= e0 && e < e1) s[e] = exp2_clamp01(fmaf(s[e], c, -off));
+        if (e >= e0 && e < e1) s[e] = clamp ? exp2_clamp01(fmaf(s[e], c, -off)) : fast_exp2(fmaf(s[e], c, -off));
 #pragma unroll
     for (int f = 0; f < 2; ++f)
         if (e0 < 8 * (f + 1) && e1 >= 8 * (f + 1)) {  // this range completes fragment f

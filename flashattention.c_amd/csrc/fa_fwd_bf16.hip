@@ -499,7 +499,8 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
                 case 7: return launch_bf16_pipelined(p, 64, 4, causal, out_f32, 0, stream);
                 case 24: return launch_bf16_pipelined(p, 64, 2, causal, out_f32, 0, stream);
                 case 22: return launch_bf16_pipelined(p, 64, 4, 0, 0, 1, stream);
-                case 25: return launch_bf16_pipelined(p, 64, 4, causal, out_f32, 3, stream);  // barrier every stage
+                case 25: return launch_bf16_pipelined(p, 64, 4, causal, out_f32, 3, stream);  // lazily rescaled mix only
+                case 26: return launch_bf16_pipelined(p, 64, 2, causal, out_f32, 3, stream);  // same, 2-wave workgroups
                 case 30: return launch_bf16_x4(p, causal, out_f32, 2, stream);
                 case 31: return launch_bf16_x4(p, causal, out_f32, 1, stream);
                 case 42: return launch_bf16_x4(p, causal, out_f32, 3, stream);   // x4, rescaling mix only

@@ -67,7 +67,8 @@ __device__ __forceinline__ void lazy_rescale2(float mxa, float mxb, float c, Blo
 //                  MFMA slots; a read issued two slots ahead stalls the in-order wave and drains the matrix pipe)
 //   MASKED       : the scores of sub-tile t+1 (first key key0_next) get the causal / sequence-end mask before their maxima
 //                  are taken -- the same pipelined step serves the diagonal and ragged tiles, no slow path
-template <int D, int KB_C, bool PROF = false, bool MASKED = false, bool CAUSAL = false>
+//   OPT          : optimistic mix (fa_bf16_common.h): exp without clamp, no maxima, no rescale test
+template <int D, int KB_C, bool PROF = false, bool MASKED = false, bool CAUSAL = false, bool OPT = false>
 __device__ __forceinline__ void pp3_step(const char* v_lds, const char* k_lds2, int kb_n2, int k_row_off, int k_g, int v_lane_off, const bf16x8& ones_a, const bf16x8 (&qfa)[D / 16],
                                          const bf16x8 (&qfb)[D / 16], f32x16& sa_cur, f32x16& sb_cur, f32x16& sa_nxt, f32x16& sb_nxt,
                                          f32x16 (&oa)[D / 32], f32x16 (&ob)[D / 32], bf16x8 (&pfa)[2], bf16x8 (&pfb)[2], BlockState& sta,
@@ -99,7 +100,7 @@ __device__ __forceinline__ void pp3_step(const char* v_lds, const char* k_lds2, 
             } else {
                 sa_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qfa[ks], sa_nxt, 0, 0, 0);
             }
-            exp_range(sa_cur, pfa, c, lz.offa, 16 * (2 * ks) / (2 * KS), 16 * (2 * ks + 1) / (2 * KS));
+            exp_range(sa_cur, pfa, c, lz.offa, 16 * (2 * ks) / (2 * KS), 16 * (2 * ks + 1) / (2 * KS), !OPT);
             __builtin_amdgcn_sched_barrier(0);
             if (NV > 1 && 2 * ks + 1 == 1) load_v_frag_asm<D, KB_C, 1 % NV>(v_addr, vlo[1 % NV], vhi[1 % NV]);
             if (NV > 3 && 2 * ks + 1 == 3) load_v_frag_asm<D, KB_C, 3 % NV>(v_addr, vlo[3 % NV], vhi[3 % NV]);
@@ -113,7 +114,7 @@ __device__ __forceinline__ void pp3_step(const char* v_lds, const char* k_lds2, 
             } else {
                 sb_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qfb[ks], sb_nxt, 0, 0, 0);
             }
-            exp_range(sa_cur, pfa, c, lz.offa, 16 * (2 * ks + 1) / (2 * KS), 16 * (2 * ks + 2) / (2 * KS));
+            exp_range(sa_cur, pfa, c, lz.offa, 16 * (2 * ks + 1) / (2 * KS), 16 * (2 * ks + 2) / (2 * KS), !OPT);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -138,7 +139,7 @@ __device__ __forceinline__ void pp3_step(const char* v_lds, const char* k_lds2, 
             sta.lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pfa[v - NV], sta.lacc, 0, 0, 0);
         }
         if (v < KS) kf[v] = load_k_frag<D>(k_lds2, k_row_off, k_g, kb_n2, v);   // scores of the NEXT step (kf is free: Q phase done)
-        exp_range(sb_cur, pfb, c, lz.offb, E1 * v / (NV + 2), E1 * (v + 1) / (NV + 2));
+        exp_range(sb_cur, pfb, c, lz.offb, E1 * v / (NV + 2), E1 * (v + 1) / (NV + 2), !OPT);
         if (MASKED && v == NV + 1) {  // K.Q^T of sub-tile t+1 finished a phase ago
             mask16(sa_nxt, key0_next, qia, n, hi, CAUSAL);
             mask16(sb_nxt, key0_next, qib, n, hi, CAUSAL);
@@ -158,19 +159,19 @@ __device__ __forceinline__ void pp3_step(const char* v_lds, const char* k_lds2, 
         } else {
             stb.lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pfb[v - NV], stb.lacc, 0, 0, 0);
         }
-        if (E1 < 16 && v < 2) exp_range(sb_cur, pfb, c, lz.offb, E1 + (16 - E1) * v / 2, E1 + (16 - E1) * (v + 1) / 2);
+        if (E1 < 16 && v < 2) exp_range(sb_cur, pfb, c, lz.offb, E1 + (16 - E1) * v / 2, E1 + (16 - E1) * (v + 1) / 2, !OPT);
 #pragma unroll
         for (int u = 0; u < 6; ++u)
-            if ((E1 < 16 ? 2 + u / 2 : u * NV / 6) == v) {
+            if (!OPT && (E1 < 16 ? 2 + u / 2 : u * NV / 6) == v) {
                 if (u < 3) lanemax_step(u, sa_nxt, pm, lma);
                 else lanemax_step(u - 3, sb_nxt, pm, lmb);
             }
         // the test is evaluated one MFMA slot before the branch that consumes it (VALU compare -> scalar branch latency)
-        if (v == NV) need = fmaxf(fmaf(lma, c, -lz.offa), fmaf(lmb, c, -lz.offb)) > 0.0f;  // off = m + kLazyThr
+        if (!OPT && v == NV) need = fmaxf(fmaf(lma, c, -lz.offa), fmaf(lmb, c, -lz.offb)) > 0.0f;  // off = m + kLazyThr
         __builtin_amdgcn_sched_barrier(0);
     }
     if (PROF) t3 = stamp();
-    if (__builtin_expect(__any(need) && honor_test, 0)) {  // honor_test is false when sub-tile t+1 does not exist
+    if (!OPT && __builtin_expect(__any(need) && honor_test, 0)) {  // honor_test is false when sub-tile t+1 does not exist
         mfma_drain();  // the last P.V / row-sum MFMAs of block B may still be in flight
         lazy_rescale2<D>(xhalf_max(lma), xhalf_max(lmb), c, sta, stb, oa, ob, lz);
     }
@@ -186,10 +187,13 @@ __device__ __forceinline__ void pp3_step(const char* v_lds, const char* k_lds2, 
 // G = stages (64 keys each) between two workgroup barriers.  A barrier costs the skew between the four waves, not a data
 // wait (measured: ~600 cycles per barrier, DMA wait ~0), so it is paid once per G stages; the price is LDS: rings of 2G tiles
 // for K and for V (G = 2: 64 KiB per workgroup, two workgroups per CU; G = 1: 32 KiB, used by the 2-wave workgroups).
-template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, bool PROF = false, int G = 2>
-__global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdParams p)
+// One tile of NWAVES * 64 query rows.  OPT: optimistic mix (fa_bf16_common.h); returns false, with nothing stored, when some
+// row of the workgroup left its safe range.
+template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, bool PROF, int G, bool OPT>
+__device__ __forceinline__ bool pp3_tile(const FwdParams& p, char* smem)
 {
     using C = Bf16Cfg<D, NWAVES>;
+    constexpr float kBias = OPT ? kOptBias : kLazyThr;
     constexpr int KS = D / 16, DB = D / 32;
     constexpr int BM = NWAVES * 64;
     constexpr int KR = 2 * G, VR = 2 * G;  // ring depths in tiles (powers of two)
@@ -197,8 +201,7 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
     constexpr int T = C::kTileBytes;
 
     const unsigned long long t_entry = PROF ? stamp() : 0;
-    __shared__ __attribute__((aligned(1024))) char smem[(KR + VR) * T];  // K ring, then V ring
-    char* const k_ring = smem;
+    char* const k_ring = smem;  // K ring, then V ring
     char* const v_ring = smem + KR * T;
 
     const int lane = threadIdx.x & 63;
@@ -311,7 +314,15 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
         }
         if (needs_mask(t, q0a)) mask16(sa, t * 32, q0a + lq, n, hi, CAUSAL);
         if (needs_mask(t, q0b)) mask16(sb, t * 32, q0b + lq, n, hi, CAUSAL);
-        lazy_rescale2<D>(rowmax16(sa), rowmax16(sb), c, sta, stb, oa, ob, lz);
+        if (OPT) {  // (only called for sub-tile 0 in this mix) fix the references for the whole row
+            const float mca = rowmax16(sa) * c, mcb = rowmax16(sb) * c;
+            sta.m = fmaf(-fabsf(mca), 0x1p-23f, mca);
+            stb.m = fmaf(-fabsf(mcb), 0x1p-23f, mcb);
+            lz.offa = sta.m + kBias;
+            lz.offb = stb.m + kBias;
+        } else {
+            lazy_rescale2<D>(rowmax16(sa), rowmax16(sb), c, sta, stb, oa, ob, lz);
+        }
     };
     // ---------------- prologue: K(0) landed -> scores of sub-tile 0, fragments of sub-tile 1 ----------------
     wait_lds_dma();
@@ -337,10 +348,10 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
             const char* v_lds = v_slot(j + g);
             const char* k_nxt = k_slot(j + g + 1);
             // step 2(j+g): scores(2(j+g)+1) from kf; P.V(2(j+g)) from V block 0; fetch for scores(2(j+g)+2): K(j+g+1) block 0
-            pp3_step<D, 0, PROF>(v_lds, k_nxt, 0, k_row_off, k_g, v_lane_off, ones_a, qfa, qfb, sa0, sb0, sa1, sb1, oa, ob, pfa, pfb, sta,
+            pp3_step<D, 0, PROF, false, false, OPT>(v_lds, k_nxt, 0, k_row_off, k_g, v_lane_off, ones_a, qfa, qfb, sa0, sb0, sa1, sb1, oa, ob, pfa, pfb, sta,
                                  stb, c, lz, kf, true, tm);
             // step 2(j+g)+1: scores(2(j+g)+2) from kf; P.V(2(j+g)+1) from V block 1; fetch for scores(2(j+g)+3): K(j+g+1) block 1
-            pp3_step<D, 1, PROF>(v_lds, k_nxt, 1, k_row_off, k_g, v_lane_off, ones_a, qfa, qfb, sa1, sb1, sa0, sb0, oa, ob, pfa, pfb, sta,
+            pp3_step<D, 1, PROF, false, false, OPT>(v_lds, k_nxt, 1, k_row_off, k_g, v_lane_off, ones_a, qfa, qfb, sa1, sb1, sa0, sb0, oa, ob, pfa, pfb, sta,
                                  stb, c, lz, kf, 2 * (j + g) + 2 < nsub, tm);
         }
     }
@@ -363,15 +374,21 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
         if (2 * j < nsub_w) {
             const char* v_lds = v_slot(j);
             const char* k_nxt = k_slot(j + 1);
-            pp3_step<D, 0, false, true, CAUSAL>(v_lds, k_nxt, 0, k_row_off, k_g, v_lane_off, ones_a, qfa, qfb, sa0, sb0, sa1, sb1, oa, ob, pfa,
+            pp3_step<D, 0, false, true, CAUSAL, OPT>(v_lds, k_nxt, 0, k_row_off, k_g, v_lane_off, ones_a, qfa, qfb, sa0, sb0, sa1, sb1, oa, ob, pfa,
                                                 pfb, sta, stb, c, lz, kf, true, nullptr, (2 * j + 1) * 32, q0a + lq, q0b + lq, n, hi);
-            pp3_step<D, 1, false, true, CAUSAL>(v_lds, k_nxt, 1, k_row_off, k_g, v_lane_off, ones_a, qfa, qfb, sa1, sb1, sa0, sb0, oa, ob, pfa,
+            pp3_step<D, 1, false, true, CAUSAL, OPT>(v_lds, k_nxt, 1, k_row_off, k_g, v_lane_off, ones_a, qfa, qfb, sa1, sb1, sa0, sb0, oa, ob, pfa,
                                                 pfb, sta, stb, c, lz, kf, true, nullptr, (2 * j + 2) * 32, q0a + lq, q0b + lq, n, hi);
         }
     }
 
-    // ---------------- store ----------------
+    // ---------------- verify (optimistic mix), store ----------------
     mfma_drain();  // the loop exit is a branch: the last P.V / row-sum MFMAs may still be in flight
+    if (OPT) {
+        // the tile stands iff no term left the safe range, which the row sums prove (fa_bf16_common.h)
+        const bool bad = !(sta.lacc[0] < kOptLimit) || !(stb.lacc[0] < kOptLimit);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // no DMA of this attempt may land after the vote
+        if (__syncthreads_or(bad ? 1 : 0)) return false;             // workgroup-wide: the redo shares tiles and barriers
+    }
     auto store_block = [&](const f32x16 (&o)[DB], const BlockState& st, int q0) {
         const float lt = st.lacc[0];
         const float inv = 1.0f / lt;
@@ -395,7 +412,7 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
                     }
                 }
             if (!PROF && p.lse != nullptr && hi == 0)
-                p.lse[(int64_t)slab * n + qi] = (st.m + kLazyThr + __builtin_amdgcn_logf(lt)) * kLn2;
+                p.lse[(int64_t)slab * n + qi] = (st.m + kBias + __builtin_amdgcn_logf(lt)) * kLn2;
         }
     };
     store_block(oa, sta, q0a);
@@ -410,6 +427,19 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
         dst[10] = (float)(((xcc & 0xf) << 16) | (((hwid >> 13) & 7) << 8) | (((hwid >> 8) & 0xf) << 4) | ((hwid >> 4) & 3));
         dst[11] = (float)(t_entry & 0xffffff);
     }
+    return true;
+}
+
+// OPTIMISTIC: try the fixed-reference mix first, redo the tile with the lazily rescaled mix if its verification fails
+template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, bool PROF = false, int G = 2, bool OPTIMISTIC = true>
+__global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdParams p)
+{
+    using C = Bf16Cfg<D, NWAVES>;
+    __shared__ __attribute__((aligned(1024))) char smem[4 * G * C::kTileBytes];
+    if (OPTIMISTIC && !PROF) {
+        if (pp3_tile<D, NWAVES, CAUSAL, OUT_F32, false, G, true>(p, smem)) return;
+    }
+    (void)pp3_tile<D, NWAVES, CAUSAL, OUT_F32, PROF, G, false>(p, smem);
 }
 
 // the buffer-form LDS-DMA addresses a slab with 32-bit byte offsets
@@ -427,7 +457,7 @@ static hipError_t launch_pp3_prof(const FwdParams& p0, hipStream_t stream)
     return hipGetLastError();
 }
 
-template <int D, int NWAVES, int G>
+template <int D, int NWAVES, int G, bool OPTIMISTIC = true>
 static hipError_t launch_pp3(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
 {
     FwdParams p = p0;
@@ -438,32 +468,32 @@ static hipError_t launch_pp3(const FwdParams& p0, int causal, int out_f32, hipSt
     dim3 grid((unsigned)total), block(NWAVES * kWave);
     if (causal) {
         if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, true, true, false, G>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, true, true, false, G, OPTIMISTIC>), grid, block, 0, stream, p);
         else
-            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, true, false, false, G>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, true, false, false, G, OPTIMISTIC>), grid, block, 0, stream, p);
     } else {
         if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, false, true, false, G>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, false, true, false, G, OPTIMISTIC>), grid, block, 0, stream, p);
         else
-            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, false, false, false, G>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, false, false, false, G, OPTIMISTIC>), grid, block, 0, stream, p);
     }
     return hipGetLastError();
 }
 
 bool bf16_pipelined_supported(const FwdParams& p, int d) { return (d == 64 || d == 32) && pp3_addressable(p, d); }
 
-// mode: 0 = product configuration (4-wave workgroups: barrier every 2 stages; 2-wave workgroups: every stage),
-//       1 = in-kernel phase timers (D = 64, non-causal; written to lse), 3 = 4-wave workgroups with a barrier every stage
+// mode: 0 = product configuration (optimistic mix first; 4-wave workgroups: barrier every 2 stages, 2-wave workgroups: every
+//       stage), 1 = in-kernel phase timers (D = 64, non-causal; written to lse), 3 = lazily rescaled mix only
 hipError_t launch_bf16_pipelined(const FwdParams& p, int d, int nwaves, int causal, int out_f32, int mode, hipStream_t stream)
 {
     if (!bf16_pipelined_supported(p, d)) return hipErrorInvalidValue;
     if (mode == 1) return d == 64 ? launch_pp3_prof(p, stream) : hipErrorInvalidValue;
     if (d == 64) {
-        if (nwaves == 2) return launch_pp3<64, 2, 1>(p, causal, out_f32, stream);
-        return mode == 3 ? launch_pp3<64, 4, 1>(p, causal, out_f32, stream) : launch_pp3<64, 4, 2>(p, causal, out_f32, stream);
+        if (nwaves == 2) return mode == 3 ? launch_pp3<64, 2, 1, false>(p, causal, out_f32, stream) : launch_pp3<64, 2, 1>(p, causal, out_f32, stream);
+        return mode == 3 ? launch_pp3<64, 4, 2, false>(p, causal, out_f32, stream) : launch_pp3<64, 4, 2>(p, causal, out_f32, stream);
     }
     if (nwaves == 2) return launch_pp3<32, 2, 1>(p, causal, out_f32, stream);
-    return mode == 3 ? launch_pp3<32, 4, 1>(p, causal, out_f32, stream) : launch_pp3<32, 4, 2>(p, causal, out_f32, stream);
+    return mode == 3 ? launch_pp3<32, 4, 2, false>(p, causal, out_f32, stream) : launch_pp3<32, 4, 2>(p, causal, out_f32, stream);
 }
 
 }  // namespace fa

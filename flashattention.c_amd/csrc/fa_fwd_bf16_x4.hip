@@ -322,15 +322,6 @@ __device__ __forceinline__ bool x4_step(const char* v_lds, const char* k_nxt, in
     return x.need;
 }
 
-// Exponent bias of the optimistic mix: p = 2^(c*s - m0 - kOptBias) with m0 the row maximum of the FIRST sub-tile, fixed for
-// the whole row.  The shift is an exact power of two in P (bf16, 8 exponent bits), O and the row sum (fp32) and cancels in
-// O / l, so the only requirement is range: the largest term of a row is >= 2^-100, and everything within 2^-24 of it stays
-// above the smallest normal bf16 (2^-126); the row sum l = sum p < 2^100 at the end proves that no term exceeded 2^100
-// (fp32 accumulators hold N * 2^100 * |v| comfortably), i.e. a row may outgrow its first 32 keys by a factor 2^200 before
-// the tile is redone with the rescaling mix.
-constexpr float kOptBias = 100.0f;
-constexpr float kOptLimit = 0x1p100f;
-
 // One 512-row tile.  OPT: optimistic mix; returns false (nothing stored) when some row of the workgroup left the safe range.
 template <int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL, bool OPT>
 __device__ __forceinline__ bool x4_tile(const FwdParams& p, char* smem)
@@ -473,15 +464,8 @@ __device__ __forceinline__ bool x4_tile(const FwdParams& p, char* smem)
 #pragma unroll
         for (int blk = 0; blk < kNB; ++blk) {
             bf16x8 pf[2];
-            if (OPT) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) s[blk][e] = fast_exp2(fmaf(s[blk][e], c, -off[blk]));
-                pf[0] = pack_bf16x8(s[blk], 0);
-                pf[1] = pack_bf16x8(s[blk], 8);
-            } else {
-                exp_range(s[blk], pf, c, off[blk], 0, 8);
-                exp_range(s[blk], pf, c, off[blk], 8, 16);
-            }
+            exp_range(s[blk], pf, c, off[blk], 0, 8, !OPT);
+            exp_range(s[blk], pf, c, off[blk], 8, 16, !OPT);
             // a VALU result needs two wait states before an MFMA may read it; hipcc counts them for its own MFMAs, not
             // for an asm one (the pipelined loop packs P at least one whole slot ahead of its first use)
             asm volatile("s_nop 1" : "+v"(pf[0]), "+v"(pf[1]));

@@ -146,9 +146,10 @@ def test_bf16_vs_oracle(bh, n, d, causal, scale):
     check(fa.forward(qd, kd, vd, causal, scale=scale), ref, bf16_tol(scale, False), "bf16-out")
 
 
-# 0 = product dispatch, 1 = phase-structured kernel, 7/25 = pipelined kernel (barrier every 2 / every stage), 24 = its 2-wave
-# workgroups, 30/31 = one-wave-per-SIMD 128-rows-per-wave kernel (barrier every 2 / every stage)
-@pytest.mark.parametrize("variant", [0, 1, 7, 24, 25, 30, 31])
+# 0 = product dispatch, 1 = phase-structured kernel, 7 / 24 = pipelined kernel with 4- / 2-wave workgroups (optimistic mix with
+# verified redo), 25 / 26 = the same with the lazily rescaled mix only, 30 / 31 = one-wave-per-SIMD 128-rows-per-wave kernel
+# (barrier every 2 / every stage), 42 = that kernel with the lazily rescaled mix only
+@pytest.mark.parametrize("variant", [0, 1, 7, 24, 25, 26, 30, 31, 42])
 @pytest.mark.parametrize("causal", [False, True])
 def test_bf16_tiling_variants_agree(variant, causal):
     q, k, v = (orc.round_to_bf16(randn(s, 3, 700, 64)) for s in (7, 8, 9))
@@ -219,13 +220,15 @@ def test_dominant_key_in_the_last_keys(n, out_f32):
         check(lse, lse_ref, 2e-2, "bf16 lse")
 
 
-@pytest.mark.parametrize("variant", [0, 24, 25, 30])
+@pytest.mark.parametrize("variant", [0, 7, 24, 25, 26, 30, 42])
 @pytest.mark.parametrize("causal", [False, True])
 def test_rescale_inside_the_pipelined_loop(variant, causal):
-    """Keys that outgrow a row's running maximum by far more than the lazy-rescale slack (2^64), placed in the middle of
-    the sequence: the rare rescale branch of the software-pipelined main loop (not the prologue / tail) has to fire, for
-    single rows, for a whole 32-row block and for neighbouring blocks of one wave, and everything already accumulated
-    at the old reference has to be scaled exactly once."""
+    """Keys that outgrow a row's first-sub-tile maximum by 2^140 .. 2^230, placed in the middle of the sequence.  Lazily
+    rescaled mix (variants 25, 26, 42 and every redo): the rare rescale branch of the software-pipelined main loop has
+    to fire, for single rows, for a whole 32-row block and for neighbouring blocks of one wave, and everything already
+    accumulated at the old reference has to be scaled exactly once.  Optimistic mix: growth below 2^200 must come out
+    right without any rescale (the LSE exposes a clamped or saturated P that O / l would hide), growth above it must
+    fail the end-of-tile verification and be redone."""
     bh, n, d = 2, 1536, 64
     q, k, v = (randn(s, bh, n, d) for s in (41, 42, 43))
     unit = lambda x: x / np.linalg.norm(x, axis=-1, keepdims=True)
