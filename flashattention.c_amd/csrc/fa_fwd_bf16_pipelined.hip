@@ -381,19 +381,21 @@ __device__ __forceinline__ bool pp3_tile(const FwdParams& p, char* smem)
         }
     }
 
-    // ---------------- verify (optimistic mix), store ----------------
+    // ---------------- store; verify (optimistic mix) ----------------
+    // The optimistic tile stores its result BEFORE the workgroup votes on it: a failed tile is simply overwritten by the redo,
+    // and nothing of the first attempt is live across the vote.
     mfma_drain();  // the loop exit is a branch: the last P.V / row-sum MFMAs may still be in flight
-    if (OPT) {
-        // the tile stands iff no term left the safe range, which the row sums prove (fa_bf16_common.h)
-        const bool bad = !(sta.lacc[0] < kOptLimit) || !(stb.lacc[0] < kOptLimit);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // no DMA of this attempt may land after the vote
-        if (__syncthreads_or(bad ? 1 : 0)) return false;             // workgroup-wide: the redo shares tiles and barriers
-    }
+    // the tile stands iff no term left the safe range, which the row sums prove (fa_bf16_common.h)
+    const bool bad = OPT && (!(sta.lacc[0] < kOptLimit) || !(stb.lacc[0] < kOptLimit));
     auto store_block = [&](const f32x16 (&o)[DB], const BlockState& st, int q0) {
+        if constexpr (OPT) asm volatile("; store, optimistic mix");  // distinct text per mix: keeps hipcc from tail-merging the
+        else asm volatile("; store, rescaled mix");                   // store code of the two inlined tiles (copies + scratch)
         const float lt = st.lacc[0];
         const float inv = 1.0f / lt;
         const int qi = q0 + lq;
         if (qi < n) {
+            if constexpr (OPT) asm volatile("; rows, optimistic mix");
+            else asm volatile("; rows, rescaled mix");
             const int64_t o_off = o_slab_off + (int64_t)qi * p.o_row_stride + 4 * hi;
 #pragma unroll
             for (int db = 0; db < DB; ++db)
@@ -417,6 +419,10 @@ __device__ __forceinline__ bool pp3_tile(const FwdParams& p, char* smem)
     };
     store_block(oa, sta, q0a);
     store_block(ob, stb, q0b);
+    if (OPT) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // stores and DMA of this attempt done before a redo starts
+        if (__syncthreads_or(bad ? 1 : 0)) return false;             // workgroup-wide: the redo shares tiles and barriers
+    }
     if (PROF && lane == 0 && p.lse != nullptr) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         float* dst = p.lse + ((int64_t)blockIdx.x * NWAVES + wave) * 16;

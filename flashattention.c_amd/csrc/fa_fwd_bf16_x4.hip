@@ -535,23 +535,30 @@ __device__ __forceinline__ bool x4_tile(const FwdParams& p, char* smem)
         }
     }
 
-    // ---------------- verify (optimistic mix), store ----------------
-    drain_accumulators(o, st);
+    // ---------------- store; verify (optimistic mix) ----------------
+    // The optimistic tile stores its result BEFORE the workgroup votes on it: a failed tile is simply overwritten by the redo,
+    // and nothing of the first attempt is live across the vote (with the store behind the vote hipcc carried the
+    // accumulators of the common path through copies and 12 MB of scratch per launch).
+    mfma_drain();
+    bool bad = false;
     if (OPT) {
         // every P was exponentiated against the first sub-tile's maximum: the tile stands iff no term left the safe range,
         // which the row sums prove (a term > 2^100, +inf or NaN makes its row sum fail this test)
-        bool bad = false;
 #pragma unroll
         for (int blk = 0; blk < kNB; ++blk) bad = bad || !(st[blk].lacc[0] < kOptLimit);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // no DMA of this attempt may land after the vote
-        if (__syncthreads_or(bad ? 1 : 0)) return false;             // workgroup-wide: the redo shares tiles and barriers
     }
 #pragma unroll
     for (int blk = 0; blk < kNB; ++blk) {
+        // (distinct text per mix: identical store code of the two inlined tiles gets tail-merged by hipcc, which then shuffles
+        // the accumulators of the common path through copies and 12 MB of scratch per launch)
+        if constexpr (OPT) asm volatile("; store, optimistic mix");
+        else asm volatile("; store, rescaled mix");
         const float lt = st[blk].lacc[0];
         const float inv = 1.0f / lt;
         const int qi = q0 + 32 * blk + lq;
         if (qi < n) {
+            if constexpr (OPT) asm volatile("; rows, optimistic mix");
+            else asm volatile("; rows, rescaled mix");
             const int64_t o_off = o_slab_off + (int64_t)qi * p.o_row_stride + 4 * hi;
 #pragma unroll
             for (int db = 0; db < DB; ++db)
@@ -571,6 +578,10 @@ __device__ __forceinline__ bool x4_tile(const FwdParams& p, char* smem)
                 }
             if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (st[blk].m + kBias + __builtin_amdgcn_logf(lt)) * kLn2;
         }
+    }
+    if (OPT) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // stores and DMA of this attempt done before a redo starts
+        if (__syncthreads_or(bad ? 1 : 0)) return false;             // workgroup-wide: the redo shares tiles and barriers
     }
     return true;
 }
