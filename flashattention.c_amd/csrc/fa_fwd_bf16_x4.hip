@@ -133,8 +133,10 @@ __device__ __host__ constexpr int x4_weight_before(int i)  // in half-slots: a 3
     return w;
 }
 constexpr int kX4Weight = x4_weight_before(kX4Slots);  // 72
-// all VALU work of the optimistic mix has to be finished before P.V of block D starts (slot 34)
-constexpr int x4_weight_end(bool opt) { return opt ? x4_weight_before(34) : kX4Weight; }
+// the VALU work of the optimistic mix has to be finished before the k-step-1 MFMAs of P.V D (slot 37; the fragment of its
+// k-step 0 is packed early enough by the dealing rule -- checked for every dependency by the script in the header comment
+// of profiles/r01_x4_schedule_check.py)
+constexpr int x4_weight_end(bool opt) { return opt ? x4_weight_before(37) : kX4Weight; }
 // VALU units are dealt out by ISSUE COST, not by count: measured beside MFMAs (profiles/ubench/ubench_clock.hip) a plain
 // VALU instruction occupies the wave's issue for 4 cycles and a v_exp_f32 for 8, so an exp element (fma + exp) costs 12, a
 // pack (4 cvt) 16, the max micro-steps 12 / 12 / 8, the test ~20 -- 1044 (896) cycles per step.  Slot i receives the units
@@ -203,6 +205,20 @@ __device__ __host__ constexpr X4Table x4_make_table(bool opt)
     }
     t.ub[kX4Slots] = nu;
     return t;
+}
+
+// A VALU result needs two wait states before an MFMA reads it, and an asm MFMA is not padded by hipcc: when the dealing rule
+// puts the pack of a P fragment into the slot right in front of the first MFMA that reads it, that MFMA gets an s_nop 1.
+__device__ __host__ constexpr bool x4_needs_pad(int i, bool opt)
+{
+    const X4Slot sl = x4_slot(i);
+    if (sl.kind == 0 || i == 0) return false;
+    const int frag = sl.kind == 1 ? sl.idx / 2 : sl.idx;
+    const X4UnitList l = x4_make_units(opt);
+    const X4Table t = x4_make_table(opt);
+    for (int u = 0; u < x4_num_units(opt); ++u)
+        if (l.u[u].kind == 1 && l.u[u].blk == sl.blk && l.u[u].idx == frag) return u >= t.ub[i - 1];
+    return false;
 }
 
 // One step.  sc: scores of sub-tile t (consumed), sn: scores of sub-tile t+1 (produced); kf: K fragments of sub-tile t+1 on
@@ -279,6 +295,7 @@ __device__ __forceinline__ void x4_slot_body(X4Ctx& x)
     if constexpr (I < 4 && !(ABL & 16)) load_v_frag_asm<D, KB_C, I>(x.v_addr, x.vlo[I], x.vhi[I]);  // ABL & 16: no LDS fragment reads
     if constexpr (I < 4 && (ABL & 16)) asm volatile("" : "=v"(x.vlo[I]), "=v"(x.vhi[I]));
     if constexpr (I < 4 && (ABL & 32)) load_v_frag_asm<D, KB_C, I>(x.v_addr, x.vlo[I], x.vhi[I]);  // ABL & 32: every fragment read issued twice
+    if constexpr (x4_needs_pad(I, OPT)) asm volatile("s_nop 1");
     if constexpr (ABL & 1) {
         // timing-only ablation: no matrix instructions
     } else if constexpr (sl.kind == 0) {
