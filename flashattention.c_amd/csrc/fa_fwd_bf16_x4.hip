@@ -586,11 +586,27 @@ __device__ __forceinline__ bool x4_tile(const FwdParams& p, char* smem)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) pk[e] = o[blk][db][4 * g + e] * inv;
                         *(f32x4*)((float*)p.o + o_off + db * 32 + 8 * g) = pk;
-                    } else {
-                        bf16x4 pk;
+                    } else if ((g & 1) == 0) {
+                        // 16-byte stores: the two lanes of a row (hi = 0 / 1) hold alternate 4-column groups; one
+                        // v_permlane32_swap per dword hands lane hi = 0 both halves of column group g and lane hi = 1 both
+                        // halves of group g + 1 (the epilogue is store-issue bound: half as many, twice as wide)
+                        bf16x4 pe, po;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) pk[e] = (__bf16)(o[blk][db][4 * g + e] * inv);
-                        *(bf16x4*)((__bf16*)p.o + o_off + db * 32 + 8 * g) = pk;
+                        for (int e = 0; e < 4; ++e) {
+                            pe[e] = (__bf16)(o[blk][db][4 * g + e] * inv);
+                            po[e] = (__bf16)(o[blk][db][4 * (g + 1) + e] * inv);
+                        }
+                        const u32x2 ue = __builtin_bit_cast(u32x2, pe), uo = __builtin_bit_cast(u32x2, po);
+                        const auto r0 = __builtin_amdgcn_permlane32_swap(ue[0], uo[0], false, false);
+                        const auto r1 = __builtin_amdgcn_permlane32_swap(ue[1], uo[1], false, false);
+                        // lanes 0..31: r[0] = own group g, r[1] = partner's group g;  lanes 32..63: r[0] = partner's group g+1, r[1] = own
+                        u32x4 w;
+                        w[0] = r0[0];
+                        w[1] = r1[0];
+                        w[2] = r0[1];
+                        w[3] = r1[1];
+                        // hi = 0: columns 8g .. 8g+7;  hi = 1: columns 8(g+1) .. 8(g+1)+7  (o_off already carries + 4 hi)
+                        *(u32x4*)((__bf16*)p.o + o_off - 4 * hi + db * 32 + 8 * (g + hi)) = w;
                     }
                 }
             if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (st[blk].m + kBias + __builtin_amdgcn_logf(lt)) * kLn2;
