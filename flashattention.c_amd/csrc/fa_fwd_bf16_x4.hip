@@ -628,6 +628,10 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdPar
     if (OPTIMISTIC && ABL == 0) {
         if (x4_tile<NWAVES, CAUSAL, OUT_F32, G, 0, true>(p, smem)) return;
     }
+    if (ABL != 0 && OPTIMISTIC) {  // timing-only ablations of the optimistic mix (results are garbage)
+        (void)x4_tile<NWAVES, CAUSAL, OUT_F32, G, ABL, true>(p, smem);
+        return;
+    }
     (void)x4_tile<NWAVES, CAUSAL, OUT_F32, G, ABL, false>(p, smem);
 }
 
