@@ -439,12 +439,17 @@ static hipError_t launch_cfg(const FwdParams& p0, int causal, int out_f32, hipSt
 
 // ---- product dispatch (variant 0) --------------------------------------------------------------------------------------
 // Measured on MI355X, steady clocks, TFLOP/s at bh = 16, n = 8192 (profiles/): d = 64 non-causal  x4 1044 / pipelined 1022;
-// d = 64 causal  pipelined 2-wave 712 / 4-wave 642 / x4 594;  d = 128  w4 1012 / phase-structured 950;  d = 32  pipelined 735.
-enum Bf16Choice { kChoosePhase, kChoosePipelined4, kChoosePipelined2, kChooseX4, kChooseW4 };
+// d = 64 causal  pipelined 2-wave 712 / 4-wave 642 / x4 594;  d = 128  x2d128 1254 / w4 1012 / phase-structured 950 (causal:
+// x2d128 1109 / phase-structured 827);  d = 32  pipelined 735.
+enum Bf16Choice { kChoosePhase, kChoosePipelined4, kChoosePipelined2, kChooseX4, kChooseW4, kChooseX2D128 };
 
 static Bf16Choice choose_bf16(int64_t bh, int64_t n, int d, int causal, bool addressable)
 {
-    if (d == 128) return causal ? kChoosePhase : kChooseW4;
+    if (d == 128) {
+        // one wave per SIMD, 256-row workgroups, one workgroup per CU: needs enough workgroups to occupy the CUs
+        if (addressable && bh * ((n + 255) / 256) >= 128) return kChooseX2D128;
+        return causal ? kChoosePhase : kChooseW4;
+    }
     if (!addressable) return kChoosePhase;
     if (d == 32) return causal ? kChoosePhase : kChoosePipelined4;  // 256-row workgroups waste too much of the causal triangle at d = 32
     // d == 64
@@ -466,6 +471,7 @@ const char* bf16_kernel_name(int64_t bh, int64_t n, int d, int causal)
         case kChoosePipelined4:
         case kChoosePipelined2: return "fa_fwd_bf16_pp3_kernel";
         case kChooseW4: return "fa_fwd_bf16_w4_kernel";
+        case kChooseX2D128: return "fa_fwd_bf16_x2_kernel";
         default: return "fa_fwd_bf16_kernel";
     }
 }
@@ -473,11 +479,13 @@ const char* bf16_kernel_name(int64_t bh, int64_t n, int d, int causal)
 hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, int variant, hipStream_t stream)
 {
     if (variant == 0) {
-        switch (choose_bf16(p.bh, p.n, d, causal, bf16_pipelined_supported(p, d))) {
+        const bool addressable = ((int64_t)(p.n - 1) * p.kv_row_stride + d) * 2 < (int64_t)0xffffffffLL;
+        switch (choose_bf16(p.bh, p.n, d, causal, addressable)) {
             case kChooseX4: return launch_bf16_x4(p, causal, out_f32, 2, stream);
             case kChoosePipelined4: return launch_bf16_pipelined(p, d, 4, causal, out_f32, 0, stream);
             case kChoosePipelined2: return launch_bf16_pipelined(p, d, 2, causal, out_f32, 0, stream);
             case kChooseW4: return launch_w4<128, 4, 2>(p, causal, out_f32, stream);
+            case kChooseX2D128: return launch_bf16_x2d128(p, causal, out_f32, 0, stream);
             default:
                 if (d == 32) return launch_cfg<32, 4, 1, 4>(p, causal, out_f32, stream);
                 if (d == 64) return launch_cfg<64, 4, 1, 4>(p, causal, out_f32, stream);
@@ -517,6 +525,10 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
                 default: return launch_bf16_pp2(p, causal, out_f32, variant, stream);  // 9 = pp2, 6, 11..21 = its ablations
             }
         case 128:
+            if (variant == 50) return launch_bf16_x2d128(p, causal, out_f32, 0, stream);   // one wave per SIMD, explicit register files
+            if (variant == 51) return launch_bf16_x2d128(p, causal, out_f32, 1, stream);
+            if (variant == 52) return launch_bf16_x2d128(p, causal, out_f32, 3, stream);
+            if (variant == 53) return launch_bf16_x2d128(p, causal, out_f32, 12, stream);
             if (variant == 10) return launch_w4<128, 4, 2>(p, causal, out_f32, stream);
             if (variant == 23) return launch_w4<128, 4, 3>(p, causal, out_f32, stream);
             return launch_cfg<128, 4, 1, 2>(p, causal, out_f32, stream);  // the pipelined kernel needs > 256 VGPRs at D = 128

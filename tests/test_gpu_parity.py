@@ -220,17 +220,31 @@ def test_dominant_key_in_the_last_keys(n, out_f32):
         check(lse, lse_ref, 2e-2, "bf16 lse")
 
 
-@pytest.mark.parametrize("variant", [0, 7, 24, 25, 26, 30, 42])
+# d = 128: 0 = product dispatch (too few workgroups here: phase-structured kernels), 10 = 4-waves/SIMD diet kernel, 50 / 51 =
+# one-wave-per-SIMD kernel (optimistic mix with verified redo; barrier every 2 / every stage), 52 = its lazily rescaled mix only
+@pytest.mark.parametrize("variant", [0, 10, 50, 51, 52])
 @pytest.mark.parametrize("causal", [False, True])
-def test_rescale_inside_the_pipelined_loop(variant, causal):
+def test_bf16_d128_tiling_variants_agree(variant, causal):
+    q, k, v = (orc.round_to_bf16(randn(s, 3, 700, 128)) for s in (17, 18, 19))
+    ref = orc.attention_f64(q, k, v, causal=causal, scale=0.125)
+    qd, kd, vd = to_dev(q, k, v, dtype=torch.bfloat16)
+    o = fa.forward(qd, kd, vd, causal, scale=0.125, kernel=f"mfma:{variant}", out_dtype=torch.float32)
+    check(o, ref, bf16_tol(0.125, True, causal, 700))
+    check(fa.forward(qd, kd, vd, causal, scale=0.125, kernel=f"mfma:{variant}"), ref, bf16_tol(0.125, False))
+
+
+@pytest.mark.parametrize("d,variant", [(64, 0), (64, 7), (64, 24), (64, 25), (64, 26), (64, 30), (64, 42), (128, 50), (128, 52)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_rescale_inside_the_pipelined_loop(d, variant, causal):
     """Keys that outgrow a row's first-sub-tile maximum by 2^140 .. 2^230, placed in the middle of the sequence.  Lazily
     rescaled mix (variants 25, 26, 42 and every redo): the rare rescale branch of the software-pipelined main loop has
     to fire, for single rows, for a whole 32-row block and for neighbouring blocks of one wave, and everything already
     accumulated at the old reference has to be scaled exactly once.  Optimistic mix: growth below 2^200 must come out
     right without any rescale (the LSE exposes a clamped or saturated P that O / l would hide), growth above it must
     fail the end-of-tile verification and be redone."""
-    bh, n, d = 2, 1536, 64
+    bh, n = 2, 1536
     q, k, v = (randn(s, bh, n, d) for s in (41, 42, 43))
+    q *= np.sqrt(64.0 / d)                         # |q| ~ 8 at either head dim (the gains below are tuned to that)
     unit = lambda x: x / np.linalg.norm(x, axis=-1, keepdims=True)
     for r, key, gain in ((3, 700, 14.0), (40, 701, 16.0), (200, 1100, 12.0), (1300, 900, 15.0), (1301, 650, 18.0), (1535, 333, 13.0)):
         k[:, key] = gain * unit(q[:, r])           # score ~ gain * |q| ~ 8 gain  ->  > 64 / log2(e) above the crowd
