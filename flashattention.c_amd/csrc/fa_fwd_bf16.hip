@@ -439,9 +439,9 @@ static hipError_t launch_cfg(const FwdParams& p0, int causal, int out_f32, hipSt
 
 // ---- product dispatch (variant 0) --------------------------------------------------------------------------------------
 // Measured on MI355X, steady clocks, TFLOP/s at bh = 16, n = 8192 (profiles/): d = 64 non-causal  x4 1044 / pipelined 1022;
-// d = 64 causal  pipelined 2-wave 712 / 4-wave 642 / x4 594;  d = 128  x2d128 1254 / w4 1012 / phase-structured 950 (causal:
-// x2d128 1109 / phase-structured 827);  d = 32  pipelined 735.
-enum Bf16Choice { kChoosePhase, kChoosePipelined4, kChoosePipelined2, kChooseX4, kChooseW4, kChooseX2D128 };
+// d = 64 causal  x2 884 / pipelined 2-wave 738 / 4-wave 642 / x4 594;  d = 128  x2 1254 / w4 1012 / phase-structured 950 (causal:
+// x2 1109 / phase-structured 827);  d = 32  pipelined 735.
+enum Bf16Choice { kChoosePhase, kChoosePipelined4, kChoosePipelined2, kChooseX4, kChooseW4, kChooseX2D128, kChooseX2D64 };
 
 static Bf16Choice choose_bf16(int64_t bh, int64_t n, int d, int causal, bool addressable)
 {
@@ -454,7 +454,14 @@ static Bf16Choice choose_bf16(int64_t bh, int64_t n, int d, int causal, bool add
     if (d == 32) return causal ? kChoosePhase : kChoosePipelined4;  // 256-row workgroups waste too much of the causal triangle at d = 32
     // d == 64
     const int64_t items256 = bh * ((n + 255) / 256), items512 = bh * ((n + 511) / 512);
-    if (causal) return items256 <= 1024 ? kChoosePipelined2 : kChoosePipelined4;  // few items + causal imbalance: 128-row workgroups pack better
+    if (causal) {
+        // With every workgroup resident at once (two-wave kernel) a causal launch lasts as long as its heaviest tile.  The
+        // one-wave-per-SIMD kernel with 256-row tiles runs one workgroup per CU, heavy tiles first, so light tiles follow heavy
+        // ones on the same CU.  Measured (TFLOP/s, pipelined 4-wave / x2): BH x N = 8 x 8192: 522 / 544, 16 x 4096: 464 / 483,
+        // 16 x 8192: 642 / 884, 4 x 16384: 520 / 594;  32 x 4096: 600 / 571, 64 x 4096: 776 / 699, 128 x 8192: 1005 / 913.
+        if (items256 <= 256 || (items256 <= 512 && n >= 8192)) return kChooseX2D64;
+        return kChoosePipelined4;
+    }
     // one wave per SIMD, 512-row workgroups, one workgroup per CU: worth it when those workgroups fill whole rounds of the
     // 256 CUs at least as well as 256-row workgroups fill the 512 slots of the two-wave kernel
     const double eff512 = (double)items512 / (double)(((items512 + 255) / 256) * 256);
@@ -471,7 +478,8 @@ const char* bf16_kernel_name(int64_t bh, int64_t n, int d, int causal)
         case kChoosePipelined4:
         case kChoosePipelined2: return "fa_fwd_bf16_pp3_kernel";
         case kChooseW4: return "fa_fwd_bf16_w4_kernel";
-        case kChooseX2D128: return "fa_fwd_bf16_x2_kernel";
+        case kChooseX2D128:
+        case kChooseX2D64: return "fa_fwd_bf16_x2_kernel";
         default: return "fa_fwd_bf16_kernel";
     }
 }
@@ -485,7 +493,8 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
             case kChoosePipelined4: return launch_bf16_pipelined(p, d, 4, causal, out_f32, 0, stream);
             case kChoosePipelined2: return launch_bf16_pipelined(p, d, 2, causal, out_f32, 0, stream);
             case kChooseW4: return launch_w4<128, 4, 2>(p, causal, out_f32, stream);
-            case kChooseX2D128: return launch_bf16_x2d128(p, causal, out_f32, 0, stream);
+            case kChooseX2D128: return launch_bf16_x2(p, 128, causal, out_f32, 0, stream);
+            case kChooseX2D64: return launch_bf16_x2(p, 64, causal, out_f32, 0, stream);
             default:
                 if (d == 32) return launch_cfg<32, 4, 1, 4>(p, causal, out_f32, stream);
                 if (d == 64) return launch_cfg<64, 4, 1, 4>(p, causal, out_f32, stream);
@@ -512,6 +521,9 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
                 case 30: return launch_bf16_x4(p, causal, out_f32, 2, stream);
                 case 31: return launch_bf16_x4(p, causal, out_f32, 1, stream);
                 case 42: return launch_bf16_x4(p, causal, out_f32, 3, stream);   // x4, rescaling mix only
+                case 50: return launch_bf16_x2(p, 64, causal, out_f32, 0, stream);   // one wave per SIMD, 64 rows per wave, 256-row tiles
+                case 51: return launch_bf16_x2(p, 64, causal, out_f32, 1, stream);
+                case 52: return launch_bf16_x2(p, 64, causal, out_f32, 3, stream);
                 case 33: return launch_bf16_x4(p, causal, out_f32, 11, stream);  // x4 timing ablations
                 case 34: return launch_bf16_x4(p, causal, out_f32, 12, stream);
                 case 35: return launch_bf16_x4(p, causal, out_f32, 13, stream);
@@ -525,10 +537,10 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
                 default: return launch_bf16_pp2(p, causal, out_f32, variant, stream);  // 9 = pp2, 6, 11..21 = its ablations
             }
         case 128:
-            if (variant == 50) return launch_bf16_x2d128(p, causal, out_f32, 0, stream);   // one wave per SIMD, explicit register files
-            if (variant == 51) return launch_bf16_x2d128(p, causal, out_f32, 1, stream);
-            if (variant == 52) return launch_bf16_x2d128(p, causal, out_f32, 3, stream);
-            if (variant == 53) return launch_bf16_x2d128(p, causal, out_f32, 12, stream);
+            if (variant == 50) return launch_bf16_x2(p, 128, causal, out_f32, 0, stream);   // one wave per SIMD, explicit register files
+            if (variant == 51) return launch_bf16_x2(p, 128, causal, out_f32, 1, stream);
+            if (variant == 52) return launch_bf16_x2(p, 128, causal, out_f32, 3, stream);
+            if (variant == 53) return launch_bf16_x2(p, 128, causal, out_f32, 12, stream);
             if (variant == 10) return launch_w4<128, 4, 2>(p, causal, out_f32, stream);
             if (variant == 23) return launch_w4<128, 4, 3>(p, causal, out_f32, stream);
             return launch_cfg<128, 4, 1, 2>(p, causal, out_f32, stream);  // the pipelined kernel needs > 256 VGPRs at D = 128

@@ -1,24 +1,39 @@
-// fa_fwd_bf16_x2d128.hip -- the one-wave-per-SIMD, explicit-register-file kernel of fa_fwd_bf16_x4.hip for D = 128: TWO 32-row
-// blocks per wave (64 query rows), 256-row workgroups, one workgroup per CU.  At D = 128 a 32x32-key block has 18 MFMAs for the
-// same 40 (48) VALU instructions as at D = 64, so the step is bound by the matrix pipe, not by instruction issue:
+// fa_fwd_bf16_x2.hip -- the one-wave-per-SIMD, explicit-register-file kernel of fa_fwd_bf16_x4.hip with TWO 32-row blocks per wave
+// (64 query rows), 256-row workgroups, one workgroup per CU; instantiated for D = 128 and D = 64.
 //
-//   step t (32 keys, 36 MFMA slots):   K.Q^T of sub-tile t+1 for A and B (16)  |  P.V + row sums of A (10)  |  P.V + row sums of B (10)
+//   step t (32 keys):   K.Q^T of sub-tile t+1 for A and B (2 KS slots)  |  P.V + row sums of A (NV + 2)  |  P.V + row sums of B (NV + 2)
 //   VALU units (exp + pack of A, B for sub-tile t; rescaled mix: lane maxima of t+1, test) dealt out by issue cost over the
-//   first 58 (64) of the 68 half-slots so that every pack precedes the first MFMA reading it (schedule check: same rule as
-//   profiles/r01_x4_schedule_check.py).  V^T fragments (8) are read in slots 0..7 and waited for once, before slot 16; the K
-//   fragments (8) of the next step are read in slots 17..24.
-// Register files: scores, K / V^T / P fragments in VGPRs; O (128), Q fragments (64), row sums in AGPRs.  See fa_fwd_bf16_x4.hip
-// for the hazards that come with asm MFMAs and for the optimistic / lazily rescaled instruction mixes.
+//   leading part of the step's half-slots so that every pack precedes the first MFMA reading it (same rule and offline check as
+//   profiles/r01_x4_schedule_check.py).  V^T fragments are read in slots 0 .. NV-1 and waited for once, before the first P.V
+//   slot; the K fragments of the next step are read in the KS slots after it.
+//
+// D = 128: a 32x32-key block has 18 MFMAs for the same 40 (48) VALU instructions as at D = 64 -- the step is bound by the matrix
+//   pipe, not by instruction issue (1254 TFLOP/s at BH = 16, N = 8192; registers: O 128 + Q 64 + row sums in AGPRs).
+// D = 64: fewer rows per wave than x4 (more LDS reads and bookkeeping per FLOP), but 256-row tiles that run as two rounds of
+//   workgroups per CU, heavy tiles first: the causal case is no longer bound by its heaviest tile.
+// See fa_fwd_bf16_x4.hip for the hazards that come with asm MFMAs and for the optimistic / lazily rescaled instruction mixes.
 #include <utility>
 #include "fa_bf16_step.h"
 #include "fa_kernels.h"
 
 namespace fa {
 
-constexpr int kNB2 = 2;   // 32-row blocks per wave
-constexpr int kKS2 = 8;   // k-steps of K.Q^T (D / 16)
-constexpr int kDB2 = 4;   // 32-column blocks of O (D / 32)
-constexpr int kNV2 = 8;   // V^T fragments per 32-key sub-tile
+constexpr int kNB2 = 2;  // 32-row blocks per wave
+template <int D>
+struct X2Shape {
+    static constexpr int KS = D / 16;          // k-steps of K.Q^T
+    static constexpr int DB = D / 32;          // 32-column blocks of O
+    static constexpr int NV = 2 * DB;          // V^T fragments per 32-key sub-tile
+    static constexpr int GRP = NV + 2;         // slots of one P.V + row-sum group
+    static constexpr int kSlots = 2 * KS + 2 * GRP;
+    static constexpr int kFirstPv = 2 * KS;    // first slot that needs the V^T fragments
+    static constexpr int kKLoad = 2 * KS + 1;  // K fragments of the next step: slots kKLoad .. kKLoad + KS - 1
+    static constexpr int kUnitsOpt = 36, kUnitsRsc = 43;
+    // VALU units are dealt out over the first kWendOpt (kWendRsc) half-slots of the step (largest values that put every pack
+    // in front of the first MFMA reading it, found offline)
+    static constexpr int kWendOpt = D == 128 ? 58 : 30;
+    static constexpr int kWendRsc = D == 128 ? 64 : 34;
+};
 
 // ---- matrix instructions with explicit register files ------------------------------------------------------------------
 // With one wave per SIMD the wave owns 256 architectural VGPRs and 256 accumulation registers (AGPRs).  VALU instructions
@@ -57,15 +72,23 @@ __device__ __forceinline__ void x2_drain_scores(f32x16 (&s)[kNB2])
 {
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(s[0]), "+v"(s[1]));
 }
-__device__ __forceinline__ void x2_drain_accumulators(f32x16 (&o)[kNB2][kDB2], BlockState (&st)[kNB2])
+template <int DB>
+__device__ __forceinline__ void x2_drain_accumulators(f32x16 (&o)[kNB2][DB], BlockState (&st)[kNB2])
 {
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
-                 : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[1][2]), "+a"(o[1][3]),
-                   "+a"(st[0].lacc), "+a"(st[1].lacc));
+    if constexpr (DB == 4) {
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+                     : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[1][2]), "+a"(o[1][3]),
+                       "+a"(st[0].lacc), "+a"(st[1].lacc));
+    } else {
+        static_assert(DB == 2, "drain written for D = 64, 128");
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+                     : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(st[0].lacc), "+a"(st[1].lacc));
+    }
 }
 
 // (rare, wave-uniform) move the exponent references of all blocks; everything still at the old reference is scaled once
-__device__ __forceinline__ void x2_rescale(const float (&mx)[kNB2], float c, BlockState (&st)[kNB2], f32x16 (&o)[kNB2][kDB2], float (&off)[kNB2])
+template <int DB>
+__device__ __forceinline__ void x2_rescale(const float (&mx)[kNB2], float c, BlockState (&st)[kNB2], f32x16 (&o)[kNB2][DB], float (&off)[kNB2])
 {
     bool any = false;
     float mc[kNB2];
@@ -76,15 +99,15 @@ __device__ __forceinline__ void x2_rescale(const float (&mx)[kNB2], float c, Blo
         any = any || (mc[b] - st[b].m > kLazyThr);
     }
     if (__builtin_expect(__any(any), 0)) {
-        asm volatile("; lazy rescale (two blocks, D = 128)" ::: "memory");
-        x2_drain_accumulators(o, st);  // the accumulators rescaled below may have an MFMA in flight (hazard not padded across the branch)
+        asm volatile("; lazy rescale (two blocks)" ::: "memory");
+        x2_drain_accumulators<DB>(o, st);  // the accumulators rescaled below may have an MFMA in flight (hazard not padded across the branch)
 #pragma unroll
         for (int b = 0; b < kNB2; ++b) {
             const float nm = fmaxf(st[b].m, mc[b]);
             const float a = fast_exp2(st[b].m - nm);
             st[b].m = nm;
 #pragma unroll
-            for (int db = 0; db < kDB2; ++db)
+            for (int db = 0; db < DB; ++db)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[b][db][r] *= a;
 #pragma unroll
@@ -101,41 +124,39 @@ struct X2Slot {
     int kind;  // 0 = K.Q^T, 1 = P.V, 2 = row sum
     int blk, idx;
 };
-__device__ __host__ constexpr X2Slot x2_pv_group(int blk, int j)  // ten slots: no two dependent MFMAs adjacent
-{
-    if (j == 4) return {2, blk, 0};
-    if (j == 9) return {2, blk, 1};
-    return {1, blk, j < 4 ? j : j - 1};  // P.V index p: V^T fragment p = tt * 4 + db, accumulator o[blk][p % 4], P fragment p / 4
-}
+template <int D>
 __device__ __host__ constexpr X2Slot x2_slot(int i)
 {
-    if (i < 16) return {0, i % 2, i / 2};          // K.Q^T A,B   k-step i/2
-    if (i < 26) return x2_pv_group(0, i - 16);     // P.V + row sums A
-    return x2_pv_group(1, i - 26);                 // P.V + row sums B
+    using S = X2Shape<D>;
+    if (i < 2 * S::KS) return {0, i % 2, i / 2};  // K.Q^T A,B   k-step i/2
+    const int blk = (i - 2 * S::KS) / S::GRP, j = (i - 2 * S::KS) % S::GRP;
+    // P.V + row sums of one block, no two dependent MFMAs adjacent: P.V index p reads V^T fragment p = tt * DB + db, accumulates
+    // into o[blk][p % DB] and takes P fragment p / DB
+    if (j == S::DB) return {2, blk, 0};
+    if (j == S::NV + 1) return {2, blk, 1};
+    return {1, blk, j < S::DB ? j : j - 1};
 }
-constexpr int kX2Slots = 36;
 // Two instruction mixes share the slot sequence:
-//   OPT = false  the lazily rescaled softmax: exp + pack of sub-tile t, lane maxima of sub-tile t+1, rescale test (85 units)
-//   OPT = true   the optimistic softmax: the exponent reference of a row is fixed after its first sub-tile (with 2^100 of
-//                headroom either way, see kOptBias), so the loop has no maxima, no test and no branch (72 units); the tile
-//                is verified at the end and redone with OPT = false if any row left the safe range.
-constexpr int x2_num_units(bool opt) { return opt ? 36 : 43; }
+//   OPT = false  the lazily rescaled softmax: exp + pack of sub-tile t, lane maxima of sub-tile t+1, rescale test (43 units)
+//   OPT = true   the optimistic softmax (fa_bf16_common.h): no maxima, no test, no branch in the loop (36 units); the tile is
+//                verified at the end and redone with OPT = false if any row left the safe range.
+template <int D>
+constexpr int x2_num_units(bool opt) { return opt ? X2Shape<D>::kUnitsOpt : X2Shape<D>::kUnitsRsc; }
+template <int D>
 __device__ __host__ constexpr int x2_weight_before(int i)  // in half-slots: a 32x32x16 slot = 2, a 16x16x32 slot = 1
 {
     int w = 0;
-    for (int k = 0; k < i; ++k) w += (x2_slot(k).kind == 2) ? 1 : 2;
+    for (int k = 0; k < i; ++k) w += (x2_slot<D>(k).kind == 2) ? 1 : 2;
     return w;
 }
-constexpr int kX2Weight = x2_weight_before(kX2Slots);  // 68
-// the step is bound by the matrix pipe: the VALU units are dealt out over the first 58 (64) half-slots, which puts every pack in
-// front of the first MFMA that reads its fragment (checked offline, see the header)
-constexpr int x2_weight_end(bool opt) { return opt ? 58 : 64; }
+template <int D>
+constexpr int x2_weight_end(bool opt) { return opt ? X2Shape<D>::kWendOpt : X2Shape<D>::kWendRsc; }
 // VALU units are dealt out by ISSUE COST, not by count: measured beside MFMAs (profiles/ubench/ubench_clock.hip) a plain
 // VALU instruction occupies the wave's issue for 4 cycles and a v_exp_f32 for 8, so an exp element (fma + exp) costs 12, a
 // pack (4 cvt) 16, the max micro-steps 12 / 12 / 8, the test ~20 -- 1044 (896) cycles per step.  Slot i receives the units
 // whose cumulative cost fits its share of the step's half-slots (24..36 cycles per full slot).
 struct X2Table {
-    int ub[kX2Slots + 1];  // VALU units dealt out before slot i
+    int ub[64];  // VALU units dealt out before slot i (36 + 1 entries used at D = 128, 20 + 1 at D = 64)
 };
 // The unit sequence.  A pack (v_cvt_pk) is scheduled two exp units after the last exponential it consumes: a VALU
 // instruction that reads the result of a transcendental issued just before it costs a wait state (hipcc pads an s_nop).
@@ -179,16 +200,18 @@ __device__ __host__ constexpr X2UnitList x2_make_units(bool opt)
     l.u[n++] = {3, 0, 0, 20};
     return l;
 }
+template <int D>
 __device__ __host__ constexpr X2Table x2_make_table(bool opt)
 {
+    constexpr int kX2Slots = X2Shape<D>::kSlots;
     const X2UnitList l = x2_make_units(opt);
-    const int nu = x2_num_units(opt), wend = x2_weight_end(opt);
+    const int nu = x2_num_units<D>(opt), wend = x2_weight_end<D>(opt);
     X2Table t{};
     int total = 0;
     for (int u = 0; u < nu; ++u) total += l.u[u].cost;
     int n = 0, cum_next = l.u[0].cost;  // cum_next: cost of units 0..n inclusive
     for (int i = 0; i <= kX2Slots; ++i) {
-        const int wb = x2_weight_before(i) < wend ? x2_weight_before(i) : wend;
+        const int wb = x2_weight_before<D>(i) < wend ? x2_weight_before<D>(i) : wend;
         const int target = total * wb / wend + 6;
         while (n < nu && cum_next <= target) {
             ++n;
@@ -202,14 +225,15 @@ __device__ __host__ constexpr X2Table x2_make_table(bool opt)
 
 // A VALU result needs two wait states before an MFMA reads it, and an asm MFMA is not padded by hipcc: when the dealing rule
 // puts the pack of a P fragment into the slot right in front of the first MFMA that reads it, that MFMA gets an s_nop 1.
+template <int D>
 __device__ __host__ constexpr bool x2_needs_pad(int i, bool opt)
 {
-    const X2Slot sl = x2_slot(i);
+    const X2Slot sl = x2_slot<D>(i);
     if (sl.kind == 0 || i == 0) return false;
-    const int frag = sl.kind == 1 ? sl.idx / 4 : sl.idx;
+    const int frag = sl.kind == 1 ? sl.idx / X2Shape<D>::DB : sl.idx;
     const X2UnitList l = x2_make_units(opt);
-    const X2Table t = x2_make_table(opt);
-    for (int u = 0; u < x2_num_units(opt); ++u)
+    const X2Table t = x2_make_table<D>(opt);
+    for (int u = 0; u < x2_num_units<D>(opt); ++u)
         if (l.u[u].kind == 1 && l.u[u].blk == sl.blk && l.u[u].idx == frag) return u >= t.ub[i - 1];
     return false;
 }
@@ -218,29 +242,30 @@ __device__ __host__ constexpr bool x2_needs_pad(int i, bool opt)
 // entry, of sub-tile t+2 (read from k_nxt / block kb_n2) on exit.  Returns the lane's rescale test for sub-tile t+1.
 // Every slot / unit index is a template parameter (fold expressions over integer sequences): nothing here relies on the
 // optimiser unrolling a 40 x 53 loop nest to resolve the register arrays.
+template <int D>
 struct X2Ctx {
     const bf16x8& ones_a;
-    const bf16x8 (&qf)[kNB2][kKS2];
+    const bf16x8 (&qf)[kNB2][X2Shape<D>::KS];
     f32x16 (&sc)[kNB2];
     f32x16 (&sn)[kNB2];
-    f32x16 (&o)[kNB2][kDB2];
+    f32x16 (&o)[kNB2][X2Shape<D>::DB];
     BlockState (&st)[kNB2];
     const float (&off)[kNB2];
-    bf16x8 (&kf)[kKS2];
+    bf16x8 (&kf)[X2Shape<D>::KS];
     float (&lm)[kNB2];
     float c;
     const char* k_nxt;
     int kb_n2, k_row_off, k_g;
     unsigned v_addr;
-    s16x4 vlo[kNV2], vhi[kNV2];
-    bf16x8 vf[kNV2];
+    s16x4 vlo[X2Shape<D>::NV], vhi[X2Shape<D>::NV];
+    bf16x8 vf[X2Shape<D>::NV];
     bf16x8 pf[kNB2][2];
     float pm[4];
     bool need;
 };
 
-template <bool OPT, int U>
-__device__ __forceinline__ void x2_unit(X2Ctx& x)
+template <int D, bool OPT, int U>
+__device__ __forceinline__ void x2_unit(X2Ctx<D>& x)
 {
     constexpr X2Unit un = x2_make_units(OPT).u[U];
     if constexpr (un.kind == 0) {
@@ -260,76 +285,85 @@ __device__ __forceinline__ void x2_unit(X2Ctx& x)
         x.need = t > 0.0f;  // off = m + kLazyThr
     }
 }
-template <bool OPT, int U0, int... Us>
-__device__ __forceinline__ void x2_units(X2Ctx& x, std::integer_sequence<int, Us...>)
+template <int D, bool OPT, int U0, int... Us>
+__device__ __forceinline__ void x2_units(X2Ctx<D>& x, std::integer_sequence<int, Us...>)
 {
-    (x2_unit<OPT, U0 + Us>(x), ...);
+    (x2_unit<D, OPT, U0 + Us>(x), ...);
 }
 
-template <int KB_C, int I, int ABL, bool OPT>
-__device__ __forceinline__ void x2_slot_body(X2Ctx& x)
+template <int D, int KB_C, int I, int ABL, bool OPT>
+__device__ __forceinline__ void x2_slot_body(X2Ctx<D>& x)
 {
-    constexpr int D = 128;
-    constexpr X2Slot sl = x2_slot(I);
-    constexpr X2Table tab = x2_make_table(OPT);
-    // The asm-issued V^T reads were started in slots 0..7 (two ds_read per fragment), at least eight slots ago: one wait
-    // in front of the first P.V slot orders them all (the K reads of the next step start after it, see below).
-    if constexpr (I == 16) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x.vlo[0]), "+v"(x.vhi[0]), "+v"(x.vlo[1]), "+v"(x.vhi[1]), "+v"(x.vlo[2]), "+v"(x.vhi[2]), "+v"(x.vlo[3]),
-                     "+v"(x.vhi[3]));
-        asm volatile("" : "+v"(x.vlo[4]), "+v"(x.vhi[4]), "+v"(x.vlo[5]), "+v"(x.vhi[5]), "+v"(x.vlo[6]), "+v"(x.vhi[6]), "+v"(x.vlo[7]), "+v"(x.vhi[7]));
+    using S = X2Shape<D>;
+    constexpr X2Slot sl = x2_slot<D>(I);
+    constexpr X2Table tab = x2_make_table<D>(OPT);
+    // The asm-issued V^T reads were started in slots 0 .. NV-1 (two ds_read per fragment), at least KS slots ago: one wait in
+    // front of the first P.V slot orders them all (the K reads of the next step start after it, see below).
+    if constexpr (I == S::kFirstPv) {
+        if constexpr (S::NV == 8) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(x.vlo[0]), "+v"(x.vhi[0]), "+v"(x.vlo[1]), "+v"(x.vhi[1]), "+v"(x.vlo[2]), "+v"(x.vhi[2]), "+v"(x.vlo[3]), "+v"(x.vhi[3]));
+            asm volatile("" : "+v"(x.vlo[4]), "+v"(x.vhi[4]), "+v"(x.vlo[5]), "+v"(x.vhi[5]), "+v"(x.vlo[6]), "+v"(x.vhi[6]), "+v"(x.vlo[7]), "+v"(x.vhi[7]));
+        } else {
+            static_assert(S::NV == 4, "fragment wait written for D = 64, 128");
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(x.vlo[0]), "+v"(x.vhi[0]), "+v"(x.vlo[1]), "+v"(x.vhi[1]), "+v"(x.vlo[2]), "+v"(x.vhi[2]), "+v"(x.vlo[3]), "+v"(x.vhi[3]));
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int v = 0; v < kNV2; ++v) x.vf[v] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(x.vlo[v], x.vhi[v], 0, 1, 2, 3, 4, 5, 6, 7));
+        for (int v = 0; v < S::NV; ++v) x.vf[v] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(x.vlo[v], x.vhi[v], 0, 1, 2, 3, 4, 5, 6, 7));
     }
-    if constexpr (I < kNV2) load_v_frag_asm<D, KB_C, I>(x.v_addr, x.vlo[I], x.vhi[I]);
-    if constexpr (x2_needs_pad(I, OPT)) asm volatile("s_nop 1");
+    if constexpr (I < S::NV) load_v_frag_asm<D, KB_C, I>(x.v_addr, x.vlo[I], x.vhi[I]);
+    if constexpr (x2_needs_pad<D>(I, OPT)) asm volatile("s_nop 1");
     if constexpr (ABL & 1) {
         // timing-only ablation: no matrix instructions
     } else if constexpr (sl.kind == 0) {
         if constexpr (sl.idx == 0) x2_mfma_s_first(x.sn[sl.blk], x.kf[sl.idx], x.qf[sl.blk][sl.idx]);
         else x2_mfma_s(x.sn[sl.blk], x.kf[sl.idx], x.qf[sl.blk][sl.idx]);
     } else if constexpr (sl.kind == 1) {
-        x2_mfma_o(x.o[sl.blk][sl.idx % 4], x.vf[sl.idx], x.pf[sl.blk][sl.idx / 4]);
+        x2_mfma_o(x.o[sl.blk][sl.idx % S::DB], x.vf[sl.idx], x.pf[sl.blk][sl.idx / S::DB]);
     } else {
         x2_mfma_l(x.st[sl.blk].lacc, x.ones_a, x.pf[sl.blk][sl.idx]);
     }
-    if constexpr (I >= 17 && I < 17 + kKS2) {  // K fragments of the next step (the last K.Q^T of this one was slot 15)
+    if constexpr (I >= S::kKLoad && I < S::kKLoad + S::KS) {  // K fragments of the next step (its last K.Q^T was slot 2 KS - 1)
         // asm, like the V^T reads: a compiler-visible LDS load would make hipcc put its own lgkmcnt waits in front of the
         // next step's K.Q^T MFMAs
-        constexpr int ks = I - 17;
+        constexpr int ks = I - S::kKLoad;
         const unsigned a = (unsigned)(size_t)(lds_s16x4_t*)(x.k_nxt + x.k_row_off + x.kb_n2 * 32 * (2 * D) + (((2 * ks) ^ x.k_g) * 16));
         asm volatile("ds_read_b128 %0, %1" : "=v"(x.kf[ks]) : "v"(a));
     }
-    if constexpr (!(ABL & 2)) x2_units<OPT, tab.ub[I]>(x, std::make_integer_sequence<int, tab.ub[I + 1] - tab.ub[I]>{});  // ABL & 2: no VALU work
+    if constexpr (!(ABL & 2)) x2_units<D, OPT, tab.ub[I]>(x, std::make_integer_sequence<int, tab.ub[I + 1] - tab.ub[I]>{});  // ABL & 2: no VALU work
     __builtin_amdgcn_sched_barrier(0);
 }
-template <int KB_C, int ABL, bool OPT, int... Is>
-__device__ __forceinline__ void x2_slots(X2Ctx& x, std::integer_sequence<int, Is...>)
+template <int D, int KB_C, int ABL, bool OPT, int... Is>
+__device__ __forceinline__ void x2_slots(X2Ctx<D>& x, std::integer_sequence<int, Is...>)
 {
-    (x2_slot_body<KB_C, Is, ABL, OPT>(x), ...);
+    (x2_slot_body<D, KB_C, Is, ABL, OPT>(x), ...);
 }
 
-template <int KB_C, int ABL = 0, bool OPT = false>
+template <int D, int KB_C, int ABL = 0, bool OPT = false>
 __device__ __forceinline__ bool x2_step(const char* v_lds, const char* k_nxt, int kb_n2, int k_row_off, int k_g, int v_lane_off,
-                                        const bf16x8& ones_a, const bf16x8 (&qf)[kNB2][kKS2], f32x16 (&sc)[kNB2], f32x16 (&sn)[kNB2],
-                                        f32x16 (&o)[kNB2][kDB2], BlockState (&st)[kNB2], float c, const float (&off)[kNB2], bf16x8 (&kf)[kKS2],
-                                        float (&lm)[kNB2])
+                                        const bf16x8& ones_a, const bf16x8 (&qf)[kNB2][X2Shape<D>::KS], f32x16 (&sc)[kNB2], f32x16 (&sn)[kNB2],
+                                        f32x16 (&o)[kNB2][X2Shape<D>::DB], BlockState (&st)[kNB2], float c, const float (&off)[kNB2],
+                                        bf16x8 (&kf)[X2Shape<D>::KS], float (&lm)[kNB2])
 {
-    X2Ctx x{ones_a, qf, sc, sn, o, st, off, kf, lm, c, k_nxt, kb_n2, k_row_off, k_g, (unsigned)(size_t)(lds_s16x4_t*)(v_lds + v_lane_off)};
+    X2Ctx<D> x{ones_a, qf, sc, sn, o, st, off, kf, lm, c, k_nxt, kb_n2, k_row_off, k_g, (unsigned)(size_t)(lds_s16x4_t*)(v_lds + v_lane_off)};
     x.need = false;
-    x2_slots<KB_C, ABL, OPT>(x, std::make_integer_sequence<int, kX2Slots>{});
-    // the K reads of slots 17..24 are more than ten MFMA slots old: this wait is free, and it keeps every asm-issued load
-    // inside the basic block that issued it (hipcc may move or spill a register across a branch without knowing a load is in flight)
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]), "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7]));
+    x2_slots<D, KB_C, ABL, OPT>(x, std::make_integer_sequence<int, X2Shape<D>::kSlots>{});
+    // the K reads are at least GRP slots old: this wait is free, and it keeps every asm-issued load inside the basic block that
+    // issued it (hipcc may move or spill a register across a branch without knowing a load is in flight)
+    if constexpr (X2Shape<D>::KS == 8)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]), "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]));
     return x.need;
 }
 
 // One 256-row tile.  OPT: optimistic mix; returns false (nothing stored) when some row of the workgroup left the safe range.
-template <int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL, bool OPT>
+template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL, bool OPT>
 __device__ __forceinline__ bool x2_tile(const FwdParams& p, char* smem)
 {
-    constexpr int D = 128, KS = kKS2, DB = kDB2;
+    constexpr int KS = X2Shape<D>::KS, DB = X2Shape<D>::DB;
     constexpr float kBias = OPT ? kOptBias : kLazyThr;
     using C = Bf16Cfg<D, NWAVES>;
     constexpr int BM = NWAVES * 32 * kNB2;
@@ -455,7 +489,7 @@ __device__ __forceinline__ bool x2_tile(const FwdParams& p, char* smem)
                 off[blk] = st[blk].m + kBias;
             }
         } else if (!OPT) {
-            x2_rescale(mx, c, st, o, off);
+            x2_rescale<DB>(mx, c, st, o, off);
         }
     };
     // exp, pack, P.V and row sums of sub-tile t for all blocks, phase-structured (tail)
@@ -501,19 +535,19 @@ __device__ __forceinline__ bool x2_tile(const FwdParams& p, char* smem)
         for (int g = 0; g < G; ++g) {
             const char* v_lds = v_slot(j + g);
             const char* k_nxt = k_slot(j + g + 1);
-            bool need = x2_step<0, ABL, OPT>(v_lds, k_nxt, 0, k_row_off, k_g, v_lane_off, ones_a, qf, s0, s1, o, st, c, off, kf, lm);
+            bool need = x2_step<D, 0, ABL, OPT>(v_lds, k_nxt, 0, k_row_off, k_g, v_lane_off, ones_a, qf, s0, s1, o, st, c, off, kf, lm);
             if (!OPT && __builtin_expect(__any(need), 0)) {
                 float mx[kNB2];
 #pragma unroll
                 for (int blk = 0; blk < kNB2; ++blk) mx[blk] = xhalf_max(lm[blk]);
-                x2_rescale(mx, c, st, o, off);
+                x2_rescale<DB>(mx, c, st, o, off);
             }
-            need = x2_step<1, ABL, OPT>(v_lds, k_nxt, 1, k_row_off, k_g, v_lane_off, ones_a, qf, s1, s0, o, st, c, off, kf, lm);
+            need = x2_step<D, 1, ABL, OPT>(v_lds, k_nxt, 1, k_row_off, k_g, v_lane_off, ones_a, qf, s1, s0, o, st, c, off, kf, lm);
             if (!OPT && __builtin_expect(__any(need) && 2 * (j + g) + 2 < nsub, 0)) {
                 float mx[kNB2];
 #pragma unroll
                 for (int blk = 0; blk < kNB2; ++blk) mx[blk] = xhalf_max(lm[blk]);
-                x2_rescale(mx, c, st, o, off);
+                x2_rescale<DB>(mx, c, st, o, off);
             }
         }
     }
@@ -606,22 +640,22 @@ __device__ __forceinline__ bool x2_tile(const FwdParams& p, char* smem)
 }
 
 // OPTIMISTIC: try the fixed-reference mix first, redo the tile with the rescaling mix if its verification fails
-template <int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL = 0, bool OPTIMISTIC = true>
+template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL = 0, bool OPTIMISTIC = true>
 __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x2_kernel(FwdParams p)
 {
-    using C = Bf16Cfg<128, NWAVES>;
+    using C = Bf16Cfg<D, NWAVES>;
     __shared__ __attribute__((aligned(1024))) char smem[4 * G * C::kTileBytes];
     if (OPTIMISTIC && ABL == 0) {
-        if (x2_tile<NWAVES, CAUSAL, OUT_F32, G, 0, true>(p, smem)) return;
+        if (x2_tile<D, NWAVES, CAUSAL, OUT_F32, G, 0, true>(p, smem)) return;
     }
     if (ABL != 0 && OPTIMISTIC) {  // timing-only ablations of the optimistic mix (results are garbage)
-        (void)x2_tile<NWAVES, CAUSAL, OUT_F32, G, ABL, true>(p, smem);
+        (void)x2_tile<D, NWAVES, CAUSAL, OUT_F32, G, ABL, true>(p, smem);
         return;
     }
-    (void)x2_tile<NWAVES, CAUSAL, OUT_F32, G, ABL, false>(p, smem);
+    (void)x2_tile<D, NWAVES, CAUSAL, OUT_F32, G, ABL, false>(p, smem);
 }
 
-template <int G, bool OPTIMISTIC = true>
+template <int D, int G, bool OPTIMISTIC = true>
 static hipError_t launch_x2(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
 {
     FwdParams p = p0;
@@ -632,33 +666,39 @@ static hipError_t launch_x2(const FwdParams& p0, int causal, int out_f32, hipStr
     dim3 grid((unsigned)total), block(NWAVES * kWave);
     if (causal) {
         if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<NWAVES, true, true, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, NWAVES, true, true, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
         else
-            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<NWAVES, true, false, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, NWAVES, true, false, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
     } else {
         if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<NWAVES, false, true, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, NWAVES, false, true, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
         else
-            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<NWAVES, false, false, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, NWAVES, false, false, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
     }
     return hipGetLastError();
 }
 
-// D = 128 only.  mode: 0 = product configuration (optimistic mix first, barrier every 2 stages), 1 = barrier every stage,
-// 3 = lazily rescaled mix only, 12 = timing-only ablation without the VALU units
-hipError_t launch_bf16_x2d128(const FwdParams& p, int causal, int out_f32, int mode, hipStream_t stream)
+// d in {64, 128}.  mode: 0 = product configuration (optimistic mix first, barrier every 2 stages), 1 = barrier every stage,
+// 3 = lazily rescaled mix only, 12 = timing-only ablation without the VALU units (D = 128)
+hipError_t launch_bf16_x2(const FwdParams& p, int d, int causal, int out_f32, int mode, hipStream_t stream)
 {
-    if (!(((int64_t)(p.n - 1) * p.kv_row_stride + 128) * 2 < (int64_t)0xffffffffLL)) return hipErrorInvalidValue;
-    if (mode == 1) return launch_x2<1>(p, causal, out_f32, stream);
-    if (mode == 3) return launch_x2<2, false>(p, causal, out_f32, stream);
+    if (d != 64 && d != 128) return hipErrorInvalidValue;
+    if (!(((int64_t)(p.n - 1) * p.kv_row_stride + d) * 2 < (int64_t)0xffffffffLL)) return hipErrorInvalidValue;
+    if (d == 64) {
+        if (mode == 1) return launch_x2<64, 1>(p, causal, out_f32, stream);
+        if (mode == 3) return launch_x2<64, 2, false>(p, causal, out_f32, stream);
+        return launch_x2<64, 2>(p, causal, out_f32, stream);
+    }
+    if (mode == 1) return launch_x2<128, 1>(p, causal, out_f32, stream);
+    if (mode == 3) return launch_x2<128, 2, false>(p, causal, out_f32, stream);
     if (mode == 12) {
         FwdParams q = p;
         q.q_tiles = (p.n + 255) / 256;
         dim3 grid((unsigned)(q.bh * q.q_tiles)), block(256);
-        hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<4, false, false, 2, 2>), grid, block, 0, stream, q);
+        hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<128, 4, false, false, 2, 2>), grid, block, 0, stream, q);
         return hipGetLastError();
     }
-    return launch_x2<2>(p, causal, out_f32, stream);
+    return launch_x2<128, 2>(p, causal, out_f32, stream);
 }
 
 }  // namespace fa

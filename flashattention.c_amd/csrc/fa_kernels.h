@@ -16,7 +16,7 @@ hipError_t launch_bf16_pipelined(const FwdParams& p, int d, int nwaves, int caus
 const char* bf16_kernel_name(int64_t bh, int64_t n, int d, int causal);  // the kernel the product dispatch picks
 bool bf16_pipelined_supported(const FwdParams& p, int d);  // d in {32, 64} and the slab addressable with 32-bit byte offsets
 hipError_t launch_bf16_x4(const FwdParams& p, int causal, int out_f32, int mode, hipStream_t stream);  // D = 64, 128 rows/wave
-hipError_t launch_bf16_x2d128(const FwdParams& p, int causal, int out_f32, int mode, hipStream_t stream);  // D = 128, 64 rows/wave, one wave per SIMD
+hipError_t launch_bf16_x2(const FwdParams& p, int d, int causal, int out_f32, int mode, hipStream_t stream);  // D = 64 / 128, 64 rows/wave, one wave per SIMD
 hipError_t launch_bf16_pp2(const FwdParams& p, int causal, int out_f32, int variant, hipStream_t stream);
 
 }  // namespace fa

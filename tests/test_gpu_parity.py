@@ -148,8 +148,9 @@ def test_bf16_vs_oracle(bh, n, d, causal, scale):
 
 # 0 = product dispatch, 1 = phase-structured kernel, 7 / 24 = pipelined kernel with 4- / 2-wave workgroups (optimistic mix with
 # verified redo), 25 / 26 = the same with the lazily rescaled mix only, 30 / 31 = one-wave-per-SIMD 128-rows-per-wave kernel
-# (barrier every 2 / every stage), 42 = that kernel with the lazily rescaled mix only
-@pytest.mark.parametrize("variant", [0, 1, 7, 24, 25, 26, 30, 31, 42])
+# (barrier every 2 / every stage), 42 = that kernel with the lazily rescaled mix only, 50 / 51 / 52 = one-wave-per-SIMD kernel
+# with 64 rows per wave (optimistic, barrier every 2 / every stage; rescaled mix only)
+@pytest.mark.parametrize("variant", [0, 1, 7, 24, 25, 26, 30, 31, 42, 50, 51, 52])
 @pytest.mark.parametrize("causal", [False, True])
 def test_bf16_tiling_variants_agree(variant, causal):
     q, k, v = (orc.round_to_bf16(randn(s, 3, 700, 64)) for s in (7, 8, 9))
@@ -233,7 +234,7 @@ def test_bf16_d128_tiling_variants_agree(variant, causal):
     check(fa.forward(qd, kd, vd, causal, scale=0.125, kernel=f"mfma:{variant}"), ref, bf16_tol(0.125, False))
 
 
-@pytest.mark.parametrize("d,variant", [(64, 0), (64, 7), (64, 24), (64, 25), (64, 26), (64, 30), (64, 42), (128, 50), (128, 52)])
+@pytest.mark.parametrize("d,variant", [(64, 0), (64, 7), (64, 24), (64, 25), (64, 26), (64, 30), (64, 42), (64, 50), (64, 52), (128, 50), (128, 52)])
 @pytest.mark.parametrize("causal", [False, True])
 def test_rescale_inside_the_pipelined_loop(d, variant, causal):
     """Keys that outgrow a row's first-sub-tile maximum by 2^140 .. 2^230, placed in the middle of the sequence.  Lazily
