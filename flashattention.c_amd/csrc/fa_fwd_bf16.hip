@@ -462,12 +462,19 @@ static Bf16Choice choose_bf16(int64_t bh, int64_t n, int d, int causal, bool add
         if (items256 <= 256 || (items256 <= 512 && n >= 8192)) return kChooseX2D64;
         return kChoosePipelined4;
     }
-    // one wave per SIMD, 512-row workgroups, one workgroup per CU: worth it when those workgroups fill whole rounds of the
-    // 256 CUs at least as well as 256-row workgroups fill the 512 slots of the two-wave kernel
-    const double eff512 = (double)items512 / (double)(((items512 + 255) / 256) * 256);
-    const double eff256 = (double)items256 / (double)(((items256 + 511) / 512) * 512);
-    const double pad512 = (double)n / (double)(((n + 511) / 512) * 512), pad256 = (double)n / (double)(((n + 255) / 256) * 256);
-    if (n >= 2048 && eff512 * pad512 >= 0.98 * eff256 * pad256) return kChooseX4;
+    // Non-causal.  Rounds of workgroups, in units of 131072 query rows of work:
+    //   x4   512-row workgroups, one per CU, ~10 % faster per row at full occupancy; a partly filled round costs a whole one;
+    //   pp3  256-row workgroups, two per CU; a last round with at most one workgroup per CU runs in ~0.71 of a round (a lone
+    //        wave gets 1 / 1.41 of a SIMD pair's throughput);
+    //   x2   256-row workgroups, one per CU: 2-4 % ahead of pp3 when there is at most one round of them.
+    // Measured (TFLOP/s, pp3 / x2 / x4), BH x N: 8 x 8192: 963 / 962 / 730, 12 x 8192: 919 / 842 / 996, 16 x 8192: 1060 / 1056 /
+    // 1166, 24 x 8192: 1075 / 1034 / 975, 16 x 4096: 849 / 876 / 662, 32 x 2048: 767 / 790 / 587, 64 x 1024: 649 / 654 / 505.
+    const double pad512 = (double)(((n + 511) / 512) * 512) / (double)n, pad256 = (double)(((n + 255) / 256) * 256) / (double)n;
+    const int64_t rem = items256 % 512;
+    const double cost_pp3 = ((double)(items256 / 512) + (rem == 0 ? 0.0 : rem <= 256 ? 0.71 : 1.0)) * pad256;
+    const double cost_x4 = (double)((items512 + 255) / 256) / 1.10 * pad512;
+    if (n >= 2048 && cost_x4 <= cost_pp3) return kChooseX4;
+    if (items256 <= 256) return kChooseX2D64;
     return kChoosePipelined4;
 }
 
