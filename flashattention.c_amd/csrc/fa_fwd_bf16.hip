@@ -440,8 +440,8 @@ static hipError_t launch_cfg(const FwdParams& p0, int causal, int out_f32, hipSt
 // ---- product dispatch (variant 0) --------------------------------------------------------------------------------------
 // Measured on MI355X, steady clocks, TFLOP/s at bh = 16, n = 8192 (profiles/): d = 64 non-causal  x4 1044 / pipelined 1022;
 // d = 64 causal  x2 884 / pipelined 2-wave 738 / 4-wave 642 / x4 594;  d = 128  x2 1254 / w4 1012 / phase-structured 950 (causal:
-// x2 1109 / phase-structured 827);  d = 32  pipelined 735.
-enum Bf16Choice { kChoosePhase, kChoosePipelined4, kChoosePipelined2, kChooseX4, kChooseW4, kChooseX2D128, kChooseX2D64 };
+// x2 1109 / phase-structured 827);  d = 32  x2 780 / pipelined 767.
+enum Bf16Choice { kChoosePhase, kChoosePipelined4, kChoosePipelined2, kChooseX4, kChooseW4, kChooseX2D128, kChooseX2D64, kChooseX2D32 };
 
 static Bf16Choice choose_bf16(int64_t bh, int64_t n, int d, int causal, bool addressable)
 {
@@ -451,7 +451,9 @@ static Bf16Choice choose_bf16(int64_t bh, int64_t n, int d, int causal, bool add
         return causal ? kChoosePhase : kChooseW4;
     }
     if (!addressable) return kChoosePhase;
-    if (d == 32) return causal ? kChoosePhase : kChoosePipelined4;  // 256-row workgroups waste too much of the causal triangle at d = 32
+    // d = 32 (TFLOP/s, x2 / pipelined / phase-structured): 16 x 8192 non-causal 780 / 767 / -, causal 428 / 415 / 416; 128 x 8192
+    // causal 709 / - / 560
+    if (d == 32) return kChooseX2D32;
     // d == 64
     const int64_t items256 = bh * ((n + 255) / 256), items512 = bh * ((n + 511) / 512);
     if (causal) {
@@ -486,7 +488,8 @@ const char* bf16_kernel_name(int64_t bh, int64_t n, int d, int causal)
         case kChoosePipelined2: return "fa_fwd_bf16_pp3_kernel";
         case kChooseW4: return "fa_fwd_bf16_w4_kernel";
         case kChooseX2D128:
-        case kChooseX2D64: return "fa_fwd_bf16_x2_kernel";
+        case kChooseX2D64:
+        case kChooseX2D32: return "fa_fwd_bf16_x2_kernel";
         default: return "fa_fwd_bf16_kernel";
     }
 }
@@ -502,6 +505,7 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
             case kChooseW4: return launch_w4<128, 4, 2>(p, causal, out_f32, stream);
             case kChooseX2D128: return launch_bf16_x2(p, 128, causal, out_f32, 0, stream);
             case kChooseX2D64: return launch_bf16_x2(p, 64, causal, out_f32, 0, stream);
+            case kChooseX2D32: return launch_bf16_x2(p, 32, causal, out_f32, 0, stream);
             default:
                 if (d == 32) return launch_cfg<32, 4, 1, 4>(p, causal, out_f32, stream);
                 if (d == 64) return launch_cfg<64, 4, 1, 4>(p, causal, out_f32, stream);
@@ -511,6 +515,8 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
     if (!bf16_pipelined_supported(p, d) && d != 128) return hipErrorInvalidValue;  // the ablation variants assume 32-bit slab offsets
     switch (d) {
         case 32:
+            if (variant == 50) return launch_bf16_x2(p, 32, causal, out_f32, 0, stream);
+            if (variant == 52) return launch_bf16_x2(p, 32, causal, out_f32, 3, stream);
             if (variant == 24) return launch_bf16_pipelined(p, 32, 2, causal, out_f32, 0, stream);
             // lockstep/pipelined kernel for the non-causal case; its 256-row workgroups waste more of the causal
             // triangle than the 128-row phase-structured kernel recovers at D = 32

@@ -31,8 +31,8 @@ struct X2Shape {
     static constexpr int kUnitsOpt = 36, kUnitsRsc = 43;
     // VALU units are dealt out over the first kWendOpt (kWendRsc) half-slots of the step (largest values that put every pack
     // in front of the first MFMA reading it, found offline)
-    static constexpr int kWendOpt = D == 128 ? 58 : 30;
-    static constexpr int kWendRsc = D == 128 ? 64 : 34;
+    static constexpr int kWendOpt = D == 128 ? 58 : D == 64 ? 30 : 16;
+    static constexpr int kWendRsc = D == 128 ? 64 : D == 64 ? 34 : 18;
 };
 
 // ---- matrix instructions with explicit register files ------------------------------------------------------------------
@@ -79,10 +79,12 @@ __device__ __forceinline__ void x2_drain_accumulators(f32x16 (&o)[kNB2][DB], Blo
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
                      : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[1][2]), "+a"(o[1][3]),
                        "+a"(st[0].lacc), "+a"(st[1].lacc));
-    } else {
-        static_assert(DB == 2, "drain written for D = 64, 128");
+    } else if constexpr (DB == 2) {
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
                      : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(st[0].lacc), "+a"(st[1].lacc));
+    } else {
+        static_assert(DB == 1, "drain written for D = 32, 64, 128");
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+a"(o[0][0]), "+a"(o[1][0]), "+a"(st[0].lacc), "+a"(st[1].lacc));
     }
 }
 
@@ -304,10 +306,12 @@ __device__ __forceinline__ void x2_slot_body(X2Ctx<D>& x)
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(x.vlo[0]), "+v"(x.vhi[0]), "+v"(x.vlo[1]), "+v"(x.vhi[1]), "+v"(x.vlo[2]), "+v"(x.vhi[2]), "+v"(x.vlo[3]), "+v"(x.vhi[3]));
             asm volatile("" : "+v"(x.vlo[4]), "+v"(x.vhi[4]), "+v"(x.vlo[5]), "+v"(x.vhi[5]), "+v"(x.vlo[6]), "+v"(x.vhi[6]), "+v"(x.vlo[7]), "+v"(x.vhi[7]));
-        } else {
-            static_assert(S::NV == 4, "fragment wait written for D = 64, 128");
+        } else if constexpr (S::NV == 4) {
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(x.vlo[0]), "+v"(x.vhi[0]), "+v"(x.vlo[1]), "+v"(x.vhi[1]), "+v"(x.vlo[2]), "+v"(x.vhi[2]), "+v"(x.vlo[3]), "+v"(x.vhi[3]));
+        } else {
+            static_assert(S::NV == 2, "fragment wait written for D = 32, 64, 128");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x.vlo[0]), "+v"(x.vhi[0]), "+v"(x.vlo[1]), "+v"(x.vhi[1]));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -354,8 +358,10 @@ __device__ __forceinline__ bool x2_step(const char* v_lds, const char* k_nxt, in
     // issued it (hipcc may move or spill a register across a branch without knowing a load is in flight)
     if constexpr (X2Shape<D>::KS == 8)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]), "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7]));
-    else
+    else if constexpr (X2Shape<D>::KS == 4)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]));
     return x.need;
 }
 
@@ -678,12 +684,17 @@ static hipError_t launch_x2(const FwdParams& p0, int causal, int out_f32, hipStr
     return hipGetLastError();
 }
 
-// d in {64, 128}.  mode: 0 = product configuration (optimistic mix first, barrier every 2 stages), 1 = barrier every stage,
+// d in {32, 64, 128}.  mode: 0 = product configuration (optimistic mix first, barrier every 2 stages), 1 = barrier every stage,
 // 3 = lazily rescaled mix only, 12 = timing-only ablation without the VALU units (D = 128)
 hipError_t launch_bf16_x2(const FwdParams& p, int d, int causal, int out_f32, int mode, hipStream_t stream)
 {
-    if (d != 64 && d != 128) return hipErrorInvalidValue;
+    if (d != 32 && d != 64 && d != 128) return hipErrorInvalidValue;
     if (!(((int64_t)(p.n - 1) * p.kv_row_stride + d) * 2 < (int64_t)0xffffffffLL)) return hipErrorInvalidValue;
+    if (d == 32) {
+        if (mode == 1) return launch_x2<32, 1>(p, causal, out_f32, stream);
+        if (mode == 3) return launch_x2<32, 2, false>(p, causal, out_f32, stream);
+        return launch_x2<32, 2>(p, causal, out_f32, stream);
+    }
     if (d == 64) {
         if (mode == 1) return launch_x2<64, 1>(p, causal, out_f32, stream);
         if (mode == 3) return launch_x2<64, 2, false>(p, causal, out_f32, stream);

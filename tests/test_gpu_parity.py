@@ -226,7 +226,19 @@ def test_dominant_key_in_the_last_keys(n, out_f32):
 @pytest.mark.parametrize("variant", [0, 10, 50, 51, 52])
 @pytest.mark.parametrize("causal", [False, True])
 def test_bf16_d128_tiling_variants_agree(variant, causal):
-    q, k, v = (orc.round_to_bf16(randn(s, 3, 700, 128)) for s in (17, 18, 19))
+    _tiling_variant_case(128, variant, causal)
+
+
+# d = 32: 0 = product dispatch (one-wave-per-SIMD kernel), 1 = phase-structured, 7 / 24 = pipelined two-wave kernel, 50 / 52 =
+# one-wave-per-SIMD kernel (optimistic / lazily rescaled mix)
+@pytest.mark.parametrize("variant", [0, 1, 7, 24, 50, 52])
+@pytest.mark.parametrize("causal", [False, True])
+def test_bf16_d32_tiling_variants_agree(variant, causal):
+    _tiling_variant_case(32, variant, causal)
+
+
+def _tiling_variant_case(d, variant, causal):
+    q, k, v = (orc.round_to_bf16(randn(s, 3, 700, d)) for s in (17, 18, 19))
     ref = orc.attention_f64(q, k, v, causal=causal, scale=0.125)
     qd, kd, vd = to_dev(q, k, v, dtype=torch.bfloat16)
     o = fa.forward(qd, kd, vd, causal, scale=0.125, kernel=f"mfma:{variant}", out_dtype=torch.float32)
@@ -234,7 +246,8 @@ def test_bf16_d128_tiling_variants_agree(variant, causal):
     check(fa.forward(qd, kd, vd, causal, scale=0.125, kernel=f"mfma:{variant}"), ref, bf16_tol(0.125, False))
 
 
-@pytest.mark.parametrize("d,variant", [(64, 0), (64, 7), (64, 24), (64, 25), (64, 26), (64, 30), (64, 42), (64, 50), (64, 52), (128, 50), (128, 52)])
+@pytest.mark.parametrize("d,variant", [(64, 0), (64, 7), (64, 24), (64, 25), (64, 26), (64, 30), (64, 42), (64, 50), (64, 52), (128, 50), (128, 52),
+                                       (32, 50), (32, 52), (32, 7)])
 @pytest.mark.parametrize("causal", [False, True])
 def test_rescale_inside_the_pipelined_loop(d, variant, causal):
     """Keys that outgrow a row's first-sub-tile maximum by 2^140 .. 2^230, placed in the middle of the sequence.  Lazily
