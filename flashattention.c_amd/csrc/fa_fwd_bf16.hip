@@ -546,6 +546,9 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
                 case 39: return launch_bf16_x4(p, causal, out_f32, 17, stream);
                 case 40: return launch_bf16_x4(p, causal, out_f32, 18, stream);
                 case 41: return launch_bf16_x4(p, causal, out_f32, 19, stream);
+                case 43: return launch_bf16_x4(p, causal, out_f32, 20, stream);
+                case 44: return launch_bf16_x4(p, causal, out_f32, 21, stream);
+                case 45: return launch_bf16_x4(p, causal, out_f32, 22, stream);
                 case 10: return launch_w4<64, 4, 4>(p, causal, out_f32, stream);       // 4 waves/SIMD on the VALU diet
                 default: return launch_bf16_pp2(p, causal, out_f32, variant, stream);  // 9 = pp2, 6, 11..21 = its ablations
             }

@@ -246,11 +246,17 @@ struct X4Ctx {
     bool need;
 };
 
-template <bool OPT, int U>
+template <bool OPT, int U, int ABL = 0>
 __device__ __forceinline__ void x4_unit(X4Ctx& x)
 {
     constexpr X4Unit un = x4_make_units(OPT).u[U];
-    if constexpr (un.kind == 0) {
+    if constexpr (un.kind == 0 && (ABL & 256)) {
+        // timing-only ablation: the exponential replaced by a plain VALU instruction of the same data flow
+        const float t = fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]);
+        float r;
+        asm volatile("v_mul_f32 %0, %1, %1" : "=v"(r) : "v"(t));
+        x.sc[un.blk][un.idx] = r;
+    } else if constexpr (un.kind == 0) {
         // optimistic mix: no clamp -- an overflow has to reach the row sum (as a huge value or +inf): that is what the final
         // check reads
         if constexpr (OPT) x.sc[un.blk][un.idx] = fast_exp2(fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]));
@@ -267,10 +273,10 @@ __device__ __forceinline__ void x4_unit(X4Ctx& x)
         x.need = t > 0.0f;  // off = m + kLazyThr
     }
 }
-template <bool OPT, int U0, int... Us>
+template <bool OPT, int ABL, int U0, int... Us>
 __device__ __forceinline__ void x4_units(X4Ctx& x, std::integer_sequence<int, Us...>)
 {
-    (x4_unit<OPT, U0 + Us>(x), ...);
+    (x4_unit<OPT, U0 + Us, ABL>(x), ...);
 }
 
 template <int KB_C, int I, int ABL, bool OPT>
@@ -312,11 +318,12 @@ __device__ __forceinline__ void x4_slot_body(X4Ctx& x)
         constexpr int ks = I - 28;
         const unsigned a = (unsigned)(size_t)(lds_s16x4_t*)(x.k_nxt + x.k_row_off + x.kb_n2 * 32 * (2 * D) + (((2 * ks) ^ x.k_g) * 16));
         if constexpr (ABL & 16) asm volatile("" : "=v"(x.kf[ks]) : "v"(a));
+        else if constexpr (ABL & 64) asm volatile("" : "+v"(x.kf[ks]) : "v"(a));  // timing-only: keep the previous step's (random) fragments
         else asm volatile("ds_read_b128 %0, %1" : "=v"(x.kf[ks]) : "v"(a));
         if constexpr (ABL & 32) asm volatile("ds_read_b128 %0, %1" : "=v"(x.kf[ks]) : "v"(a));
     }
-    if constexpr (!(ABL & 2)) x4_units<OPT, tab.ub[I]>(x, std::make_integer_sequence<int, tab.ub[I + 1] - tab.ub[I]>{});  // ABL & 2: no VALU work
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!(ABL & 2)) x4_units<OPT, ABL, tab.ub[I]>(x, std::make_integer_sequence<int, tab.ub[I + 1] - tab.ub[I]>{});  // ABL & 2: no VALU work
+    if constexpr (!(ABL & 128)) __builtin_amdgcn_sched_barrier(0);  // ABL & 128: slots not pinned (hipcc schedules the step)
 }
 template <int KB_C, int ABL, bool OPT, int... Is>
 __device__ __forceinline__ void x4_slots(X4Ctx& x, std::integer_sequence<int, Is...>)
@@ -683,6 +690,9 @@ hipError_t launch_bf16_x4(const FwdParams& p, int causal, int out_f32, int mode,
     if (mode == 17) return launch_x4_ablation<16>(p, stream); // no LDS fragment reads
     if (mode == 18) return launch_x4_ablation<17>(p, stream); // no LDS fragment reads, no MFMA
     if (mode == 19) return launch_x4_ablation<32>(p, stream); // every LDS fragment read issued twice (results stay valid)
+    if (mode == 20) return launch_x4_ablation<64>(p, stream);  // K fragments not re-read
+    if (mode == 21) return launch_x4_ablation<128>(p, stream); // slots not pinned by sched_barrier
+    if (mode == 22) return launch_x4_ablation<256>(p, stream); // v_exp_f32 replaced by v_mul_f32
     return launch_x4<2>(p, causal, out_f32, stream);
 }
 
