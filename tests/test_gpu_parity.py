@@ -272,6 +272,28 @@ def test_rescale_inside_the_pipelined_loop(d, variant, causal):
     check(lse, lse_ref, 2e-2, f"lse variant {variant}")
 
 
+def test_fuzz_shapes_through_the_dispatch_against_rung0():
+    """Random (bh, n, d, causal, scale) through the product dispatch -- every kernel family and the ragged / tiny / one-round /
+    many-round branches of choose_bf16() get hit -- against the rung-0 kernel on the same bf16-valued inputs."""
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for case in range(48):
+        d = int(rng.choice([32, 64, 128]))
+        bh = int(rng.integers(1, 41))
+        n = int(rng.choice([rng.integers(1, 130), rng.integers(130, 1100), rng.integers(1100, 3000)]))
+        causal = bool(rng.integers(0, 2))
+        scale = float(rng.choice([1.0, 0.5, d ** -0.5]))
+        g = torch.Generator(device="cpu").manual_seed(1000 + case)
+        q, k, v = (torch.randn(bh, n, d, generator=g).to(torch.bfloat16).to(dev()) for _ in range(3))
+        ref = fa.forward(q.float(), k.float(), v.float(), causal, scale=scale, kernel="naive")
+        out = fa.forward(q, k, v, causal, scale=scale, out_dtype=torch.float32)
+        assert not torch.isnan(out).any(), f"NaN: case {case} bh={bh} n={n} d={d} causal={causal}"
+        err = float((out - ref).abs().max())
+        worst = max(worst, err)
+        assert err < bf16_tol(1.0, True), f"case {case} bh={bh} n={n} d={d} causal={causal} scale={scale}: {err:.3e}"
+    OBSERVED.append(("fuzz through dispatch, worst of 48", worst, bf16_tol(1.0, True)))
+
+
 def test_graph_replay_timing_entry():
     q, k, v = (torch.randn(4, 512, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
     ms_stream = fa.time_forward(q, k, v, False, warmup=1, iters=5)
