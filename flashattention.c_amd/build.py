@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libflashattn_amd.so")
 DRIVER_PATH = os.path.join(PKG_DIR, "fa_driver")
 ARCH = "gfx950"
 
-LIB_SOURCES = ["fa_api.cpp", "fa_naive.hip", "fa_fwd_f32.hip", "fa_fwd_bf16.hip", "fa_fwd_bf16_pipelined.hip", "fa_fwd_bf16_pp2.hip", "fa_fwd_bf16_x4.hip", "fa_fwd_bf16_x2.hip"]
+LIB_SOURCES = ["fa_api.cpp", "fa_naive.hip", "fa_fwd_f32.hip", "fa_fwd_f32_split.hip", "fa_fwd_bf16.hip", "fa_fwd_bf16_pipelined.hip", "fa_fwd_bf16_pp2.hip", "fa_fwd_bf16_x4.hip", "fa_fwd_bf16_x2.hip"]
 HEADERS = ["fa_common.h", "fa_kernels.h", "fa_bf16_common.h", os.path.join(ROOT, "include", "flashattn_amd.h")]
 COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
                 "-I", os.path.join(ROOT, "include")]

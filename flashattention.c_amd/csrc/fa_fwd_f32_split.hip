@@ -1,0 +1,350 @@
+// fa_fwd_f32_split.hip -- fused flash-attention forward for fp32 tensors on the bf16 matrix pipe (gfx950).
+//
+// Same contract as fa_fwd_f32.hip (fp32 Q/K/V in, fp32 O out; replaces flash_tiled_coarse{,_causal},
+// /root/reference/src/flashattention.cu:139-579), but both contractions run as THREE v_mfma_f32_32x32x16_bf16 on
+// two-term bf16 splits of their fp32 operands:
+//
+//     x = x_hi + x_lo,   x_hi = bf16(x),  x_lo = bf16(x - x_hi)          (16 significant bits, fp32 exponent range)
+//     a.b ~= a_hi.b_hi + a_lo.b_hi + a_hi.b_lo                            (the dropped a_lo.b_lo is 2^-18 relative)
+//
+// with fp32 accumulation in the matrix core.  The bf16 pipe is 16x the fp32 one on this chip (2.5 PF vs 157 TF dense), so
+// the triple product is still ~5x faster than v_mfma_f32_32x32x2_f32, and the result stays within ~1e-4 of the fp64
+// oracle at scale 1 -- inside the 1e-3 fp32 tolerance of the path, two orders of magnitude tighter than bf16 tensors.
+//
+//   workgroup   NWAVES waves x QB blocks of 32 query rows; K/V tiles of 32 keys.
+//   HBM -> LDS  fp32 K/V rows are loaded into registers (two global_load_dwordx4 per 8 values), split there, and written
+//               as FOUR bf16 images per tile (K_hi, K_lo, V_hi, V_lo) in the layouts of fa_bf16_common.h: K row-major with
+//               XOR-swizzled 16-byte slots (ds_read_b128 A fragments), V as [key/4][col/16][4][16] sub-tiles
+//               (ds_read_b64_tr_b16 hands out V^T fragments).  Register-staged double buffering: the loads of tile j+1 are
+//               in flight while tile j is consumed; one barrier per tile.  Rows past the end of the slab are zeros.
+//   S^T = K Q'^T   Q' = Q * scale*log2(e) in fp32 (one rounding per element), then split: scores arrive in the exp2 domain.
+//   softmax     running row maximum with a lazily updated reference (rescale only when a row outgrows it by 2^64):
+//               p = exp2(s - m_ref) in fp32, row sums in fp32 on the VALU, P split into hi/lo in registers.
+//   O^T += V^T P^T   same key permutation trick as the bf16 kernels: P never leaves its registers.
+#include "fa_bf16_common.h"
+#include "fa_kernels.h"
+#include <type_traits>
+
+namespace fa {
+
+constexpr int kKvSplit = 32;         // keys per tile
+constexpr float kSplitSlack = 64.0f; // exp2-domain head room of the lazily updated row reference
+
+template <int D>
+struct SplitCfg {
+    static constexpr int kRowBytes = 2 * D;
+    static constexpr int kImageBytes = kKvSplit * kRowBytes;  // one bf16 image (hi or lo) of a K or V tile
+    static constexpr int kStageBytes = 4 * kImageBytes;       // K_hi, K_lo, V_hi, V_lo
+    static constexpr int kGroups = kKvSplit * D / 8;          // 8-element (32-byte fp32) groups per tile
+};
+
+// two-term bf16 split of eight fp32 values
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __bf16 ha = (__bf16)a[i], hb = (__bf16)b[i];
+        hi[i] = ha;
+        hi[i + 4] = hb;
+        lo[i] = (__bf16)(a[i] - (float)ha);
+        lo[i + 4] = (__bf16)(b[i] - (float)hb);
+    }
+}
+
+__device__ __forceinline__ void split_p(const f32x16& s, int base, bf16x8& hi, bf16x8& lo)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)s[base + i];
+        hi[i] = h;
+        lo[i] = (__bf16)(s[base + i] - (float)h);
+    }
+}
+
+template <int D, int NWAVES, int QB, bool CAUSAL, int MINBLOCKS>
+__global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_kernel(FwdParams p)
+{
+    using C = SplitCfg<D>;
+    constexpr int KS = D / 16;   // k-steps of S^T = K Q^T
+    constexpr int DB = D / 32;   // 32-wide blocks of the head dim in O^T
+    constexpr int NT = NWAVES * kWave;
+    constexpr int BM = NWAVES * QB * 32;
+    constexpr int GPT = (C::kGroups + NT - 1) / NT;  // groups per thread and tile
+
+    __shared__ __attribute__((aligned(1024))) char smem[2 * C::kStageBytes];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, hi = lane >> 5;
+
+    const int total = p.bh * p.q_tiles;
+    const int w = xcd_remap(blockIdx.x, total);
+    const int slab = w / p.q_tiles;
+    int qt = w % p.q_tiles;
+    if (CAUSAL) qt = p.q_tiles - 1 - qt;  // longest (latest) q tiles first
+    const int n = p.n;
+    const int q0 = qt * BM + wave * (QB * 32);
+
+    const int b = slab / p.heads, h = slab % p.heads;
+    const float* qg = (const float*)p.q + b * p.q_batch_stride + h * p.q_head_stride;
+    const float* kg = (const float*)p.k + b * p.kv_batch_stride + h * p.kv_head_stride;
+    const float* vg = (const float*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
+    float* og = (float*)p.o + b * p.o_batch_stride + h * p.o_head_stride;
+
+    int kv_end = n;
+    if (CAUSAL) kv_end = min(n, qt * BM + BM);
+    const int nt = (kv_end + kKvSplit - 1) / kKvSplit;
+
+    // ---- this thread's pieces of a tile: group g = tid + i * NT -> (row, 8-column slot) of K and of V
+    int g_row[GPT], g_src[GPT], g_kdst[GPT], g_vdst[GPT];
+    bool g_on[GPT];
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+        const int g = tid + i * NT;
+        g_on[i] = g < C::kGroups;
+        const int row = g / (D / 8), c8 = g % (D / 8);
+        g_row[i] = row;
+        g_src[i] = row * p.kv_row_stride + c8 * 8;
+        g_kdst[i] = row * C::kRowBytes + ((c8 ^ k_swizzle<D>(row)) * 16);
+        g_vdst[i] = 2 * C::kImageBytes + ((row / 4) * (D / 16) + c8 / 2) * 128 + (row % 4) * 32 + (c8 & 1) * 16;
+    }
+    f32x4 kst[GPT][2], vst[GPT][2];
+    auto load_tile = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) {
+            const bool ok = g_on[i] && (kv0 + g_row[i] < n);
+            const int64_t off = (int64_t)kv0 * p.kv_row_stride + g_src[i];
+            const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+            kst[i][0] = ok ? *(const f32x4*)(kg + off) : z;
+            kst[i][1] = ok ? *(const f32x4*)(kg + off + 4) : z;
+            vst[i][0] = ok ? *(const f32x4*)(vg + off) : z;
+            vst[i][1] = ok ? *(const f32x4*)(vg + off + 4) : z;
+        }
+    };
+    auto store_tile = [&](char* stage) {
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) {
+            if (!g_on[i]) continue;
+            bf16x8 h8, l8;
+            split8(kst[i][0], kst[i][1], h8, l8);
+            *(bf16x8*)(stage + g_kdst[i]) = h8;
+            *(bf16x8*)(stage + C::kImageBytes + g_kdst[i]) = l8;
+            split8(vst[i][0], vst[i][1], h8, l8);
+            *(bf16x8*)(stage + g_vdst[i]) = h8;
+            *(bf16x8*)(stage + C::kImageBytes + g_vdst[i]) = l8;
+        }
+    };
+
+    load_tile(0);
+
+    // ---- Q' fragments (B operand of S^T = K Q'^T), hi and lo: lane (lq, hi) holds Q'[q][16*ks + 8*hi .. +7]
+    bf16x8 qh[QB][KS], ql[QB][KS];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qrow = min(q0 + qb * 32 + lq, n - 1);
+        const float* qr = qg + (int64_t)qrow * p.q_row_stride + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f32x4 a = *(const f32x4*)(qr + ks * 16) * p.scale_log2e;
+            const f32x4 c = *(const f32x4*)(qr + ks * 16 + 4) * p.scale_log2e;
+            split8(a, c, qh[qb][ks], ql[qb][ks]);
+        }
+    }
+
+    f32x16 o[QB][DB];
+    f32x16 minit[QB];    // -m_ref of this lane's row in all 16 registers: the accumulator the first K.Q'^T product starts from
+    float m[QB], l[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        m[qb] = 0.0f;
+        l[qb] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) minit[qb][r] = 0.0f;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.0f;
+    }
+
+    const int k_row_off = lq * C::kRowBytes;
+    const int k_g = hi ^ k_swizzle<D>(lq);
+    int k_off[KS];   // per-lane byte offset of the K fragment of k-step ks inside an image (swizzle resolved once)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) k_off[ks] = k_row_off + (((2 * ks) ^ k_g) * 16);
+    const int li = lane & 15;
+    const int v_lane_off = (hi * (D / 16) + ((lane >> 4) & 1)) * 128 + (li >> 2) * 32 + (li & 3) * 8;
+
+    store_tile(smem);
+    __syncthreads();
+
+    // one K/V tile; STG (compile-time) is the LDS stage it lives in, so every fragment read is base register + immediate
+    auto step = [&](auto stg_c, int j) {
+        constexpr int STG = decltype(stg_c)::value;
+        const bool more = j + 1 < nt;
+        if (more) load_tile((j + 1) * kKvSplit);
+        const int kv0 = j * kKvSplit;
+        const char* kh_lds = smem + STG * C::kStageBytes;
+        const char* vh_lds = kh_lds + 2 * C::kImageBytes;
+
+        if (!(CAUSAL && kv0 > q0 + QB * 32 - 1)) {   // else: tile entirely above this wave's diagonal
+            // ================= S'^T = K Q'^T - m_ref, three products =================
+            f32x16 s[QB];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kfh = *(const bf16x8*)(kh_lds + k_off[ks]);
+                const bf16x8 kfl = *(const bf16x8*)(kh_lds + C::kImageBytes + k_off[ks]);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl, qh[qb][ks], ks == 0 ? minit[qb] : s[qb], 0, 0, 0);
+                    s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, ql[qb][ks], s[qb], 0, 0, 0);
+                    s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, qh[qb][ks], s[qb], 0, 0, 0);
+                }
+            }
+
+            // The branches below hide the scores' consumers from hipcc's hazard padding ("MFMA write -> VALU read" is only
+            // padded inside a basic block): let the last product retire, tied to the registers it writes.
+            if constexpr (QB == 1) asm volatile("s_nop 15\n\ts_nop 2" : "+v"(s[0]));
+            else asm volatile("s_nop 15\n\ts_nop 2" : "+v"(s[0]), "+v"(s[QB - 1]));
+
+            // ================= online softmax (registers only) =================
+            const bool need_mask = (kv0 + kKvSplit > n) || (CAUSAL && (kv0 + kKvSplit - 1 > q0));
+            bf16x8 ph[QB][2], pl[QB][2];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                if (need_mask) {
+                    asm volatile("; mask" ::: "memory");  // not speculatable: keeps the wave-uniform `if` a real branch
+                    const int qi = q0 + qb * 32 + lq;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kv0 + 4 * hi + (r & 3) + 8 * (r >> 2);
+                        if ((key >= n) || (CAUSAL && key > qi)) s[qb][r] = -INFINITY;
+                    }
+                }
+                float mx = fmaxf(s[qb][0], s[qb][1]);
+#pragma unroll
+                for (int r = 2; r < 16; r += 2) mx = max3_safe(mx, s[qb][r], s[qb][r + 1]);
+                mx = xhalf_max(mx);                                  // row maximum relative to m_ref
+                const bool grow = (j == 0) || (mx > kSplitSlack);    // tile 0 sets the reference (m_ref starts at 0)
+                if (__builtin_amdgcn_ballot_w64(grow) != 0) {        // wave-uniform, rare after the first tile
+                    asm volatile("; rescale" ::: "memory");
+                    const float delta = grow ? mx : 0.0f;
+                    const float alpha = (j == 0) ? 0.0f : fast_exp2(-delta);
+                    m[qb] += delta;
+                    l[qb] *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        s[qb][r] -= delta;
+                        minit[qb][r] = -m[qb];
+                    }
+#pragma unroll
+                    for (int db = 0; db < DB; ++db)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[qb][db][r] *= alpha;
+                }
+                float rs0 = 0.0f, rs1 = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    s[qb][r] = fast_exp2(s[qb][r]);
+                    s[qb][r + 1] = fast_exp2(s[qb][r + 1]);
+                    // scalar adds (v_pk_add_f32 stalls the matrix pipe's issue for 32 cycles); the s_nop is the wait state a
+                    // transcendental result needs before a plain VALU instruction may read it -- hipcc cannot see into the asm
+                    asm("s_nop 0\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3"
+                        : "+v"(rs0), "+v"(rs1) : "v"(s[qb][r]), "v"(s[qb][r + 1]));
+                }
+                l[qb] += rs0 + rs1;
+                split_p(s[qb], 0, ph[qb][0], pl[qb][0]);
+                split_p(s[qb], 8, ph[qb][1], pl[qb][1]);
+            }
+
+            // ================= O^T += V^T P^T, three products =================
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const int off0 = ((4 * t + 0) * (D / 16) + 2 * db) * 128;
+                    const int off1 = ((4 * t + 2) * (D / 16) + 2 * db) * 128;
+                    const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + v_lane_off + off0));
+                    const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + v_lane_off + off1));
+                    const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + C::kImageBytes + v_lane_off + off0));
+                    const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + C::kImageBytes + v_lane_off + off1));
+                    const bf16x8 vfh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    const bf16x8 vfl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) {
+                        o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfl, ph[qb][t], o[qb][db], 0, 0, 0);
+                        o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh, pl[qb][t], o[qb][db], 0, 0, 0);
+                        o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh, ph[qb][t], o[qb][db], 0, 0, 0);
+                    }
+                }
+        }
+
+        // stage STG^1 was last read in step j-1; every wave has passed the barrier that ended that step
+        if (more) store_tile(smem + (STG ^ 1) * C::kStageBytes);
+        __syncthreads();
+    };
+
+    int j = 0;
+    for (; j + 1 < nt; j += 2) {
+        step(std::integral_constant<int, 0>{}, j);
+        step(std::integral_constant<int, 1>{}, j + 1);
+    }
+    if (j < nt) step(std::integral_constant<int, 0>{}, j);
+
+    // ================= epilogue: O / l, store =================
+    mfma_drain();  // the loop exit is a branch: the last P.V MFMAs may still be in flight
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const float lt = xhalf_sum(l[qb]);
+        const float inv = 1.0f / lt;
+        const int qi = q0 + qb * 32 + lq;
+        if (qi < n) {
+            float* orow = og + (int64_t)qi * p.o_row_stride + 4 * hi;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = o[qb][db][4 * g + e] * inv;
+                    *(f32x4*)(orow + db * 32 + 8 * g) = pk;
+                }
+            if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (m[qb] + __builtin_amdgcn_logf(lt)) * kLn2;
+        }
+    }
+}
+
+template <int D, int NWAVES, int QB, int MINBLOCKS>
+static hipError_t launch_split(const FwdParams& p0, int causal, hipStream_t stream)
+{
+    FwdParams p = p0;
+    constexpr int BM = NWAVES * QB * 32;
+    p.q_tiles = (p.n + BM - 1) / BM;
+    const int64_t total = (int64_t)p.bh * p.q_tiles;
+    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)total), block(NWAVES * kWave);
+    if (causal)
+        hipLaunchKernelGGL((fa_fwd_f32_split_kernel<D, NWAVES, QB, true, MINBLOCKS>), grid, block, 0, stream, p);
+    else
+        hipLaunchKernelGGL((fa_fwd_f32_split_kernel<D, NWAVES, QB, false, MINBLOCKS>), grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+// mode: 0 = default tiling for d; 1 = one 32-row block per wave, two workgroups per CU; 2 = two blocks per wave, one workgroup per CU
+hipError_t launch_f32_split(const FwdParams& p, int d, int causal, int mode, hipStream_t stream)
+{
+    switch (d) {
+        case 32:
+            return mode == 2 ? launch_split<32, 4, 2, 1>(p, causal, stream) : launch_split<32, 4, 1, 2>(p, causal, stream);
+        case 64:
+            if (mode == 1) return launch_split<64, 4, 1, 2>(p, causal, stream);
+            if (mode == 2) return launch_split<64, 4, 2, 1>(p, causal, stream);
+            return launch_split<64, 4, 2, 2>(p, causal, stream);
+        case 128:
+            if (mode == 1) return launch_split<128, 4, 1, 1>(p, causal, stream);
+            return launch_split<128, 4, 2, 1>(p, causal, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace fa
