@@ -18,8 +18,12 @@
 //               (ds_read_b64_tr_b16 hands out V^T fragments).  Register-staged double buffering: the loads of tile j+1 are
 //               in flight while tile j is consumed; one barrier per tile.  Rows past the end of the slab are zeros.
 //   S^T = K Q'^T   Q' = Q * scale*log2(e) in fp32 (one rounding per element), then split: scores arrive in the exp2 domain.
-//   softmax     running row maximum with a lazily updated reference (rescale only when a row outgrows it by 2^64):
-//               p = exp2(s - m_ref) in fp32, row sums in fp32 on the VALU, P split into hi/lo in registers.
+//   softmax     optimistic, like the bf16 kernels: p = exp2(s - m0) with m0 the row maximum of the FIRST tile, fixed for the
+//               whole row and folded into the accumulator the first K.Q'^T product starts from -- the main loop has no
+//               maximum, no subtraction, no rescale and no branch.  fp32 P has 2^127 of head room: the row sum l < 2^100 and
+//               finite outputs at the end of the tile prove nothing overflowed; otherwise the workgroup redoes its tile
+//               with the textbook running maximum (p <= 1), which is correct for every input.  Row sums in fp32 on the
+//               VALU, P split into hi/lo in registers.
 //   O^T += V^T P^T   same key permutation trick as the bf16 kernels: P never leaves its registers.
 #include "fa_bf16_common.h"
 #include "fa_kernels.h"
@@ -28,7 +32,7 @@
 namespace fa {
 
 constexpr int kKvSplit = 32;         // keys per tile
-constexpr float kSplitSlack = 64.0f; // exp2-domain head room of the lazily updated row reference
+constexpr float kSplitLimit = 0x1p100f;  // optimistic pass: a row sum below this proves that no term overflowed
 
 template <int D>
 struct SplitCfg {
@@ -38,27 +42,56 @@ struct SplitCfg {
     static constexpr int kGroups = kKvSplit * D / 8;          // 8-element (32-byte fp32) groups per tile
 };
 
-// two-term bf16 split of eight fp32 values
+// two-term bf16 split of a pair of fp32 values: hi = bf16(x) (round to nearest even), lo = bf16(x - hi).  The two
+// conversions stay visible to hipcc (it pads the hazards around them: transcendental result -> VALU, VALU -> MFMA operand);
+// the four instructions in between are asm so that they stay scalar: v_pk_add_f32 blocks the matrix pipe's issue.
+__device__ __forceinline__ void split2(float a, float b, bf16x2& hi, bf16x2& lo)
+{
+    hi[0] = (__bf16)a;
+    hi[1] = (__bf16)b;
+    float la, lb;
+    asm("v_lshlrev_b32 %0, 16, %2\n\tv_and_b32 %1, 0xffff0000, %2\n\tv_sub_f32 %0, %3, %0\n\tv_sub_f32 %1, %4, %1"
+        : "=&v"(la), "=&v"(lb)
+        : "v"(__builtin_bit_cast(unsigned, hi)), "v"(a), "v"(b));
+    lo[0] = (__bf16)la;
+    lo[1] = (__bf16)lb;
+}
+
 __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo)
 {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const __bf16 ha = (__bf16)a[i], hb = (__bf16)b[i];
-        hi[i] = ha;
-        hi[i + 4] = hb;
-        lo[i] = (__bf16)(a[i] - (float)ha);
-        lo[i + 4] = (__bf16)(b[i] - (float)hb);
+    for (int i = 0; i < 4; i += 2) {
+        bf16x2 h, l;
+        split2(a[i], a[i + 1], h, l);
+        hi[i] = h[0], hi[i + 1] = h[1], lo[i] = l[0], lo[i + 1] = l[1];
+        split2(b[i], b[i + 1], h, l);
+        hi[i + 4] = h[0], hi[i + 5] = h[1], lo[i + 4] = l[0], lo[i + 5] = l[1];
     }
 }
 
 __device__ __forceinline__ void split_p(const f32x16& s, int base, bf16x8& hi, bf16x8& lo)
 {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const __bf16 h = (__bf16)s[base + i];
-        hi[i] = h;
-        lo[i] = (__bf16)(s[base + i] - (float)h);
+    for (int i = 0; i < 8; i += 2) {
+        bf16x2 h, l;
+        split2(s[base + i], s[base + i + 1], h, l);
+        hi[i] = h[0], hi[i + 1] = h[1], lo[i] = l[0], lo[i + 1] = l[1];
     }
+}
+
+// The K.Q'^T chain is asm: its first product reads the accumulator from registers DISTINCT from its destination (the
+// builtin insists on D == C and copies the 16 registers of C first), and hipcc must not be tempted to park the scores in
+// AGPRs between products.  hipcc knows nothing about the inside of an asm statement, hence
+//   s_nop 1   in front of every product: an operand may have been copied into place (v_accvgpr_read_b32, v_mov_b32) by
+//             the instruction before, and VALU write -> MFMA read needs two wait states;
+//   scores_retire() after the chain, before any VALU instruction may read the scores.
+__device__ __forceinline__ void mfma_from(f32x16& d, const bf16x8& a, const bf16x8& b, const f32x16& c)
+{
+    asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+}
+__device__ __forceinline__ void mfma_acc(f32x16& d, const bf16x8& a, const bf16x8& b)
+{
+    asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
 }
 
 template <int D, int NWAVES, int QB, bool CAUSAL, int MINBLOCKS>
@@ -136,8 +169,6 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
         }
     };
 
-    load_tile(0);
-
     // ---- Q' fragments (B operand of S^T = K Q'^T), hi and lo: lane (lq, hi) holds Q'[q][16*ks + 8*hi .. +7]
     bf16x8 qh[QB][KS], ql[QB][KS];
 #pragma unroll
@@ -152,21 +183,6 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
         }
     }
 
-    f32x16 o[QB][DB];
-    f32x16 minit[QB];    // -m_ref of this lane's row in all 16 registers: the accumulator the first K.Q'^T product starts from
-    float m[QB], l[QB];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        m[qb] = 0.0f;
-        l[qb] = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) minit[qb][r] = 0.0f;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.0f;
-    }
-
     const int k_row_off = lq * C::kRowBytes;
     const int k_g = hi ^ k_swizzle<D>(lq);
     int k_off[KS];   // per-lane byte offset of the K fragment of k-step ks inside an image (swizzle resolved once)
@@ -175,143 +191,197 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     const int li = lane & 15;
     const int v_lane_off = (hi * (D / 16) + ((lane >> 4) & 1)) * 128 + (li >> 2) * 32 + (li & 3) * 8;
 
-    store_tile(smem);
-    __syncthreads();
+    // The whole tile, OPT = optimistic pass (fixed reference m0) or the textbook redo.  Returns whether this lane's rows
+    // came out inside the range the optimistic pass can prove.
+    auto run_tile = [&](auto opt_c) -> bool {
+        constexpr bool OPT = decltype(opt_c)::value;
+        f32x16 o[QB][DB];
+        f32x16 minit[QB];   // -m_ref of this lane's row in all 16 registers: the accumulator the first product starts from
+        float m[QB], l[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            m[qb] = 0.0f;
+            l[qb] = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) minit[qb][r] = 0.0f;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.0f;
+        }
 
-    // one K/V tile; STG (compile-time) is the LDS stage it lives in, so every fragment read is base register + immediate
-    auto step = [&](auto stg_c, int j) {
-        constexpr int STG = decltype(stg_c)::value;
-        const bool more = j + 1 < nt;
-        if (more) load_tile((j + 1) * kKvSplit);
-        const int kv0 = j * kKvSplit;
-        const char* kh_lds = smem + STG * C::kStageBytes;
-        const char* vh_lds = kh_lds + 2 * C::kImageBytes;
-
-        if (!(CAUSAL && kv0 > q0 + QB * 32 - 1)) {   // else: tile entirely above this wave's diagonal
-            // ================= S'^T = K Q'^T - m_ref, three products =================
-            f32x16 s[QB];
+        // scores of one tile for all QB blocks: three products per k-step, the first one starting from minit
+        auto scores = [&](const char* kh_lds, f32x16 (&s)[QB]) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 kfh = *(const bf16x8*)(kh_lds + k_off[ks]);
                 const bf16x8 kfl = *(const bf16x8*)(kh_lds + C::kImageBytes + k_off[ks]);
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
-                    s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl, qh[qb][ks], ks == 0 ? minit[qb] : s[qb], 0, 0, 0);
-                    s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, ql[qb][ks], s[qb], 0, 0, 0);
-                    s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, qh[qb][ks], s[qb], 0, 0, 0);
+                    if (ks == 0) mfma_from(s[qb], kfl, qh[qb][ks], minit[qb]);
+                    else mfma_acc(s[qb], kfl, qh[qb][ks]);
+                    mfma_acc(s[qb], kfh, ql[qb][ks]);
+                    mfma_acc(s[qb], kfh, qh[qb][ks]);
                 }
             }
-
-            // The branches below hide the scores' consumers from hipcc's hazard padding ("MFMA write -> VALU read" is only
-            // padded inside a basic block): let the last product retire, tied to the registers it writes.
+            // let the last product retire (19 wait states cover its 8 passes), tied to the registers the chain writes
             if constexpr (QB == 1) asm volatile("s_nop 15\n\ts_nop 2" : "+v"(s[0]));
             else asm volatile("s_nop 15\n\ts_nop 2" : "+v"(s[0]), "+v"(s[QB - 1]));
+        };
+        auto mask = [&](f32x16& sq, int kv0, int qi) {
+            asm volatile("; mask" ::: "memory");  // not speculatable: keeps the caller's wave-uniform `if` a real branch
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kv0 + 4 * hi + (r & 3) + 8 * (r >> 2);
+                if ((key >= n) || (CAUSAL && key > qi)) sq[r] = -INFINITY;
+            }
+        };
+        auto row_max = [&](const f32x16& sq) {
+            float mx = fmaxf(sq[0], sq[1]);
+#pragma unroll
+            for (int r = 2; r < 16; r += 2) mx = max3_safe(mx, sq[r], sq[r + 1]);
+            return xhalf_max(mx);
+        };
 
-            // ================= online softmax (registers only) =================
-            const bool need_mask = (kv0 + kKvSplit > n) || (CAUSAL && (kv0 + kKvSplit - 1 > q0));
-            bf16x8 ph[QB][2], pl[QB][2];
+        load_tile(0);
+        store_tile(smem);
+        __syncthreads();
+
+        if constexpr (OPT) {
+            // reference of each row: the maximum over the first tile (every row sees key 0, so it is finite for finite inputs)
+            f32x16 s[QB];
+            scores(smem, s);
+            const bool need_mask = (kKvSplit > n) || (CAUSAL && (kKvSplit - 1 > q0));
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
-                if (need_mask) {
-                    asm volatile("; mask" ::: "memory");  // not speculatable: keeps the wave-uniform `if` a real branch
-                    const int qi = q0 + qb * 32 + lq;
+                if (need_mask) mask(s[qb], 0, q0 + qb * 32 + lq);
+                m[qb] = row_max(s[qb]);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kv0 + 4 * hi + (r & 3) + 8 * (r >> 2);
-                        if ((key >= n) || (CAUSAL && key > qi)) s[qb][r] = -INFINITY;
+                for (int r = 0; r < 16; ++r) minit[qb][r] = -m[qb];
+            }
+        }
+
+        // one K/V tile; STG (compile-time) is the LDS stage it lives in, so every fragment read is base register + immediate
+        auto step = [&](auto stg_c, int j) {
+            constexpr int STG = decltype(stg_c)::value;
+            const bool more = j + 1 < nt;
+            if (more) load_tile((j + 1) * kKvSplit);
+            const int kv0 = j * kKvSplit;
+            const char* kh_lds = smem + STG * C::kStageBytes;
+            const char* vh_lds = kh_lds + 2 * C::kImageBytes;
+
+            if (!(CAUSAL && kv0 > q0 + QB * 32 - 1)) {   // else: tile entirely above this wave's diagonal
+                f32x16 s[QB];
+                scores(kh_lds, s);   // S'^T = K Q'^T - m_ref
+
+                // ================= softmax (registers only) =================
+                const bool need_mask = (kv0 + kKvSplit > n) || (CAUSAL && (kv0 + kKvSplit - 1 > q0));
+                bf16x8 ph[QB][2], pl[QB][2];
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    if (need_mask) mask(s[qb], kv0, q0 + qb * 32 + lq);
+                    if constexpr (!OPT) {
+                        const float mx = row_max(s[qb]);                  // row maximum relative to m_ref
+                        const bool grow = (j == 0) || (mx > 0.0f);        // tile 0 sets the reference (m_ref starts at 0)
+                        if (__builtin_amdgcn_ballot_w64(grow) != 0) {     // wave-uniform
+                            asm volatile("; rescale" ::: "memory");
+                            const float delta = grow ? mx : 0.0f;
+                            const float alpha = (j == 0) ? 0.0f : fast_exp2(-delta);
+                            m[qb] += delta;
+                            l[qb] *= alpha;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                s[qb][r] -= delta;
+                                minit[qb][r] = -m[qb];
+                            }
+#pragma unroll
+                            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) o[qb][db][r] *= alpha;
+                        }
                     }
-                }
-                float mx = fmaxf(s[qb][0], s[qb][1]);
+                    float rs0 = 0.0f, rs1 = 0.0f;
 #pragma unroll
-                for (int r = 2; r < 16; r += 2) mx = max3_safe(mx, s[qb][r], s[qb][r + 1]);
-                mx = xhalf_max(mx);                                  // row maximum relative to m_ref
-                const bool grow = (j == 0) || (mx > kSplitSlack);    // tile 0 sets the reference (m_ref starts at 0)
-                if (__builtin_amdgcn_ballot_w64(grow) != 0) {        // wave-uniform, rare after the first tile
-                    asm volatile("; rescale" ::: "memory");
-                    const float delta = grow ? mx : 0.0f;
-                    const float alpha = (j == 0) ? 0.0f : fast_exp2(-delta);
-                    m[qb] += delta;
-                    l[qb] *= alpha;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        s[qb][r] -= delta;
-                        minit[qb][r] = -m[qb];
+                    for (int r = 0; r < 16; r += 2) {
+                        s[qb][r] = fast_exp2(s[qb][r]);
+                        s[qb][r + 1] = fast_exp2(s[qb][r + 1]);
+                        // scalar adds (v_pk_add_f32 blocks the matrix pipe's issue); the s_nop is the wait state a
+                        // transcendental result needs before a plain VALU instruction may read it -- invisible to hipcc here
+                        asm("s_nop 0\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3"
+                            : "+v"(rs0), "+v"(rs1) : "v"(s[qb][r]), "v"(s[qb][r + 1]));
                     }
-#pragma unroll
-                    for (int db = 0; db < DB; ++db)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) o[qb][db][r] *= alpha;
+                    l[qb] += rs0 + rs1;
+                    split_p(s[qb], 0, ph[qb][0], pl[qb][0]);
+                    split_p(s[qb], 8, ph[qb][1], pl[qb][1]);
                 }
-                float rs0 = 0.0f, rs1 = 0.0f;
+
+                // ================= O^T += V^T P^T, three products =================
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    s[qb][r] = fast_exp2(s[qb][r]);
-                    s[qb][r + 1] = fast_exp2(s[qb][r + 1]);
-                    // scalar adds (v_pk_add_f32 stalls the matrix pipe's issue for 32 cycles); the s_nop is the wait state a
-                    // transcendental result needs before a plain VALU instruction may read it -- hipcc cannot see into the asm
-                    asm("s_nop 0\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3"
-                        : "+v"(rs0), "+v"(rs1) : "v"(s[qb][r]), "v"(s[qb][r + 1]));
-                }
-                l[qb] += rs0 + rs1;
-                split_p(s[qb], 0, ph[qb][0], pl[qb][0]);
-                split_p(s[qb], 8, ph[qb][1], pl[qb][1]);
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int db = 0; db < DB; ++db) {
+                        const int off0 = ((4 * t + 0) * (D / 16) + 2 * db) * 128;
+                        const int off1 = ((4 * t + 2) * (D / 16) + 2 * db) * 128;
+                        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + v_lane_off + off0));
+                        const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + v_lane_off + off1));
+                        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + C::kImageBytes + v_lane_off + off0));
+                        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + C::kImageBytes + v_lane_off + off1));
+                        const bf16x8 vfh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                        const bf16x8 vfl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) {
+                            o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfl, ph[qb][t], o[qb][db], 0, 0, 0);
+                            o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh, pl[qb][t], o[qb][db], 0, 0, 0);
+                            o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh, ph[qb][t], o[qb][db], 0, 0, 0);
+                        }
+                    }
             }
 
-            // ================= O^T += V^T P^T, three products =================
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const int off0 = ((4 * t + 0) * (D / 16) + 2 * db) * 128;
-                    const int off1 = ((4 * t + 2) * (D / 16) + 2 * db) * 128;
-                    const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + v_lane_off + off0));
-                    const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + v_lane_off + off1));
-                    const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + C::kImageBytes + v_lane_off + off0));
-                    const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + C::kImageBytes + v_lane_off + off1));
-                    const bf16x8 vfh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-                    const bf16x8 vfl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-                    for (int qb = 0; qb < QB; ++qb) {
-                        o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfl, ph[qb][t], o[qb][db], 0, 0, 0);
-                        o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh, pl[qb][t], o[qb][db], 0, 0, 0);
-                        o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh, ph[qb][t], o[qb][db], 0, 0, 0);
-                    }
-                }
-        }
+            // stage STG^1 was last read in step j-1; every wave has passed the barrier that ended that step
+            if (more) store_tile(smem + (STG ^ 1) * C::kStageBytes);
+            __syncthreads();
+        };
 
-        // stage STG^1 was last read in step j-1; every wave has passed the barrier that ended that step
-        if (more) store_tile(smem + (STG ^ 1) * C::kStageBytes);
-        __syncthreads();
+        int j = 0;
+        for (; j + 1 < nt; j += 2) {
+            step(std::integral_constant<int, 0>{}, j);
+            step(std::integral_constant<int, 1>{}, j + 1);
+        }
+        if (j < nt) step(std::integral_constant<int, 0>{}, j);
+
+        // ================= epilogue: O / l, store =================
+        mfma_drain();  // the loop exit is a branch: the last P.V MFMAs may still be in flight
+        bool ok = true;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const float lt = xhalf_sum(l[qb]);
+            const float inv = 1.0f / lt;
+            const int qi = q0 + qb * 32 + lq;
+            float mag = 0.0f;
+            if (qi < n) {
+                float* orow = og + (int64_t)qi * p.o_row_stride + 4 * hi;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            pk[e] = o[qb][db][4 * g + e] * inv;
+                            if (OPT) mag += fabsf(pk[e]);
+                        }
+                        *(f32x4*)(orow + db * 32 + 8 * g) = pk;
+                    }
+                if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (m[qb] + __builtin_amdgcn_logf(lt)) * kLn2;
+                if (OPT) ok = ok && (lt < kSplitLimit) && (mag < INFINITY);   // false for NaN as well
+            }
+        }
+        return ok;
     };
 
-    int j = 0;
-    for (; j + 1 < nt; j += 2) {
-        step(std::integral_constant<int, 0>{}, j);
-        step(std::integral_constant<int, 1>{}, j + 1);
-    }
-    if (j < nt) step(std::integral_constant<int, 0>{}, j);
-
-    // ================= epilogue: O / l, store =================
-    mfma_drain();  // the loop exit is a branch: the last P.V MFMAs may still be in flight
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const float lt = xhalf_sum(l[qb]);
-        const float inv = 1.0f / lt;
-        const int qi = q0 + qb * 32 + lq;
-        if (qi < n) {
-            float* orow = og + (int64_t)qi * p.o_row_stride + 4 * hi;
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 pk;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[e] = o[qb][db][4 * g + e] * inv;
-                    *(f32x4*)(orow + db * 32 + 8 * g) = pk;
-                }
-            if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (m[qb] + __builtin_amdgcn_logf(lt)) * kLn2;
-        }
-    }
+    // results are stored before the vote (a rejected tile is simply overwritten by the redo)
+    const bool ok = run_tile(std::true_type{});
+    if (__syncthreads_or(!ok)) run_tile(std::false_type{});
 }
 
 template <int D, int NWAVES, int QB, int MINBLOCKS>
