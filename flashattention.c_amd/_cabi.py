@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libflashattn_amd.so")
 
 FA_OK = 0
 FA_DTYPE_F32, FA_DTYPE_BF16, FA_DTYPE_BF16_OUT_F32 = 0, 1, 2
-FA_KERNEL_AUTO, FA_KERNEL_NAIVE, FA_KERNEL_MFMA = 0, 1, 2
+FA_KERNEL_AUTO, FA_KERNEL_NAIVE, FA_KERNEL_MFMA, FA_KERNEL_SPLIT = 0, 1, 2, 3
 
 # every symbol include/flashattn_amd.h declares
 EXPORTED_SYMBOLS = (

@@ -29,6 +29,9 @@ LIB_SOURCES = ["fa_api.cpp", "fa_naive.hip", "fa_fwd_f32.hip", "fa_fwd_f32_split
 HEADERS = ["fa_common.h", "fa_kernels.h", "fa_bf16_common.h", os.path.join(ROOT, "include", "flashattn_amd.h")]
 COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
                 "-I", os.path.join(ROOT, "include")]
+# per-source extras.  The split kernel keeps its fp32 arithmetic scalar: the SLP vectoriser would pair it into
+# v_pk_add_f32 / v_pk_mul_f32, which block the matrix pipe's issue for a full MFMA slot each on gfx950.
+EXTRA_FLAGS = {"fa_fwd_f32_split.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc() -> str:
@@ -52,7 +55,7 @@ def _compile(src: str, force: bool) -> str:
     srcp = os.path.join(CSRC, src)
     if not force and _mtime(obj) > max(_mtime(srcp), _newest_dep()):
         return obj
-    cmd = [hipcc(), *COMMON_FLAGS, "-x", "hip", "-c", srcp, "-o", obj]
+    cmd = [hipcc(), *COMMON_FLAGS, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", srcp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")

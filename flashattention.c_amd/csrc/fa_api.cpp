@@ -59,7 +59,7 @@ int validate_common(const void* q, const void* k, const void* v, const void* o, 
 fa::FwdParams make_params(const void* q, const void* k, const void* v, void* o, float* lse, int64_t bh, int64_t n, int32_t d,
                           float scale)
 {
-    fa::FwdParams p;
+    fa::FwdParams p{};
     memset(&p, 0, sizeof(p));
     p.q = q;
     p.k = k;
@@ -84,12 +84,17 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
         if (dtype != FA_DTYPE_F32) return fail(FA_ERR_UNSUPPORTED, "the naive kernel is fp32 only");
         if (d > 256) return fail(FA_ERR_UNSUPPORTED, "naive kernel supports head dim <= 256 (got %d)", d);
         e = fa::launch_naive_f32(p, d, causal ? 1 : 0, stream);
-    } else if (sel.kind == FA_KERNEL_AUTO || sel.kind == FA_KERNEL_MFMA) {
+    } else if (sel.kind == FA_KERNEL_AUTO || sel.kind == FA_KERNEL_MFMA || sel.kind == FA_KERNEL_SPLIT) {
         if (!head_dim_supported(d))
             return fail(FA_ERR_UNSUPPORTED, "head dim %d not instantiated for the MFMA kernels (32, 64, 128)", d);
-        e = (dtype == FA_DTYPE_F32)
-                ? fa::launch_fwd_f32(p, d, causal ? 1 : 0, sel.variant, stream)
-                : fa::launch_fwd_bf16(p, d, causal ? 1 : 0, dtype == FA_DTYPE_BF16_OUT_F32 ? 1 : 0, sel.variant, stream);
+        if (sel.kind == FA_KERNEL_SPLIT && dtype != FA_DTYPE_F32)
+            return fail(FA_ERR_UNSUPPORTED, "the split kernel takes fp32 tensors (bf16 tensors need no split)");
+        if (dtype != FA_DTYPE_F32)
+            e = fa::launch_fwd_bf16(p, d, causal ? 1 : 0, dtype == FA_DTYPE_BF16_OUT_F32 ? 1 : 0, sel.variant, stream);
+        else if (sel.kind == FA_KERNEL_MFMA)
+            e = fa::launch_fwd_f32(p, d, causal ? 1 : 0, sel.variant, stream);       // exact fp32 arithmetic
+        else
+            e = fa::launch_f32_split(p, d, causal ? 1 : 0, sel.variant, stream);     // AUTO: fp32 tensors on the bf16 pipe
     } else {
         return fail(FA_ERR_UNSUPPORTED, "unknown kernel id %d", sel.kind);
     }
@@ -161,7 +166,7 @@ int fa_forward_packed_qkv(const float* inp, float* out, int32_t B, int32_t T, in
     if ((int64_t)B * NH > 0x7fffffffLL) return fail(FA_ERR_INVALID_ARGUMENT, "B*NH too large");
     // (B, T, 3C): q at column h*hs, k at C + h*hs, v at 2C + h*hs of each token row
     // (attention_forward_cpu, /root/reference/src/llm.c/attention_forward.cu:66,74,115)
-    fa::FwdParams p;
+    fa::FwdParams p{};
     memset(&p, 0, sizeof(p));
     p.q = inp;
     p.k = inp + C;
@@ -268,7 +273,7 @@ const char* fa_version(void) { return "flashattn_amd abi 1 gfx950 (hip, mfma f32
 const char* fa_kernel_name_for(int32_t dtype, int32_t d, int32_t causal, int64_t bh, int64_t n)
 {
     if (!head_dim_supported(d) || bh < 1 || n < 1) return nullptr;
-    if (dtype == FA_DTYPE_F32) return "fa_fwd_f32_kernel";
+    if (dtype == FA_DTYPE_F32) return "fa_fwd_f32_split_kernel";
     if (dtype == FA_DTYPE_BF16 || dtype == FA_DTYPE_BF16_OUT_F32) return fa::bf16_kernel_name(bh, n, d, causal);
     return nullptr;
 }

@@ -226,7 +226,7 @@ static hipError_t launch_cfg_f32(const FwdParams& p0, int causal, hipStream_t st
 
 hipError_t launch_fwd_f32(const FwdParams& p, int d, int causal, int variant, hipStream_t stream)
 {
-    if (variant >= 60 && variant <= 62) return launch_f32_split(p, d, causal, variant - 60, stream);
+    (void)variant;
     switch (d) {
         case 32: return launch_cfg_f32<32, 4, 4>(p, causal, stream);
         case 64: return launch_cfg_f32<64, 4, 4>(p, causal, stream);

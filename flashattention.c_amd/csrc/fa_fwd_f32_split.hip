@@ -57,6 +57,29 @@ __device__ __forceinline__ void split2(float a, float b, bf16x2& hi, bf16x2& lo)
     lo[1] = (__bf16)lb;
 }
 
+// the same split in plain C++ (this file is compiled without the SLP vectoriser, so the subtractions stay scalar): every
+// instruction visible to hipcc's scheduler and hazard padding -- used by the software-pipelined fast pass
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ void split2c(float a, float b, bf16x2& hi, bf16x2& lo)
+{
+    const f32x2_t ab = {a, b};
+    hi = __builtin_convertvector(ab, bf16x2);
+    const f32x2_t hf = __builtin_convertvector(hi, f32x2_t);
+    const f32x2_t lv = {a - hf[0], b - hf[1]};
+    lo = __builtin_convertvector(lv, bf16x2);
+}
+__device__ __forceinline__ void split8c(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {
+        bf16x2 h, l;
+        split2c(a[i], a[i + 1], h, l);
+        hi[i] = h[0], hi[i + 1] = h[1], lo[i] = l[0], lo[i + 1] = l[1];
+        split2c(b[i], b[i + 1], h, l);
+        hi[i + 4] = h[0], hi[i + 5] = h[1], lo[i + 4] = l[0], lo[i + 5] = l[1];
+    }
+}
+
 __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo)
 {
 #pragma unroll
@@ -94,7 +117,7 @@ __device__ __forceinline__ void mfma_acc(f32x16& d, const bf16x8& a, const bf16x
     asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
 }
 
-template <int D, int NWAVES, int QB, bool CAUSAL, int MINBLOCKS>
+template <int D, int NWAVES, int QB, bool CAUSAL, int MINBLOCKS, bool PIPE>
 __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_kernel(FwdParams p)
 {
     using C = SplitCfg<D>;
@@ -379,12 +402,241 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
         return ok;
     };
 
+    // -----------------------------------------------------------------------------------------------------------------
+    // The fast pass: reference-free optimistic softmax, p = exp2(s) -- no maximum, no subtraction, nothing between the
+    // matrix core and v_exp_f32 -- software pipelined two tiles deep.  One wave cannot overlap its own dependent phases, and
+    // a second wave on the SIMD does not help either (a wave waiting to issue an MFMA holds the vector issue port), so
+    // iteration j gives the matrix pipe two jobs that do not depend on this iteration's VALU work:
+    //      matrix pipe   S(j+1) = K(j+1) Q'^T          and    O += V(j-1)^T P(j-1)^T
+    //      VALU          P(j) = split(exp2(S(j)))      and    the fp32 -> hi/lo conversion of K(j+2), V(j)
+    // in ONE basic block of plain builtins, which hipcc's scheduler interleaves (sched_group_barrier pins the rhythm).
+    // K(j+2) replaces K(j) and V(j) replaces V(j-2) in their two-stage LDS rings at the end of the iteration; one barrier per
+    // tile.  A causal wave does not skip the (at most 2*QB*NWAVES - 1) tiles above its diagonal, it masks them: no branches.
+    // fp32 P, l and O have 2^127 of head room either way: a row whose sum ends up in (2^-100, 2^100) with finite outputs
+    // provably lost nothing; any other row sends its workgroup to the textbook redo above.
+    // -----------------------------------------------------------------------------------------------------------------
+    auto run_fast = [&]() -> bool {
+        f32x16 o[QB][DB];
+        float l[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            l[qb] = 0.0f;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.0f;
+        }
+        const int last_tile = nt - 1;
+        // loads of tile t (clamped: a redundant copy of the last tile lands in a stage nobody reads any more)
+        auto load_k = [&](int t) {
+            const int kv0 = min(t, last_tile) * kKvSplit;
+#pragma unroll
+            for (int i = 0; i < GPT; ++i) {
+                const bool ok = g_on[i] && (kv0 + g_row[i] < n);
+                const int64_t off = (int64_t)kv0 * p.kv_row_stride + g_src[i];
+                const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+                kst[i][0] = ok ? *(const f32x4*)(kg + off) : z;
+                kst[i][1] = ok ? *(const f32x4*)(kg + off + 4) : z;
+            }
+        };
+        auto load_v = [&](int t) {
+            const int kv0 = min(t, last_tile) * kKvSplit;
+#pragma unroll
+            for (int i = 0; i < GPT; ++i) {
+                const bool ok = g_on[i] && (kv0 + g_row[i] < n);
+                const int64_t off = (int64_t)kv0 * p.kv_row_stride + g_src[i];
+                const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+                vst[i][0] = ok ? *(const f32x4*)(vg + off) : z;
+                vst[i][1] = ok ? *(const f32x4*)(vg + off + 4) : z;
+            }
+        };
+        auto store_k = [&](char* stage) {
+#pragma unroll
+            for (int i = 0; i < GPT; ++i) {
+                if (!g_on[i]) continue;
+                bf16x8 h8, l8;
+                split8c(kst[i][0], kst[i][1], h8, l8);
+                *(bf16x8*)(stage + g_kdst[i]) = h8;
+                *(bf16x8*)(stage + C::kImageBytes + g_kdst[i]) = l8;
+            }
+        };
+        auto store_v = [&](char* stage) {
+#pragma unroll
+            for (int i = 0; i < GPT; ++i) {
+                if (!g_on[i]) continue;
+                bf16x8 h8, l8;
+                split8c(vst[i][0], vst[i][1], h8, l8);
+                *(bf16x8*)(stage + g_vdst[i]) = h8;
+                *(bf16x8*)(stage + C::kImageBytes + g_vdst[i]) = l8;
+            }
+        };
+        auto qk = [&](const char* kh_lds, f32x16 (&s)[QB]) {
+            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kfh = *(const bf16x8*)(kh_lds + k_off[ks]);
+                const bf16x8 kfl = *(const bf16x8*)(kh_lds + C::kImageBytes + k_off[ks]);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl, qh[qb][ks], ks == 0 ? zero : s[qb], 0, 0, 0);
+                    s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, ql[qb][ks], s[qb], 0, 0, 0);
+                    s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, qh[qb][ks], s[qb], 0, 0, 0);
+                }
+            }
+        };
+        // P(j) = split(exp2(S(j))), row sums
+        auto softmax = [&](f32x16 (&s)[QB], bf16x8 (&ph)[QB][2], bf16x8 (&pl)[QB][2], bool need_mask, int kv0) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                if (need_mask) {
+                    asm volatile("; mask" ::: "memory");  // not speculatable: keeps the wave-uniform `if` a real branch
+                    const int qi = q0 + qb * 32 + lq;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kv0 + 4 * hi + (r & 3) + 8 * (r >> 2);
+                        if ((key >= n) || (CAUSAL && key > qi)) s[qb][r] = -INFINITY;
+                    }
+                }
+                float rs0 = 0.0f, rs1 = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int i = 0; i < 8; i += 2) {
+                        const float p0 = fast_exp2(s[qb][8 * t + i]), p1 = fast_exp2(s[qb][8 * t + i + 1]);
+                        rs0 += p0;
+                        rs1 += p1;
+                        bf16x2 h2, l2;
+                        split2c(p0, p1, h2, l2);
+                        ph[qb][t][i] = h2[0], ph[qb][t][i + 1] = h2[1], pl[qb][t][i] = l2[0], pl[qb][t][i + 1] = l2[1];
+                    }
+                l[qb] += rs0 + rs1;
+            }
+        };
+        auto pv = [&](const bf16x8 (&ph)[QB][2], const bf16x8 (&pl)[QB][2], const char* vh_lds) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const int off0 = ((4 * t + 0) * (D / 16) + 2 * db) * 128;
+                    const int off1 = ((4 * t + 2) * (D / 16) + 2 * db) * 128;
+                    const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + v_lane_off + off0));
+                    const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + v_lane_off + off1));
+                    const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + C::kImageBytes + v_lane_off + off0));
+                    const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + C::kImageBytes + v_lane_off + off1));
+                    const bf16x8 vfh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    const bf16x8 vfl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) {
+                        o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfl, ph[qb][t], o[qb][db], 0, 0, 0);
+                        o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh, pl[qb][t], o[qb][db], 0, 0, 0);
+                        o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh, ph[qb][t], o[qb][db], 0, 0, 0);
+                    }
+                }
+        };
+        auto needs_mask = [&](int kv0) { return (kv0 + kKvSplit > n) || (CAUSAL && (kv0 + kKvSplit - 1 > q0)); };
+
+        // ---- prologue: K(0) and K(1) staged, scores of tile 0 under way
+        load_k(0);
+        store_k(smem);
+        load_k(1);
+        store_k(smem + C::kStageBytes);
+        __syncthreads();
+        f32x16 sa[QB], sb[QB];
+        bf16x8 pha[QB][2], pla[QB][2], phb[QB][2], plb[QB][2];
+        qk(smem, sa);
+
+        // Iteration j, tile j in stage STG = j & 1.  In: scores `cur` of tile j, P `pprev` of tile j-1.  Out: scores `next`
+        // of tile j+1, P `pcur` of tile j.  FIRST has no P.V, LAST no K.Q^T; only a LAST or causal iteration can need masks.
+        auto step = [&](auto stg_c, auto first_c, auto last_c, int j, f32x16 (&cur)[QB], f32x16 (&next)[QB],
+                        bf16x8 (&phc)[QB][2], bf16x8 (&plc)[QB][2], bf16x8 (&php)[QB][2], bf16x8 (&plp)[QB][2]) {
+            constexpr int STG = decltype(stg_c)::value;
+            constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+            char* st_cur = smem + STG * C::kStageBytes;
+            char* st_oth = smem + (STG ^ 1) * C::kStageBytes;
+            if (!LAST) load_k(j + 2);
+            load_v(j);
+            if (!LAST) qk(st_oth, next);                                   // K(j+1)
+            const int kv0 = j * kKvSplit;
+            softmax(cur, phc, plc, (LAST || CAUSAL) && needs_mask(kv0), kv0);
+            if (!FIRST) pv(php, plp, st_oth + 2 * C::kImageBytes);          // V(j-1)
+            if (!LAST) store_k(st_cur);                                     // K(j+2) over K(j)
+            store_v(st_cur);                                                // V(j) over V(j-2)
+            if constexpr (!LAST && !FIRST) {
+                // rhythm of the block: one matrix instruction, then its share of the vector work
+                constexpr int kMfma = 48 * QB * (D / 64) > 0 ? 12 * QB * (D / 32) : 1;
+#pragma unroll
+                for (int i = 0; i < kMfma; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // LDS read
+                }
+            }
+            __syncthreads();
+        };
+        constexpr std::integral_constant<int, 0> S0{};
+        constexpr std::integral_constant<int, 1> S1{};
+        constexpr std::true_type T{};
+        constexpr std::false_type F{};
+        const char* v_last;   // V image of the last tile
+        if (nt == 1) {
+            step(S0, T, T, 0, sa, sb, pha, pla, phb, plb);
+            pv(pha, pla, smem + 2 * C::kImageBytes);
+        } else {
+            step(S0, T, F, 0, sa, sb, pha, pla, phb, plb);       // P(0) -> a
+            int j = 1;
+            for (; j + 2 < nt; j += 2) {                          // j odd here
+                step(S1, F, F, j, sb, sa, phb, plb, pha, pla);     // P(j) -> b, consumes a
+                step(S0, F, F, j + 1, sa, sb, pha, pla, phb, plb); // P(j+1) -> a, consumes b
+            }
+            if (nt - j == 2) {
+                step(S1, F, F, j, sb, sa, phb, plb, pha, pla);
+                step(S0, F, T, j + 1, sa, sb, pha, pla, phb, plb);
+                pv(pha, pla, smem + 2 * C::kImageBytes);           // V(nt-1), nt-1 even: stage 0
+            } else {
+                step(S1, F, T, j, sb, sa, phb, plb, pha, pla);
+                pv(phb, plb, smem + C::kStageBytes + 2 * C::kImageBytes);   // nt-1 odd: stage 1
+            }
+        }
+        (void)v_last;
+
+        // ================= epilogue: O / l, store =================
+        mfma_drain();  // the last P.V MFMAs may still be in flight
+        bool ok = true;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const float lt = xhalf_sum(l[qb]);
+            const float inv = 1.0f / lt;
+            const int qi = q0 + qb * 32 + lq;
+            float mag = 0.0f;
+            if (qi < n) {
+                float* orow = og + (int64_t)qi * p.o_row_stride + 4 * hi;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            pk[e] = o[qb][db][4 * g + e] * inv;
+                            mag += fabsf(pk[e]);
+                        }
+                        *(f32x4*)(orow + db * 32 + 8 * g) = pk;
+                    }
+                if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = __builtin_amdgcn_logf(lt) * kLn2;
+                ok = ok && (lt > 1.0f / kSplitLimit) && (lt < kSplitLimit) && (mag < INFINITY);   // false for NaN as well
+            }
+        }
+        return ok;
+    };
+
     // results are stored before the vote (a rejected tile is simply overwritten by the redo)
-    const bool ok = run_tile(std::true_type{});
+    bool ok;
+    if constexpr (PIPE) ok = run_fast();
+    else ok = run_tile(std::true_type{});
     if (__syncthreads_or(!ok)) run_tile(std::false_type{});
 }
 
-template <int D, int NWAVES, int QB, int MINBLOCKS>
+template <int D, int NWAVES, int QB, int MINBLOCKS, bool PIPE>
 static hipError_t launch_split(const FwdParams& p0, int causal, hipStream_t stream)
 {
     FwdParams p = p0;
@@ -394,25 +646,38 @@ static hipError_t launch_split(const FwdParams& p0, int causal, hipStream_t stre
     if (total > 0x7fffffffLL) return hipErrorInvalidValue;
     dim3 grid((unsigned)total), block(NWAVES * kWave);
     if (causal)
-        hipLaunchKernelGGL((fa_fwd_f32_split_kernel<D, NWAVES, QB, true, MINBLOCKS>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((fa_fwd_f32_split_kernel<D, NWAVES, QB, true, MINBLOCKS, PIPE>), grid, block, 0, stream, p);
     else
-        hipLaunchKernelGGL((fa_fwd_f32_split_kernel<D, NWAVES, QB, false, MINBLOCKS>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((fa_fwd_f32_split_kernel<D, NWAVES, QB, false, MINBLOCKS, PIPE>), grid, block, 0, stream, p);
     return hipGetLastError();
 }
 
-// mode: 0 = default tiling for d; 1 = one 32-row block per wave, two workgroups per CU; 2 = two blocks per wave, one workgroup per CU
+// mode 0 = the product choice for (d, causal) (c3 / c2 shapes on MI355X, ms non-causal | causal at B=2 H=8 N=8192:
+// d=64 one block per wave 0.78 | 0.47, two blocks 0.78 | 0.46; d=128 one block 2.11 | 1.14;
+// d=32 two blocks 0.45 | 0.42, one block 0.47 | 0.30); 1 = one 32-row block per wave, 2 = two blocks per wave,
+// 3 = software-pipelined reference-free pass, one block per wave, 4 = the same with two blocks per wave
 hipError_t launch_f32_split(const FwdParams& p, int d, int causal, int mode, hipStream_t stream)
 {
     switch (d) {
         case 32:
-            return mode == 2 ? launch_split<32, 4, 2, 1>(p, causal, stream) : launch_split<32, 4, 1, 2>(p, causal, stream);
+            if (mode == 0) mode = causal ? 1 : 2;
+            if (mode == 1) return launch_split<32, 4, 1, 2, false>(p, causal, stream);
+            if (mode == 2) return launch_split<32, 4, 2, 1, false>(p, causal, stream);
+            if (mode == 3) return launch_split<32, 4, 1, 2, true>(p, causal, stream);
+            if (mode == 4) return launch_split<32, 4, 2, 1, true>(p, causal, stream);
+            return hipErrorInvalidValue;
         case 64:
-            if (mode == 1) return launch_split<64, 4, 1, 2>(p, causal, stream);
-            if (mode == 2) return launch_split<64, 4, 2, 1>(p, causal, stream);
-            return launch_split<64, 4, 2, 2>(p, causal, stream);
-        case 128:
-            if (mode == 1) return launch_split<128, 4, 1, 1>(p, causal, stream);
-            return launch_split<128, 4, 2, 1>(p, causal, stream);
+            if (mode == 0) mode = 1;
+            if (mode == 1) return launch_split<64, 4, 1, 2, false>(p, causal, stream);
+            if (mode == 2) return launch_split<64, 4, 2, 1, false>(p, causal, stream);
+            if (mode == 3) return launch_split<64, 4, 1, 2, true>(p, causal, stream);
+            if (mode == 4) return launch_split<64, 4, 2, 1, true>(p, causal, stream);
+            return hipErrorInvalidValue;
+        case 128:   // two blocks per wave do not fit the register file at d = 128 (Q', O and two score tiles: scratch in the loop)
+            if (mode == 0) mode = 1;
+            if (mode == 1) return launch_split<128, 4, 1, 1, false>(p, causal, stream);
+            if (mode == 3) return launch_split<128, 4, 1, 1, true>(p, causal, stream);
+            return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }

@@ -29,7 +29,8 @@ __all__ = ["forward", "forward_packed_qkv", "load", "time_forward", "SUPPORTED_H
 
 SUPPORTED_HEAD_DIMS = (32, 64, 128)
 _DTYPES = {torch.float32: _cabi.FA_DTYPE_F32, torch.bfloat16: _cabi.FA_DTYPE_BF16}
-_KERNELS = {"auto": _cabi.FA_KERNEL_AUTO, "naive": _cabi.FA_KERNEL_NAIVE, "mfma": _cabi.FA_KERNEL_MFMA}
+_KERNELS = {"auto": _cabi.FA_KERNEL_AUTO, "naive": _cabi.FA_KERNEL_NAIVE, "mfma": _cabi.FA_KERNEL_MFMA,
+            "exact": _cabi.FA_KERNEL_MFMA, "split": _cabi.FA_KERNEL_SPLIT}
 
 
 def _kernel_id(kernel: Union[str, int]) -> int:
@@ -71,7 +72,9 @@ def forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = Fa
     Returns a new tensor shaped like ``q`` (the reference allocates with ``torch::zeros``; here ``torch.empty`` is
     enough because every element is written).  ``return_lse=True`` additionally returns the (BH, N) fp32 row
     log-sum-exp -- the quantity the reference's unused ``O_l`` buffer was reserved for.  ``out_dtype=torch.float32``
-    with bf16 inputs stores the fp32 accumulator unrounded (FA_DTYPE_BF16_OUT_F32).
+    with bf16 inputs stores the fp32 accumulator unrounded (FA_DTYPE_BF16_OUT_F32).  fp32 tensors: ``kernel="auto"`` /
+    ``"split"`` run both contractions on the bf16 matrix pipe as three products of two-term bf16 splits (within 1e-3 of
+    the fp32 reference, see include/flashattn_amd.h), ``kernel="exact"`` (= ``"mfma"``) computes in fp32 arithmetic.
     """
     bh, n, d = _check_qkv(q, k, v)
     kid = _kernel_id(kernel)

@@ -47,7 +47,11 @@ typedef enum fa_status {
 } fa_status;
 
 typedef enum fa_dtype {
-    FA_DTYPE_F32 = 0, /* fp32 in, fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 out -- the reference's dtype */
+    FA_DTYPE_F32 = 0, /* fp32 in, fp32 out -- the reference's dtype.  FA_KERNEL_AUTO / FA_KERNEL_SPLIT compute both
+                         contractions as three bf16 MFMA products of two-term bf16 splits of the fp32 operands (16
+                         significant bits per operand, fp32 accumulate; max-abs error against fp64 ~2e-4 on unit-variance
+                         data at scale 1, ~1e-5 at 1/sqrt(d) -- inside the 1e-3 fp32 tolerance of the path, 2.6x faster);
+                         FA_KERNEL_MFMA computes in exact fp32 (v_mfma_f32_32x32x2_f32, ~2e-5 / ~1e-6) */
     FA_DTYPE_BF16 = 1,        /* bf16 in, bf16 MFMA with fp32 accumulate and fp32 softmax, bf16 out     */
     FA_DTYPE_BF16_OUT_F32 = 2 /* same kernel, O written as fp32 (the accumulator precision)             */
 } fa_dtype;
@@ -55,7 +59,8 @@ typedef enum fa_dtype {
 typedef enum fa_kernel {
     FA_KERNEL_AUTO = 0,  /* fastest kernel instantiated for (dtype, d)                                  */
     FA_KERNEL_NAIVE = 1, /* rung-0 scalar kernel: fp32 only, any d <= 256; on-device cross-check        */
-    FA_KERNEL_MFMA = 2   /* the tiled MFMA kernel for (dtype, d); d in {32, 64, 128}                     */
+    FA_KERNEL_MFMA = 2,  /* the tiled MFMA kernel in the arithmetic of `dtype`; d in {32, 64, 128}          */
+    FA_KERNEL_SPLIT = 3  /* fp32 tensors on the bf16 matrix pipe (split products, see FA_DTYPE_F32); fp32 only */
 } fa_kernel;
 
 /*
