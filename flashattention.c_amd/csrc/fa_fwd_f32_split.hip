@@ -28,6 +28,7 @@
 #include "fa_bf16_common.h"
 #include "fa_kernels.h"
 #include <type_traits>
+#include <utility>
 
 namespace fa {
 
@@ -55,6 +56,13 @@ __device__ __forceinline__ void split2(float a, float b, bf16x2& hi, bf16x2& lo)
         : "v"(__builtin_bit_cast(unsigned, hi)), "v"(a), "v"(b));
     lo[0] = (__bf16)la;
     lo[1] = (__bf16)lb;
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>), in order: compile-time indices for the slot schedule
+template <class F, int... Is>
+__device__ __forceinline__ void for_each_index(F&& f, std::integer_sequence<int, Is...>)
+{
+    (f(std::integral_constant<int, Is>{}), ...);
 }
 
 // the same split in plain C++ (this file is compiled without the SLP vectoriser, so the subtractions stay scalar): every
@@ -157,8 +165,8 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     bool g_on[GPT];
 #pragma unroll
     for (int i = 0; i < GPT; ++i) {
-        const int g = tid + i * NT;
-        g_on[i] = g < C::kGroups;
+        const int g = (tid + i * NT) % C::kGroups;   // d = 32: the upper half of the workgroup duplicates the lower half's pieces
+        g_on[i] = true;
         const int row = g / (D / 8), c8 = g % (D / 8);
         g_row[i] = row;
         g_src[i] = row * p.kv_row_stride + c8 * 8;
@@ -417,37 +425,35 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     // -----------------------------------------------------------------------------------------------------------------
     auto run_fast = [&]() -> bool {
         f32x16 o[QB][DB];
-        float l[QB];
+        float la[QB], lb[QB];   // two partial row sums per block (even / odd score registers)
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            l[qb] = 0.0f;
+            la[qb] = lb[qb] = 0.0f;
 #pragma unroll
             for (int db = 0; db < DB; ++db)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.0f;
         }
-        const int last_tile = nt - 1;
-        // loads of tile t (clamped: a redundant copy of the last tile lands in a stage nobody reads any more)
+        // loads of tile t through buffer descriptors: rows past the end of the slab come back as zeros from the bounds check,
+        // so there is no branch (a branch inside the loop body lets LLVM sink vector work out of its slot)
+        const unsigned slab_bytes = ((unsigned)(n - 1) * (unsigned)p.kv_row_stride + D) * 4u;
+        const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kg, 0, slab_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vg, 0, slab_bytes, 0x00020000);
+        const unsigned tile_step = (unsigned)kKvSplit * (unsigned)p.kv_row_stride * 4u;
         auto load_k = [&](int t) {
-            const int kv0 = min(t, last_tile) * kKvSplit;
+            const unsigned soff = (unsigned)t * tile_step;
 #pragma unroll
             for (int i = 0; i < GPT; ++i) {
-                const bool ok = g_on[i] && (kv0 + g_row[i] < n);
-                const int64_t off = (int64_t)kv0 * p.kv_row_stride + g_src[i];
-                const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-                kst[i][0] = ok ? *(const f32x4*)(kg + off) : z;
-                kst[i][1] = ok ? *(const f32x4*)(kg + off + 4) : z;
+                kst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, g_src[i] * 4, soff, 0));
+                kst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, g_src[i] * 4 + 16, soff, 0));
             }
         };
         auto load_v = [&](int t) {
-            const int kv0 = min(t, last_tile) * kKvSplit;
+            const unsigned soff = (unsigned)t * tile_step;
 #pragma unroll
             for (int i = 0; i < GPT; ++i) {
-                const bool ok = g_on[i] && (kv0 + g_row[i] < n);
-                const int64_t off = (int64_t)kv0 * p.kv_row_stride + g_src[i];
-                const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-                vst[i][0] = ok ? *(const f32x4*)(vg + off) : z;
-                vst[i][1] = ok ? *(const f32x4*)(vg + off + 4) : z;
+                vst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, g_src[i] * 4, soff, 0));
+                vst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, g_src[i] * 4 + 16, soff, 0));
             }
         };
         auto store_k = [&](char* stage) {
@@ -497,19 +503,17 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                         if ((key >= n) || (CAUSAL && key > qi)) s[qb][r] = -INFINITY;
                     }
                 }
-                float rs0 = 0.0f, rs1 = 0.0f;
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int i = 0; i < 8; i += 2) {
                         const float p0 = fast_exp2(s[qb][8 * t + i]), p1 = fast_exp2(s[qb][8 * t + i + 1]);
-                        rs0 += p0;
-                        rs1 += p1;
+                        la[qb] += p0;
+                        lb[qb] += p1;
                         bf16x2 h2, l2;
                         split2c(p0, p1, h2, l2);
                         ph[qb][t][i] = h2[0], ph[qb][t][i + 1] = h2[1], pl[qb][t][i] = l2[0], pl[qb][t][i + 1] = l2[1];
                     }
-                l[qb] += rs0 + rs1;
             }
         };
         auto pv = [&](const bf16x8 (&ph)[QB][2], const bf16x8 (&pl)[QB][2], const char* vh_lds) {
@@ -544,6 +548,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
         f32x16 sa[QB], sb[QB];
         bf16x8 pha[QB][2], pla[QB][2], phb[QB][2], plb[QB][2];
         qk(smem, sa);
+        __syncthreads();   // iteration 0 overwrites K(0) with K(2): every wave must have read its K(0) fragments first
 
         // Iteration j, tile j in stage STG = j & 1.  In: scores `cur` of tile j, P `pprev` of tile j-1.  Out: scores `next`
         // of tile j+1, P `pcur` of tile j.  FIRST has no P.V, LAST no K.Q^T; only a LAST or causal iteration can need masks.
@@ -555,21 +560,105 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
             char* st_oth = smem + (STG ^ 1) * C::kStageBytes;
             if (!LAST) load_k(j + 2);
             load_v(j);
-            if (!LAST) qk(st_oth, next);                                   // K(j+1)
             const int kv0 = j * kKvSplit;
-            softmax(cur, phc, plc, (LAST || CAUSAL) && needs_mask(kv0), kv0);
-            if (!FIRST) pv(php, plp, st_oth + 2 * C::kImageBytes);          // V(j-1)
-            if (!LAST) store_k(st_cur);                                     // K(j+2) over K(j)
-            store_v(st_cur);                                                // V(j) over V(j-2)
-            if constexpr (!LAST && !FIRST) {
-                // rhythm of the block: one matrix instruction, then its share of the vector work
-                constexpr int kMfma = 48 * QB * (D / 64) > 0 ? 12 * QB * (D / 32) : 1;
+            if constexpr (FIRST || LAST) {   // executed once each: plain phases
+                if (!LAST) qk(st_oth, next);                                   // K(j+1)
+                softmax(cur, phc, plc, (LAST || CAUSAL) && needs_mask(kv0), kv0);
+                if (!FIRST) pv(php, plp, st_oth + 2 * C::kImageBytes);          // V(j-1)
+                if (!LAST) store_k(st_cur);                                     // K(j+2) over K(j)
+                store_v(st_cur);                                                // V(j) over V(j-2)
+            } else {
+                // ---- the steady state: a static slot schedule.  Slot I issues ONE matrix instruction -- group g = I / MPG
+                // is a k-step of K(j+1).Q'^T (g < KS) or a (key half, head-dim block) of V(j-1)^T.P(j-1)^T -- preceded
+                // by the fragment reads of the NEXT group and followed by its share of the vector work (a unit = one
+                // pair of scores: 2 exp, 2 adds, split; or four fp32 values of the K(j+2) / V(j) pieces of this thread:
+                // split, and the LDS writes once a piece is complete).  sched_barrier pins the slots; inside a slot hipcc
+                // orders (and pads) as it likes.
+                if (CAUSAL && needs_mask(kv0)) {
 #pragma unroll
-                for (int i = 0; i < kMfma; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // VALU
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // LDS read
+                    for (int qb = 0; qb < QB; ++qb) {
+                        asm volatile("; mask" ::: "memory");
+                        const int qi = q0 + qb * 32 + lq;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = kv0 + 4 * hi + (r & 3) + 8 * (r >> 2);
+                            if (key > qi) cur[qb][r] = -INFINITY;
+                        }
+                    }
                 }
+                constexpr int MPG = 3 * QB, NG = KS + 2 * DB, NSLOT = NG * MPG;
+                constexpr int NU_S = 8 * QB, NU = NU_S + 4 * GPT;
+                bf16x8 fh[2], fl[2];       // fragments of the current / next group
+                bf16x8 ch[2][GPT], cl[2][GPT];   // converted pieces (K, V) being assembled
+                const char* k_img = st_oth;                          // K(j+1) hi (lo at + kImageBytes)
+                const char* v_img = st_oth + 2 * C::kImageBytes;     // V(j-1) hi
+                auto load_frags = [&](auto gc) {
+                    constexpr int G = decltype(gc)::value;
+                    if constexpr (G < KS) {
+                        fh[G & 1] = *(const bf16x8*)(k_img + k_off[G]);
+                        fl[G & 1] = *(const bf16x8*)(k_img + C::kImageBytes + k_off[G]);
+                    } else {
+                        constexpr int t = (G - KS) / DB, db = (G - KS) % DB;
+                        constexpr int off0 = ((4 * t + 0) * (D / 16) + 2 * db) * 128;
+                        constexpr int off1 = ((4 * t + 2) * (D / 16) + 2 * db) * 128;
+                        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_img + v_lane_off + off0));
+                        const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_img + v_lane_off + off1));
+                        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_img + C::kImageBytes + v_lane_off + off0));
+                        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_img + C::kImageBytes + v_lane_off + off1));
+                        fh[G & 1] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                        fl[G & 1] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
+                };
+                auto unit = [&](auto uc) {
+                    constexpr int U = decltype(uc)::value;
+                    if constexpr (U < NU_S) {
+                        constexpr int qb = U / 8, t = (U % 8) / 4, i = 2 * (U % 4);
+                        const float p0 = fast_exp2(cur[qb][8 * t + i]), p1 = fast_exp2(cur[qb][8 * t + i + 1]);
+                        la[qb] += p0;
+                        lb[qb] += p1;
+                        bf16x2 h2, l2;
+                        split2c(p0, p1, h2, l2);
+                        phc[qb][t][i] = h2[0], phc[qb][t][i + 1] = h2[1], plc[qb][t][i] = l2[0], plc[qb][t][i + 1] = l2[1];
+                    } else {
+                        constexpr int c = U - NU_S, gi = c / 4, which = (c % 4) / 2, half = c % 2;
+                        const f32x4 x = which ? vst[gi][half] : kst[gi][half];
+                        bf16x2 h2, l2;
+                        split2c(x[0], x[1], h2, l2);
+                        ch[which][gi][4 * half + 0] = h2[0], ch[which][gi][4 * half + 1] = h2[1];
+                        cl[which][gi][4 * half + 0] = l2[0], cl[which][gi][4 * half + 1] = l2[1];
+                        split2c(x[2], x[3], h2, l2);
+                        ch[which][gi][4 * half + 2] = h2[0], ch[which][gi][4 * half + 3] = h2[1];
+                        cl[which][gi][4 * half + 2] = l2[0], cl[which][gi][4 * half + 3] = l2[1];
+                        if constexpr (half == 1) {   // piece complete: K(j+2) over K(j), V(j) over V(j-2), both in this tile's stage
+                            char* dst = st_cur + (which ? g_vdst[gi] : g_kdst[gi]);
+                            *(bf16x8*)dst = ch[which][gi];
+                            *(bf16x8*)(dst + C::kImageBytes) = cl[which][gi];
+                        }
+                    }
+                };
+                const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                load_frags(std::integral_constant<int, 0>{});
+                auto slot = [&](auto ic) {
+                    constexpr int I = decltype(ic)::value;
+                    constexpr int G = I / MPG, M = I % MPG, qb = M / 3, term = M % 3;
+                    if constexpr (M == 0 && G + 1 < NG) load_frags(std::integral_constant<int, G + 1>{});
+                    const bf16x8& a = (term == 0) ? fl[G & 1] : fh[G & 1];
+                    if constexpr (G < KS) {
+                        const bf16x8& bq = (term == 1) ? ql[qb][G] : qh[qb][G];
+                        if constexpr (G == 0 && term == 0) next[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, zero, 0, 0, 0);
+                        else next[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, next[qb], 0, 0, 0);
+                    } else {
+                        constexpr int t = (G - KS) / DB, db = (G - KS) % DB;
+                        const bf16x8& bp = (term == 1) ? plp[qb][t] : php[qb][t];
+                        o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bp, o[qb][db], 0, 0, 0);
+                    }
+                    // units whose slot this is: unit u sits in slot floor(u * NSLOT / NU)
+                    constexpr int u_lo = (I * NU + NSLOT - 1) / NSLOT, u_hi = ((I + 1) * NU + NSLOT - 1) / NSLOT;
+                    for_each_index([&](auto k) { unit(std::integral_constant<int, u_lo + decltype(k)::value>{}); },
+                                   std::make_integer_sequence<int, (u_hi > u_lo ? u_hi - u_lo : 0)>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                for_each_index(slot, std::make_integer_sequence<int, NSLOT>{});
             }
             __syncthreads();
         };
@@ -604,7 +693,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
         bool ok = true;
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            const float lt = xhalf_sum(l[qb]);
+            const float lt = xhalf_sum(la[qb] + lb[qb]);
             const float inv = 1.0f / lt;
             const int qi = q0 + qb * 32 + lq;
             float mag = 0.0f;
