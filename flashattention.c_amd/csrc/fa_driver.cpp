@@ -175,7 +175,8 @@ static double peak_tflops(const std::string& dtype) { return dtype == "bf16" ? 2
 static void run_one(const Args& a, Buffers& b, int variant, const std::vector<float>* ref)
 {
     const int dt = a.dtype == "bf16" ? FA_DTYPE_BF16 : FA_DTYPE_F32;
-    const int kernel = FA_KERNEL_MFMA | (variant << 8);
+    // --dtype f32: the exact fp32 kernel; --dtype f32s: fp32 tensors through the split kernel (variant = its tiling mode)
+    const int kernel = (a.dtype == "f32s" ? FA_KERNEL_SPLIT : FA_KERNEL_MFMA) | (variant << 8);
     const size_t esz = dt == FA_DTYPE_BF16 ? 2 : 4;
     HIP_OK(hipMemset(b.o, 0xff, b.ne * esz));
     fa_ok(fa_forward_ex(b.q, b.k, b.v, b.o, nullptr, a.bh, a.n, a.d, a.scale, a.causal, dt, kernel, nullptr), "fa_forward_ex");

@@ -587,7 +587,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                     }
                 }
                 constexpr int MPG = 3 * QB, NG = KS + 2 * DB, NSLOT = NG * MPG;
-                constexpr int NU_S = 8 * QB, NU = NU_S + 4 * GPT;
+                constexpr int NU_S = 8 * QB, NU = 2 * (NU_S + 4 * GPT);   // NU counts half units
                 bf16x8 fh[2], fl[2];       // fragments of the current / next group
                 bf16x8 ch[2][GPT], cl[2][GPT];   // converted pieces (K, V) being assembled
                 const char* k_img = st_oth;                          // K(j+1) hi (lo at + kImageBytes)
@@ -609,27 +609,31 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                         fl[G & 1] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
                     }
                 };
+                // half units: (2u) = exp + row sums of a score pair / split of the first two values of a piece,
+                //             (2u+1) = hi/lo split of that pair / split of the other two values (+ LDS writes of a whole piece)
                 auto unit = [&](auto uc) {
-                    constexpr int U = decltype(uc)::value;
+                    constexpr int U = decltype(uc)::value / 2, H = decltype(uc)::value % 2;
                     if constexpr (U < NU_S) {
                         constexpr int qb = U / 8, t = (U % 8) / 4, i = 2 * (U % 4);
-                        const float p0 = fast_exp2(cur[qb][8 * t + i]), p1 = fast_exp2(cur[qb][8 * t + i + 1]);
-                        la[qb] += p0;
-                        lb[qb] += p1;
-                        bf16x2 h2, l2;
-                        split2c(p0, p1, h2, l2);
-                        phc[qb][t][i] = h2[0], phc[qb][t][i + 1] = h2[1], plc[qb][t][i] = l2[0], plc[qb][t][i + 1] = l2[1];
+                        if constexpr (H == 0) {
+                            const float p0 = fast_exp2(cur[qb][8 * t + i]), p1 = fast_exp2(cur[qb][8 * t + i + 1]);
+                            la[qb] += p0;
+                            lb[qb] += p1;
+                            cur[qb][8 * t + i] = p0;        // the scores are dead: keep P in their registers until the split
+                            cur[qb][8 * t + i + 1] = p1;
+                        } else {
+                            bf16x2 h2, l2;
+                            split2c(cur[qb][8 * t + i], cur[qb][8 * t + i + 1], h2, l2);
+                            phc[qb][t][i] = h2[0], phc[qb][t][i + 1] = h2[1], plc[qb][t][i] = l2[0], plc[qb][t][i + 1] = l2[1];
+                        }
                     } else {
                         constexpr int c = U - NU_S, gi = c / 4, which = (c % 4) / 2, half = c % 2;
                         const f32x4 x = which ? vst[gi][half] : kst[gi][half];
                         bf16x2 h2, l2;
-                        split2c(x[0], x[1], h2, l2);
-                        ch[which][gi][4 * half + 0] = h2[0], ch[which][gi][4 * half + 1] = h2[1];
-                        cl[which][gi][4 * half + 0] = l2[0], cl[which][gi][4 * half + 1] = l2[1];
-                        split2c(x[2], x[3], h2, l2);
-                        ch[which][gi][4 * half + 2] = h2[0], ch[which][gi][4 * half + 3] = h2[1];
-                        cl[which][gi][4 * half + 2] = l2[0], cl[which][gi][4 * half + 3] = l2[1];
-                        if constexpr (half == 1) {   // piece complete: K(j+2) over K(j), V(j) over V(j-2), both in this tile's stage
+                        split2c(x[2 * H], x[2 * H + 1], h2, l2);
+                        ch[which][gi][4 * half + 2 * H] = h2[0], ch[which][gi][4 * half + 2 * H + 1] = h2[1];
+                        cl[which][gi][4 * half + 2 * H] = l2[0], cl[which][gi][4 * half + 2 * H + 1] = l2[1];
+                        if constexpr (half == 1 && H == 1) {   // piece complete: K(j+2) over K(j), V(j) over V(j-2), both in this tile's stage
                             char* dst = st_cur + (which ? g_vdst[gi] : g_kdst[gi]);
                             *(bf16x8*)dst = ch[which][gi];
                             *(bf16x8*)(dst + C::kImageBytes) = cl[which][gi];
@@ -640,7 +644,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                 load_frags(std::integral_constant<int, 0>{});
                 auto slot = [&](auto ic) {
                     constexpr int I = decltype(ic)::value;
-                    constexpr int G = I / MPG, M = I % MPG, qb = M / 3, term = M % 3;
+                    constexpr int G = I / MPG, M = I % MPG, term = M / QB, qb = M % QB;   // consecutive products alternate accumulators
                     if constexpr (M == 0 && G + 1 < NG) load_frags(std::integral_constant<int, G + 1>{});
                     const bf16x8& a = (term == 0) ? fl[G & 1] : fh[G & 1];
                     if constexpr (G < KS) {
@@ -741,29 +745,43 @@ static hipError_t launch_split(const FwdParams& p0, int causal, hipStream_t stre
     return hipGetLastError();
 }
 
-// mode 0 = the product choice for (d, causal) (c3 / c2 shapes on MI355X, ms non-causal | causal at B=2 H=8 N=8192:
-// d=64 one block per wave 0.78 | 0.47, two blocks 0.78 | 0.46; d=128 one block 2.11 | 1.14;
-// d=32 two blocks 0.45 | 0.42, one block 0.47 | 0.30); 1 = one 32-row block per wave, 2 = two blocks per wave,
-// 3 = software-pipelined reference-free pass, one block per wave, 4 = the same with two blocks per wave
+// mode 0 = the product choice; 1 / 2 = first-tile-reference pass with one / two 32-row blocks per wave (tiles above a causal
+// wave's diagonal are skipped), 3 / 4 = software-pipelined reference-free pass with one / two blocks per wave (slot-pinned
+// steady state; causal tiles above the diagonal are masked, not skipped).  Measured on MI355X, ms non-causal | causal:
+//   B=2 H=8 N=8192 d=64    m1 0.757 | 0.473   m3 0.706 | 0.410   m4 0.655 | 0.376      (exact fp32 kernel: 2.06 | 1.66)
+//   B=8 H=16 N=1024 d=64   m1 0.104 | 0.083   m3 0.097 | 0.084   m4 0.099 | 0.095      (0.265 | 0.287)
+//   B=2 H=8 N=8192 d=128   m1 1.775 | 1.081   m3 1.686 | 0.762                         (4.03 | 2.47)
+//   B=2 H=8 N=8192 d=32    m1 0.479 | 0.328   m3 0.455 | 0.295   m4 0.434 | 0.271      (1.14 | 0.86)
+static int choose_split(const FwdParams& p, int d, int causal)
+{
+    // the pipelined pass addresses K/V through 32-bit buffer offsets
+    const bool addressable = ((uint64_t)(p.n - 1) * (uint64_t)p.kv_row_stride + (uint64_t)d) * 4u < (1ull << 32);
+    if (!addressable || (causal && p.n < 2048)) return 1;   // short causal rows: skipping beats masking
+    if (d == 128) return 3;                                  // two blocks per wave do not fit the register file at d = 128
+    const int64_t tiles256 = (int64_t)p.bh * ((p.n + 255) / 256);
+    return tiles256 >= 256 ? 4 : 3;                          // small grids: 128-row workgroups fill more CUs
+}
+
+const char* f32_split_kernel_name() { return "fa_fwd_f32_split_kernel"; }
+
 hipError_t launch_f32_split(const FwdParams& p, int d, int causal, int mode, hipStream_t stream)
 {
+    if (mode == 0) mode = choose_split(p, d, causal);
+    if ((mode == 3 || mode == 4) && ((uint64_t)(p.n - 1) * (uint64_t)p.kv_row_stride + (uint64_t)d) * 4u >= (1ull << 32)) mode -= 2;
     switch (d) {
         case 32:
-            if (mode == 0) mode = causal ? 1 : 2;
             if (mode == 1) return launch_split<32, 4, 1, 2, false>(p, causal, stream);
             if (mode == 2) return launch_split<32, 4, 2, 1, false>(p, causal, stream);
             if (mode == 3) return launch_split<32, 4, 1, 2, true>(p, causal, stream);
             if (mode == 4) return launch_split<32, 4, 2, 1, true>(p, causal, stream);
             return hipErrorInvalidValue;
         case 64:
-            if (mode == 0) mode = 1;
             if (mode == 1) return launch_split<64, 4, 1, 2, false>(p, causal, stream);
             if (mode == 2) return launch_split<64, 4, 2, 1, false>(p, causal, stream);
             if (mode == 3) return launch_split<64, 4, 1, 2, true>(p, causal, stream);
             if (mode == 4) return launch_split<64, 4, 2, 1, true>(p, causal, stream);
             return hipErrorInvalidValue;
-        case 128:   // two blocks per wave do not fit the register file at d = 128 (Q', O and two score tiles: scratch in the loop)
-            if (mode == 0) mode = 1;
+        case 128:
             if (mode == 1) return launch_split<128, 4, 1, 1, false>(p, causal, stream);
             if (mode == 3) return launch_split<128, 4, 1, 1, true>(p, causal, stream);
             return hipErrorInvalidValue;

@@ -154,7 +154,7 @@ def test_split_kernel_tilings(d, mode, causal):
     check(fa.forward(*to_dev(qb, kb, vb), causal, scale=0.125, kernel=f"split:{mode}"), ref, 2e-5, "bf16-valued inputs")
 
 
-@pytest.mark.parametrize("d,mode", [(64, 0), (64, 2), (64, 3), (64, 4), (128, 0), (128, 3), (32, 0), (32, 3)])
+@pytest.mark.parametrize("d,mode", [(64, 0), (64, 2), (64, 3), (64, 4), (128, 0), (128, 1), (128, 3), (32, 0), (32, 1), (32, 3), (32, 4), (64, 1)])
 @pytest.mark.parametrize("causal", [False, True])
 def test_split_kernel_redo_outside_the_optimistic_range(d, mode, causal):
     """Rows whose scores leave the range the optimistic pass can prove (exp2-domain row sums outside 2^-100 .. 2^100, or a
@@ -331,6 +331,28 @@ def test_fuzz_shapes_through_the_dispatch_against_rung0():
         worst = max(worst, err)
         assert err < bf16_tol(1.0, True), f"case {case} bh={bh} n={n} d={d} causal={causal} scale={scale}: {err:.3e}"
     OBSERVED.append(("fuzz through dispatch, worst of 48", worst, bf16_tol(1.0, True)))
+
+
+def test_fuzz_fp32_shapes_through_the_dispatch_against_rung0():
+    """fp32 tensors through FA_KERNEL_AUTO (the split kernel and its per-shape tiling choice) against the rung-0 fp32
+    kernel on random shapes, including grids that switch between the tilings, ragged lengths and short causal rows."""
+    rng = np.random.default_rng(4321)
+    worst = 0.0
+    for case in range(40):
+        d = int(rng.choice([32, 64, 128]))
+        bh = int(rng.integers(1, 41))
+        n = int(rng.choice([rng.integers(1, 130), rng.integers(130, 1100), rng.integers(1100, 4500)]))
+        causal = bool(rng.integers(0, 2))
+        scale = float(rng.choice([1.0, 0.5, d ** -0.5]))
+        g = torch.Generator(device="cpu").manual_seed(2000 + case)
+        q, k, v = (torch.randn(bh, n, d, generator=g).to(dev()) for _ in range(3))
+        ref = fa.forward(q, k, v, causal, scale=scale, kernel="naive")
+        out = fa.forward(q, k, v, causal, scale=scale)
+        assert not torch.isnan(out).any(), f"NaN: case {case} bh={bh} n={n} d={d} causal={causal}"
+        err = float((out - ref).abs().max())
+        worst = max(worst, err)
+        assert err < TOL_F32, f"case {case} bh={bh} n={n} d={d} causal={causal} scale={scale}: {err:.3e}"
+    OBSERVED.append(("fp32 fuzz through dispatch, worst of 40", worst, TOL_F32))
 
 
 def test_graph_replay_timing_entry():
