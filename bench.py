@@ -215,8 +215,10 @@ def main():
         achieved = fwd_flop(bh, n, d, causal) / (kms * 1e-3) / 1e12
         elem = 2 if dtype == "bf16" else 4
         pmc = load_pmc_traffic()
-        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_TFLOPS[dtype], 4),
+        # fp32 tensors run on the bf16 pipe with three products per contraction: their ceiling is a third of the bf16 peak
+        peak = PEAK_TFLOPS["bf16"] / 3.0 if dtype == "f32" else PEAK_TFLOPS[dtype]
+        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4),
                 "traffic": (pmc or {}).get(f"{args.workload}_hbm_bytes_per_launch"),
                 "kernel": _cabi.lib().fa_kernel_name_for(1 if dtype == "bf16" else 0, d, int(causal), bh, n).decode(),
                 "kernel_ms": round(kms, 4),
@@ -230,18 +232,32 @@ def main():
                 gms = fa.time_forward(q, k, v, causal, scale=args.scale, warmup=3, iters=max(10, min(args.steps, 50)), out=out, graph=True)
                 gtf = fwd_flop(bh, n, d, causal) / (gms * 1e-3) / 1e12
                 extras["graph_replay"] = {"kernel_ms": round(gms, 4), "tflops": round(gtf, 2),
-                                          "frac_mfma_peak": round(gtf / PEAK_TFLOPS[dtype], 4)}
+                                          "frac_mfma_peak": round(gtf / peak, 4)}
             except Exception as e:  # pragma: no cover - informational only
                 extras["graph_replay"] = {"error": repr(e)}
         if not args.no_extras and world == 1 and args.workload == "c4":
-            # the same shape in exact fp32 (config c3) and the README shape (c2), a few launches each
+            # the same shape with fp32 tensors (config c3) and the README shape (c2), a few launches each: the product
+            # path for fp32 tensors (FA_KERNEL_AUTO: three bf16 MFMA products of two-term splits, fp32 accumulate) and the
+            # exact fp32-arithmetic kernel beside it.  Algorithmic TFLOP/s in both cases; the split kernel executes 3x that
+            # on the bf16 pipe, the exact one 1x on the fp32 pipe.
             for name in ("c3", "c2"):
                 B2, H2, d2, n2, dt2, _ = WORKLOADS[name]
                 q2, k2, v2 = make_inputs(B2 * H2, n2, d2, dt2, device, seed=1)
-                ms2 = fa.time_forward(q2, k2, v2, causal, scale=args.scale, warmup=10 if name == "c3" else 100, iters=10 if name == "c3" else 50)
-                tf2 = fwd_flop(B2 * H2, n2, d2, causal) / (ms2 * 1e-3) / 1e12
-                extras[name] = {"workload": f"B={B2} H={H2} d={d2} N={n2} {dt2}", "ms": round(ms2, 4), "tflops": round(tf2, 2),
-                                "frac_mfma_peak": round(tf2 / PEAK_TFLOPS[dt2], 4)}
+                fl2 = fwd_flop(B2 * H2, n2, d2, causal)
+                ent = {"workload": f"B={B2} H={H2} d={d2} N={n2} {dt2}"}
+                for label, kern in (("split", "auto"), ("exact", "exact")):
+                    ms2 = fa.time_forward(q2, k2, v2, causal, scale=args.scale, kernel=kern, warmup=30 if name == "c3" else 100,
+                                          iters=10 if name == "c3" else 50)
+                    tf2 = fl2 / (ms2 * 1e-3) / 1e12
+                    ent[label] = {"ms": round(ms2, 4), "tflops": round(tf2, 2)}
+                    if label == "split":
+                        ent[label].update(arithmetic="3 bf16 MFMA products of hi/lo splits, fp32 accumulate (FA_KERNEL_AUTO)",
+                                          frac_bf16_mfma_peak_at_3x_flop=round(3.0 * tf2 / PEAK_TFLOPS["bf16"], 4))
+                    else:
+                        ent[label].update(arithmetic="v_mfma_f32_32x32x2_f32 (FA_KERNEL_MFMA)",
+                                          frac_f32_mfma_peak=round(tf2 / PEAK_TFLOPS["f32"], 4))
+                ent["ms"], ent["tflops"] = ent["split"]["ms"], ent["split"]["tflops"]
+                extras[name] = ent
                 del q2, k2, v2
             torch.cuda.synchronize()
 

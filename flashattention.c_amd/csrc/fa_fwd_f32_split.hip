@@ -8,23 +8,28 @@
 //     a.b ~= a_hi.b_hi + a_lo.b_hi + a_hi.b_lo                            (the dropped a_lo.b_lo is 2^-18 relative)
 //
 // with fp32 accumulation in the matrix core.  The bf16 pipe is 16x the fp32 one on this chip (2.5 PF vs 157 TF dense), so
-// the triple product is still ~5x faster than v_mfma_f32_32x32x2_f32, and the result stays within ~1e-4 of the fp64
-// oracle at scale 1 -- inside the 1e-3 fp32 tolerance of the path, two orders of magnitude tighter than bf16 tensors.
+// three products still beat v_mfma_f32_32x32x2_f32 by 5x on the matrix pipe, and the result stays within ~2e-4 of the fp64
+// oracle on unit-variance data at scale 1 (~1e-5 at 1/sqrt(d)) -- inside the 1e-3 fp32 tolerance of the path, two orders of
+// magnitude tighter than bf16 tensors.  The error of a score is ~2^-17.6 * sqrt(sum (q_i k_i)^2) <= 5e-6 |q||k| scale; callers
+// whose logits need more than that select the exact kernel (FA_KERNEL_MFMA).  fp32 range is kept (bf16 exponent).
 //
 //   workgroup   NWAVES waves x QB blocks of 32 query rows; K/V tiles of 32 keys.
-//   HBM -> LDS  fp32 K/V rows are loaded into registers (two global_load_dwordx4 per 8 values), split there, and written
-//               as FOUR bf16 images per tile (K_hi, K_lo, V_hi, V_lo) in the layouts of fa_bf16_common.h: K row-major with
+//   HBM -> LDS  fp32 K/V rows are loaded into registers (two 16-byte loads per 8 values), split there, and written as FOUR
+//               bf16 images per tile (K_hi, K_lo, V_hi, V_lo) in the layouts of fa_bf16_common.h: K row-major with
 //               XOR-swizzled 16-byte slots (ds_read_b128 A fragments), V as [key/4][col/16][4][16] sub-tiles
-//               (ds_read_b64_tr_b16 hands out V^T fragments).  Register-staged double buffering: the loads of tile j+1 are
-//               in flight while tile j is consumed; one barrier per tile.  Rows past the end of the slab are zeros.
+//               (ds_read_b64_tr_b16 hands out V^T fragments).  Rows past the end of the slab are zeros.
 //   S^T = K Q'^T   Q' = Q * scale*log2(e) in fp32 (one rounding per element), then split: scores arrive in the exp2 domain.
-//   softmax     optimistic, like the bf16 kernels: p = exp2(s - m0) with m0 the row maximum of the FIRST tile, fixed for the
-//               whole row and folded into the accumulator the first K.Q'^T product starts from -- the main loop has no
-//               maximum, no subtraction, no rescale and no branch.  fp32 P has 2^127 of head room: the row sum l < 2^100 and
-//               finite outputs at the end of the tile prove nothing overflowed; otherwise the workgroup redoes its tile
-//               with the textbook running maximum (p <= 1), which is correct for every input.  Row sums in fp32 on the
-//               VALU, P split into hi/lo in registers.
-//   O^T += V^T P^T   same key permutation trick as the bf16 kernels: P never leaves its registers.
+//   O^T += V^T P^T   same key permutation trick as the bf16 kernels: P never leaves its registers (split there into hi/lo).
+//   softmax     optimistic, in two flavours selected per shape by choose_split():
+//     run_fast  reference-free: p = exp2(s), nothing between the matrix core and v_exp_f32; software pipelined two tiles
+//               deep with a static slot schedule (one matrix instruction, then its share of the vector work) so that the
+//               single wave of a SIMD keeps both pipes busy -- see the comment at run_fast.
+//     run_tile<OPT>  p = exp2(s - m0) with m0 the row maximum of the first tile folded into the accumulator the first
+//               product starts from; phases in sequence, tiles above a causal wave's diagonal skipped (short causal rows).
+//               fp32 P, l and O have 2^127 of head room either way: a row whose sum stays inside (2^-100, 2^100) with finite
+//               outputs provably lost nothing.  Any other row sends its workgroup to
+//     run_tile<!OPT>  the textbook running maximum (p <= 1), correct for every input; results are stored before the vote, a
+//               rejected tile is simply overwritten.
 #include "fa_bf16_common.h"
 #include "fa_kernels.h"
 #include <type_traits>
@@ -670,7 +675,6 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
         constexpr std::integral_constant<int, 1> S1{};
         constexpr std::true_type T{};
         constexpr std::false_type F{};
-        const char* v_last;   // V image of the last tile
         if (nt == 1) {
             step(S0, T, T, 0, sa, sb, pha, pla, phb, plb);
             pv(pha, pla, smem + 2 * C::kImageBytes);
@@ -690,7 +694,6 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                 pv(phb, plb, smem + C::kStageBytes + 2 * C::kImageBytes);   // nt-1 odd: stage 1
             }
         }
-        (void)v_last;
 
         // ================= epilogue: O / l, store =================
         mfma_drain();  // the last P.V MFMAs may still be in flight
