@@ -750,19 +750,25 @@ static hipError_t launch_split(const FwdParams& p0, int causal, hipStream_t stre
 
 // mode 0 = the product choice; 1 / 2 = first-tile-reference pass with one / two 32-row blocks per wave (tiles above a causal
 // wave's diagonal are skipped), 3 / 4 = software-pipelined reference-free pass with one / two blocks per wave (slot-pinned
-// steady state; causal tiles above the diagonal are masked, not skipped).  Measured on MI355X, ms non-causal | causal:
-//   B=2 H=8 N=8192 d=64    m1 0.757 | 0.473   m3 0.706 | 0.410   m4 0.655 | 0.376      (exact fp32 kernel: 2.06 | 1.66)
-//   B=8 H=16 N=1024 d=64   m1 0.104 | 0.083   m3 0.097 | 0.084   m4 0.099 | 0.095      (0.265 | 0.287)
-//   B=2 H=8 N=8192 d=128   m1 1.775 | 1.081   m3 1.686 | 0.762                         (4.03 | 2.47)
-//   B=2 H=8 N=8192 d=32    m1 0.479 | 0.328   m3 0.455 | 0.295   m4 0.434 | 0.271      (1.14 | 0.86)
+// steady state; causal tiles above the diagonal are masked, not skipped).  Measured on MI355X (one box, interleaved, ms):
+//   d=64  BH=16  N=8192   non-causal m1 0.757  m3 0.706  m4 0.655 | causal m1 0.473  m3 0.410  m4 0.376   (exact: 2.06 | 1.66)
+//   d=64  BH=128 N=1024   non-causal m1 0.107  m3 0.100  m4 0.100 | causal m1 0.084  m3 0.085  m4 0.095   (0.265 | 0.287)
+//   d=64  BH=32  N=4096   causal m1 0.265  m3 0.235  m4 0.283;  BH=32 N=2048 causal m1 0.095  m3 0.083  m4 0.085
+//   d=64  BH=8   N=4096   non-causal m1 0.123  m3 0.103  m4 0.136      (128 tiles of 256 rows: half the CUs idle with m4)
+//   d=128 BH=16  N=8192   non-causal m1 1.775  m3 1.942 | causal m1 1.080  m3 0.796                       (4.03 | 2.47)
+//   d=32  BH=16  N=8192   non-causal m2 0.476  m3 0.474  m4 0.450 | causal m1 0.328  m3 0.295  m4 0.271   (1.14 | 0.86)
 static int choose_split(const FwdParams& p, int d, int causal)
 {
     // the pipelined pass addresses K/V through 32-bit buffer offsets
     const bool addressable = ((uint64_t)(p.n - 1) * (uint64_t)p.kv_row_stride + (uint64_t)d) * 4u < (1ull << 32);
-    if (!addressable || (causal && p.n < 2048)) return 1;   // short causal rows: skipping beats masking
-    if (d == 128) return 3;                                  // two blocks per wave do not fit the register file at d = 128
+    if (!addressable) return 1;
     const int64_t tiles256 = (int64_t)p.bh * ((p.n + 255) / 256);
-    return tiles256 >= 256 ? 4 : 3;                          // small grids: 128-row workgroups fill more CUs
+    if (causal) {
+        if (p.n <= 1024) return 1;                                         // short rows: skipping tiles beats masking them
+        return (d != 128 && p.n >= 8192 && tiles256 >= 256) ? 4 : 3;     // 256-row tiles only pay on long rows
+    }
+    if (d == 128) return 1;   // two blocks per wave do not fit the register file; one block is faster phase-sequential
+    return tiles256 >= 256 ? 4 : 3;                                        // small grids: 128-row workgroups fill more CUs
 }
 
 const char* f32_split_kernel_name() { return "fa_fwd_f32_split_kernel"; }

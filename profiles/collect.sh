@@ -15,7 +15,15 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
     --kernel-trace -d $OUT/pmc_sq1 -- python3 $BENCH > $OUT/pmc_sq1.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_SALU \
     --kernel-trace -d $OUT/pmc_sq2 -- python3 $BENCH > $OUT/pmc_sq2.log 2>&1
+# the fp32-tensor workload (c3) through the same bench: kernel durations and matrix-pipe / HBM counters of the split kernel
+BENCH3="$R/bench.py --workload c3 --steps 20 --warmup 3 --no-cpu-baseline --no-extras"
+rocprofv3 --kernel-trace --stats -d $OUT/stats_c3 -- python3 $BENCH3 > $OUT/stats_c3.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES \
+    --kernel-trace -d $OUT/pmc_c3_sq -- python3 $BENCH3 > $OUT/pmc_c3_sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_c3_fetch -- python3 $BENCH3 > $OUT/pmc_c3_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_c3_write -- python3 $BENCH3 > $OUT/pmc_c3_write.log 2>&1
 cd $R
+python3 bench.py --workload c3 --no-cpu-baseline > $OUT/bench_line_c3.json 2> $OUT/bench_c3.err
 python3 bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 python3 profiles/summarize_rocpd.py $OUT $TAG --out $OUT
 grep -h '"metric"' $OUT/*.log | head -3

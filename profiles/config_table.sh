@@ -1,0 +1,37 @@
+#!/bin/bash
+# profiles/config_table.sh -- the per-config timing table of DESIGN.md §3 (C driver, steady clocks) and the README-shape
+# harness table.  Run on the GPU box: gpurun -- 'bash profiles/config_table.sh > gpurun_out/config_table.txt 2> gpurun_out/harness.txt'
+D=./flashattention.c_amd/fa_driver
+W="--warmup 150 --iters 50 --check 0"
+echo "== c4 non-causal: dispatch(0)=x4 opt, 42=x4 rescaling, 7=pp3 opt, 25=pp3 rescaling"
+for v in 0 42 7 25; do $D --mode rand --bh 16 --n 8192 --d 64 --dtype bf16 $W --variant $v; done
+echo "== bh=128"
+for v in 0 7; do $D --mode rand --bh 128 --n 8192 --d 64 --dtype bf16 --warmup 20 --iters 10 --check 0 --variant $v; done
+echo "== causal c4 / bh=128"
+$D --mode rand --bh 16 --n 8192 --d 64 --dtype bf16 $W --variant 0 --causal 1
+$D --mode rand --bh 128 --n 8192 --d 64 --dtype bf16 --warmup 20 --iters 10 --check 0 --variant 0 --causal 1
+echo "== d=32, d=128"
+$D --mode rand --bh 16 --n 8192 --d 32 --dtype bf16 $W --variant 0
+$D --mode rand --bh 16 --n 8192 --d 128 --dtype bf16 $W --variant 0
+$D --mode rand --bh 16 --n 8192 --d 128 --dtype bf16 $W --variant 0 --causal 1
+echo "== fp32 tensors, split kernel (f32s; variant 0 = product choice, 1..4 = its tilings): c3, c3 causal, c2, d=128, d=32"
+for v in 0 1 3 4; do $D --mode rand --bh 16 --n 8192 --d 64 --dtype f32s --warmup 60 --iters 20 --check 0 --variant $v; done
+$D --mode rand --bh 16 --n 8192 --d 64 --dtype f32s --warmup 60 --iters 20 --check 0 --causal 1
+$D --mode rand --bh 128 --n 1024 --d 64 --dtype f32s --warmup 200 --iters 50 --check 0
+$D --mode rand --bh 16 --n 8192 --d 128 --dtype f32s --warmup 40 --iters 10 --check 0
+$D --mode rand --bh 16 --n 8192 --d 32 --dtype f32s --warmup 60 --iters 20 --check 0
+echo "== fp32 tensors, exact fp32 arithmetic: c3, c2"
+$D --mode rand --bh 16 --n 8192 --d 64 --dtype f32 --warmup 20 --iters 10 --check 0
+$D --mode rand --bh 128 --n 1024 --d 64 --dtype f32 --warmup 100 --iters 30 --check 0
+H="python3 -m flashattention_c_amd.harness.bench_flashattention --iters 50 --warmup 100"
+{
+for hd in 64 32 128; do for dt in f32 bf16; do
+  $H --batch_size 2 --n_head 8 --seq_len 8192 --head_dim $hd --dtype $dt
+done; done
+for hd in 64 32; do for dt in f32 bf16; do
+  $H --batch_size 16 --n_head 8 --seq_len 1024 --head_dim $hd --dtype $dt
+done; done
+$H --batch_size 2 --n_head 8 --seq_len 8192 --head_dim 64 --dtype bf16 --masking
+$H --batch_size 2 --n_head 8 --seq_len 8192 --head_dim 128 --dtype bf16 --masking
+$H --batch_size 2 --n_head 8 --seq_len 8192 --head_dim 64 --dtype f32 --masking
+} 1>&2
