@@ -34,6 +34,22 @@ def test_library_exports_every_declared_symbol():
     assert L.fa_kernel_name(_cabi.FA_DTYPE_F32, 48, 0) is None
 
 
+def test_kernel_ids_match_the_header_and_the_python_names():
+    hdr = open(os.path.join(ROOT, "include", "flashattn_amd.h")).read()
+    for name in ("FA_KERNEL_AUTO", "FA_KERNEL_NAIVE", "FA_KERNEL_MFMA", "FA_KERNEL_SPLIT", "FA_DTYPE_F32", "FA_DTYPE_BF16",
+                 "FA_DTYPE_BF16_OUT_F32"):
+        m = re.search(name + r"\s*=\s*(\d+)", hdr)
+        assert m and int(m.group(1)) == getattr(_cabi, name), name
+    from flashattention_c_amd import flash
+    assert flash._kernel_id("split:4") == _cabi.FA_KERNEL_SPLIT | (4 << 8)
+    assert flash._kernel_id("exact") == flash._kernel_id("mfma") == _cabi.FA_KERNEL_MFMA
+    assert flash._kernel_id("auto") == _cabi.FA_KERNEL_AUTO
+    with pytest.raises(ValueError):
+        flash._kernel_id("fast")
+    L = _cabi.lib()
+    assert L.fa_kernel_name(_cabi.FA_DTYPE_F32, 64, 0) == b"fa_fwd_f32_split_kernel"   # fp32 tensors: the bf16 matrix pipe
+
+
 def test_cabi_rejects_bad_arguments_without_touching_a_device():
     L = _cabi.lib()
     buf = ctypes.create_string_buffer(4096)
@@ -54,6 +70,9 @@ def test_cabi_rejects_bad_arguments_without_touching_a_device():
     assert L.fa_forward(p, p, p, p, 1, 32, 48, 1.0, 0, 0, None) == 2
     assert b"48" in L.fa_last_error()
     assert L.fa_forward_ex(p, p, p, p, None, 1, 32, 64, 1.0, 0, 0, 9, None) == 2
+    # the split kernel is an fp32-tensor kernel: bf16 tensors are refused before any launch
+    assert L.fa_forward_ex(p, p, p, p, None, 1, 32, 64, 1.0, 0, _cabi.FA_DTYPE_BF16, _cabi.FA_KERNEL_SPLIT, None) == 2
+    assert b"fp32" in L.fa_last_error()
     assert L.fa_forward_packed_qkv(p, p, 1, 8, 96, 5, None) == 1      # C % NH != 0
     assert L.fa_forward_packed_qkv(p, p, 1, 8, 96, 2, None) == 2      # hs = 48 not instantiated
     ms = ctypes.c_float()
