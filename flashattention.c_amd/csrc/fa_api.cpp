@@ -76,6 +76,17 @@ fa::FwdParams make_params(const void* q, const void* k, const void* v, void* o, 
     return p;
 }
 
+// FA_F32_AUTO=exact in the environment makes FA_KERNEL_AUTO compute fp32 tensors in fp32 arithmetic (FA_KERNEL_MFMA) process-wide:
+// the switch for a deployment whose logits are too wide for 16-bit operands, without touching call sites.  Read once.
+bool f32_auto_is_exact()
+{
+    static const bool exact = [] {
+        const char* e = getenv("FA_F32_AUTO");
+        return e != nullptr && strcmp(e, "exact") == 0;
+    }();
+    return exact;
+}
+
 int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int32_t kernel, hipStream_t stream)
 {
     const KernelSel sel = decode_kernel(kernel);
@@ -91,7 +102,7 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
             return fail(FA_ERR_UNSUPPORTED, "the split kernel takes fp32 tensors (bf16 tensors need no split)");
         if (dtype != FA_DTYPE_F32)
             e = fa::launch_fwd_bf16(p, d, causal ? 1 : 0, dtype == FA_DTYPE_BF16_OUT_F32 ? 1 : 0, sel.variant, stream);
-        else if (sel.kind == FA_KERNEL_MFMA)
+        else if (sel.kind == FA_KERNEL_MFMA || (sel.kind == FA_KERNEL_AUTO && f32_auto_is_exact()))
             e = fa::launch_fwd_f32(p, d, causal ? 1 : 0, sel.variant, stream);       // exact fp32 arithmetic
         else
             e = fa::launch_f32_split(p, d, causal ? 1 : 0, sel.variant, stream);     // AUTO: fp32 tensors on the bf16 pipe
@@ -273,7 +284,7 @@ const char* fa_version(void) { return "flashattn_amd abi 1 gfx950 (hip, mfma f32
 const char* fa_kernel_name_for(int32_t dtype, int32_t d, int32_t causal, int64_t bh, int64_t n)
 {
     if (!head_dim_supported(d) || bh < 1 || n < 1) return nullptr;
-    if (dtype == FA_DTYPE_F32) return "fa_fwd_f32_split_kernel";
+    if (dtype == FA_DTYPE_F32) return f32_auto_is_exact() ? "fa_fwd_f32_kernel" : "fa_fwd_f32_split_kernel";
     if (dtype == FA_DTYPE_BF16 || dtype == FA_DTYPE_BF16_OUT_F32) return fa::bf16_kernel_name(bh, n, d, causal);
     return nullptr;
 }

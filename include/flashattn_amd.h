@@ -51,7 +51,8 @@ typedef enum fa_dtype {
                          contractions as three bf16 MFMA products of two-term bf16 splits of the fp32 operands (16
                          significant bits per operand, fp32 accumulate; max-abs error against fp64 ~2e-4 on unit-variance
                          data at scale 1, ~1e-5 at 1/sqrt(d) -- inside the 1e-3 fp32 tolerance of the path, 2.6x faster);
-                         FA_KERNEL_MFMA computes in exact fp32 (v_mfma_f32_32x32x2_f32, ~2e-5 / ~1e-6) */
+                         FA_KERNEL_MFMA computes in exact fp32 (v_mfma_f32_32x32x2_f32, ~2e-5 / ~1e-6); the environment variable
+                         FA_F32_AUTO=exact makes that the FA_KERNEL_AUTO choice for the whole process */
     FA_DTYPE_BF16 = 1,        /* bf16 in, bf16 MFMA with fp32 accumulate and fp32 softmax, bf16 out     */
     FA_DTYPE_BF16_OUT_F32 = 2 /* same kernel, O written as fp32 (the accumulator precision)             */
 } fa_dtype;

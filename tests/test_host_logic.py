@@ -50,6 +50,21 @@ def test_kernel_ids_match_the_header_and_the_python_names():
     assert L.fa_kernel_name(_cabi.FA_DTYPE_F32, 64, 0) == b"fa_fwd_f32_split_kernel"   # fp32 tensors: the bf16 matrix pipe
 
 
+def test_fp32_auto_choice_follows_the_environment_switch():
+    """FA_F32_AUTO=exact (read once per process) turns FA_KERNEL_AUTO for fp32 tensors into the fp32-arithmetic kernel."""
+    import subprocess, sys
+    code = ("from flashattention_c_amd import _cabi; L = _cabi.lib(); "
+            "print(L.fa_kernel_name(_cabi.FA_DTYPE_F32, 64, 0).decode())")
+    for env_val, want in ((None, "fa_fwd_f32_split_kernel"), ("exact", "fa_fwd_f32_kernel"), ("split", "fa_fwd_f32_split_kernel")):
+        env = dict(os.environ)
+        env.pop("FA_F32_AUTO", None)
+        if env_val is not None:
+            env["FA_F32_AUTO"] = env_val
+        out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.strip().splitlines()[-1] == want
+
+
 def test_cabi_rejects_bad_arguments_without_touching_a_device():
     L = _cabi.lib()
     buf = ctypes.create_string_buffer(4096)
