@@ -748,14 +748,16 @@ static hipError_t launch_split(const FwdParams& p0, int causal, hipStream_t stre
     return hipGetLastError();
 }
 
-// mode 0 = the product choice; 1 / 2 = first-tile-reference pass with one / two 32-row blocks per wave (tiles above a causal
+// mode 0 = the product choice; 5 / 6 (d = 128) = modes 1 / 3 with eight waves per workgroup; 1 / 2 = first-tile-reference pass with one / two 32-row blocks per wave (tiles above a causal
 // wave's diagonal are skipped), 3 / 4 = software-pipelined reference-free pass with one / two blocks per wave (slot-pinned
 // steady state; causal tiles above the diagonal are masked, not skipped).  Measured on MI355X (one box, interleaved, ms):
 //   d=64  BH=16  N=8192   non-causal m1 0.757  m3 0.706  m4 0.655 | causal m1 0.473  m3 0.410  m4 0.376   (exact: 2.06 | 1.66)
 //   d=64  BH=128 N=1024   non-causal m1 0.107  m3 0.100  m4 0.100 | causal m1 0.084  m3 0.085  m4 0.095   (0.265 | 0.287)
 //   d=64  BH=32  N=4096   causal m1 0.265  m3 0.235  m4 0.283;  BH=32 N=2048 causal m1 0.095  m3 0.083  m4 0.085
 //   d=64  BH=8   N=4096   non-causal m1 0.123  m3 0.103  m4 0.136      (128 tiles of 256 rows: half the CUs idle with m4)
-//   d=128 BH=16  N=8192   non-causal m1 1.775  m3 1.942 | causal m1 1.080  m3 0.796                       (4.03 | 2.47)
+//   d=128 BH=16  N=8192   non-causal m1 1.775  m3 1.942  m5 1.300  m6 1.790 | causal m1 1.080  m3 0.796  m5 0.702   (4.03 | 2.47)
+//   d=128 BH=128 N=1024   non-causal m1 0.253  m3 0.244  m5 0.186 | causal m1 0.243  m3 0.168  m5 0.157
+//   (8-wave workgroups at d=64 / d=32 -- tried as m5..m7 -- lose to m4: 0.79 / 0.70 / 0.84 vs 0.66 at BH=16 N=8192 d=64)
 //   d=32  BH=16  N=8192   non-causal m2 0.476  m3 0.474  m4 0.450 | causal m1 0.328  m3 0.295  m4 0.271   (1.14 | 0.86)
 static int choose_split(const FwdParams& p, int d, int causal)
 {
@@ -763,11 +765,16 @@ static int choose_split(const FwdParams& p, int d, int causal)
     const bool addressable = ((uint64_t)(p.n - 1) * (uint64_t)p.kv_row_stride + (uint64_t)d) * 4u < (1ull << 32);
     if (!addressable) return 1;
     const int64_t tiles256 = (int64_t)p.bh * ((p.n + 255) / 256);
+    if (d == 128) {
+        // two blocks per wave do not fit the register file; EIGHT waves of one block each (256-row workgroups, two waves per
+        // SIMD, phases in sequence) halve the K/V conversion work and the L2 traffic per row
+        if (tiles256 >= 256) return 5;
+        return causal ? 3 : 1;
+    }
     if (causal) {
         if (p.n <= 1024) return 1;                                         // short rows: skipping tiles beats masking them
-        return (d != 128 && p.n >= 8192 && tiles256 >= 256) ? 4 : 3;     // 256-row tiles only pay on long rows
+        return (p.n >= 8192 && tiles256 >= 256) ? 4 : 3;                 // 256-row tiles only pay on long rows
     }
-    if (d == 128) return 1;   // two blocks per wave do not fit the register file; one block is faster phase-sequential
     return tiles256 >= 256 ? 4 : 3;                                        // small grids: 128-row workgroups fill more CUs
 }
 
@@ -793,6 +800,8 @@ hipError_t launch_f32_split(const FwdParams& p, int d, int causal, int mode, hip
         case 128:
             if (mode == 1) return launch_split<128, 4, 1, 1, false>(p, causal, stream);
             if (mode == 3) return launch_split<128, 4, 1, 1, true>(p, causal, stream);
+            if (mode == 5) return launch_split<128, 8, 1, 1, false>(p, causal, stream);   // 8 waves: 256-row workgroups
+            if (mode == 6) return launch_split<128, 8, 1, 1, true>(p, causal, stream);
             return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
