@@ -236,6 +236,18 @@ def main():
             except Exception as e:  # pragma: no cover - informational only
                 extras["graph_replay"] = {"error": repr(e)}
         if not args.no_extras and world == 1 and args.workload == "c4":
+            # the accurate bf16 mode on the same tensors (FA_KERNEL_SPLIT: P and Q*scale*log2e in 16 significant bits, fp32 out)
+            try:
+                o32 = torch.empty(q.shape, dtype=torch.float32, device=device)
+                ams = fa.time_forward(q, k, v, causal, scale=args.scale, kernel="split", warmup=30, iters=20, out=o32)
+                atf = fwd_flop(bh, n, d, causal) / (ams * 1e-3) / 1e12
+                extras["c4_accurate_mode"] = {"kernel_ms": round(ams, 4), "tflops": round(atf, 2),
+                                              "frac_bf16_mfma_peak_at_2x_flop": round(2.0 * atf / PEAK_TFLOPS["bf16"], 4),
+                                              "what": "bf16 tensors, two bf16 MFMA products per contraction (hi/lo of P and Q'), "
+                                                      "fp32 out; max-abs error ~1e-4 vs fp64 at scale 1 (default kernels ~5e-3)"}
+                del o32
+            except Exception as e:  # pragma: no cover - informational only
+                extras["c4_accurate_mode"] = {"error": repr(e)}
             # the same shape with fp32 tensors (config c3) and the README shape (c2), a few launches each: the product
             # path for fp32 tensors (FA_KERNEL_AUTO: three bf16 MFMA products of two-term splits, fp32 accumulate) and the
             # exact fp32-arithmetic kernel beside it.  Algorithmic TFLOP/s in both cases; the split kernel executes 3x that

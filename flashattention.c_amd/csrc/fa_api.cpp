@@ -98,9 +98,9 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
     } else if (sel.kind == FA_KERNEL_AUTO || sel.kind == FA_KERNEL_MFMA || sel.kind == FA_KERNEL_SPLIT) {
         if (!head_dim_supported(d))
             return fail(FA_ERR_UNSUPPORTED, "head dim %d not instantiated for the MFMA kernels (32, 64, 128)", d);
-        if (sel.kind == FA_KERNEL_SPLIT && dtype != FA_DTYPE_F32)
-            return fail(FA_ERR_UNSUPPORTED, "the split kernel takes fp32 tensors (bf16 tensors need no split)");
-        if (dtype != FA_DTYPE_F32)
+        if (sel.kind == FA_KERNEL_SPLIT && dtype != FA_DTYPE_F32)   // bf16 tensors, P and Q' carried in 16 bits: the accurate bf16 mode
+            e = fa::launch_bf16_split(p, d, causal ? 1 : 0, dtype == FA_DTYPE_BF16_OUT_F32 ? 1 : 0, sel.variant, stream);
+        else if (dtype != FA_DTYPE_F32)
             e = fa::launch_fwd_bf16(p, d, causal ? 1 : 0, dtype == FA_DTYPE_BF16_OUT_F32 ? 1 : 0, sel.variant, stream);
         else if (sel.kind == FA_KERNEL_MFMA || (sel.kind == FA_KERNEL_AUTO && f32_auto_is_exact()))
             e = fa::launch_fwd_f32(p, d, causal ? 1 : 0, sel.variant, stream);       // exact fp32 arithmetic

@@ -46,6 +46,7 @@ struct FwdParams {
     int64_t q_head_stride;
     int64_t kv_head_stride;
     int64_t o_head_stride;
+    int32_t o_is_bf16;      // split kernel only: O is bf16 (bf16 tensors); 0 = fp32
 };
 
 // Map the linear workgroup id onto (slab, q-tile) so that each XCD owns a contiguous range of work items

@@ -130,10 +130,28 @@ __device__ __forceinline__ void mfma_acc(f32x16& d, const bf16x8& a, const bf16x
     asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
 }
 
-template <int D, int NWAVES, int QB, bool CAUSAL, int MINBLOCKS, bool PIPE>
+// four consecutive output values: fp32, or bf16 when the caller's O is bf16 (p.o_is_bf16, bf16 tensors only)
+__device__ __forceinline__ void store4(const FwdParams& p, int64_t off, const f32x4& v)
+{
+    if (p.o_is_bf16) {
+        bf16x4 b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = (__bf16)v[e];
+        *(bf16x4*)((__bf16*)p.o + off) = b;
+    } else {
+        *(f32x4*)((float*)p.o + off) = v;
+    }
+}
+
+// IN_BF16: bf16 tensors through the same machinery ("accurate" bf16 mode, FA_KERNEL_SPLIT with a bf16 dtype): K and V are
+// exact in one bf16 term, so only Q' = Q*scale*log2(e) and P are split -- two products per contraction instead of three, no
+// conversion work -- and the result is as close to the fp64 oracle as with fp32 tensors (P is not rounded to 8 bits).
+template <int D, int NWAVES, int QB, bool CAUSAL, int MINBLOCKS, bool PIPE, bool IN_BF16>
 __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_kernel(FwdParams p)
 {
     using C = SplitCfg<D>;
+    using T = std::conditional_t<IN_BF16, __bf16, float>;   // element type of Q, K, V
+    constexpr int NPROD = IN_BF16 ? 2 : 3;                  // matrix products per contraction
     constexpr int KS = D / 16;   // k-steps of S^T = K Q^T
     constexpr int DB = D / 32;   // 32-wide blocks of the head dim in O^T
     constexpr int NT = NWAVES * kWave;
@@ -156,10 +174,10 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     const int q0 = qt * BM + wave * (QB * 32);
 
     const int b = slab / p.heads, h = slab % p.heads;
-    const float* qg = (const float*)p.q + b * p.q_batch_stride + h * p.q_head_stride;
-    const float* kg = (const float*)p.k + b * p.kv_batch_stride + h * p.kv_head_stride;
-    const float* vg = (const float*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
-    float* og = (float*)p.o + b * p.o_batch_stride + h * p.o_head_stride;
+    const T* qg = (const T*)p.q + b * p.q_batch_stride + h * p.q_head_stride;
+    const T* kg = (const T*)p.k + b * p.kv_batch_stride + h * p.kv_head_stride;
+    const T* vg = (const T*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
+    const int64_t o_slab = b * p.o_batch_stride + h * p.o_head_stride;   // elements (fp32 or bf16 output, p.o_is_bf16)
 
     int kv_end = n;
     if (CAUSAL) kv_end = min(n, qt * BM + BM);
@@ -185,23 +203,33 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
             const bool ok = g_on[i] && (kv0 + g_row[i] < n);
             const int64_t off = (int64_t)kv0 * p.kv_row_stride + g_src[i];
             const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-            kst[i][0] = ok ? *(const f32x4*)(kg + off) : z;
-            kst[i][1] = ok ? *(const f32x4*)(kg + off + 4) : z;
-            vst[i][0] = ok ? *(const f32x4*)(vg + off) : z;
-            vst[i][1] = ok ? *(const f32x4*)(vg + off + 4) : z;
+            if constexpr (IN_BF16) {   // eight bf16 values = one 16-byte register group, passed through unchanged
+                kst[i][0] = ok ? *(const f32x4*)(kg + off) : z;
+                vst[i][0] = ok ? *(const f32x4*)(vg + off) : z;
+            } else {
+                kst[i][0] = ok ? *(const f32x4*)(kg + off) : z;
+                kst[i][1] = ok ? *(const f32x4*)(kg + off + 4) : z;
+                vst[i][0] = ok ? *(const f32x4*)(vg + off) : z;
+                vst[i][1] = ok ? *(const f32x4*)(vg + off + 4) : z;
+            }
         }
     };
     auto store_tile = [&](char* stage) {
 #pragma unroll
         for (int i = 0; i < GPT; ++i) {
             if (!g_on[i]) continue;
-            bf16x8 h8, l8;
-            split8(kst[i][0], kst[i][1], h8, l8);
-            *(bf16x8*)(stage + g_kdst[i]) = h8;
-            *(bf16x8*)(stage + C::kImageBytes + g_kdst[i]) = l8;
-            split8(vst[i][0], vst[i][1], h8, l8);
-            *(bf16x8*)(stage + g_vdst[i]) = h8;
-            *(bf16x8*)(stage + C::kImageBytes + g_vdst[i]) = l8;
+            if constexpr (IN_BF16) {
+                *(f32x4*)(stage + g_kdst[i]) = kst[i][0];
+                *(f32x4*)(stage + g_vdst[i]) = vst[i][0];
+            } else {
+                bf16x8 h8, l8;
+                split8(kst[i][0], kst[i][1], h8, l8);
+                *(bf16x8*)(stage + g_kdst[i]) = h8;
+                *(bf16x8*)(stage + C::kImageBytes + g_kdst[i]) = l8;
+                split8(vst[i][0], vst[i][1], h8, l8);
+                *(bf16x8*)(stage + g_vdst[i]) = h8;
+                *(bf16x8*)(stage + C::kImageBytes + g_vdst[i]) = l8;
+            }
         }
     };
 
@@ -210,11 +238,18 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const int qrow = min(q0 + qb * 32 + lq, n - 1);
-        const float* qr = qg + (int64_t)qrow * p.q_row_stride + hi * 8;
+        const T* qr = qg + (int64_t)qrow * p.q_row_stride + hi * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const f32x4 a = *(const f32x4*)(qr + ks * 16) * p.scale_log2e;
-            const f32x4 c = *(const f32x4*)(qr + ks * 16 + 4) * p.scale_log2e;
+            f32x4 a, c;
+            if constexpr (IN_BF16) {
+                const bf16x8 q8 = *(const bf16x8*)(qr + ks * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = (float)q8[e] * p.scale_log2e, c[e] = (float)q8[e + 4] * p.scale_log2e;
+            } else {
+                a = *(const f32x4*)(qr + ks * 16) * p.scale_log2e;
+                c = *(const f32x4*)(qr + ks * 16 + 4) * p.scale_log2e;
+            }
             split8(a, c, qh[qb][ks], ql[qb][ks]);
         }
     }
@@ -251,13 +286,22 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 kfh = *(const bf16x8*)(kh_lds + k_off[ks]);
-                const bf16x8 kfl = *(const bf16x8*)(kh_lds + C::kImageBytes + k_off[ks]);
+                if constexpr (IN_BF16) {
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) {
-                    if (ks == 0) mfma_from(s[qb], kfl, qh[qb][ks], minit[qb]);
-                    else mfma_acc(s[qb], kfl, qh[qb][ks]);
-                    mfma_acc(s[qb], kfh, ql[qb][ks]);
-                    mfma_acc(s[qb], kfh, qh[qb][ks]);
+                    for (int qb = 0; qb < QB; ++qb) {
+                        if (ks == 0) mfma_from(s[qb], kfh, ql[qb][ks], minit[qb]);
+                        else mfma_acc(s[qb], kfh, ql[qb][ks]);
+                        mfma_acc(s[qb], kfh, qh[qb][ks]);
+                    }
+                } else {
+                    const bf16x8 kfl = *(const bf16x8*)(kh_lds + C::kImageBytes + k_off[ks]);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) {
+                        if (ks == 0) mfma_from(s[qb], kfl, qh[qb][ks], minit[qb]);
+                        else mfma_acc(s[qb], kfl, qh[qb][ks]);
+                        mfma_acc(s[qb], kfh, ql[qb][ks]);
+                        mfma_acc(s[qb], kfh, qh[qb][ks]);
+                    }
                 }
             }
             // let the last product retire (19 wait states cover its 8 passes), tied to the registers the chain writes
@@ -360,13 +404,16 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                         const int off1 = ((4 * t + 2) * (D / 16) + 2 * db) * 128;
                         const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + v_lane_off + off0));
                         const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + v_lane_off + off1));
-                        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + C::kImageBytes + v_lane_off + off0));
-                        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + C::kImageBytes + v_lane_off + off1));
                         const bf16x8 vfh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-                        const bf16x8 vfl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                        if constexpr (!IN_BF16) {
+                            const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + C::kImageBytes + v_lane_off + off0));
+                            const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + C::kImageBytes + v_lane_off + off1));
+                            const bf16x8 vfl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                            for (int qb = 0; qb < QB; ++qb) o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfl, ph[qb][t], o[qb][db], 0, 0, 0);
+                        }
 #pragma unroll
                         for (int qb = 0; qb < QB; ++qb) {
-                            o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfl, ph[qb][t], o[qb][db], 0, 0, 0);
                             o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh, pl[qb][t], o[qb][db], 0, 0, 0);
                             o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh, ph[qb][t], o[qb][db], 0, 0, 0);
                         }
@@ -395,7 +442,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
             const int qi = q0 + qb * 32 + lq;
             float mag = 0.0f;
             if (qi < n) {
-                float* orow = og + (int64_t)qi * p.o_row_stride + 4 * hi;
+                const int64_t o_off = o_slab + (int64_t)qi * p.o_row_stride + 4 * hi;
 #pragma unroll
                 for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -406,7 +453,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                             pk[e] = o[qb][db][4 * g + e] * inv;
                             if (OPT) mag += fabsf(pk[e]);
                         }
-                        *(f32x4*)(orow + db * 32 + 8 * g) = pk;
+                        store4(p, o_off + db * 32 + 8 * g, pk);
                     }
                 if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (m[qb] + __builtin_amdgcn_logf(lt)) * kLn2;
                 if (OPT) ok = ok && (lt < kSplitLimit) && (mag < INFINITY);   // false for NaN as well
@@ -441,44 +488,55 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
         }
         // loads of tile t through buffer descriptors: rows past the end of the slab come back as zeros from the bounds check,
         // so there is no branch (a branch inside the loop body lets LLVM sink vector work out of its slot)
-        const unsigned slab_bytes = ((unsigned)(n - 1) * (unsigned)p.kv_row_stride + D) * 4u;
+        constexpr unsigned ES = sizeof(T);
+        const unsigned slab_bytes = ((unsigned)(n - 1) * (unsigned)p.kv_row_stride + D) * ES;
         const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kg, 0, slab_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vg, 0, slab_bytes, 0x00020000);
-        const unsigned tile_step = (unsigned)kKvSplit * (unsigned)p.kv_row_stride * 4u;
+        const unsigned tile_step = (unsigned)kKvSplit * (unsigned)p.kv_row_stride * ES;
         auto load_k = [&](int t) {
             const unsigned soff = (unsigned)t * tile_step;
 #pragma unroll
             for (int i = 0; i < GPT; ++i) {
-                kst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, g_src[i] * 4, soff, 0));
-                kst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, g_src[i] * 4 + 16, soff, 0));
+                kst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, g_src[i] * ES, soff, 0));
+                if constexpr (!IN_BF16)
+                    kst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, g_src[i] * ES + 16, soff, 0));
             }
         };
         auto load_v = [&](int t) {
             const unsigned soff = (unsigned)t * tile_step;
 #pragma unroll
             for (int i = 0; i < GPT; ++i) {
-                vst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, g_src[i] * 4, soff, 0));
-                vst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, g_src[i] * 4 + 16, soff, 0));
+                vst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, g_src[i] * ES, soff, 0));
+                if constexpr (!IN_BF16)
+                    vst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, g_src[i] * ES + 16, soff, 0));
             }
         };
         auto store_k = [&](char* stage) {
 #pragma unroll
             for (int i = 0; i < GPT; ++i) {
                 if (!g_on[i]) continue;
-                bf16x8 h8, l8;
-                split8c(kst[i][0], kst[i][1], h8, l8);
-                *(bf16x8*)(stage + g_kdst[i]) = h8;
-                *(bf16x8*)(stage + C::kImageBytes + g_kdst[i]) = l8;
+                if constexpr (IN_BF16) {
+                    *(f32x4*)(stage + g_kdst[i]) = kst[i][0];
+                } else {
+                    bf16x8 h8, l8;
+                    split8c(kst[i][0], kst[i][1], h8, l8);
+                    *(bf16x8*)(stage + g_kdst[i]) = h8;
+                    *(bf16x8*)(stage + C::kImageBytes + g_kdst[i]) = l8;
+                }
             }
         };
         auto store_v = [&](char* stage) {
 #pragma unroll
             for (int i = 0; i < GPT; ++i) {
                 if (!g_on[i]) continue;
-                bf16x8 h8, l8;
-                split8c(vst[i][0], vst[i][1], h8, l8);
-                *(bf16x8*)(stage + g_vdst[i]) = h8;
-                *(bf16x8*)(stage + C::kImageBytes + g_vdst[i]) = l8;
+                if constexpr (IN_BF16) {
+                    *(f32x4*)(stage + g_vdst[i]) = vst[i][0];
+                } else {
+                    bf16x8 h8, l8;
+                    split8c(vst[i][0], vst[i][1], h8, l8);
+                    *(bf16x8*)(stage + g_vdst[i]) = h8;
+                    *(bf16x8*)(stage + C::kImageBytes + g_vdst[i]) = l8;
+                }
             }
         };
         auto qk = [&](const char* kh_lds, f32x16 (&s)[QB]) {
@@ -486,12 +544,20 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 kfh = *(const bf16x8*)(kh_lds + k_off[ks]);
-                const bf16x8 kfl = *(const bf16x8*)(kh_lds + C::kImageBytes + k_off[ks]);
+                if constexpr (IN_BF16) {
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) {
-                    s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl, qh[qb][ks], ks == 0 ? zero : s[qb], 0, 0, 0);
-                    s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, ql[qb][ks], s[qb], 0, 0, 0);
-                    s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, qh[qb][ks], s[qb], 0, 0, 0);
+                    for (int qb = 0; qb < QB; ++qb) {
+                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, ql[qb][ks], ks == 0 ? zero : s[qb], 0, 0, 0);
+                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, qh[qb][ks], s[qb], 0, 0, 0);
+                    }
+                } else {
+                    const bf16x8 kfl = *(const bf16x8*)(kh_lds + C::kImageBytes + k_off[ks]);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) {
+                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl, qh[qb][ks], ks == 0 ? zero : s[qb], 0, 0, 0);
+                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, ql[qb][ks], s[qb], 0, 0, 0);
+                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, qh[qb][ks], s[qb], 0, 0, 0);
+                    }
                 }
             }
         };
@@ -530,13 +596,16 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                     const int off1 = ((4 * t + 2) * (D / 16) + 2 * db) * 128;
                     const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + v_lane_off + off0));
                     const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + v_lane_off + off1));
-                    const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + C::kImageBytes + v_lane_off + off0));
-                    const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + C::kImageBytes + v_lane_off + off1));
                     const bf16x8 vfh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-                    const bf16x8 vfl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    if constexpr (!IN_BF16) {
+                        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + C::kImageBytes + v_lane_off + off0));
+                        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + C::kImageBytes + v_lane_off + off1));
+                        const bf16x8 vfl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfl, ph[qb][t], o[qb][db], 0, 0, 0);
+                    }
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) {
-                        o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfl, ph[qb][t], o[qb][db], 0, 0, 0);
                         o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh, pl[qb][t], o[qb][db], 0, 0, 0);
                         o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh, ph[qb][t], o[qb][db], 0, 0, 0);
                     }
@@ -591,8 +660,10 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                         }
                     }
                 }
-                constexpr int MPG = 3 * QB, NG = KS + 2 * DB, NSLOT = NG * MPG;
-                constexpr int NU_S = 8 * QB, NU = 2 * (NU_S + 4 * GPT);   // NU counts half units
+                constexpr int MPG = NPROD * QB, NG = KS + 2 * DB, NSLOT = NG * MPG;
+                constexpr int NU_S = 8 * QB;                                     // score pairs
+                constexpr int NU_C = IN_BF16 ? 2 * GPT : 8 * GPT;               // K/V pieces: plain stores, or half units of the split
+                constexpr int NU = 2 * NU_S + NU_C;                              // half units
                 bf16x8 fh[2], fl[2];       // fragments of the current / next group
                 bf16x8 ch[2][GPT], cl[2][GPT];   // converted pieces (K, V) being assembled
                 const char* k_img = st_oth;                          // K(j+1) hi (lo at + kImageBytes)
@@ -601,24 +672,29 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                     constexpr int G = decltype(gc)::value;
                     if constexpr (G < KS) {
                         fh[G & 1] = *(const bf16x8*)(k_img + k_off[G]);
-                        fl[G & 1] = *(const bf16x8*)(k_img + C::kImageBytes + k_off[G]);
+                        if constexpr (!IN_BF16) fl[G & 1] = *(const bf16x8*)(k_img + C::kImageBytes + k_off[G]);
                     } else {
                         constexpr int t = (G - KS) / DB, db = (G - KS) % DB;
                         constexpr int off0 = ((4 * t + 0) * (D / 16) + 2 * db) * 128;
                         constexpr int off1 = ((4 * t + 2) * (D / 16) + 2 * db) * 128;
                         const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_img + v_lane_off + off0));
                         const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_img + v_lane_off + off1));
-                        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_img + C::kImageBytes + v_lane_off + off0));
-                        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_img + C::kImageBytes + v_lane_off + off1));
                         fh[G & 1] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-                        fl[G & 1] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                        if constexpr (!IN_BF16) {
+                            const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_img + C::kImageBytes + v_lane_off + off0));
+                            const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_img + C::kImageBytes + v_lane_off + off1));
+                            fl[G & 1] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                        }
                     }
                 };
                 // half units: (2u) = exp + row sums of a score pair / split of the first two values of a piece,
                 //             (2u+1) = hi/lo split of that pair / split of the other two values (+ LDS writes of a whole piece)
                 auto unit = [&](auto uc) {
-                    constexpr int U = decltype(uc)::value / 2, H = decltype(uc)::value % 2;
-                    if constexpr (U < NU_S) {
+                    constexpr int X = decltype(uc)::value, U = X / 2, H = X % 2;
+                    if constexpr (X >= 2 * NU_S && IN_BF16) {   // bf16 tensors: a piece is stored as it came
+                        constexpr int c = X - 2 * NU_S, gi = c / 2, which = c % 2;
+                        *(f32x4*)(st_cur + (which ? g_vdst[gi] : g_kdst[gi])) = which ? vst[gi][0] : kst[gi][0];
+                    } else if constexpr (U < NU_S) {
                         constexpr int qb = U / 8, t = (U % 8) / 4, i = 2 * (U % 4);
                         if constexpr (H == 0) {
                             const float p0 = fast_exp2(cur[qb][8 * t + i]), p1 = fast_exp2(cur[qb][8 * t + i + 1]);
@@ -651,14 +727,16 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                     constexpr int I = decltype(ic)::value;
                     constexpr int G = I / MPG, M = I % MPG, term = M / QB, qb = M % QB;   // consecutive products alternate accumulators
                     if constexpr (M == 0 && G + 1 < NG) load_frags(std::integral_constant<int, G + 1>{});
-                    const bf16x8& a = (term == 0) ? fl[G & 1] : fh[G & 1];
+                    // fp32 tensors: lo.hi, hi.lo, hi.hi; bf16 tensors (K, V exact in one term): hi.lo, hi.hi
+                    constexpr bool a_lo = !IN_BF16 && term == 0, b_lo = IN_BF16 ? term == 0 : term == 1;
+                    const bf16x8& a = a_lo ? fl[G & 1] : fh[G & 1];
                     if constexpr (G < KS) {
-                        const bf16x8& bq = (term == 1) ? ql[qb][G] : qh[qb][G];
+                        const bf16x8& bq = b_lo ? ql[qb][G] : qh[qb][G];
                         if constexpr (G == 0 && term == 0) next[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, zero, 0, 0, 0);
                         else next[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, next[qb], 0, 0, 0);
                     } else {
                         constexpr int t = (G - KS) / DB, db = (G - KS) % DB;
-                        const bf16x8& bp = (term == 1) ? plp[qb][t] : php[qb][t];
+                        const bf16x8& bp = b_lo ? plp[qb][t] : php[qb][t];
                         o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bp, o[qb][db], 0, 0, 0);
                     }
                     // units whose slot this is: unit u sits in slot floor(u * NSLOT / NU)
@@ -673,24 +751,24 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
         };
         constexpr std::integral_constant<int, 0> S0{};
         constexpr std::integral_constant<int, 1> S1{};
-        constexpr std::true_type T{};
-        constexpr std::false_type F{};
+        constexpr std::true_type YES{};
+        constexpr std::false_type NO{};
         if (nt == 1) {
-            step(S0, T, T, 0, sa, sb, pha, pla, phb, plb);
+            step(S0, YES, YES, 0, sa, sb, pha, pla, phb, plb);
             pv(pha, pla, smem + 2 * C::kImageBytes);
         } else {
-            step(S0, T, F, 0, sa, sb, pha, pla, phb, plb);       // P(0) -> a
+            step(S0, YES, NO, 0, sa, sb, pha, pla, phb, plb);       // P(0) -> a
             int j = 1;
             for (; j + 2 < nt; j += 2) {                          // j odd here
-                step(S1, F, F, j, sb, sa, phb, plb, pha, pla);     // P(j) -> b, consumes a
-                step(S0, F, F, j + 1, sa, sb, pha, pla, phb, plb); // P(j+1) -> a, consumes b
+                step(S1, NO, NO, j, sb, sa, phb, plb, pha, pla);     // P(j) -> b, consumes a
+                step(S0, NO, NO, j + 1, sa, sb, pha, pla, phb, plb); // P(j+1) -> a, consumes b
             }
             if (nt - j == 2) {
-                step(S1, F, F, j, sb, sa, phb, plb, pha, pla);
-                step(S0, F, T, j + 1, sa, sb, pha, pla, phb, plb);
+                step(S1, NO, NO, j, sb, sa, phb, plb, pha, pla);
+                step(S0, NO, YES, j + 1, sa, sb, pha, pla, phb, plb);
                 pv(pha, pla, smem + 2 * C::kImageBytes);           // V(nt-1), nt-1 even: stage 0
             } else {
-                step(S1, F, T, j, sb, sa, phb, plb, pha, pla);
+                step(S1, NO, YES, j, sb, sa, phb, plb, pha, pla);
                 pv(phb, plb, smem + C::kStageBytes + 2 * C::kImageBytes);   // nt-1 odd: stage 1
             }
         }
@@ -705,7 +783,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
             const int qi = q0 + qb * 32 + lq;
             float mag = 0.0f;
             if (qi < n) {
-                float* orow = og + (int64_t)qi * p.o_row_stride + 4 * hi;
+                const int64_t o_off = o_slab + (int64_t)qi * p.o_row_stride + 4 * hi;
 #pragma unroll
                 for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -716,7 +794,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                             pk[e] = o[qb][db][4 * g + e] * inv;
                             mag += fabsf(pk[e]);
                         }
-                        *(f32x4*)(orow + db * 32 + 8 * g) = pk;
+                        store4(p, o_off + db * 32 + 8 * g, pk);
                     }
                 if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = __builtin_amdgcn_logf(lt) * kLn2;
                 ok = ok && (lt > 1.0f / kSplitLimit) && (lt < kSplitLimit) && (mag < INFINITY);   // false for NaN as well
@@ -732,7 +810,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     if (__syncthreads_or(!ok)) run_tile(std::false_type{});
 }
 
-template <int D, int NWAVES, int QB, int MINBLOCKS, bool PIPE>
+template <int D, int NWAVES, int QB, int MINBLOCKS, bool PIPE, bool IN_BF16 = false>
 static hipError_t launch_split(const FwdParams& p0, int causal, hipStream_t stream)
 {
     FwdParams p = p0;
@@ -742,9 +820,9 @@ static hipError_t launch_split(const FwdParams& p0, int causal, hipStream_t stre
     if (total > 0x7fffffffLL) return hipErrorInvalidValue;
     dim3 grid((unsigned)total), block(NWAVES * kWave);
     if (causal)
-        hipLaunchKernelGGL((fa_fwd_f32_split_kernel<D, NWAVES, QB, true, MINBLOCKS, PIPE>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((fa_fwd_f32_split_kernel<D, NWAVES, QB, true, MINBLOCKS, PIPE, IN_BF16>), grid, block, 0, stream, p);
     else
-        hipLaunchKernelGGL((fa_fwd_f32_split_kernel<D, NWAVES, QB, false, MINBLOCKS, PIPE>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((fa_fwd_f32_split_kernel<D, NWAVES, QB, false, MINBLOCKS, PIPE, IN_BF16>), grid, block, 0, stream, p);
     return hipGetLastError();
 }
 
@@ -759,10 +837,15 @@ static hipError_t launch_split(const FwdParams& p0, int causal, hipStream_t stre
 //   d=128 BH=128 N=1024   non-causal m1 0.253  m3 0.244  m5 0.186 | causal m1 0.243  m3 0.168  m5 0.157
 //   (8-wave workgroups at d=64 / d=32 -- tried as m5..m7 -- lose to m4: 0.79 / 0.70 / 0.84 vs 0.66 at BH=16 N=8192 d=64)
 //   d=32  BH=16  N=8192   non-causal m2 0.476  m3 0.474  m4 0.450 | causal m1 0.328  m3 0.295  m4 0.271   (1.14 | 0.86)
-static int choose_split(const FwdParams& p, int d, int causal)
+static bool split_addressable(const FwdParams& p, int d, unsigned elem_size)
+{
+    return ((uint64_t)(p.n - 1) * (uint64_t)p.kv_row_stride + (uint64_t)d) * elem_size < (1ull << 32);
+}
+
+static int choose_split(const FwdParams& p, int d, int causal, unsigned elem_size)
 {
     // the pipelined pass addresses K/V through 32-bit buffer offsets
-    const bool addressable = ((uint64_t)(p.n - 1) * (uint64_t)p.kv_row_stride + (uint64_t)d) * 4u < (1ull << 32);
+    const bool addressable = split_addressable(p, d, elem_size);
     if (!addressable) return 1;
     const int64_t tiles256 = (int64_t)p.bh * ((p.n + 255) / 256);
     if (d == 128) {
@@ -782,8 +865,8 @@ const char* f32_split_kernel_name() { return "fa_fwd_f32_split_kernel"; }
 
 hipError_t launch_f32_split(const FwdParams& p, int d, int causal, int mode, hipStream_t stream)
 {
-    if (mode == 0) mode = choose_split(p, d, causal);
-    if ((mode == 3 || mode == 4) && ((uint64_t)(p.n - 1) * (uint64_t)p.kv_row_stride + (uint64_t)d) * 4u >= (1ull << 32)) mode -= 2;
+    if (mode == 0) mode = choose_split(p, d, causal, 4);
+    if ((mode == 3 || mode == 4 || mode == 6) && !split_addressable(p, d, 4)) mode = 1;
     switch (d) {
         case 32:
             if (mode == 1) return launch_split<32, 4, 1, 2, false>(p, causal, stream);
@@ -802,6 +885,34 @@ hipError_t launch_f32_split(const FwdParams& p, int d, int causal, int mode, hip
             if (mode == 3) return launch_split<128, 4, 1, 1, true>(p, causal, stream);
             if (mode == 5) return launch_split<128, 8, 1, 1, false>(p, causal, stream);   // 8 waves: 256-row workgroups
             if (mode == 6) return launch_split<128, 8, 1, 1, true>(p, causal, stream);
+            return hipErrorInvalidValue;
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// bf16 tensors through the split machinery (FA_KERNEL_SPLIT with a bf16 dtype): same modes, same choice; out_f32 selects the
+// fp32 or the bf16 output.  Measured (B=2 H=8 N=8192 d=64, fp32 out): see DESIGN.md section 3.5.
+hipError_t launch_bf16_split(const FwdParams& p0, int d, int causal, int out_f32, int mode, hipStream_t stream)
+{
+    FwdParams p = p0;
+    p.o_is_bf16 = out_f32 ? 0 : 1;
+    if (mode == 0) mode = choose_split(p, d, causal, 2);
+    if ((mode == 3 || mode == 4 || mode == 6) && !split_addressable(p, d, 2)) mode = 1;
+    switch (d) {
+        case 32:
+            if (mode == 1) return launch_split<32, 4, 1, 2, false, true>(p, causal, stream);
+            if (mode == 3) return launch_split<32, 4, 1, 2, true, true>(p, causal, stream);
+            if (mode == 4) return launch_split<32, 4, 2, 1, true, true>(p, causal, stream);
+            return hipErrorInvalidValue;
+        case 64:
+            if (mode == 1) return launch_split<64, 4, 1, 2, false, true>(p, causal, stream);
+            if (mode == 3) return launch_split<64, 4, 1, 2, true, true>(p, causal, stream);
+            if (mode == 4) return launch_split<64, 4, 2, 1, true, true>(p, causal, stream);
+            return hipErrorInvalidValue;
+        case 128:
+            if (mode == 1) return launch_split<128, 4, 1, 1, false, true>(p, causal, stream);
+            if (mode == 3) return launch_split<128, 4, 1, 1, true, true>(p, causal, stream);
+            if (mode == 5) return launch_split<128, 8, 1, 1, false, true>(p, causal, stream);
             return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }

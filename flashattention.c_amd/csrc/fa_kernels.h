@@ -12,6 +12,8 @@ hipError_t launch_fwd_f32(const FwdParams& p, int d, int causal, int variant, hi
 hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, int variant, hipStream_t stream);
 // fp32 tensors on the bf16 matrix pipe (three products of two-term bf16 splits); called by launch_fwd_f32
 hipError_t launch_f32_split(const FwdParams& p, int d, int causal, int mode, hipStream_t stream);
+// bf16 tensors through the same split machinery (K, V exact in one term; Q' and P split): the accurate bf16 mode
+hipError_t launch_bf16_split(const FwdParams& p, int d, int causal, int out_f32, int mode, hipStream_t stream);
 
 // bf16 kernels living in their own translation units (called by launch_fwd_bf16)
 hipError_t launch_bf16_pipelined(const FwdParams& p, int d, int nwaves, int causal, int out_f32, int mode, hipStream_t stream);

@@ -75,6 +75,8 @@ def forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = Fa
     with bf16 inputs stores the fp32 accumulator unrounded (FA_DTYPE_BF16_OUT_F32).  fp32 tensors: ``kernel="auto"`` /
     ``"split"`` run both contractions on the bf16 matrix pipe as three products of two-term bf16 splits (within 1e-3 of
     the fp32 reference, see include/flashattn_amd.h), ``kernel="exact"`` (= ``"mfma"``) computes in fp32 arithmetic.
+    bf16 tensors with ``kernel="split"``: the accurate bf16 mode (P and the scaled Q carried in 16 significant bits; ~1e-4 of
+    the fp64 result at scale 1 with ``out_dtype=torch.float32``, at about twice the time of the default kernels).
     """
     bh, n, d = _check_qkv(q, k, v)
     kid = _kernel_id(kernel)
@@ -134,18 +136,23 @@ def time_forward(q, k, v, causal: bool = False, *, scale: float = 1.0, kernel: U
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     if out is None:
         out = torch.empty_like(q)
+    dt = _DTYPES[q.dtype]
+    if out.dtype != q.dtype:
+        if not (q.dtype == torch.bfloat16 and out.dtype == torch.float32):
+            raise TypeError(f"out dtype {out.dtype} not supported for {q.dtype} inputs")
+        dt = _cabi.FA_DTYPE_BF16_OUT_F32
     ms = ctypes.c_float(0.0)
     with torch.cuda.device(q.device):
         if graph:
             torch.cuda.current_stream().synchronize()
             rc = _cabi.lib().fa_time_forward_graph(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), bh, n, d, float(scale),
-                                                   int(bool(causal)), _DTYPES[q.dtype], _kernel_id(kernel), int(warmup), int(iters),
+                                                   int(bool(causal)), dt, _kernel_id(kernel), int(warmup), int(iters),
                                                    ctypes.byref(ms))
             _cabi.check(rc)
             return float(ms.value)
         stream = torch.cuda.current_stream().cuda_stream
         rc = _cabi.lib().fa_time_forward(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), bh, n, d, float(scale),
-                                         int(bool(causal)), _DTYPES[q.dtype], _kernel_id(kernel), ctypes.c_void_p(stream),
+                                         int(bool(causal)), dt, _kernel_id(kernel), ctypes.c_void_p(stream),
                                          int(warmup), int(iters), ctypes.byref(ms))
     _cabi.check(rc)
     return float(ms.value)

@@ -61,7 +61,10 @@ typedef enum fa_kernel {
     FA_KERNEL_AUTO = 0,  /* fastest kernel instantiated for (dtype, d)                                  */
     FA_KERNEL_NAIVE = 1, /* rung-0 scalar kernel: fp32 only, any d <= 256; on-device cross-check        */
     FA_KERNEL_MFMA = 2,  /* the tiled MFMA kernel in the arithmetic of `dtype`; d in {32, 64, 128}          */
-    FA_KERNEL_SPLIT = 3  /* fp32 tensors on the bf16 matrix pipe (split products, see FA_DTYPE_F32); fp32 only */
+    FA_KERNEL_SPLIT = 3  /* split products on the bf16 matrix pipe.  fp32 tensors: see FA_DTYPE_F32 (the AUTO choice there).
+                            bf16 tensors: the ACCURATE bf16 mode -- K, V exact in one term, Q*scale*log2e and P carried as
+                            hi + lo (two products per contraction): max-abs error ~1e-4 against fp64 at scale 1 with
+                            FA_DTYPE_BF16_OUT_F32 (the AUTO kernels round P to 8 bits: ~5e-3), at ~2x their time */
 } fa_kernel;
 
 /*

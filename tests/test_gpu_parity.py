@@ -333,6 +333,40 @@ def test_fuzz_shapes_through_the_dispatch_against_rung0():
     OBSERVED.append(("fuzz through dispatch, worst of 48", worst, bf16_tol(1.0, True)))
 
 
+# bf16 tensors through the split machinery (kernel="split"): K and V are exact in one bf16 term, Q*scale*log2e and P are carried
+# as hi + lo -- the bf16 path that meets the 1e-3 bar of the north star at scale 1 (the fast kernels round P to 8 bits: 5e-3)
+@pytest.mark.parametrize("d,mode", [(64, 0), (64, 1), (64, 3), (64, 4), (128, 0), (128, 1), (128, 3), (128, 5), (32, 0), (32, 1), (32, 3), (32, 4)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_bf16_tensors_accurate_mode(d, mode, causal):
+    q, k, v = (orc.round_to_bf16(randn(s, 2, 700, d)) for s in (1, 2, 3))
+    qd, kd, vd = to_dev(q, k, v, dtype=torch.bfloat16)
+    for scale in (1.0, 0.125):
+        ref, lse_ref = orc.attention_f64(q, k, v, causal=causal, scale=scale, return_lse=True)
+        o, lse = fa.forward(qd, kd, vd, causal, scale=scale, kernel=f"split:{mode}", out_dtype=torch.float32, return_lse=True)
+        check(o, ref, TOL_F32, f"bf16 split:{mode} scale {scale}")          # observed <= 1.3e-4 at scale 1
+        check(lse, lse_ref, TOL_F32, f"bf16 split:{mode} lse scale {scale}")
+        ob = fa.forward(qd, kd, vd, causal, scale=scale, kernel=f"split:{mode}")   # bf16 output: its own rounding only
+        check(ob, ref, bf16_tol(scale, False), f"bf16 split:{mode} bf16 out")
+
+
+@pytest.mark.parametrize("d,mode", [(64, 0), (64, 1), (64, 3), (128, 0), (128, 3), (32, 0)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_bf16_tensors_accurate_mode_redo(d, mode, causal):
+    """The accurate bf16 mode outside the optimistic range: same inputs as the fp32 redo test, bf16-valued."""
+    bh, n = 2, 1536
+    q, k, v = (randn(s, bh, n, d) for s in (41, 42, 43))
+    q *= np.sqrt(64.0 / d)
+    unit = lambda x: x / np.linalg.norm(x, axis=-1, keepdims=True)
+    for r, key, gain in ((3, 700, 14.0), (40, 701, 16.0), (200, 1100, 12.0), (1300, 900, 15.0), (1301, 650, 18.0), (70, 9, 13.0)):
+        k[:, key] = gain * unit(q[:, r])
+    q[1, 500] *= -4.0
+    qb, kb, vb = (orc.round_to_bf16(t) for t in (q, k, v))
+    ref, lse_ref = orc.attention_f64(qb, kb, vb, causal=causal, return_lse=True)
+    o, lse = fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, kernel=f"split:{mode}", out_dtype=torch.float32, return_lse=True)
+    check(o, ref, 3e-3, f"bf16 split:{mode}")
+    check(lse, lse_ref, 3e-3, f"bf16 split:{mode} lse")
+
+
 def test_fuzz_fp32_shapes_through_the_dispatch_against_rung0():
     """fp32 tensors through FA_KERNEL_AUTO (the split kernel and its per-shape tiling choice) against the rung-0 fp32
     kernel on random shapes, including grids that switch between the tilings, ragged lengths and short causal rows."""

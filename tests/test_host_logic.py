@@ -85,9 +85,6 @@ def test_cabi_rejects_bad_arguments_without_touching_a_device():
     assert L.fa_forward(p, p, p, p, 1, 32, 48, 1.0, 0, 0, None) == 2
     assert b"48" in L.fa_last_error()
     assert L.fa_forward_ex(p, p, p, p, None, 1, 32, 64, 1.0, 0, 0, 9, None) == 2
-    # the split kernel is an fp32-tensor kernel: bf16 tensors are refused before any launch
-    assert L.fa_forward_ex(p, p, p, p, None, 1, 32, 64, 1.0, 0, _cabi.FA_DTYPE_BF16, _cabi.FA_KERNEL_SPLIT, None) == 2
-    assert b"fp32" in L.fa_last_error()
     assert L.fa_forward_packed_qkv(p, p, 1, 8, 96, 5, None) == 1      # C % NH != 0
     assert L.fa_forward_packed_qkv(p, p, 1, 8, 96, 2, None) == 2      # hs = 48 not instantiated
     ms = ctypes.c_float()
