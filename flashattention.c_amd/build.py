@@ -25,13 +25,17 @@ LIB_PATH = os.path.join(PKG_DIR, "libflashattn_amd.so")
 DRIVER_PATH = os.path.join(PKG_DIR, "fa_driver")
 ARCH = "gfx950"
 
-LIB_SOURCES = ["fa_api.cpp", "fa_naive.hip", "fa_fwd_f32.hip", "fa_fwd_f32_split.hip", "fa_fwd_bf16.hip", "fa_fwd_bf16_pipelined.hip", "fa_fwd_bf16_pp2.hip", "fa_fwd_bf16_x4.hip", "fa_fwd_bf16_x2.hip"]
-HEADERS = ["fa_common.h", "fa_kernels.h", "fa_bf16_common.h", os.path.join(ROOT, "include", "flashattn_amd.h")]
+# longest translation units first: the thread pool starts them in this order
+LIB_SOURCES = ["fa_fwd_bf16_x4_ablation.hip", "fa_fwd_bf16_x4.hip", "fa_fwd_bf16_x4_causal.hip", "fa_fwd_bf16_x2.hip",
+               "fa_fwd_bf16_pipelined.hip", "fa_split_f32_d64.hip", "fa_split_f32_d128.hip", "fa_split_f32_d32.hip",
+               "fa_split_bf16_d64.hip", "fa_split_bf16_d128.hip", "fa_split_bf16_d32.hip", "fa_fwd_bf16_pp2.hip", "fa_fwd_bf16.hip",
+               "fa_fwd_f32.hip", "fa_fwd_f32_split.hip", "fa_fwd_bf16_split.hip", "fa_naive.hip", "fa_api.cpp"]
+HEADERS = ["fa_common.h", "fa_kernels.h", "fa_bf16_common.h", "fa_split_kernel.h", "fa_bf16_x4_kernel.h", "fa_bf16_step.h", os.path.join(ROOT, "include", "flashattn_amd.h")]
 COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
                 "-I", os.path.join(ROOT, "include")]
 # per-source extras.  The split kernel keeps its fp32 arithmetic scalar: the SLP vectoriser would pair it into
 # v_pk_add_f32 / v_pk_mul_f32, which block the matrix pipe's issue for a full MFMA slot each on gfx950.
-EXTRA_FLAGS = {"fa_fwd_f32_split.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {f"fa_split_{dt}_d{d}.hip": ["-fno-slp-vectorize"] for dt in ("f32", "bf16") for d in (32, 64, 128)}
 
 
 def hipcc() -> str:
@@ -62,7 +66,7 @@ def _compile(src: str, force: bool) -> str:
     return obj
 
 
-def build(force: bool = False, jobs: int = 4, verbose: bool = False) -> str:
+def build(force: bool = False, jobs: int = 8, verbose: bool = False) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     with ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), LIB_SOURCES))
@@ -86,7 +90,7 @@ def build(force: bool = False, jobs: int = 4, verbose: bool = False) -> str:
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
-    ap.add_argument("--jobs", type=int, default=4)
+    ap.add_argument("--jobs", type=int, default=8)
     a = ap.parse_args()
     build(force=a.force, jobs=a.jobs, verbose=True)
     sys.exit(0)

@@ -1,0 +1,11 @@
+// fa_split_bf16_d32.hip -- the split-kernel instantiations for bf16 tensors at head dim 32 (fa_split_kernel.h)
+#include "fa_split_kernel.h"
+
+namespace fa {
+
+hipError_t split_launch_bf16_d32(const FwdParams& p, int causal, int mode, hipStream_t stream)
+{
+    return launch_split_modes<32, true>(p, causal, mode, stream);
+}
+
+}  // namespace fa

@@ -1,0 +1,11 @@
+// fa_split_f32_d32.hip -- the split-kernel instantiations for fp32 tensors at head dim 32 (fa_split_kernel.h)
+#include "fa_split_kernel.h"
+
+namespace fa {
+
+hipError_t split_launch_f32_d32(const FwdParams& p, int causal, int mode, hipStream_t stream)
+{
+    return launch_split_modes<32, false>(p, causal, mode, stream);
+}
+
+}  // namespace fa

@@ -1,0 +1,893 @@
+// fa_split_kernel.h -- fused flash-attention forward on the bf16 matrix pipe with split (hi + lo) operands (gfx950): the kernel
+// template shared by fa_fwd_f32_split.hip (fp32 tensors) and fa_fwd_bf16_split.hip (bf16 tensors, accurate mode).
+//
+// Same contract as fa_fwd_f32.hip (fp32 Q/K/V in, fp32 O out; replaces flash_tiled_coarse{,_causal},
+// /root/reference/src/flashattention.cu:139-579), but both contractions run as THREE v_mfma_f32_32x32x16_bf16 on
+// two-term bf16 splits of their fp32 operands:
+//
+//     x = x_hi + x_lo,   x_hi = bf16(x),  x_lo = bf16(x - x_hi)          (16 significant bits, fp32 exponent range)
+//     a.b ~= a_hi.b_hi + a_lo.b_hi + a_hi.b_lo                            (the dropped a_lo.b_lo is 2^-18 relative)
+//
+// with fp32 accumulation in the matrix core.  The bf16 pipe is 16x the fp32 one on this chip (2.5 PF vs 157 TF dense), so
+// three products still beat v_mfma_f32_32x32x2_f32 by 5x on the matrix pipe, and the result stays within ~2e-4 of the fp64
+// oracle on unit-variance data at scale 1 (~1e-5 at 1/sqrt(d)) -- inside the 1e-3 fp32 tolerance of the path, two orders of
+// magnitude tighter than bf16 tensors.  The error of a score is ~2^-17.6 * sqrt(sum (q_i k_i)^2) <= 5e-6 |q||k| scale; callers
+// whose logits need more than that select the exact kernel (FA_KERNEL_MFMA).  fp32 range is kept (bf16 exponent).
+//
+//   workgroup   NWAVES waves x QB blocks of 32 query rows; K/V tiles of 32 keys.
+//   HBM -> LDS  fp32 K/V rows are loaded into registers (two 16-byte loads per 8 values), split there, and written as FOUR
+//               bf16 images per tile (K_hi, K_lo, V_hi, V_lo) in the layouts of fa_bf16_common.h: K row-major with
+//               XOR-swizzled 16-byte slots (ds_read_b128 A fragments), V as [key/4][col/16][4][16] sub-tiles
+//               (ds_read_b64_tr_b16 hands out V^T fragments).  Rows past the end of the slab are zeros.
+//   S^T = K Q'^T   Q' = Q * scale*log2(e) in fp32 (one rounding per element), then split: scores arrive in the exp2 domain.
+//   O^T += V^T P^T   same key permutation trick as the bf16 kernels: P never leaves its registers (split there into hi/lo).
+//   softmax     optimistic, in two flavours selected per shape by choose_split():
+//     run_fast  reference-free: p = exp2(s), nothing between the matrix core and v_exp_f32; software pipelined two tiles
+//               deep with a static slot schedule (one matrix instruction, then its share of the vector work) so that the
+//               single wave of a SIMD keeps both pipes busy -- see the comment at run_fast.
+//     run_tile<OPT>  p = exp2(s - m0) with m0 the row maximum of the first tile folded into the accumulator the first
+//               product starts from; phases in sequence, tiles above a causal wave's diagonal skipped (short causal rows).
+//               fp32 P, l and O have 2^127 of head room either way: a row whose sum stays inside (2^-100, 2^100) with finite
+//               outputs provably lost nothing.  Any other row sends its workgroup to
+//     run_tile<!OPT>  the textbook running maximum (p <= 1), correct for every input; results are stored before the vote, a
+//               rejected tile is simply overwritten.
+#pragma once
+#include "fa_bf16_common.h"
+#include "fa_kernels.h"
+#include <type_traits>
+#include <utility>
+
+namespace fa {
+
+constexpr int kKvSplit = 32;         // keys per tile
+constexpr float kSplitLimit = 0x1p100f;  // optimistic pass: a row sum below this proves that no term overflowed
+
+template <int D>
+struct SplitCfg {
+    static constexpr int kRowBytes = 2 * D;
+    static constexpr int kImageBytes = kKvSplit * kRowBytes;  // one bf16 image (hi or lo) of a K or V tile
+    static constexpr int kStageBytes = 4 * kImageBytes;       // K_hi, K_lo, V_hi, V_lo
+    static constexpr int kGroups = kKvSplit * D / 8;          // 8-element (32-byte fp32) groups per tile
+};
+
+// two-term bf16 split of a pair of fp32 values: hi = bf16(x) (round to nearest even), lo = bf16(x - hi).  The two
+// conversions stay visible to hipcc (it pads the hazards around them: transcendental result -> VALU, VALU -> MFMA operand);
+// the four instructions in between are asm so that they stay scalar: v_pk_add_f32 blocks the matrix pipe's issue.
+__device__ __forceinline__ void split2(float a, float b, bf16x2& hi, bf16x2& lo)
+{
+    hi[0] = (__bf16)a;
+    hi[1] = (__bf16)b;
+    float la, lb;
+    asm("v_lshlrev_b32 %0, 16, %2\n\tv_and_b32 %1, 0xffff0000, %2\n\tv_sub_f32 %0, %3, %0\n\tv_sub_f32 %1, %4, %1"
+        : "=&v"(la), "=&v"(lb)
+        : "v"(__builtin_bit_cast(unsigned, hi)), "v"(a), "v"(b));
+    lo[0] = (__bf16)la;
+    lo[1] = (__bf16)lb;
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>), in order: compile-time indices for the slot schedule
+template <class F, int... Is>
+__device__ __forceinline__ void for_each_index(F&& f, std::integer_sequence<int, Is...>)
+{
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+
+// the same split in plain C++ (this file is compiled without the SLP vectoriser, so the subtractions stay scalar): every
+// instruction visible to hipcc's scheduler and hazard padding -- used by the software-pipelined fast pass
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ void split2c(float a, float b, bf16x2& hi, bf16x2& lo)
+{
+    const f32x2_t ab = {a, b};
+    hi = __builtin_convertvector(ab, bf16x2);
+    const f32x2_t hf = __builtin_convertvector(hi, f32x2_t);
+    const f32x2_t lv = {a - hf[0], b - hf[1]};
+    lo = __builtin_convertvector(lv, bf16x2);
+}
+__device__ __forceinline__ void split8c(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {
+        bf16x2 h, l;
+        split2c(a[i], a[i + 1], h, l);
+        hi[i] = h[0], hi[i + 1] = h[1], lo[i] = l[0], lo[i + 1] = l[1];
+        split2c(b[i], b[i + 1], h, l);
+        hi[i + 4] = h[0], hi[i + 5] = h[1], lo[i + 4] = l[0], lo[i + 5] = l[1];
+    }
+}
+
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {
+        bf16x2 h, l;
+        split2(a[i], a[i + 1], h, l);
+        hi[i] = h[0], hi[i + 1] = h[1], lo[i] = l[0], lo[i + 1] = l[1];
+        split2(b[i], b[i + 1], h, l);
+        hi[i + 4] = h[0], hi[i + 5] = h[1], lo[i + 4] = l[0], lo[i + 5] = l[1];
+    }
+}
+
+__device__ __forceinline__ void split_p(const f32x16& s, int base, bf16x8& hi, bf16x8& lo)
+{
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        bf16x2 h, l;
+        split2(s[base + i], s[base + i + 1], h, l);
+        hi[i] = h[0], hi[i + 1] = h[1], lo[i] = l[0], lo[i + 1] = l[1];
+    }
+}
+
+// The K.Q'^T chain is asm: its first product reads the accumulator from registers DISTINCT from its destination (the
+// builtin insists on D == C and copies the 16 registers of C first), and hipcc must not be tempted to park the scores in
+// AGPRs between products.  hipcc knows nothing about the inside of an asm statement, hence
+//   s_nop 1   in front of every product: an operand may have been copied into place (v_accvgpr_read_b32, v_mov_b32) by
+//             the instruction before, and VALU write -> MFMA read needs two wait states;
+//   scores_retire() after the chain, before any VALU instruction may read the scores.
+__device__ __forceinline__ void mfma_from(f32x16& d, const bf16x8& a, const bf16x8& b, const f32x16& c)
+{
+    asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+}
+__device__ __forceinline__ void mfma_acc(f32x16& d, const bf16x8& a, const bf16x8& b)
+{
+    asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+}
+
+// four consecutive output values: fp32, or bf16 when the caller's O is bf16 (p.o_is_bf16, bf16 tensors only)
+__device__ __forceinline__ void store4(const FwdParams& p, int64_t off, const f32x4& v)
+{
+    if (p.o_is_bf16) {
+        bf16x4 b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = (__bf16)v[e];
+        *(bf16x4*)((__bf16*)p.o + off) = b;
+    } else {
+        *(f32x4*)((float*)p.o + off) = v;
+    }
+}
+
+// IN_BF16: bf16 tensors through the same machinery ("accurate" bf16 mode, FA_KERNEL_SPLIT with a bf16 dtype): K and V are
+// exact in one bf16 term, so only Q' = Q*scale*log2(e) and P are split -- two products per contraction instead of three, no
+// conversion work -- and the result is as close to the fp64 oracle as with fp32 tensors (P is not rounded to 8 bits).
+template <int D, int NWAVES, int QB, bool CAUSAL, int MINBLOCKS, bool PIPE, bool IN_BF16>
+__global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_kernel(FwdParams p)
+{
+    using C = SplitCfg<D>;
+    using T = std::conditional_t<IN_BF16, __bf16, float>;   // element type of Q, K, V
+    constexpr int NPROD = IN_BF16 ? 2 : 3;                  // matrix products per contraction
+    constexpr int KS = D / 16;   // k-steps of S^T = K Q^T
+    constexpr int DB = D / 32;   // 32-wide blocks of the head dim in O^T
+    constexpr int NT = NWAVES * kWave;
+    constexpr int BM = NWAVES * QB * 32;
+    constexpr int GPT = (C::kGroups + NT - 1) / NT;  // groups per thread and tile
+
+    __shared__ __attribute__((aligned(1024))) char smem[2 * C::kStageBytes];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, hi = lane >> 5;
+
+    const int total = p.bh * p.q_tiles;
+    const int w = xcd_remap(blockIdx.x, total);
+    const int slab = w / p.q_tiles;
+    int qt = w % p.q_tiles;
+    if (CAUSAL) qt = p.q_tiles - 1 - qt;  // longest (latest) q tiles first
+    const int n = p.n;
+    const int q0 = qt * BM + wave * (QB * 32);
+
+    const int b = slab / p.heads, h = slab % p.heads;
+    const T* qg = (const T*)p.q + b * p.q_batch_stride + h * p.q_head_stride;
+    const T* kg = (const T*)p.k + b * p.kv_batch_stride + h * p.kv_head_stride;
+    const T* vg = (const T*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
+    const int64_t o_slab = b * p.o_batch_stride + h * p.o_head_stride;   // elements (fp32 or bf16 output, p.o_is_bf16)
+
+    int kv_end = n;
+    if (CAUSAL) kv_end = min(n, qt * BM + BM);
+    const int nt = (kv_end + kKvSplit - 1) / kKvSplit;
+
+    // ---- this thread's pieces of a tile: group g = tid + i * NT -> (row, 8-column slot) of K and of V
+    int g_row[GPT], g_src[GPT], g_kdst[GPT], g_vdst[GPT];
+    bool g_on[GPT];
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+        const int g = (tid + i * NT) % C::kGroups;   // d = 32: the upper half of the workgroup duplicates the lower half's pieces
+        g_on[i] = true;
+        const int row = g / (D / 8), c8 = g % (D / 8);
+        g_row[i] = row;
+        g_src[i] = row * p.kv_row_stride + c8 * 8;
+        g_kdst[i] = row * C::kRowBytes + ((c8 ^ k_swizzle<D>(row)) * 16);
+        g_vdst[i] = 2 * C::kImageBytes + ((row / 4) * (D / 16) + c8 / 2) * 128 + (row % 4) * 32 + (c8 & 1) * 16;
+    }
+    f32x4 kst[GPT][2], vst[GPT][2];
+    auto load_tile = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) {
+            const bool ok = g_on[i] && (kv0 + g_row[i] < n);
+            const int64_t off = (int64_t)kv0 * p.kv_row_stride + g_src[i];
+            const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (IN_BF16) {   // eight bf16 values = one 16-byte register group, passed through unchanged
+                kst[i][0] = ok ? *(const f32x4*)(kg + off) : z;
+                vst[i][0] = ok ? *(const f32x4*)(vg + off) : z;
+            } else {
+                kst[i][0] = ok ? *(const f32x4*)(kg + off) : z;
+                kst[i][1] = ok ? *(const f32x4*)(kg + off + 4) : z;
+                vst[i][0] = ok ? *(const f32x4*)(vg + off) : z;
+                vst[i][1] = ok ? *(const f32x4*)(vg + off + 4) : z;
+            }
+        }
+    };
+    auto store_tile = [&](char* stage) {
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) {
+            if (!g_on[i]) continue;
+            if constexpr (IN_BF16) {
+                *(f32x4*)(stage + g_kdst[i]) = kst[i][0];
+                *(f32x4*)(stage + g_vdst[i]) = vst[i][0];
+            } else {
+                bf16x8 h8, l8;
+                split8(kst[i][0], kst[i][1], h8, l8);
+                *(bf16x8*)(stage + g_kdst[i]) = h8;
+                *(bf16x8*)(stage + C::kImageBytes + g_kdst[i]) = l8;
+                split8(vst[i][0], vst[i][1], h8, l8);
+                *(bf16x8*)(stage + g_vdst[i]) = h8;
+                *(bf16x8*)(stage + C::kImageBytes + g_vdst[i]) = l8;
+            }
+        }
+    };
+
+    // ---- Q' fragments (B operand of S^T = K Q'^T), hi and lo: lane (lq, hi) holds Q'[q][16*ks + 8*hi .. +7]
+    bf16x8 qh[QB][KS], ql[QB][KS];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qrow = min(q0 + qb * 32 + lq, n - 1);
+        const T* qr = qg + (int64_t)qrow * p.q_row_stride + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            f32x4 a, c;
+            if constexpr (IN_BF16) {
+                const bf16x8 q8 = *(const bf16x8*)(qr + ks * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = (float)q8[e] * p.scale_log2e, c[e] = (float)q8[e + 4] * p.scale_log2e;
+            } else {
+                a = *(const f32x4*)(qr + ks * 16) * p.scale_log2e;
+                c = *(const f32x4*)(qr + ks * 16 + 4) * p.scale_log2e;
+            }
+            split8(a, c, qh[qb][ks], ql[qb][ks]);
+        }
+    }
+
+    const int k_row_off = lq * C::kRowBytes;
+    const int k_g = hi ^ k_swizzle<D>(lq);
+    int k_off[KS];   // per-lane byte offset of the K fragment of k-step ks inside an image (swizzle resolved once)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) k_off[ks] = k_row_off + (((2 * ks) ^ k_g) * 16);
+    const int li = lane & 15;
+    const int v_lane_off = (hi * (D / 16) + ((lane >> 4) & 1)) * 128 + (li >> 2) * 32 + (li & 3) * 8;
+
+    // The whole tile, OPT = optimistic pass (fixed reference m0) or the textbook redo.  Returns whether this lane's rows
+    // came out inside the range the optimistic pass can prove.
+    auto run_tile = [&](auto opt_c) -> bool {
+        constexpr bool OPT = decltype(opt_c)::value;
+        f32x16 o[QB][DB];
+        f32x16 minit[QB];   // -m_ref of this lane's row in all 16 registers: the accumulator the first product starts from
+        float m[QB], l[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            m[qb] = 0.0f;
+            l[qb] = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) minit[qb][r] = 0.0f;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.0f;
+        }
+
+        // scores of one tile for all QB blocks: three products per k-step, the first one starting from minit
+        auto scores = [&](const char* kh_lds, f32x16 (&s)[QB]) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kfh = *(const bf16x8*)(kh_lds + k_off[ks]);
+                if constexpr (IN_BF16) {
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) {
+                        if (ks == 0) mfma_from(s[qb], kfh, ql[qb][ks], minit[qb]);
+                        else mfma_acc(s[qb], kfh, ql[qb][ks]);
+                        mfma_acc(s[qb], kfh, qh[qb][ks]);
+                    }
+                } else {
+                    const bf16x8 kfl = *(const bf16x8*)(kh_lds + C::kImageBytes + k_off[ks]);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) {
+                        if (ks == 0) mfma_from(s[qb], kfl, qh[qb][ks], minit[qb]);
+                        else mfma_acc(s[qb], kfl, qh[qb][ks]);
+                        mfma_acc(s[qb], kfh, ql[qb][ks]);
+                        mfma_acc(s[qb], kfh, qh[qb][ks]);
+                    }
+                }
+            }
+            // let the last product retire (19 wait states cover its 8 passes), tied to the registers the chain writes
+            if constexpr (QB == 1) asm volatile("s_nop 15\n\ts_nop 2" : "+v"(s[0]));
+            else asm volatile("s_nop 15\n\ts_nop 2" : "+v"(s[0]), "+v"(s[QB - 1]));
+        };
+        auto mask = [&](f32x16& sq, int kv0, int qi) {
+            asm volatile("; mask" ::: "memory");  // not speculatable: keeps the caller's wave-uniform `if` a real branch
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kv0 + 4 * hi + (r & 3) + 8 * (r >> 2);
+                if ((key >= n) || (CAUSAL && key > qi)) sq[r] = -INFINITY;
+            }
+        };
+        auto row_max = [&](const f32x16& sq) {
+            float mx = fmaxf(sq[0], sq[1]);
+#pragma unroll
+            for (int r = 2; r < 16; r += 2) mx = max3_safe(mx, sq[r], sq[r + 1]);
+            return xhalf_max(mx);
+        };
+
+        load_tile(0);
+        store_tile(smem);
+        __syncthreads();
+
+        if constexpr (OPT) {
+            // reference of each row: the maximum over the first tile (every row sees key 0, so it is finite for finite inputs)
+            f32x16 s[QB];
+            scores(smem, s);
+            const bool need_mask = (kKvSplit > n) || (CAUSAL && (kKvSplit - 1 > q0));
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                if (need_mask) mask(s[qb], 0, q0 + qb * 32 + lq);
+                m[qb] = row_max(s[qb]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) minit[qb][r] = -m[qb];
+            }
+        }
+
+        // one K/V tile; STG (compile-time) is the LDS stage it lives in, so every fragment read is base register + immediate
+        auto step = [&](auto stg_c, int j) {
+            constexpr int STG = decltype(stg_c)::value;
+            const bool more = j + 1 < nt;
+            if (more) load_tile((j + 1) * kKvSplit);
+            const int kv0 = j * kKvSplit;
+            const char* kh_lds = smem + STG * C::kStageBytes;
+            const char* vh_lds = kh_lds + 2 * C::kImageBytes;
+
+            if (!(CAUSAL && kv0 > q0 + QB * 32 - 1)) {   // else: tile entirely above this wave's diagonal
+                f32x16 s[QB];
+                scores(kh_lds, s);   // S'^T = K Q'^T - m_ref
+
+                // ================= softmax (registers only) =================
+                const bool need_mask = (kv0 + kKvSplit > n) || (CAUSAL && (kv0 + kKvSplit - 1 > q0));
+                bf16x8 ph[QB][2], pl[QB][2];
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    if (need_mask) mask(s[qb], kv0, q0 + qb * 32 + lq);
+                    if constexpr (!OPT) {
+                        const float mx = row_max(s[qb]);                  // row maximum relative to m_ref
+                        const bool grow = (j == 0) || (mx > 0.0f);        // tile 0 sets the reference (m_ref starts at 0)
+                        if (__builtin_amdgcn_ballot_w64(grow) != 0) {     // wave-uniform
+                            asm volatile("; rescale" ::: "memory");
+                            const float delta = grow ? mx : 0.0f;
+                            const float alpha = (j == 0) ? 0.0f : fast_exp2(-delta);
+                            m[qb] += delta;
+                            l[qb] *= alpha;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                s[qb][r] -= delta;
+                                minit[qb][r] = -m[qb];
+                            }
+#pragma unroll
+                            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) o[qb][db][r] *= alpha;
+                        }
+                    }
+                    float rs0 = 0.0f, rs1 = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        s[qb][r] = fast_exp2(s[qb][r]);
+                        s[qb][r + 1] = fast_exp2(s[qb][r + 1]);
+                        // scalar adds (v_pk_add_f32 blocks the matrix pipe's issue); the s_nop is the wait state a
+                        // transcendental result needs before a plain VALU instruction may read it -- invisible to hipcc here
+                        asm("s_nop 0\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3"
+                            : "+v"(rs0), "+v"(rs1) : "v"(s[qb][r]), "v"(s[qb][r + 1]));
+                    }
+                    l[qb] += rs0 + rs1;
+                    split_p(s[qb], 0, ph[qb][0], pl[qb][0]);
+                    split_p(s[qb], 8, ph[qb][1], pl[qb][1]);
+                }
+
+                // ================= O^T += V^T P^T, three products =================
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int db = 0; db < DB; ++db) {
+                        const int off0 = ((4 * t + 0) * (D / 16) + 2 * db) * 128;
+                        const int off1 = ((4 * t + 2) * (D / 16) + 2 * db) * 128;
+                        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + v_lane_off + off0));
+                        const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + v_lane_off + off1));
+                        const bf16x8 vfh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                        if constexpr (!IN_BF16) {
+                            const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + C::kImageBytes + v_lane_off + off0));
+                            const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + C::kImageBytes + v_lane_off + off1));
+                            const bf16x8 vfl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                            for (int qb = 0; qb < QB; ++qb) o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfl, ph[qb][t], o[qb][db], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) {
+                            o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh, pl[qb][t], o[qb][db], 0, 0, 0);
+                            o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh, ph[qb][t], o[qb][db], 0, 0, 0);
+                        }
+                    }
+            }
+
+            // stage STG^1 was last read in step j-1; every wave has passed the barrier that ended that step
+            if (more) store_tile(smem + (STG ^ 1) * C::kStageBytes);
+            __syncthreads();
+        };
+
+        int j = 0;
+        for (; j + 1 < nt; j += 2) {
+            step(std::integral_constant<int, 0>{}, j);
+            step(std::integral_constant<int, 1>{}, j + 1);
+        }
+        if (j < nt) step(std::integral_constant<int, 0>{}, j);
+
+        // ================= epilogue: O / l, store =================
+        mfma_drain();  // the loop exit is a branch: the last P.V MFMAs may still be in flight
+        bool ok = true;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const float lt = xhalf_sum(l[qb]);
+            const float inv = 1.0f / lt;
+            const int qi = q0 + qb * 32 + lq;
+            float mag = 0.0f;
+            if (qi < n) {
+                const int64_t o_off = o_slab + (int64_t)qi * p.o_row_stride + 4 * hi;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            pk[e] = o[qb][db][4 * g + e] * inv;
+                            if (OPT) mag += fabsf(pk[e]);
+                        }
+                        store4(p, o_off + db * 32 + 8 * g, pk);
+                    }
+                if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (m[qb] + __builtin_amdgcn_logf(lt)) * kLn2;
+                if (OPT) ok = ok && (lt < kSplitLimit) && (mag < INFINITY);   // false for NaN as well
+            }
+        }
+        return ok;
+    };
+
+    // -----------------------------------------------------------------------------------------------------------------
+    // The fast pass: reference-free optimistic softmax, p = exp2(s) -- no maximum, no subtraction, nothing between the
+    // matrix core and v_exp_f32 -- software pipelined two tiles deep.  One wave cannot overlap its own dependent phases, and
+    // a second wave on the SIMD does not help either (a wave waiting to issue an MFMA holds the vector issue port), so
+    // iteration j gives the matrix pipe two jobs that do not depend on this iteration's VALU work:
+    //      matrix pipe   S(j+1) = K(j+1) Q'^T          and    O += V(j-1)^T P(j-1)^T
+    //      VALU          P(j) = split(exp2(S(j)))      and    the fp32 -> hi/lo conversion of K(j+2), V(j)
+    // in ONE basic block of plain builtins, which hipcc's scheduler interleaves (sched_group_barrier pins the rhythm).
+    // K(j+2) replaces K(j) and V(j) replaces V(j-2) in their two-stage LDS rings at the end of the iteration; one barrier per
+    // tile.  A causal wave does not skip the (at most 2*QB*NWAVES - 1) tiles above its diagonal, it masks them: no branches.
+    // fp32 P, l and O have 2^127 of head room either way: a row whose sum ends up in (2^-100, 2^100) with finite outputs
+    // provably lost nothing; any other row sends its workgroup to the textbook redo above.
+    // -----------------------------------------------------------------------------------------------------------------
+    auto run_fast = [&]() -> bool {
+        f32x16 o[QB][DB];
+        float la[QB], lb[QB];   // two partial row sums per block (even / odd score registers)
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            la[qb] = lb[qb] = 0.0f;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.0f;
+        }
+        // loads of tile t through buffer descriptors: rows past the end of the slab come back as zeros from the bounds check,
+        // so there is no branch (a branch inside the loop body lets LLVM sink vector work out of its slot)
+        constexpr unsigned ES = sizeof(T);
+        const unsigned slab_bytes = ((unsigned)(n - 1) * (unsigned)p.kv_row_stride + D) * ES;
+        const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kg, 0, slab_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vg, 0, slab_bytes, 0x00020000);
+        const unsigned tile_step = (unsigned)kKvSplit * (unsigned)p.kv_row_stride * ES;
+        auto load_k = [&](int t) {
+            const unsigned soff = (unsigned)t * tile_step;
+#pragma unroll
+            for (int i = 0; i < GPT; ++i) {
+                kst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, g_src[i] * ES, soff, 0));
+                if constexpr (!IN_BF16)
+                    kst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, g_src[i] * ES + 16, soff, 0));
+            }
+        };
+        auto load_v = [&](int t) {
+            const unsigned soff = (unsigned)t * tile_step;
+#pragma unroll
+            for (int i = 0; i < GPT; ++i) {
+                vst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, g_src[i] * ES, soff, 0));
+                if constexpr (!IN_BF16)
+                    vst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, g_src[i] * ES + 16, soff, 0));
+            }
+        };
+        auto store_k = [&](char* stage) {
+#pragma unroll
+            for (int i = 0; i < GPT; ++i) {
+                if (!g_on[i]) continue;
+                if constexpr (IN_BF16) {
+                    *(f32x4*)(stage + g_kdst[i]) = kst[i][0];
+                } else {
+                    bf16x8 h8, l8;
+                    split8c(kst[i][0], kst[i][1], h8, l8);
+                    *(bf16x8*)(stage + g_kdst[i]) = h8;
+                    *(bf16x8*)(stage + C::kImageBytes + g_kdst[i]) = l8;
+                }
+            }
+        };
+        auto store_v = [&](char* stage) {
+#pragma unroll
+            for (int i = 0; i < GPT; ++i) {
+                if (!g_on[i]) continue;
+                if constexpr (IN_BF16) {
+                    *(f32x4*)(stage + g_vdst[i]) = vst[i][0];
+                } else {
+                    bf16x8 h8, l8;
+                    split8c(vst[i][0], vst[i][1], h8, l8);
+                    *(bf16x8*)(stage + g_vdst[i]) = h8;
+                    *(bf16x8*)(stage + C::kImageBytes + g_vdst[i]) = l8;
+                }
+            }
+        };
+        auto qk = [&](const char* kh_lds, f32x16 (&s)[QB]) {
+            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kfh = *(const bf16x8*)(kh_lds + k_off[ks]);
+                if constexpr (IN_BF16) {
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) {
+                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, ql[qb][ks], ks == 0 ? zero : s[qb], 0, 0, 0);
+                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, qh[qb][ks], s[qb], 0, 0, 0);
+                    }
+                } else {
+                    const bf16x8 kfl = *(const bf16x8*)(kh_lds + C::kImageBytes + k_off[ks]);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) {
+                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl, qh[qb][ks], ks == 0 ? zero : s[qb], 0, 0, 0);
+                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, ql[qb][ks], s[qb], 0, 0, 0);
+                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, qh[qb][ks], s[qb], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        // P(j) = split(exp2(S(j))), row sums
+        auto softmax = [&](f32x16 (&s)[QB], bf16x8 (&ph)[QB][2], bf16x8 (&pl)[QB][2], bool need_mask, int kv0) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                if (need_mask) {
+                    asm volatile("; mask" ::: "memory");  // not speculatable: keeps the wave-uniform `if` a real branch
+                    const int qi = q0 + qb * 32 + lq;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kv0 + 4 * hi + (r & 3) + 8 * (r >> 2);
+                        if ((key >= n) || (CAUSAL && key > qi)) s[qb][r] = -INFINITY;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int i = 0; i < 8; i += 2) {
+                        const float p0 = fast_exp2(s[qb][8 * t + i]), p1 = fast_exp2(s[qb][8 * t + i + 1]);
+                        la[qb] += p0;
+                        lb[qb] += p1;
+                        bf16x2 h2, l2;
+                        split2c(p0, p1, h2, l2);
+                        ph[qb][t][i] = h2[0], ph[qb][t][i + 1] = h2[1], pl[qb][t][i] = l2[0], pl[qb][t][i + 1] = l2[1];
+                    }
+            }
+        };
+        auto pv = [&](const bf16x8 (&ph)[QB][2], const bf16x8 (&pl)[QB][2], const char* vh_lds) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const int off0 = ((4 * t + 0) * (D / 16) + 2 * db) * 128;
+                    const int off1 = ((4 * t + 2) * (D / 16) + 2 * db) * 128;
+                    const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + v_lane_off + off0));
+                    const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + v_lane_off + off1));
+                    const bf16x8 vfh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    if constexpr (!IN_BF16) {
+                        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + C::kImageBytes + v_lane_off + off0));
+                        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vh_lds + C::kImageBytes + v_lane_off + off1));
+                        const bf16x8 vfl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfl, ph[qb][t], o[qb][db], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) {
+                        o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh, pl[qb][t], o[qb][db], 0, 0, 0);
+                        o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh, ph[qb][t], o[qb][db], 0, 0, 0);
+                    }
+                }
+        };
+        auto needs_mask = [&](int kv0) { return (kv0 + kKvSplit > n) || (CAUSAL && (kv0 + kKvSplit - 1 > q0)); };
+
+        // ---- prologue: K(0) and K(1) staged, scores of tile 0 under way
+        load_k(0);
+        store_k(smem);
+        load_k(1);
+        store_k(smem + C::kStageBytes);
+        __syncthreads();
+        f32x16 sa[QB], sb[QB];
+        bf16x8 pha[QB][2], pla[QB][2], phb[QB][2], plb[QB][2];
+        qk(smem, sa);
+        __syncthreads();   // iteration 0 overwrites K(0) with K(2): every wave must have read its K(0) fragments first
+
+        // Iteration j, tile j in stage STG = j & 1.  In: scores `cur` of tile j, P `pprev` of tile j-1.  Out: scores `next`
+        // of tile j+1, P `pcur` of tile j.  FIRST has no P.V, LAST no K.Q^T; only a LAST or causal iteration can need masks.
+        auto step = [&](auto stg_c, auto first_c, auto last_c, int j, f32x16 (&cur)[QB], f32x16 (&next)[QB],
+                        bf16x8 (&phc)[QB][2], bf16x8 (&plc)[QB][2], bf16x8 (&php)[QB][2], bf16x8 (&plp)[QB][2]) {
+            constexpr int STG = decltype(stg_c)::value;
+            constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+            char* st_cur = smem + STG * C::kStageBytes;
+            char* st_oth = smem + (STG ^ 1) * C::kStageBytes;
+            if (!LAST) load_k(j + 2);
+            load_v(j);
+            const int kv0 = j * kKvSplit;
+            if constexpr (FIRST || LAST) {   // executed once each: plain phases
+                if (!LAST) qk(st_oth, next);                                   // K(j+1)
+                softmax(cur, phc, plc, (LAST || CAUSAL) && needs_mask(kv0), kv0);
+                if (!FIRST) pv(php, plp, st_oth + 2 * C::kImageBytes);          // V(j-1)
+                if (!LAST) store_k(st_cur);                                     // K(j+2) over K(j)
+                store_v(st_cur);                                                // V(j) over V(j-2)
+            } else {
+                // ---- the steady state: a static slot schedule.  Slot I issues ONE matrix instruction -- group g = I / MPG
+                // is a k-step of K(j+1).Q'^T (g < KS) or a (key half, head-dim block) of V(j-1)^T.P(j-1)^T -- preceded
+                // by the fragment reads of the NEXT group and followed by its share of the vector work (a unit = one
+                // pair of scores: 2 exp, 2 adds, split; or four fp32 values of the K(j+2) / V(j) pieces of this thread:
+                // split, and the LDS writes once a piece is complete).  sched_barrier pins the slots; inside a slot hipcc
+                // orders (and pads) as it likes.
+                if (CAUSAL && needs_mask(kv0)) {
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) {
+                        asm volatile("; mask" ::: "memory");
+                        const int qi = q0 + qb * 32 + lq;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = kv0 + 4 * hi + (r & 3) + 8 * (r >> 2);
+                            if (key > qi) cur[qb][r] = -INFINITY;
+                        }
+                    }
+                }
+                constexpr int MPG = NPROD * QB, NG = KS + 2 * DB, NSLOT = NG * MPG;
+                constexpr int NU_S = 8 * QB;                                     // score pairs
+                constexpr int NU_C = IN_BF16 ? 2 * GPT : 8 * GPT;               // K/V pieces: plain stores, or half units of the split
+                constexpr int NU = 2 * NU_S + NU_C;                              // half units
+                bf16x8 fh[2], fl[2];       // fragments of the current / next group
+                bf16x8 ch[2][GPT], cl[2][GPT];   // converted pieces (K, V) being assembled
+                const char* k_img = st_oth;                          // K(j+1) hi (lo at + kImageBytes)
+                const char* v_img = st_oth + 2 * C::kImageBytes;     // V(j-1) hi
+                auto load_frags = [&](auto gc) {
+                    constexpr int G = decltype(gc)::value;
+                    if constexpr (G < KS) {
+                        fh[G & 1] = *(const bf16x8*)(k_img + k_off[G]);
+                        if constexpr (!IN_BF16) fl[G & 1] = *(const bf16x8*)(k_img + C::kImageBytes + k_off[G]);
+                    } else {
+                        constexpr int t = (G - KS) / DB, db = (G - KS) % DB;
+                        constexpr int off0 = ((4 * t + 0) * (D / 16) + 2 * db) * 128;
+                        constexpr int off1 = ((4 * t + 2) * (D / 16) + 2 * db) * 128;
+                        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_img + v_lane_off + off0));
+                        const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_img + v_lane_off + off1));
+                        fh[G & 1] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                        if constexpr (!IN_BF16) {
+                            const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_img + C::kImageBytes + v_lane_off + off0));
+                            const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_img + C::kImageBytes + v_lane_off + off1));
+                            fl[G & 1] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                        }
+                    }
+                };
+                // half units: (2u) = exp + row sums of a score pair / split of the first two values of a piece,
+                //             (2u+1) = hi/lo split of that pair / split of the other two values (+ LDS writes of a whole piece)
+                auto unit = [&](auto uc) {
+                    constexpr int X = decltype(uc)::value, U = X / 2, H = X % 2;
+                    if constexpr (X >= 2 * NU_S && IN_BF16) {   // bf16 tensors: a piece is stored as it came
+                        constexpr int c = X - 2 * NU_S, gi = c / 2, which = c % 2;
+                        *(f32x4*)(st_cur + (which ? g_vdst[gi] : g_kdst[gi])) = which ? vst[gi][0] : kst[gi][0];
+                    } else if constexpr (U < NU_S) {
+                        constexpr int qb = U / 8, t = (U % 8) / 4, i = 2 * (U % 4);
+                        if constexpr (H == 0) {
+                            const float p0 = fast_exp2(cur[qb][8 * t + i]), p1 = fast_exp2(cur[qb][8 * t + i + 1]);
+                            la[qb] += p0;
+                            lb[qb] += p1;
+                            cur[qb][8 * t + i] = p0;        // the scores are dead: keep P in their registers until the split
+                            cur[qb][8 * t + i + 1] = p1;
+                        } else {
+                            bf16x2 h2, l2;
+                            split2c(cur[qb][8 * t + i], cur[qb][8 * t + i + 1], h2, l2);
+                            phc[qb][t][i] = h2[0], phc[qb][t][i + 1] = h2[1], plc[qb][t][i] = l2[0], plc[qb][t][i + 1] = l2[1];
+                        }
+                    } else {
+                        constexpr int c = U - NU_S, gi = c / 4, which = (c % 4) / 2, half = c % 2;
+                        const f32x4 x = which ? vst[gi][half] : kst[gi][half];
+                        bf16x2 h2, l2;
+                        split2c(x[2 * H], x[2 * H + 1], h2, l2);
+                        ch[which][gi][4 * half + 2 * H] = h2[0], ch[which][gi][4 * half + 2 * H + 1] = h2[1];
+                        cl[which][gi][4 * half + 2 * H] = l2[0], cl[which][gi][4 * half + 2 * H + 1] = l2[1];
+                        if constexpr (half == 1 && H == 1) {   // piece complete: K(j+2) over K(j), V(j) over V(j-2), both in this tile's stage
+                            char* dst = st_cur + (which ? g_vdst[gi] : g_kdst[gi]);
+                            *(bf16x8*)dst = ch[which][gi];
+                            *(bf16x8*)(dst + C::kImageBytes) = cl[which][gi];
+                        }
+                    }
+                };
+                const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                load_frags(std::integral_constant<int, 0>{});
+                auto slot = [&](auto ic) {
+                    constexpr int I = decltype(ic)::value;
+                    constexpr int G = I / MPG, M = I % MPG, term = M / QB, qb = M % QB;   // consecutive products alternate accumulators
+                    if constexpr (M == 0 && G + 1 < NG) load_frags(std::integral_constant<int, G + 1>{});
+                    // fp32 tensors: lo.hi, hi.lo, hi.hi; bf16 tensors (K, V exact in one term): hi.lo, hi.hi
+                    constexpr bool a_lo = !IN_BF16 && term == 0, b_lo = IN_BF16 ? term == 0 : term == 1;
+                    const bf16x8& a = a_lo ? fl[G & 1] : fh[G & 1];
+                    if constexpr (G < KS) {
+                        const bf16x8& bq = b_lo ? ql[qb][G] : qh[qb][G];
+                        if constexpr (G == 0 && term == 0) next[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, zero, 0, 0, 0);
+                        else next[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, next[qb], 0, 0, 0);
+                    } else {
+                        constexpr int t = (G - KS) / DB, db = (G - KS) % DB;
+                        const bf16x8& bp = b_lo ? plp[qb][t] : php[qb][t];
+                        o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bp, o[qb][db], 0, 0, 0);
+                    }
+                    // units whose slot this is: unit u sits in slot floor(u * NSLOT / NU)
+                    constexpr int u_lo = (I * NU + NSLOT - 1) / NSLOT, u_hi = ((I + 1) * NU + NSLOT - 1) / NSLOT;
+                    for_each_index([&](auto k) { unit(std::integral_constant<int, u_lo + decltype(k)::value>{}); },
+                                   std::make_integer_sequence<int, (u_hi > u_lo ? u_hi - u_lo : 0)>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                for_each_index(slot, std::make_integer_sequence<int, NSLOT>{});
+            }
+            __syncthreads();
+        };
+        constexpr std::integral_constant<int, 0> S0{};
+        constexpr std::integral_constant<int, 1> S1{};
+        constexpr std::true_type YES{};
+        constexpr std::false_type NO{};
+        if (nt == 1) {
+            step(S0, YES, YES, 0, sa, sb, pha, pla, phb, plb);
+            pv(pha, pla, smem + 2 * C::kImageBytes);
+        } else {
+            step(S0, YES, NO, 0, sa, sb, pha, pla, phb, plb);       // P(0) -> a
+            int j = 1;
+            for (; j + 2 < nt; j += 2) {                          // j odd here
+                step(S1, NO, NO, j, sb, sa, phb, plb, pha, pla);     // P(j) -> b, consumes a
+                step(S0, NO, NO, j + 1, sa, sb, pha, pla, phb, plb); // P(j+1) -> a, consumes b
+            }
+            if (nt - j == 2) {
+                step(S1, NO, NO, j, sb, sa, phb, plb, pha, pla);
+                step(S0, NO, YES, j + 1, sa, sb, pha, pla, phb, plb);
+                pv(pha, pla, smem + 2 * C::kImageBytes);           // V(nt-1), nt-1 even: stage 0
+            } else {
+                step(S1, NO, YES, j, sb, sa, phb, plb, pha, pla);
+                pv(phb, plb, smem + C::kStageBytes + 2 * C::kImageBytes);   // nt-1 odd: stage 1
+            }
+        }
+
+        // ================= epilogue: O / l, store =================
+        mfma_drain();  // the last P.V MFMAs may still be in flight
+        bool ok = true;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const float lt = xhalf_sum(la[qb] + lb[qb]);
+            const float inv = 1.0f / lt;
+            const int qi = q0 + qb * 32 + lq;
+            float mag = 0.0f;
+            if (qi < n) {
+                const int64_t o_off = o_slab + (int64_t)qi * p.o_row_stride + 4 * hi;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            pk[e] = o[qb][db][4 * g + e] * inv;
+                            mag += fabsf(pk[e]);
+                        }
+                        store4(p, o_off + db * 32 + 8 * g, pk);
+                    }
+                if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = __builtin_amdgcn_logf(lt) * kLn2;
+                ok = ok && (lt > 1.0f / kSplitLimit) && (lt < kSplitLimit) && (mag < INFINITY);   // false for NaN as well
+            }
+        }
+        return ok;
+    };
+
+    // results are stored before the vote (a rejected tile is simply overwritten by the redo)
+    bool ok;
+    if constexpr (PIPE) ok = run_fast();
+    else ok = run_tile(std::true_type{});
+    if (__syncthreads_or(!ok)) run_tile(std::false_type{});
+}
+
+template <int D, int NWAVES, int QB, int MINBLOCKS, bool PIPE, bool IN_BF16 = false>
+static hipError_t launch_split(const FwdParams& p0, int causal, hipStream_t stream)
+{
+    FwdParams p = p0;
+    constexpr int BM = NWAVES * QB * 32;
+    p.q_tiles = (p.n + BM - 1) / BM;
+    const int64_t total = (int64_t)p.bh * p.q_tiles;
+    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)total), block(NWAVES * kWave);
+    if (causal)
+        hipLaunchKernelGGL((fa_fwd_f32_split_kernel<D, NWAVES, QB, true, MINBLOCKS, PIPE, IN_BF16>), grid, block, 0, stream, p);
+    else
+        hipLaunchKernelGGL((fa_fwd_f32_split_kernel<D, NWAVES, QB, false, MINBLOCKS, PIPE, IN_BF16>), grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+// mode 0 = the product choice; 5 (d = 128) = mode 1 with eight waves per workgroup; 1 / 2 = first-tile-reference pass with one / two 32-row blocks per wave (tiles above a causal
+// wave's diagonal are skipped), 3 / 4 = software-pipelined reference-free pass with one / two blocks per wave (slot-pinned
+// steady state; causal tiles above the diagonal are masked, not skipped).  Measured on MI355X (one box, interleaved, ms):
+//   d=64  BH=16  N=8192   non-causal m1 0.757  m3 0.706  m4 0.655 | causal m1 0.473  m3 0.410  m4 0.376   (exact: 2.06 | 1.66)
+//   d=64  BH=128 N=1024   non-causal m1 0.107  m3 0.100  m4 0.100 | causal m1 0.084  m3 0.085  m4 0.095   (0.265 | 0.287)
+//   d=64  BH=32  N=4096   causal m1 0.265  m3 0.235  m4 0.283;  BH=32 N=2048 causal m1 0.095  m3 0.083  m4 0.085
+//   d=64  BH=8   N=4096   non-causal m1 0.123  m3 0.103  m4 0.136      (128 tiles of 256 rows: half the CUs idle with m4)
+//   d=128 BH=16  N=8192   non-causal m1 1.775  m3 1.942  m5 1.300 (pipelined 8-wave: 1.790) | causal m1 1.080  m3 0.796  m5 0.702   (4.03 | 2.47)
+//   d=128 BH=128 N=1024   non-causal m1 0.253  m3 0.244  m5 0.186 | causal m1 0.243  m3 0.168  m5 0.157
+//   (8-wave workgroups at d=64 / d=32 -- tried as m5..m7 -- lose to m4: 0.79 / 0.70 / 0.84 vs 0.66 at BH=16 N=8192 d=64)
+//   d=32  BH=16  N=8192   non-causal m2 0.476  m3 0.474  m4 0.450 | causal m1 0.328  m3 0.295  m4 0.271   (1.14 | 0.86)
+static bool split_addressable(const FwdParams& p, int d, unsigned elem_size)
+{
+    return ((uint64_t)(p.n - 1) * (uint64_t)p.kv_row_stride + (uint64_t)d) * elem_size < (1ull << 32);
+}
+
+static int choose_split(const FwdParams& p, int d, int causal, unsigned elem_size)
+{
+    // the pipelined pass addresses K/V through 32-bit buffer offsets
+    const bool addressable = split_addressable(p, d, elem_size);
+    if (!addressable) return 1;
+    const int64_t tiles256 = (int64_t)p.bh * ((p.n + 255) / 256);
+    if (d == 128) {
+        // two blocks per wave do not fit the register file; EIGHT waves of one block each (256-row workgroups, two waves per
+        // SIMD, phases in sequence) halve the K/V conversion work and the L2 traffic per row
+        if (tiles256 >= 256) return 5;
+        return causal ? 3 : 1;
+    }
+    if (causal) {
+        if (p.n <= 1024) return 1;                                         // short rows: skipping tiles beats masking them
+        return (p.n >= 8192 && tiles256 >= 256) ? 4 : 3;                 // 256-row tiles only pay on long rows
+    }
+    return tiles256 >= 256 ? 4 : 3;                                        // small grids: 128-row workgroups fill more CUs
+}
+
+// every tiling instantiated for head dim D (one translation unit per (dtype, D): fa_split_{f32,bf16}_d{32,64,128}.hip, so the
+// instantiations compile in parallel)
+template <int D, bool IN_BF16>
+static hipError_t launch_split_modes(const FwdParams& p, int causal, int mode, hipStream_t stream)
+{
+    if constexpr (D == 128) {
+        if (mode == 1) return launch_split<128, 4, 1, 1, false, IN_BF16>(p, causal, stream);
+        if (mode == 3) return launch_split<128, 4, 1, 1, true, IN_BF16>(p, causal, stream);
+        if (mode == 5) return launch_split<128, 8, 1, 1, false, IN_BF16>(p, causal, stream);   // 8 waves: 256-row workgroups
+    } else {
+        if (mode == 1) return launch_split<D, 4, 1, 2, false, IN_BF16>(p, causal, stream);
+        if constexpr (!IN_BF16)
+            if (mode == 2) return launch_split<D, 4, 2, 1, false, false>(p, causal, stream);
+        if (mode == 3) return launch_split<D, 4, 1, 2, true, IN_BF16>(p, causal, stream);
+        if (mode == 4) return launch_split<D, 4, 2, 1, true, IN_BF16>(p, causal, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// defined in fa_split_{f32,bf16}_d{32,64,128}.hip
+hipError_t split_launch_f32_d32(const FwdParams& p, int causal, int mode, hipStream_t stream);
+hipError_t split_launch_f32_d64(const FwdParams& p, int causal, int mode, hipStream_t stream);
+hipError_t split_launch_f32_d128(const FwdParams& p, int causal, int mode, hipStream_t stream);
+hipError_t split_launch_bf16_d32(const FwdParams& p, int causal, int mode, hipStream_t stream);
+hipError_t split_launch_bf16_d64(const FwdParams& p, int causal, int mode, hipStream_t stream);
+hipError_t split_launch_bf16_d128(const FwdParams& p, int causal, int mode, hipStream_t stream);
+
+}  // namespace fa

@@ -139,7 +139,7 @@ def test_fp32_vs_oracle(bh, n, d, causal, kernel):
 
 # every tiling of the split kernel: 1 / 2 = one / two 32-row blocks per wave (first-tile reference), 3 / 4 = the software-
 # pipelined reference-free pass; ragged length (700 = 21 tiles + 28 keys), both scales, LSE as well
-@pytest.mark.parametrize("d,mode", [(64, 1), (64, 2), (64, 3), (64, 4), (128, 1), (128, 3), (128, 5), (128, 6), (32, 1), (32, 2), (32, 3), (32, 4)])
+@pytest.mark.parametrize("d,mode", [(64, 1), (64, 2), (64, 3), (64, 4), (128, 1), (128, 3), (128, 5), (32, 1), (32, 2), (32, 3), (32, 4)])
 @pytest.mark.parametrize("causal", [False, True])
 def test_split_kernel_tilings(d, mode, causal):
     q, k, v = (randn(s, 2, 700, d) for s in (1, 2, 3))
@@ -154,7 +154,7 @@ def test_split_kernel_tilings(d, mode, causal):
     check(fa.forward(*to_dev(qb, kb, vb), causal, scale=0.125, kernel=f"split:{mode}"), ref, 2e-5, "bf16-valued inputs")
 
 
-@pytest.mark.parametrize("d,mode", [(64, 0), (64, 2), (64, 3), (64, 4), (128, 0), (128, 1), (128, 3), (128, 5), (128, 6), (32, 0), (32, 1), (32, 3), (32, 4), (64, 1)])
+@pytest.mark.parametrize("d,mode", [(64, 0), (64, 2), (64, 3), (64, 4), (128, 0), (128, 1), (128, 3), (128, 5), (32, 0), (32, 1), (32, 3), (32, 4), (64, 1)])
 @pytest.mark.parametrize("causal", [False, True])
 def test_split_kernel_redo_outside_the_optimistic_range(d, mode, causal):
     """Rows whose scores leave the range the optimistic pass can prove (exp2-domain row sums outside 2^-100 .. 2^100, or a
