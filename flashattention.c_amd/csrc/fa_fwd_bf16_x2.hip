@@ -1,4 +1,4 @@
-// fa_fwd_bf16_x2.hip -- the one-wave-per-SIMD, explicit-register-file kernel of fa_fwd_bf16_x4.hip with TWO 32-row blocks per wave
+// fa_fwd_bf16_x2.hip -- the one-wave-per-SIMD, explicit-register-file kernel of fa_bf16_x4_kernel.h with TWO 32-row blocks per wave
 // (64 query rows), 256-row workgroups, one workgroup per CU; instantiated for D = 128 and D = 64.
 //
 //   step t (32 keys):   K.Q^T of sub-tile t+1 for A and B (2 KS slots)  |  P.V + row sums of A (NV + 2)  |  P.V + row sums of B (NV + 2)
@@ -11,7 +11,7 @@
 //   pipe, not by instruction issue (1254 TFLOP/s at BH = 16, N = 8192; registers: O 128 + Q 64 + row sums in AGPRs).
 // D = 64: fewer rows per wave than x4 (more LDS reads and bookkeeping per FLOP), but 256-row tiles that run as two rounds of
 //   workgroups per CU, heavy tiles first: the causal case is no longer bound by its heaviest tile.
-// See fa_fwd_bf16_x4.hip for the hazards that come with asm MFMAs and for the optimistic / lazily rescaled instruction mixes.
+// See fa_bf16_x4_kernel.h for the hazards that come with asm MFMAs and for the optimistic / lazily rescaled instruction mixes.
 #include <utility>
 #include "fa_bf16_step.h"
 #include "fa_kernels.h"

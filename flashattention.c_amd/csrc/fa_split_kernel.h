@@ -1,5 +1,6 @@
 // fa_split_kernel.h -- fused flash-attention forward on the bf16 matrix pipe with split (hi + lo) operands (gfx950): the kernel
-// template shared by fa_fwd_f32_split.hip (fp32 tensors) and fa_fwd_bf16_split.hip (bf16 tensors, accurate mode).
+// template instantiated per (dtype, head dim) in fa_split_{f32,bf16}_d{32,64,128}.hip; dispatch in fa_fwd_f32_split.hip (fp32 tensors) and
+// fa_fwd_bf16_split.hip (bf16 tensors, accurate mode).
 //
 // Same contract as fa_fwd_f32.hip (fp32 Q/K/V in, fp32 O out; replaces flash_tiled_coarse{,_causal},
 // /root/reference/src/flashattention.cu:139-579), but both contractions run as THREE v_mfma_f32_32x32x16_bf16 on

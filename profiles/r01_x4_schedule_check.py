@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Offline check of the static schedule of fa_fwd_bf16_x4.hip: rebuilds the slot sequence, the VALU unit list and the
+"""Offline check of the static schedule of fa_bf16_x4_kernel.h: rebuilds the slot sequence, the VALU unit list and the
 cost-weighted dealing table exactly as the constexpr code does, and verifies every dependency (a pack is dealt out before
 the first MFMA that reads its fragment; the lane maxima of a block start after its last K.Q^T).  Run after any change to
 x4_slot / x4_make_units / x4_weight_end."""
