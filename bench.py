@@ -9,13 +9,18 @@ Contract (one JSON line on stdout from rank 0):
     the time is the MAX over ranks; `value` = algorithmic FLOP of all ranks / that time, in TFLOP/s.
   * N = 1 workload = the configuration BASELINE.json's metric is quoted on: B=2 H=8 d=64 N=8192, bf16 MFMA path
     (config "c4").  N > 1: every rank runs that same shard (weak scaling; the batch*head axis shards
-    with NO collective on the data path -- each slab is independent, /root/reference/src/flashattention.cu:144).
-    `--workload c5` instead splits B=64 H=16 (1024 slabs) across the ranks (strong scaling) and says so.
+    with NO collective on the data path -- each slab is independent, /root/reference/src/flashattention.cu:144), and
+    `extra.c5` carries BASELINE config 5, B=64 H=16 (1024 slabs) split across the ranks (strong scaling), timed with the same
+    protocol.  `--workload c5` makes that the headline value instead.
+  * `python bench.py --gpus N` with N > 1 works as typed: when it is not already running under torch.distributed.run it
+    starts `python -m torch.distributed.run --nproc-per-node N ... bench.py` as a CHILD process (before anything here has
+    touched a GPU) and relays rank 0's line.  Under torch.distributed.run (RANK / WORLD_SIZE set) it is one rank.
   * "roofline": dominant kernel's algorithmic FLOP per launch / its mean launch duration measured with HIP events on
-    the launch stream (fa_time_forward in the C ABI) against the dense MFMA peak of the dtype.
-  * "cpu_baseline": the CPU oracle (oracle/attention_oracle.c, OpenMP) timed on this box's host cores on a bounded
-    sample of the same workload (rank 0, N = 1 only) -- a reported baseline, not the optimisation target.  PyTorch's
-    CPU SDPA on the full fp32 shape is reported next to it ("cpu_sdpa").
+    the launch stream (fa_time_forward in the C ABI) against the dense MFMA peak of the pipe that kernel computes on.
+  * "cpu_baseline": PyTorch's CPU SDPA (fp32, scale 1.0 -- the reference bench's own oracle expression,
+    bench_flashattention.py:36-40, as BASELINE.md section 3 prescribes) on this box's host cores, on a bounded sample of the
+    same workload (rank 0, N = 1 only) -- a reported baseline, not the optimisation target.  The C oracle's timing is
+    in `extra.cpu_oracle_port`.
 The product path has no fallback: if the HIP library is missing this script fails.
 """
 from __future__ import annotations
@@ -23,6 +28,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -57,6 +64,28 @@ def dist_env():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     return rank, world, local
+
+
+def under_launcher() -> bool:
+    return "RANK" in os.environ and "WORLD_SIZE" in os.environ
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n: int, argv) -> int:
+    """`python bench.py --gpus N` typed directly: run the N ranks as a child torch.distributed.run job and relay its output.
+    Nothing in this (parent) process has touched a GPU or may touch one afterwards."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    r = subprocess.run(cmd, env=env)
+    return r.returncode
 
 
 def init_dist(world: int, backend: str):
@@ -94,14 +123,18 @@ def timed_region(step_fn, steps: int, warmup: int, sync_fn, world: int, dist=Non
 
 def make_inputs(bh: int, n: int, d: int, dtype: str, device, seed: int):
     import torch
-    g = torch.Generator(device="cpu").manual_seed(seed)
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    if getattr(device, "type", "cpu") == "cuda" and bh * n * d > (1 << 27):
+        # big shards (c5: 1 GiB per tensor) are generated on the device; same distribution, per-rank seed
+        g = torch.Generator(device=device).manual_seed(seed)
+        return [torch.randn(bh, n, d, generator=g, device=device, dtype=torch.float32).to(tdt) for _ in range(3)]
+    g = torch.Generator(device="cpu").manual_seed(seed)
     # generated on the host in fp32 (as the reference bench does, bench_flashattention.py:31-33), then moved
     return [torch.randn(bh, n, d, generator=g, dtype=torch.float32).to(tdt).to(device) for _ in range(3)]
 
 
-def cpu_baseline(n: int, d: int, causal: bool, scale: float):
-    """Oracle ("port") on a bounded sample: whole heads of the same N and d, count chosen for ~10-30 s of CPU work."""
+def cpu_oracle_port(total_heads: int, n: int, d: int, causal: bool, scale: float):
+    """The C oracle (oracle/attention_oracle.c, fp64 accumulate, OpenMP) on a bounded sample: whole heads of the same N and d."""
     import numpy as np
     from oracle import oracle as orc
     rng = np.random.default_rng(0)
@@ -110,7 +143,7 @@ def cpu_baseline(n: int, d: int, causal: bool, scale: float):
     t0 = time.perf_counter()
     orc.attention_f64(q, k, v, causal=causal, scale=scale)   # one full head: sizes the sample (and warms the threads)
     dt = time.perf_counter() - t0
-    heads = int(max(1, min(16, 15.0 // max(dt, 1e-3))))
+    heads = int(max(1, min(total_heads, 10.0 // max(dt, 1e-3))))
     if heads > 1:
         q, k, v = (rng.standard_normal((heads, n, d)).astype(np.float32) for _ in range(3))
         t0 = time.perf_counter()
@@ -118,15 +151,22 @@ def cpu_baseline(n: int, d: int, causal: bool, scale: float):
         dt = time.perf_counter() - t0
     tf = fwd_flop(heads, n, d, causal) / dt / 1e12
     return {"value": round(tf, 5), "unit": "TFLOP/s", "cores": cores, "kind": "port",
-            "sample": f"{heads} of 16 heads at N={n} d={d} fp64-accumulate C oracle (OpenMP), {dt:.1f} s",
-            "ms_per_full_workload_est": round(dt / heads * 16 * 1e3, 1)}
+            "sample": f"{heads} of {total_heads} heads at N={n} d={d}, fp64-accumulate C oracle (OpenMP), {dt:.1f} s",
+            "ms_per_full_workload_est": round(dt / heads * total_heads * 1e3, 1)}
 
 
-def cpu_sdpa(bh: int, n: int, d: int, causal: bool, scale: float):
+def cpu_sdpa_baseline(total_heads: int, n: int, d: int, causal: bool, scale: float, budget_s: float = 20.0):
+    """PyTorch CPU SDPA, fp32: the reference bench's oracle expression (softmax(q k^T) v, scale 1.0 --
+    bench_flashattention.py:36-40; identical to F.scaled_dot_product_attention(scale=1.0) on CPU)."""
     import torch
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(0)
-    q, k, v = (torch.randn(bh, n, d, generator=g) for _ in range(3))
+    q, k, v = (torch.randn(1, n, d, generator=g) for _ in range(3))
+    t0 = time.perf_counter()
+    F.scaled_dot_product_attention(q, k, v, is_causal=causal, scale=scale)   # one head: sizes the sample, warms the thread pool
+    dt1 = time.perf_counter() - t0
+    heads = int(max(1, min(total_heads, (budget_s / 4.0) // max(dt1, 1e-4))))
+    q, k, v = (torch.randn(heads, n, d, generator=g) for _ in range(3))
     F.scaled_dot_product_attention(q, k, v, is_causal=causal, scale=scale)
     ts = []
     for _ in range(3):
@@ -134,9 +174,11 @@ def cpu_sdpa(bh: int, n: int, d: int, causal: bool, scale: float):
         F.scaled_dot_product_attention(q, k, v, is_causal=causal, scale=scale)
         ts.append(time.perf_counter() - t0)
     med = sorted(ts)[1]
-    return {"ms": round(med * 1e3, 1), "tflops": round(fwd_flop(bh, n, d, causal) / med / 1e12, 4),
-            "threads": torch.get_num_threads(), "host_cpus": os.cpu_count(), "dtype": "f32",
-            "what": "torch.nn.functional.scaled_dot_product_attention on the host, full fp32 shape"}
+    return {"value": round(fwd_flop(heads, n, d, causal) / med / 1e12, 5), "unit": "TFLOP/s", "cores": torch.get_num_threads(),
+            "kind": "reference",
+            "sample": f"torch CPU scaled_dot_product_attention fp32 (= the reference bench's oracle expression, bench_flashattention.py:36-40), "
+                      f"{heads} of {total_heads} heads at N={n} d={d}, median of 3 after 1 warm-up, {med * 1e3:.0f} ms per call",
+            "host_cpus": os.cpu_count(), "ms_per_full_workload_est": round(med / heads * total_heads * 1e3, 1)}
 
 
 def load_pmc_traffic():
@@ -151,6 +193,17 @@ def load_pmc_traffic():
     return None
 
 
+def kernel_peak(kernel_name: str, dtype: str):
+    """Dense peak of the matrix pipe the named kernel computes on, and how its executed FLOP relate to the algorithmic ones."""
+    if kernel_name == "fa_fwd_f32_kernel":
+        return PEAK_TFLOPS["f32"], "fp32 MFMA (v_mfma_f32_32x32x2_f32), 1x the algorithmic FLOP"
+    if kernel_name == "fa_fwd_f32_split_kernel" and dtype == "f32":
+        return PEAK_TFLOPS["bf16"] / 3.0, "bf16 MFMA peak / 3: three bf16 products per contraction (hi/lo splits of fp32 operands)"
+    if kernel_name == "fa_fwd_f32_split_kernel":
+        return PEAK_TFLOPS["bf16"] / 2.0, "bf16 MFMA peak / 2: two bf16 products per contraction (hi/lo terms of P and Q')"
+    return PEAK_TFLOPS["bf16"], "bf16 / fp16 MFMA dense peak, 1x the algorithmic FLOP"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,20 +216,27 @@ def main():
                     help="untimed device warm-up before the W warm-up steps: an idle MI355X needs ~100 ms of load before its "
                          "clocks settle (the first ~100 launches of a 0.3 ms kernel run ~10 %% slow)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary fp32 measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL)")
+    ap.add_argument("--cpu-stub", action="store_true",
+                    help="TEST HOOK (tests/test_distributed_gloo.py): exercise launcher, sharding and timing protocol on CPU ranks with a "
+                         "sleep instead of the kernel; the line it prints says so and carries no measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and not under_launcher():
+        # before anything touches a GPU: the ranks are children, this process only relays (never exec from a GPU process)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
     rank, world, local = dist_env()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
+    if args.cpu_stub:
+        return stub_main(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the flash-attention forward has no CPU path")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    dist = init_dist(world, "nccl") if world > 1 else None
+    dist = init_dist(world, args.backend) if world > 1 else None
 
     import flashattention_c_amd as fa  # raises if libflashattn_amd.so is missing -- no fallback
     from flashattention_c_amd import _cabi
@@ -197,34 +257,65 @@ def main():
     def step():
         fa.forward(q, k, v, causal, scale=args.scale, out=out)
 
-    if args.prewarm_ms > 0:  # untimed: bring the device out of its idle power state
-        t_end = time.perf_counter() + args.prewarm_ms * 1e-3
-        while time.perf_counter() < t_end:
-            for _ in range(10):
-                step()
-            torch.cuda.synchronize()
+    def prewarm(fn):
+        if args.prewarm_ms > 0:  # untimed: bring the device out of its idle power state
+            t_end = time.perf_counter() + args.prewarm_ms * 1e-3
+            while time.perf_counter() < t_end:
+                for _ in range(10):
+                    fn()
+                torch.cuda.synchronize()
+
+    prewarm(step)
     dt = timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, world, dist, device)
     ms_per_step = dt / args.steps * 1e3
     value = fwd_flop(global_bh, n, d, causal) * args.steps / dt / 1e12
+    route = fa.last_forward_route()   # 0: single launch; 1 / 2: primary / fallback kernel of a conditional chain (fp32 guard)
+
+    extras = {}
+    # ---- BASELINE config 5 (B=64 H=16, 1024 slabs) sharded over the ranks, same timing protocol: at N = 1 the whole of it on one GPU
+    if not args.no_extras and args.workload == "c4":
+        B5, H5, d5, n5, dt5, _ = WORKLOADS["c5"]
+        s0, s1 = fa.shard_range(B5 * H5, world, rank)
+        q5, k5, v5 = make_inputs(s1 - s0, n5, d5, dt5, device, seed=100 + rank)
+        o5 = torch.empty_like(q5)
+        step5 = lambda: fa.forward(q5, k5, v5, causal, scale=args.scale, out=o5)  # noqa: E731
+        k5_steps = max(3, min(args.steps, 10))
+        dt5s = timed_region(step5, k5_steps, 2, torch.cuda.synchronize, world, dist, device)
+        tf5 = fwd_flop(B5 * H5, n5, d5, causal) * k5_steps / dt5s / 1e12
+        extras["c5"] = {"workload": f"B={B5} H={H5} d={d5} N={n5} {dt5}: 1024 slabs, contiguous split over {world} GPU(s), no collective",
+                        "scaling": "strong", "n_gpus": world, "bh_per_gpu": s1 - s0, "steps": k5_steps,
+                        "ms_per_step": round(dt5s / k5_steps * 1e3, 4), "tflops": round(tf5, 2), "tflops_per_gpu": round(tf5 / world, 2),
+                        "frac_bf16_mfma_peak_per_gpu": round(tf5 / world / PEAK_TFLOPS["bf16"], 4)}
+        del q5, k5, v5, o5
+        torch.cuda.empty_cache()
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, inside the C ABI
     roof = None
-    extras = {}
     if rank == 0:
+        L = _cabi.lib()
+        dt_id = _cabi.FA_DTYPE_BF16 if dtype == "bf16" else _cabi.FA_DTYPE_F32
+        kname = L.fa_kernel_name_for(dt_id, d, int(causal), bh, n).decode()
+        if dtype == "f32" and route == 2:
+            kname = "fa_fwd_f32_kernel"   # the logit-width guard sent this workload to the exact kernel
         kms = fa.time_forward(q, k, v, causal, scale=args.scale, warmup=3, iters=max(10, min(args.steps, 50)), out=out)
         achieved = fwd_flop(bh, n, d, causal) / (kms * 1e-3) / 1e12
         elem = 2 if dtype == "bf16" else 4
-        pmc = load_pmc_traffic()
-        # fp32 tensors run on the bf16 pipe with three products per contraction: their ceiling is a third of the bf16 peak
-        peak = PEAK_TFLOPS["bf16"] / 3.0 if dtype == "f32" else PEAK_TFLOPS[dtype]
+        pmc = load_pmc_traffic() or {}
+        peak, peak_note = kernel_peak(kname, dtype)
+        # traffic: HBM bytes of one launch from the committed rocprofv3 PMC passes of this command -- a STATIC figure, quoted only
+        # while the kernel it was measured on is still the kernel this run launches
+        traffic = pmc.get(f"{args.workload}_hbm_bytes_per_launch") if pmc.get(f"{args.workload}_kernel") == kname and not causal else None
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4),
-                "traffic": (pmc or {}).get(f"{args.workload}_hbm_bytes_per_launch"),
-                "kernel": _cabi.lib().fa_kernel_name_for(1 if dtype == "bf16" else 0, d, int(causal), bh, n).decode(),
-                "kernel_ms": round(kms, 4),
+                "frac": round(achieved / peak, 4), "traffic": traffic,
+                "traffic_source": (f"profiles/pmc_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                   f"{pmc.get('_tag', '?')}; 2*FETCH_SIZE + WRITE_SIZE)") if traffic is not None else None,
+                "kernel": kname, "kernel_ms": round(kms, 4), "peak_note": peak_note,
                 "algorithmic_flop_per_launch": fwd_flop(bh, n, d, causal),
                 "algorithmic_hbm_bytes_per_launch": algorithmic_bytes(bh, n, d, elem),
                 "hbm_gbps_at_algorithmic_bytes": round(algorithmic_bytes(bh, n, d, elem) / (kms * 1e-3) / 1e9, 1)}
+        if dtype == "f32":
+            roof["arithmetic"] = {0: "single launch", 1: "split products on the bf16 pipe (guard quiet)",
+                                  2: "exact fp32 (logit-width guard fired)"}[route]
         if not args.no_extras:
             # the same launches captured into one hipGraph and replayed (no stream-launch gap between kernels); reported
             # beside the stream-launch figures above, never instead of them
@@ -236,50 +327,15 @@ def main():
             except Exception as e:  # pragma: no cover - informational only
                 extras["graph_replay"] = {"error": repr(e)}
         if not args.no_extras and world == 1 and args.workload == "c4":
-            # the accurate bf16 mode on the same tensors (FA_KERNEL_SPLIT: P and Q*scale*log2e in 16 significant bits, fp32 out)
-            try:
-                o32 = torch.empty(q.shape, dtype=torch.float32, device=device)
-                ams = fa.time_forward(q, k, v, causal, scale=args.scale, kernel="split", warmup=30, iters=20, out=o32)
-                atf = fwd_flop(bh, n, d, causal) / (ams * 1e-3) / 1e12
-                extras["c4_accurate_mode"] = {"kernel_ms": round(ams, 4), "tflops": round(atf, 2),
-                                              "frac_bf16_mfma_peak_at_2x_flop": round(2.0 * atf / PEAK_TFLOPS["bf16"], 4),
-                                              "what": "bf16 tensors, two bf16 MFMA products per contraction (hi/lo of P and Q'), "
-                                                      "fp32 out; max-abs error ~1e-4 vs fp64 at scale 1 (default kernels ~5e-3)"}
-                del o32
-            except Exception as e:  # pragma: no cover - informational only
-                extras["c4_accurate_mode"] = {"error": repr(e)}
-            # the same shape with fp32 tensors (config c3) and the README shape (c2), a few launches each: the product
-            # path for fp32 tensors (FA_KERNEL_AUTO: three bf16 MFMA products of two-term splits, fp32 accumulate) and the
-            # exact fp32-arithmetic kernel beside it.  Algorithmic TFLOP/s in both cases; the split kernel executes 3x that
-            # on the bf16 pipe, the exact one 1x on the fp32 pipe.
-            for name in ("c3", "c2"):
-                B2, H2, d2, n2, dt2, _ = WORKLOADS[name]
-                q2, k2, v2 = make_inputs(B2 * H2, n2, d2, dt2, device, seed=1)
-                fl2 = fwd_flop(B2 * H2, n2, d2, causal)
-                ent = {"workload": f"B={B2} H={H2} d={d2} N={n2} {dt2}"}
-                for label, kern in (("split", "auto"), ("exact", "exact")):
-                    ms2 = fa.time_forward(q2, k2, v2, causal, scale=args.scale, kernel=kern, warmup=30 if name == "c3" else 100,
-                                          iters=10 if name == "c3" else 50)
-                    tf2 = fl2 / (ms2 * 1e-3) / 1e12
-                    ent[label] = {"ms": round(ms2, 4), "tflops": round(tf2, 2)}
-                    if label == "split":
-                        ent[label].update(arithmetic="3 bf16 MFMA products of hi/lo splits, fp32 accumulate (FA_KERNEL_AUTO)",
-                                          frac_bf16_mfma_peak_at_3x_flop=round(3.0 * tf2 / PEAK_TFLOPS["bf16"], 4))
-                    else:
-                        ent[label].update(arithmetic="v_mfma_f32_32x32x2_f32 (FA_KERNEL_MFMA)",
-                                          frac_f32_mfma_peak=round(tf2 / PEAK_TFLOPS["f32"], 4))
-                ent["ms"], ent["tflops"] = ent["split"]["ms"], ent["split"]["tflops"]
-                extras[name] = ent
-                del q2, k2, v2
-            torch.cuda.synchronize()
+            extras.update(c4_side_measurements(fa, _cabi, q, k, v, causal, args, device))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(n, d, causal, args.scale)
+        cpu = cpu_sdpa_baseline(total_bh, n, d, causal, args.scale)
         try:
-            extras["cpu_sdpa"] = cpu_sdpa(total_bh, n, d, causal, args.scale)
+            extras["cpu_oracle_port"] = cpu_oracle_port(total_bh, n, d, causal, args.scale)
         except Exception as e:  # pragma: no cover - informational only
-            extras["cpu_sdpa"] = {"error": repr(e)}
+            extras["cpu_oracle_port"] = {"error": repr(e)}
 
     if world > 1:
         dist.barrier()
@@ -297,6 +353,132 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "extra": extras,
         }
         print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def c4_side_measurements(fa, _cabi, q, k, v, causal, args, device):
+    """Rank 0, N = 1, workload c4: every other shape SURVEY.md section 8(d) / the README name, a few launches each (HIP events on the
+    launch stream; algorithmic TFLOP/s).  Informational: the headline value and roofline above are c4's."""
+    import torch
+    ex = {}
+    bh, n, d = q.shape
+    flop = fwd_flop(bh, n, d, causal)
+
+    def timed(what, fn_kwargs, flop_, tensors=(q, k, v), peak=PEAK_TFLOPS["bf16"], note=None, warm=30, iters=20):
+        try:
+            ms = fa.time_forward(*tensors, warmup=warm, iters=iters, **fn_kwargs)
+            tf = flop_ / (ms * 1e-3) / 1e12
+            ent = {"kernel_ms": round(ms, 4), "tflops": round(tf, 2), "frac_mfma_peak": round(tf / peak, 4)}
+            if note:
+                ent["what"] = note
+            ex[what] = ent
+        except Exception as e:  # pragma: no cover - informational only
+            ex[what] = {"error": repr(e)}
+
+    # the accurate bf16 path on the same tensors: what fa_forward picks for an fp32 output (fp16 P, FA_KERNEL_P16)
+    o32 = torch.empty(q.shape, dtype=torch.float32, device=device)
+    timed("c4_accurate_mode", dict(causal=causal, scale=args.scale, out=o32), flop,
+          note="bf16 Q, K; P and V in fp16 (v_mfma_f32_32x32x16_f16), fp32 out -- FA_KERNEL_AUTO for an fp32 output; includes the bf16->fp16 "
+               "copy of V; max-abs error < 1e-3 vs the fp32 reference at scale 1 (bf16-P kernels ~5e-3); 1x the algorithmic FLOP")
+    if "kernel_ms" in ex.get("c4_accurate_mode", {}):
+        ex["c4_accurate_mode"]["frac"] = ex["c4_accurate_mode"]["frac_mfma_peak"]
+        ex["c4_accurate_mode"]["route"] = fa.last_forward_route()
+    timed("c4_accurate_mode_split", dict(causal=causal, scale=args.scale, out=o32, kernel="split"), flop, peak=PEAK_TFLOPS["bf16"] / 2.0,
+          note="the round-1 accurate mode (hi + lo bf16 terms of P and Q'; two products per contraction), frac of bf16 peak / 2", iters=10)
+    del o32
+    out = torch.empty_like(q)
+    # SURVEY 8(d): causal reported separately; 1/sqrt(d) as a second line
+    timed("c4_causal", dict(causal=True, scale=args.scale, out=out), fwd_flop(bh, n, d, True), note="c4 shape, causal (algorithmic FLOP halved)")
+    timed("c4_scale_rsqrt_d", dict(causal=causal, scale=d ** -0.5, out=out), flop, note="c4 shape at scale 1/sqrt(d) instead of the reference's 1.0")
+    # README rows 2 and 4 (d = 32), bf16 and fp32 tensors
+    for name, (B2, H2, n2) in (("d32_n8192", (2, 8, 8192)), ("d32_n1024", (8, 16, 1024))):
+        q2, k2, v2 = make_inputs(B2 * H2, n2, 32, "bf16", device, seed=2)
+        fl2 = fwd_flop(B2 * H2, n2, 32, causal)
+        timed(name + "_bf16", dict(causal=causal, scale=args.scale), fl2, tensors=(q2, k2, v2), note=f"README shape B={B2} H={H2} d=32 N={n2}, bf16 tensors",
+              warm=30 if n2 > 2048 else 200, iters=20 if n2 > 2048 else 100)
+        q3, k3, v3 = (t.float() for t in (q2, k2, v2))
+        timed(name + "_f32", dict(causal=causal, scale=args.scale), fl2, tensors=(q3, k3, v3), peak=PEAK_TFLOPS["bf16"] / 3.0,
+              note=f"README shape B={B2} H={H2} d=32 N={n2}, fp32 tensors (FA_KERNEL_AUTO), frac of bf16 peak / 3",
+              warm=30 if n2 > 2048 else 200, iters=10 if n2 > 2048 else 100)
+        del q2, k2, v2, q3, k3, v3
+    # the same shape with fp32 tensors (config c3) and the README shape (c2): FA_KERNEL_AUTO (split products behind the logit-width
+    # guard; the route says which arithmetic produced the output) and the exact fp32-arithmetic kernel beside it
+    for name in ("c3", "c2"):
+        B2, H2, d2, n2, dt2, _ = WORKLOADS[name]
+        q2, k2, v2 = make_inputs(B2 * H2, n2, d2, dt2, device, seed=1)
+        fl2 = fwd_flop(B2 * H2, n2, d2, causal)
+        ent = {"workload": f"B={B2} H={H2} d={d2} N={n2} {dt2}"}
+        for label, kern in (("auto", "auto"), ("exact", "exact")):
+            ms2 = fa.time_forward(q2, k2, v2, causal, scale=args.scale, kernel=kern, warmup=30 if name == "c3" else 100,
+                                  iters=10 if name == "c3" else 50)
+            tf2 = fl2 / (ms2 * 1e-3) / 1e12
+            ent[label] = {"ms": round(ms2, 4), "tflops": round(tf2, 2)}
+            if label == "auto":
+                r = fa.last_forward_route()
+                ent[label].update(arithmetic="3 bf16 MFMA products of hi/lo splits, fp32 accumulate, logit-width guard + conditional exact launch "
+                                             "included in the time" if r == 1 else "exact fp32 (guard fired)", route=r,
+                                  frac_bf16_mfma_peak_at_3x_flop=round(3.0 * tf2 / PEAK_TFLOPS["bf16"], 4))
+            else:
+                ent[label].update(arithmetic="v_mfma_f32_32x32x2_f32 (FA_KERNEL_MFMA)",
+                                  frac_f32_mfma_peak=round(tf2 / PEAK_TFLOPS["f32"], 4))
+        ent["ms"], ent["tflops"] = ent["auto"]["ms"], ent["auto"]["tflops"]
+        ex[name] = ent
+        del q2, k2, v2
+    # llm.c harness size (attention_forward.cu:1217-1220): B=6 T=4096 C=768 NH=12, packed (B, T, 3C) fp32, causal, 1/sqrt(hs); mean of
+    # 100 launches like benchmark_kernel (:1279-1288)
+    try:
+        B6, T6, C6, NH6 = 6, 4096, 768, 12
+        inp = torch.rand(B6, T6, 3 * C6, device=device) * 2.0 - 1.0
+        for _ in range(10):
+            fa.forward_packed_qkv(inp, NH6)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(100):
+            fa.forward_packed_qkv(inp, NH6)
+        e1.record()
+        e1.synchronize()
+        ms6 = e0.elapsed_time(e1) / 100.0
+        fl6 = fwd_flop(B6 * NH6, T6, C6 // NH6, True)
+        ex["llmc_packed_qkv"] = {"workload": f"B={B6} T={T6} C={C6} NH={NH6} fp32 packed QKV, causal, scale 1/sqrt(64)", "ms": round(ms6, 4),
+                                 "tflops": round(fl6 / (ms6 * 1e-3) / 1e12, 2), "route": fa.last_forward_route(),
+                                 "what": "fa_forward_packed_qkv (replaces attention_forward6 incl. its permute / unpermute kernels), mean of 100 launches"}
+        del inp
+    except Exception as e:  # pragma: no cover - informational only
+        ex["llmc_packed_qkv"] = {"error": repr(e)}
+    torch.cuda.synchronize()
+    return ex
+
+
+def stub_main(args, rank: int, world: int):
+    """--cpu-stub: the launcher / sharding / timing protocol on CPU ranks (gloo), the kernel replaced by a sleep proportional to
+    the rank's shard.  Not a measurement -- covers `python bench.py --gpus N` end to end where there is no GPU."""
+    import flashattention_c_amd as fa
+    dist = init_dist(world, "gloo") if world > 1 else None
+    B, H, d, n, dtype, scaling = WORKLOADS[args.workload]
+    total_bh = B * H
+    if scaling == "strong":
+        b0, b1 = fa.shard_range(total_bh, world, rank)
+        bh, global_bh = b1 - b0, total_bh
+    else:
+        bh, global_bh = total_bh, total_bh * world
+    step = lambda: time.sleep(1e-5 * bh)  # noqa: E731
+    dt = timed_region(step, args.steps, args.warmup, lambda: None, world, dist, None)
+    b5 = fa.shard_range(1024, world, rank)
+    sizes = [b5[1] - b5[0]]
+    if world > 1:
+        import torch
+        t = torch.tensor(sizes, dtype=torch.int64)
+        dist.all_reduce(t)
+        sizes = [int(t.item())]
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "STUB (no GPU, no measurement): launcher / sharding / timing protocol only", "value": None, "unit": "TFLOP/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+                          "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": dtype, "data": "none (cpu stub)",
+                          "config": {"workload": f"{args.workload} (cpu stub)", "global_bh": global_bh, "bh_per_gpu": bh},
+                          "roofline": None, "cpu_baseline": None, "extra": {"c5": {"slabs_covered": sizes[0], "n_gpus": world}}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -9,12 +9,12 @@ LIB_PATH = os.path.join(PKG_DIR, "libflashattn_amd.so")
 
 FA_OK = 0
 FA_DTYPE_F32, FA_DTYPE_BF16, FA_DTYPE_BF16_OUT_F32 = 0, 1, 2
-FA_KERNEL_AUTO, FA_KERNEL_NAIVE, FA_KERNEL_MFMA, FA_KERNEL_SPLIT = 0, 1, 2, 3
+FA_KERNEL_AUTO, FA_KERNEL_NAIVE, FA_KERNEL_MFMA, FA_KERNEL_SPLIT, FA_KERNEL_P16 = 0, 1, 2, 3, 4
 
 # every symbol include/flashattn_amd.h declares
 EXPORTED_SYMBOLS = (
     "fa_forward", "fa_forward_ex", "fa_forward_sharded", "fa_forward_packed_qkv", "fa_time_forward", "fa_time_forward_graph",
-    "fa_last_error", "fa_device_count", "fa_version", "fa_kernel_name", "fa_kernel_name_for",
+    "fa_last_forward_route", "fa_last_error", "fa_device_count", "fa_version", "fa_kernel_name", "fa_kernel_name_for",
 )
 
 
@@ -48,6 +48,8 @@ def lib() -> ctypes.CDLL:
     L.fa_time_forward.restype = ctypes.c_int
     L.fa_time_forward_graph.argtypes = [vp, vp, vp, vp, i64, i64, i32, f32, i32, i32, i32, i32, i32, ctypes.POINTER(f32)]
     L.fa_time_forward_graph.restype = ctypes.c_int
+    L.fa_last_forward_route.argtypes = [vp, ctypes.POINTER(i32)]
+    L.fa_last_forward_route.restype = ctypes.c_int
     L.fa_last_error.argtypes = []
     L.fa_last_error.restype = ctypes.c_char_p
     L.fa_device_count.argtypes = []

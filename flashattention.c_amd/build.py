@@ -6,7 +6,13 @@ Counterpart of the reference's import-time JIT build
 ``flashattention.c_amd/libflashattn_amd.so`` next to the sources so that it travels with the tree.
 hipcc cross-compiles for gfx950 without a GPU present.
 
-    python flashattention.c_amd/build.py [--force] [--jobs N]
+    python flashattention.c_amd/build.py [--force] [--jobs N] [--ablation] [--torch-binding]
+
+``--ablation`` additionally builds ``libflashattn_amd_ablation.so`` (+ ``fa_driver_ablation``): the same sources compiled with
+``-DFA_ABLATION=1`` plus the timing-only ablation instantiations quoted in DESIGN.md section 4 (results are garbage by design).
+They are NOT part of the product library: its ``fa_forward_ex`` rejects their variant numbers.
+``--torch-binding`` builds ``flash_torch_binding*.so``, the compiled pybind translation unit of INTEGRATION.md section 1
+(``torch::Tensor forward(Q, K, V, bool causal)``, /root/reference/src/main.cpp:3-6) against the installed torch-ROCm.
 """
 from __future__ import annotations
 
@@ -26,10 +32,17 @@ DRIVER_PATH = os.path.join(PKG_DIR, "fa_driver")
 ARCH = "gfx950"
 
 # longest translation units first: the thread pool starts them in this order
-LIB_SOURCES = ["fa_fwd_bf16_x4_ablation.hip", "fa_fwd_bf16_x4.hip", "fa_fwd_bf16_x4_causal.hip", "fa_fwd_bf16_x2.hip",
+LIB_SOURCES = ["fa_fwd_bf16_x4.hip", "fa_fwd_bf16_x4_causal.hip", "fa_fwd_bf16_x2.hip",
                "fa_fwd_bf16_pipelined.hip", "fa_split_f32_d64.hip", "fa_split_f32_d128.hip", "fa_split_f32_d32.hip",
-               "fa_split_bf16_d64.hip", "fa_split_bf16_d128.hip", "fa_split_bf16_d32.hip", "fa_fwd_bf16_pp2.hip", "fa_fwd_bf16.hip",
+               "fa_split_bf16_d64.hip", "fa_split_bf16_d128.hip", "fa_split_bf16_d32.hip", "fa_fwd_bf16.hip",
+               "fa_fwd_bf16_x4_p16.hip", "fa_fwd_bf16_x4_p16_causal.hip", "fa_cvt.hip",
                "fa_fwd_f32.hip", "fa_fwd_f32_split.hip", "fa_fwd_bf16_split.hip", "fa_naive.hip", "fa_api.cpp"]
+# timing-only instantiations (garbage results): only in libflashattn_amd_ablation.so
+ABLATION_SOURCES = ["fa_fwd_bf16_x4_ablation.hip", "fa_fwd_bf16_pp2.hip"]
+# product sources whose text depends on FA_ABLATION (the variant dispatch): recompiled for the ablation library, the rest is shared
+ABLATION_DEPENDENT = ["fa_fwd_bf16.hip", "fa_fwd_bf16_x4.hip", "fa_fwd_bf16_pipelined.hip", "fa_fwd_bf16_x2.hip", "fa_api.cpp"]
+ABL_LIB_PATH = os.path.join(PKG_DIR, "libflashattn_amd_ablation.so")
+ABL_DRIVER_PATH = os.path.join(PKG_DIR, "fa_driver_ablation")
 HEADERS = ["fa_common.h", "fa_kernels.h", "fa_bf16_common.h", "fa_split_kernel.h", "fa_bf16_x4_kernel.h", "fa_bf16_step.h", os.path.join(ROOT, "include", "flashattn_amd.h")]
 COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
                 "-I", os.path.join(ROOT, "include")]
@@ -54,43 +67,97 @@ def _newest_dep() -> float:
     return max(_mtime(d) for d in deps + [os.path.abspath(__file__)])
 
 
-def _compile(src: str, force: bool) -> str:
-    obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
+def _compile(src: str, force: bool, ablation: bool = False) -> str:
+    obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + (".abl.o" if ablation else ".o"))
     srcp = os.path.join(CSRC, src)
     if not force and _mtime(obj) > max(_mtime(srcp), _newest_dep()):
         return obj
-    cmd = [hipcc(), *COMMON_FLAGS, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", srcp, "-o", obj]
+    cmd = [hipcc(), *COMMON_FLAGS, f"-DFA_ABLATION={1 if ablation else 0}", *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", srcp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
     return obj
 
 
-def build(force: bool = False, jobs: int = 8, verbose: bool = False) -> str:
-    os.makedirs(OBJ_DIR, exist_ok=True)
-    with ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), LIB_SOURCES))
-    if force or _mtime(LIB_PATH) < max(_mtime(o) for o in objs):
-        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+def _link(lib_path: str, objs, force: bool) -> None:
+    if force or _mtime(lib_path) < max(_mtime(o) for o in objs):
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib_path, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+
+
+def _build_driver(out: str, lib_path: str, libname: str, force: bool) -> None:
     drv_src = os.path.join(CSRC, "fa_driver.cpp")
-    if os.path.exists(drv_src) and (force or _mtime(DRIVER_PATH) < max(_mtime(drv_src), _mtime(LIB_PATH))):
+    if os.path.exists(drv_src) and (force or _mtime(out) < max(_mtime(drv_src), _mtime(lib_path))):
         cmd = [hipcc(), "-O2", "-std=c++17", f"--offload-arch={ARCH}", "-x", "hip", "-I", os.path.join(ROOT, "include"),
-               drv_src, "-o", DRIVER_PATH, "-L", PKG_DIR, "-lflashattn_amd", "-Wl,-rpath,$ORIGIN"]
+               drv_src, "-o", out, "-L", PKG_DIR, f"-l{libname}", "-Wl,-rpath,$ORIGIN"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"driver build failed:\n{r.stdout}\n{r.stderr}")
+
+
+def build(force: bool = False, jobs: int = 8, verbose: bool = False, ablation: bool = False, torch_binding: bool = False) -> str:
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), LIB_SOURCES))
+        abl_objs = []
+        if ablation:
+            abl_objs = list(ex.map(lambda s: _compile(s, force, True), ABLATION_SOURCES + ABLATION_DEPENDENT))
+            abl_objs += [o for s_, o in zip(LIB_SOURCES, objs) if s_ not in ABLATION_DEPENDENT]
+    _link(LIB_PATH, objs, force)
+    _build_driver(DRIVER_PATH, LIB_PATH, "flashattn_amd", force)
+    if ablation:
+        _link(ABL_LIB_PATH, abl_objs, force)
+        _build_driver(ABL_DRIVER_PATH, ABL_LIB_PATH, "flashattn_amd_ablation", force)
+    if torch_binding:
+        build_torch_binding(force=force, verbose=verbose)
     if verbose:
-        print(f"built {LIB_PATH}")
+        print(f"built {LIB_PATH}" + (f" and {ABL_LIB_PATH}" if ablation else ""))
     return LIB_PATH
+
+
+TORCH_BINDING_NAME = "flash_torch_binding"
+
+
+def torch_binding_path() -> str:
+    import sysconfig
+    return os.path.join(PKG_DIR, TORCH_BINDING_NAME + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_torch_binding(force: bool = False, verbose: bool = False) -> str:
+    """The reference's main.cpp surface as a compiled pybind11 module over the C ABI (csrc/fa_torch_binding.cpp)."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    src = os.path.join(CSRC, "fa_torch_binding.cpp")
+    out = torch_binding_path()
+    if not force and _mtime(out) > max(_mtime(src), _mtime(LIB_PATH), _mtime(os.path.join(ROOT, "include", "flashattn_amd.h"))):
+        return out
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    incs = [i for p in ce.include_paths() for i in ("-isystem", p)] + ["-isystem", sysconfig.get_paths()["include"],
+                                                                        "-isystem", os.path.join(rocm, "include")]
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    abi = int(getattr(torch._C, "_GLIBCXX_USE_CXX11_ABI", True))
+    cmd = [hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "c++", src, "-o", out, "-I", os.path.join(ROOT, "include"), *incs,
+           f"-D_GLIBCXX_USE_CXX11_ABI={abi}", f"-DTORCH_EXTENSION_NAME={TORCH_BINDING_NAME}", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-L", PKG_DIR, "-lflashattn_amd", "-L", tlib, "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", "-ltorch_python",
+           "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}", "-Wno-unused-command-line-argument"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"torch binding build failed:\n{r.stdout[-3000:]}\n{r.stderr[-6000:]}")
+    if verbose:
+        print(f"built {out}")
+    return out
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=8)
+    ap.add_argument("--ablation", action="store_true", help="also build libflashattn_amd_ablation.so + fa_driver_ablation")
+    ap.add_argument("--torch-binding", action="store_true", help="also build the pybind11 module of INTEGRATION.md section 1")
     a = ap.parse_args()
-    build(force=a.force, jobs=a.jobs, verbose=True)
+    build(force=a.force, jobs=a.jobs, verbose=True, ablation=a.ablation, torch_binding=a.torch_binding)
     sys.exit(0)

@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -53,6 +54,15 @@ int validate_common(const void* q, const void* k, const void* v, const void* o, 
     if (!(scale > 0.0f) || !std::isfinite(scale)) return fail(FA_ERR_INVALID_ARGUMENT, "scale must be finite and > 0 (got %g)", (double)scale);
     if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_BF16_OUT_F32)
         return fail(FA_ERR_UNSUPPORTED, "unknown dtype %d", dtype);
+    // o must not overlap an input: a tile whose optimistic pass fails its verification is recomputed from q, k, v AFTER the
+    // first attempt was stored
+    const uint64_t elems = (uint64_t)bh * (uint64_t)n * (uint64_t)d;
+    const uint64_t in_bytes = elems * (dtype == FA_DTYPE_F32 ? 4u : 2u), out_bytes = elems * (dtype == FA_DTYPE_BF16 ? 2u : 4u);
+    const uintptr_t ob = reinterpret_cast<uintptr_t>(o);
+    for (const void* t : {q, k, v}) {
+        const uintptr_t tb = reinterpret_cast<uintptr_t>(t);
+        if (ob < tb + in_bytes && tb < ob + out_bytes) return fail(FA_ERR_INVALID_ARGUMENT, "o overlaps an input tensor (q, k or v)");
+    }
     return FA_OK;
 }
 
@@ -76,6 +86,71 @@ fa::FwdParams make_params(const void* q, const void* k, const void* v, void* o, 
     return p;
 }
 
+// ---- conditional launch chains ------------------------------------------------------------------------------------------------
+// Two FA_KERNEL_AUTO paths are chains of launches on the caller's stream in which a later kernel runs or skips itself depending on
+// what an earlier one found on the device (nothing is read back, nothing synchronises):
+//   fp32 tensors   split kernel (bf16 pipe, 16-bit operand terms; raises the word when the logits are too wide for that)
+//                  -> exact fp32 kernel, only if the word is raised;
+//   bf16 tensors with fp32 output   V -> fp16 copy (raises the word when some |v| >= 2^16) -> fp16-P kernel unless raised
+//                  -> split kernel (hi + lo bf16 terms of P) only if raised.
+// The word lives in a per-device ring of 32-bit slots; "raised" means "equals this call's serial number", so a slot never needs
+// clearing and concurrent calls (other streams, other threads) cannot see each other's verdicts.  A replayed hipGraph reuses its
+// captured slot and serial: a verdict left by an earlier replay can only send a later one down the slower, more careful kernel.
+constexpr int kFlagSlots = 4096;
+__device__ uint32_t g_flag_ring[kFlagSlots];
+constexpr int kMaxDevices = 64;
+std::atomic<uint32_t*> g_ring_base[kMaxDevices];
+std::atomic<bool> g_pool_tuned[kMaxDevices];
+std::atomic<uint32_t> g_serial{1};
+
+struct FlagRef {
+    uint32_t* word = nullptr;
+    uint32_t serial = 0;
+};
+thread_local FlagRef t_last_flag;   // chain state of this thread's most recent forward (fa_last_forward_route)
+thread_local int t_last_chain = 0;  // 0 = no chain, 1 = fp32 guard, 2 = fp16-P
+
+int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -1;
+    return dev;
+}
+
+bool next_flag(FlagRef& f)
+{
+    const int dev = current_device();
+    if (dev < 0) return false;
+    uint32_t* base = g_ring_base[dev].load(std::memory_order_acquire);
+    if (base == nullptr) {
+        void* sym = nullptr;
+        if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_flag_ring)) != hipSuccess || sym == nullptr) return false;
+        base = static_cast<uint32_t*>(sym);
+        g_ring_base[dev].store(base, std::memory_order_release);
+    }
+    uint32_t serial = g_serial.fetch_add(1, std::memory_order_relaxed);
+    if (serial == 0) serial = g_serial.fetch_add(1, std::memory_order_relaxed);   // 0 is the ring's initial content
+    f.word = base + serial % kFlagSlots;
+    f.serial = serial;
+    return true;
+}
+
+// Stream-ordered scratch (the fp16 copy of V): hipMallocAsync from the device's default pool, released behind the last kernel that
+// reads it.  The pool keeps what it has handed out (release threshold raised once per device), so steady-state calls do not
+// reach the driver.  Capturable: inside a stream capture the pair becomes graph memory nodes.
+hipError_t scratch_alloc(void** ptr, size_t bytes, hipStream_t stream)
+{
+    const int dev = current_device();
+    if (dev >= 0 && !g_pool_tuned[dev].exchange(true)) {
+        hipMemPool_t pool = nullptr;
+        if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool != nullptr) {
+            uint64_t keep = ~0ull;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+    }
+    return hipMallocAsync(ptr, bytes, stream);
+}
+
 // FA_F32_AUTO=exact in the environment makes FA_KERNEL_AUTO compute fp32 tensors in fp32 arithmetic (FA_KERNEL_MFMA) process-wide:
 // the switch for a deployment whose logits are too wide for 16-bit operands, without touching call sites.  Read once.
 bool f32_auto_is_exact()
@@ -87,28 +162,101 @@ bool f32_auto_is_exact()
     return exact;
 }
 
+// bf16 tensors, fp16 P: V -> fp16 scratch copy, fp16-P kernel, split kernel as the conditional fallback
+int launch_p16_chain(const fa::FwdParams& p0, int32_t d, int32_t causal, int32_t out_f32, hipStream_t stream)
+{
+    FlagRef f;
+    if (!next_flag(f)) return fail(FA_ERR_HIP, "no device flag ring (hipGetSymbolAddress failed)");
+    const size_t bytes = (size_t)p0.bh * (size_t)p0.n * (size_t)d * 2u;
+    void* v16 = nullptr;
+    hipError_t e = scratch_alloc(&v16, bytes, stream);
+    if (e != hipSuccess) return fail(FA_ERR_HIP, "hipMallocAsync(%zu bytes) for the fp16 copy of V failed: %s", bytes, hipGetErrorString(e));
+    e = fa::launch_cvt_v_f16(p0.v, v16, (int64_t)p0.bh * p0.n * d, f.word, f.serial, stream);
+    if (e == hipSuccess) {
+        fa::FwdParams p = p0;
+        p.v = v16;
+        p.flag = f.word;
+        p.flag_serial = f.serial;
+        p.flag_mode = 1;   // skip if the copy found a value fp16 cannot hold
+        e = fa::launch_bf16_x4_p16(p, causal ? 1 : 0, out_f32, stream);
+    }
+    if (e == hipSuccess) {
+        fa::FwdParams p = p0;
+        p.flag = f.word;
+        p.flag_serial = f.serial;
+        p.flag_mode = 2;   // run only in that case
+        e = fa::launch_bf16_split(p, d, causal ? 1 : 0, out_f32, 0, stream);
+    }
+    const hipError_t ef = hipFreeAsync(v16, stream);
+    if (e == hipSuccess) e = ef;
+    if (e != hipSuccess) return fail(FA_ERR_HIP, "fp16-P launch chain failed: %s", hipGetErrorString(e));
+    t_last_flag = f;
+    t_last_chain = 2;
+    return FA_OK;
+}
+
+// fp32 tensors, FA_KERNEL_AUTO: split kernel with the logit-width guard, exact kernel as the conditional fallback
+int launch_f32_guarded(const fa::FwdParams& p0, int32_t d, int32_t causal, hipStream_t stream)
+{
+    FlagRef f;
+    if (!next_flag(f)) return fail(FA_ERR_HIP, "no device flag ring (hipGetSymbolAddress failed)");
+    fa::FwdParams p = p0;
+    p.flag = f.word;
+    p.flag_serial = f.serial;
+    p.flag_mode = 3;
+    hipError_t e = fa::launch_f32_split(p, d, causal ? 1 : 0, 0, stream);
+    if (e == hipSuccess) {
+        p.flag_mode = 2;
+        e = fa::launch_fwd_f32(p, d, causal ? 1 : 0, 0, stream);
+    }
+    if (e != hipSuccess) return fail(FA_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    t_last_flag = f;
+    t_last_chain = 1;
+    return FA_OK;
+}
+
+bool p16_available(const fa::FwdParams& p, int32_t d) { return d == 64 && fa::bf16_pipelined_supported(p, 64); }
+
 int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int32_t kernel, hipStream_t stream)
 {
     const KernelSel sel = decode_kernel(kernel);
     hipError_t e = hipSuccess;
+    t_last_chain = 0;
     if (sel.kind == FA_KERNEL_NAIVE) {
         if (dtype != FA_DTYPE_F32) return fail(FA_ERR_UNSUPPORTED, "the naive kernel is fp32 only");
         if (d > 256) return fail(FA_ERR_UNSUPPORTED, "naive kernel supports head dim <= 256 (got %d)", d);
         e = fa::launch_naive_f32(p, d, causal ? 1 : 0, stream);
-    } else if (sel.kind == FA_KERNEL_AUTO || sel.kind == FA_KERNEL_MFMA || sel.kind == FA_KERNEL_SPLIT) {
+    } else if (sel.kind == FA_KERNEL_AUTO || sel.kind == FA_KERNEL_MFMA || sel.kind == FA_KERNEL_SPLIT || sel.kind == FA_KERNEL_P16) {
         if (!head_dim_supported(d))
             return fail(FA_ERR_UNSUPPORTED, "head dim %d not instantiated for the MFMA kernels (32, 64, 128)", d);
-        if (sel.kind == FA_KERNEL_SPLIT && dtype != FA_DTYPE_F32)   // bf16 tensors, P and Q' carried in 16 bits: the accurate bf16 mode
-            e = fa::launch_bf16_split(p, d, causal ? 1 : 0, dtype == FA_DTYPE_BF16_OUT_F32 ? 1 : 0, sel.variant, stream);
-        else if (dtype != FA_DTYPE_F32)
-            e = fa::launch_fwd_bf16(p, d, causal ? 1 : 0, dtype == FA_DTYPE_BF16_OUT_F32 ? 1 : 0, sel.variant, stream);
-        else if (sel.kind == FA_KERNEL_MFMA || (sel.kind == FA_KERNEL_AUTO && f32_auto_is_exact()))
+        const int out_f32 = dtype == FA_DTYPE_BF16_OUT_F32 ? 1 : 0;
+        if (dtype != FA_DTYPE_F32) {
+            // bf16 tensors.  AUTO: a caller who asks for the fp32 accumulator gets the accurate P (fp16 where instantiated, hi + lo
+            // bf16 terms elsewhere: within 1e-3 of the fp32 reference at scale 1); a bf16 output rounds at 2^-9 of |O| anyway
+            // and takes the fastest kernels (bf16 P).  MFMA / SPLIT / P16 force one family.
+            if (sel.kind == FA_KERNEL_P16 && !p16_available(p, d))
+                return fail(FA_ERR_UNSUPPORTED, "the fp16-P kernel is instantiated for head dim 64 and slabs below 4 GiB (got d = %d)", d);
+            if (sel.kind == FA_KERNEL_P16 || (sel.kind == FA_KERNEL_AUTO && out_f32 && sel.variant == 0 && p16_available(p, d)))
+                return launch_p16_chain(p, d, causal, out_f32, stream);
+            if (sel.kind == FA_KERNEL_SPLIT || (sel.kind == FA_KERNEL_AUTO && out_f32 && sel.variant == 0))
+                e = fa::launch_bf16_split(p, d, causal ? 1 : 0, out_f32, sel.variant, stream);
+            else
+                e = fa::launch_fwd_bf16(p, d, causal ? 1 : 0, out_f32, sel.variant, stream);
+        } else if (sel.kind == FA_KERNEL_P16) {
+            return fail(FA_ERR_UNSUPPORTED, "FA_KERNEL_P16 is a bf16-tensor kernel");
+        } else if (sel.kind == FA_KERNEL_MFMA || (sel.kind == FA_KERNEL_AUTO && f32_auto_is_exact())) {
             e = fa::launch_fwd_f32(p, d, causal ? 1 : 0, sel.variant, stream);       // exact fp32 arithmetic
-        else
-            e = fa::launch_f32_split(p, d, causal ? 1 : 0, sel.variant, stream);     // AUTO: fp32 tensors on the bf16 pipe
+        } else if (sel.kind == FA_KERNEL_AUTO && sel.variant == 0) {
+            return launch_f32_guarded(p, d, causal, stream);                         // split products behind the logit-width guard
+        } else {
+            e = fa::launch_f32_split(p, d, causal ? 1 : 0, sel.variant, stream);     // SPLIT: fp32 tensors on the bf16 pipe, unguarded
+        }
     } else {
         return fail(FA_ERR_UNSUPPORTED, "unknown kernel id %d", sel.kind);
     }
+    if (e == hipErrorInvalidValue && sel.variant != 0)
+        return fail(FA_ERR_UNSUPPORTED, "tiling %d is not a shipped tiling of kernel family %d for head dim %d (timing-only ablations "
+                                        "are built into libflashattn_amd_ablation.so only)", sel.variant, sel.kind, d);
     if (e != hipSuccess) return fail(FA_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return FA_OK;
 }
@@ -270,6 +418,20 @@ int fa_time_forward_graph(const void* q, const void* k, const void* v, void* o, 
     return time_forward_impl(q, k, v, o, bh, n, d, scale, causal, dtype, kernel, nullptr, warmup, iters, ms_per_forward, true);
 }
 
+int fa_last_forward_route(void* stream, int32_t* route)
+{
+    g_err[0] = 0;
+    if (!route) return fail(FA_ERR_INVALID_ARGUMENT, "null route pointer");
+    *route = 0;
+    if (t_last_chain == 0) return FA_OK;
+    uint32_t word = 0;
+    hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    if (e == hipSuccess) e = hipMemcpy(&word, t_last_flag.word, sizeof(word), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(FA_ERR_HIP, "reading the chain's flag word failed: %s", hipGetErrorString(e));
+    *route = word == t_last_flag.serial ? 2 : 1;
+    return FA_OK;
+}
+
 const char* fa_last_error(void) { return g_err; }
 
 int fa_device_count(void)
@@ -279,13 +441,22 @@ int fa_device_count(void)
     return n;
 }
 
-const char* fa_version(void) { return "flashattn_amd abi 1 gfx950 (hip, mfma f32 32x32x2 / bf16 32x32x16, lds-dma)"; }
+const char* fa_version(void)
+{
+#if FA_ABLATION
+    return "flashattn_amd abi 2 gfx950 (hip, mfma f32 32x32x2 / bf16, f16 32x32x16, lds-dma) +ablation";
+#else
+    return "flashattn_amd abi 2 gfx950 (hip, mfma f32 32x32x2 / bf16, f16 32x32x16, lds-dma)";
+#endif
+}
 
 const char* fa_kernel_name_for(int32_t dtype, int32_t d, int32_t causal, int64_t bh, int64_t n)
 {
     if (!head_dim_supported(d) || bh < 1 || n < 1) return nullptr;
     if (dtype == FA_DTYPE_F32) return f32_auto_is_exact() ? "fa_fwd_f32_kernel" : "fa_fwd_f32_split_kernel";
-    if (dtype == FA_DTYPE_BF16 || dtype == FA_DTYPE_BF16_OUT_F32) return fa::bf16_kernel_name(bh, n, d, causal);
+    if (dtype == FA_DTYPE_BF16) return fa::bf16_kernel_name(bh, n, d, causal);
+    if (dtype == FA_DTYPE_BF16_OUT_F32)   // the accurate P (see fa_dtype): fp16 at head dim 64 (slabs below 4 GiB), hi + lo bf16 terms elsewhere
+        return (d == 64 && ((n - 1) * 64 + 64) * 2 < 0xffffffffLL) ? "fa_fwd_bf16_x4_p16_kernel" : "fa_fwd_f32_split_kernel";
     return nullptr;
 }
 

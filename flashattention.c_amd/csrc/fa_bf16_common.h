@@ -148,6 +148,21 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(const f32x16& s, int base)
     return r;
 }
 
+// P fragment in the format of the second contraction: bf16 (default) or fp16 (round to nearest even: v_cvt_pk_f16_f32)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <bool PF>
+__device__ __forceinline__ bf16x8 pack_p16x8(const f32x16& s, int base)
+{
+    if constexpr (PF) {
+        f16x8 r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = (_Float16)s[base + i];
+        return __builtin_bit_cast(bf16x8, r);
+    } else {
+        return pack_bf16x8(s, base);
+    }
+}
+
 template <int D>
 __device__ __forceinline__ void qk_block(const char* k_lds, int k_row_off, int k_g, const bf16x8 (&qf)[D / 16], f32x16 (&s)[2])
 {
@@ -219,13 +234,21 @@ constexpr float kOptLimit = 0x1p100f;
 
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
+template <bool PF = false>
 __device__ __forceinline__ bf16x8 rowsum_a_operand(int lane)
 {
     const bool one = (((lane & 15) >> 2) & 1) == ((lane >> 4) & 1);
-    bf16x8 a;
+    if constexpr (PF) {
+        f16x8 a;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = one ? (__bf16)1.0f : (__bf16)0.0f;
-    return a;
+        for (int i = 0; i < 8; ++i) a[i] = one ? (_Float16)1.0f : (_Float16)0.0f;
+        return __builtin_bit_cast(bf16x8, a);
+    } else {
+        bf16x8 a;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = one ? (__bf16)1.0f : (__bf16)0.0f;
+        return a;
+    }
 }
 
 struct BlockState {   // running softmax state of one 32-row block (per lane: one query row, half of its keys)

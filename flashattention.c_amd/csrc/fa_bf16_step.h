@@ -60,6 +60,7 @@ __device__ __forceinline__ void mask16(f32x16& s, int key0, int qi, int n, int h
 
 // exp + pack of one block's 16 scores, element range [e0, e1) and pack of fragment(s) whose elements are complete
 // (clamp = false: the optimistic mix, where an overflow has to reach the row sum instead of being clamped away)
+template <bool PF = false>
 __device__ __forceinline__ void exp_range(f32x16& s, bf16x8 (&pf)[2], float c, float off, int e0, int e1, bool clamp = true)
 {
 #pragma unroll
@@ -68,7 +69,7 @@ __device__ __forceinline__ void exp_range(f32x16& s, bf16x8 (&pf)[2], float c, f
 #pragma unroll
     for (int f = 0; f < 2; ++f)
         if (e0 < 8 * (f + 1) && e1 >= 8 * (f + 1)) {  // this range completes fragment f
-            pf[f] = pack_bf16x8(s, 8 * f);
+            pf[f] = pack_p16x8<PF>(s, 8 * f);
             asm volatile("" : "+v"(pf[f]));
         }
 }

@@ -47,14 +47,36 @@ __device__ __forceinline__ void mfma_s(f32x16& s, const bf16x8& kf, const bf16x8
 {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(kf), "a"(q));
 }
+// PF (here and below): P and the V image are fp16 instead of bf16 (the accurate mode, see X4Soft); the 16-bit fragments travel in
+// the same register types either way.
+template <bool PF = false>
 __device__ __forceinline__ void mfma_o(f32x16& o, const bf16x8& vf, const bf16x8& pfrag)
 {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(vf), "v"(pfrag));
+    if constexpr (PF) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(o) : "v"(vf), "v"(pfrag));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(vf), "v"(pfrag));
 }
+template <bool PF = false>
 __device__ __forceinline__ void mfma_l(f32x4_t& l, const bf16x8& ones, const bf16x8& pfrag)
 {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(pfrag));
+    if constexpr (PF) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(pfrag));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(pfrag));
 }
+
+// Exponent bookkeeping of the three softmax mixes: p = 2^(c*s - m - kBias), and (rescaled mixes) the reference m of a wave moves
+// when some score of the next sub-tile has c*s - m - kBias > kThr.
+//   optimistic, bf16 P   m fixed after the first sub-tile, 2^100 of room either way, verified at the end (fa_bf16_common.h)
+//   rescaled,   bf16 P   p <= 1 with the row maximum anywhere in 2^-64 .. 1 between two moves of the reference
+//   rescaled,   fp16 P   fp16 spans 2^-14 .. 2^16 (normal): the row maximum is put at 2^-5 when the reference moves and may grow to
+//                        2^14 before it moves again -- entries more than 2^-9 below a row maximum at the low end of that window
+//                        become subnormal (absolute error <= 2^-25, i.e. <= 2^-20 of the maximum: below the 2^-11 rounding of P
+//                        itself).  On unit-variance data at scale 1 (N = 8192, d = 64) a 128-row wave moves its references ~4
+//                        times per tile; at 1/sqrt(d) never after the first sub-tile.
+template <bool OPT, bool PF>
+struct X4Soft {
+    static_assert(!(OPT && PF), "fp16 P has no room for a fixed exponent reference");
+    static constexpr float kBias = OPT ? kOptBias : PF ? 5.0f : kLazyThr;
+    static constexpr float kThr = PF ? 14.0f : 0.0f;
+};
 
 // mfma_drain() with the registers it protects as operands: the drain is an asm statement without a data dependence of its
 // own, and hipcc is free to schedule the VALU consumers of an asm MFMA's result in front of it (it did: the optimistic
@@ -71,15 +93,17 @@ __device__ __forceinline__ void drain_accumulators(f32x16 (&o)[kNB][2], BlockSta
 }
 
 // (rare, wave-uniform) move the exponent references of all blocks; everything still at the old reference is scaled once
+template <bool PF = false>
 __device__ __forceinline__ void x4_rescale(const float (&mx)[kNB], float c, BlockState (&st)[kNB], f32x16 (&o)[kNB][2], float (&off)[kNB])
 {
+    using SM = X4Soft<false, PF>;
     bool any = false;
     float mc[kNB];
 #pragma unroll
     for (int b = 0; b < kNB; ++b) {
         mc[b] = mx[b] * c;
         mc[b] = fmaf(-fabsf(mc[b]), 0x1p-23f, mc[b]);
-        any = any || (mc[b] - st[b].m > kLazyThr);
+        any = any || (mc[b] - st[b].m > SM::kBias + SM::kThr);
     }
     if (__builtin_expect(__any(any), 0)) {
         asm volatile("; lazy rescale (four blocks)" ::: "memory");
@@ -98,7 +122,7 @@ __device__ __forceinline__ void x4_rescale(const float (&mx)[kNB], float c, Bloc
         }
     }
 #pragma unroll
-    for (int b = 0; b < kNB; ++b) off[b] = st[b].m + kLazyThr;
+    for (int b = 0; b < kNB; ++b) off[b] = st[b].m + SM::kBias;
 }
 
 // ---- static schedule of one step -------------------------------------------------------------------------------------
@@ -250,7 +274,7 @@ struct X4Ctx {
     bool need;
 };
 
-template <bool OPT, int U, int ABL = 0>
+template <bool OPT, int U, int ABL = 0, bool PF = false>
 __device__ __forceinline__ void x4_unit(X4Ctx& x)
 {
     constexpr X4Unit un = x4_make_units(OPT).u[U];
@@ -263,10 +287,11 @@ __device__ __forceinline__ void x4_unit(X4Ctx& x)
     } else if constexpr (un.kind == 0) {
         // optimistic mix: no clamp -- an overflow has to reach the row sum (as a huge value or +inf): that is what the final
         // check reads
-        if constexpr (OPT) x.sc[un.blk][un.idx] = fast_exp2(fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]));
+        // fp16 P: no clamp either -- p ranges up to 2^kThr by design
+        if constexpr (OPT || PF) x.sc[un.blk][un.idx] = fast_exp2(fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]));
         else x.sc[un.blk][un.idx] = exp2_clamp01(fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]));
     } else if constexpr (un.kind == 1) {
-        x.pf[un.blk][un.idx] = pack_bf16x8(x.sc[un.blk], 8 * un.idx);
+        x.pf[un.blk][un.idx] = pack_p16x8<PF>(x.sc[un.blk], 8 * un.idx);
         asm volatile("" : "+v"(x.pf[un.blk][un.idx]));
     } else if constexpr (un.kind == 2) {
         lanemax_step(un.idx, x.sn[un.blk], x.pm, x.lm[un.blk]);
@@ -274,16 +299,16 @@ __device__ __forceinline__ void x4_unit(X4Ctx& x)
         float t = fmaf(x.lm[0], x.c, -x.off[0]);
 #pragma unroll
         for (int b = 1; b < kNB; ++b) t = fmaxf(t, fmaf(x.lm[b], x.c, -x.off[b]));
-        x.need = t > 0.0f;  // off = m + kLazyThr
+        x.need = t > X4Soft<false, PF>::kThr;  // off = m + kBias
     }
 }
-template <bool OPT, int ABL, int U0, int... Us>
+template <bool OPT, int ABL, bool PF, int U0, int... Us>
 __device__ __forceinline__ void x4_units(X4Ctx& x, std::integer_sequence<int, Us...>)
 {
-    (x4_unit<OPT, U0 + Us, ABL>(x), ...);
+    (x4_unit<OPT, U0 + Us, ABL, PF>(x), ...);
 }
 
-template <int KB_C, int I, int ABL, bool OPT>
+template <int KB_C, int I, int ABL, bool OPT, bool PF>
 __device__ __forceinline__ void x4_slot_body(X4Ctx& x)
 {
     constexpr int D = 64;
@@ -312,9 +337,9 @@ __device__ __forceinline__ void x4_slot_body(X4Ctx& x)
         if constexpr (sl.idx == 0) mfma_s_first(x.sn[sl.blk], x.kf[sl.idx], x.qf[sl.blk][sl.idx]);
         else mfma_s(x.sn[sl.blk], x.kf[sl.idx], x.qf[sl.blk][sl.idx]);
     } else if constexpr (sl.kind == 1) {
-        mfma_o(x.o[sl.blk][sl.idx % 2], x.vf[sl.idx], x.pf[sl.blk][sl.idx / 2]);
+        mfma_o<PF>(x.o[sl.blk][sl.idx % 2], x.vf[sl.idx], x.pf[sl.blk][sl.idx / 2]);
     } else {
-        mfma_l(x.st[sl.blk].lacc, x.ones_a, x.pf[sl.blk][sl.idx]);
+        mfma_l<PF>(x.st[sl.blk].lacc, x.ones_a, x.pf[sl.blk][sl.idx]);
     }
     if constexpr (I >= 28 && I < 32) {  // K fragments of the next step (the last K.Q^T of this one was slot 27)
         // asm, like the V^T reads: a compiler-visible LDS load would make hipcc put its own lgkmcnt waits in front of the
@@ -326,16 +351,16 @@ __device__ __forceinline__ void x4_slot_body(X4Ctx& x)
         else asm volatile("ds_read_b128 %0, %1" : "=v"(x.kf[ks]) : "v"(a));
         if constexpr (ABL & 32) asm volatile("ds_read_b128 %0, %1" : "=v"(x.kf[ks]) : "v"(a));
     }
-    if constexpr (!(ABL & 2)) x4_units<OPT, ABL, tab.ub[I]>(x, std::make_integer_sequence<int, tab.ub[I + 1] - tab.ub[I]>{});  // ABL & 2: no VALU work
+    if constexpr (!(ABL & 2)) x4_units<OPT, ABL, PF, tab.ub[I]>(x, std::make_integer_sequence<int, tab.ub[I + 1] - tab.ub[I]>{});  // ABL & 2: no VALU work
     if constexpr (!(ABL & 128)) __builtin_amdgcn_sched_barrier(0);  // ABL & 128: slots not pinned (hipcc schedules the step)
 }
-template <int KB_C, int ABL, bool OPT, int... Is>
+template <int KB_C, int ABL, bool OPT, bool PF, int... Is>
 __device__ __forceinline__ void x4_slots(X4Ctx& x, std::integer_sequence<int, Is...>)
 {
-    (x4_slot_body<KB_C, Is, ABL, OPT>(x), ...);
+    (x4_slot_body<KB_C, Is, ABL, OPT, PF>(x), ...);
 }
 
-template <int KB_C, int ABL = 0, bool OPT = false>
+template <int KB_C, int ABL = 0, bool OPT = false, bool PF = false>
 __device__ __forceinline__ bool x4_step(const char* v_lds, const char* k_nxt, int kb_n2, int k_row_off, int k_g, int v_lane_off,
                                         const bf16x8& ones_a, const bf16x8 (&qf)[kNB][4], f32x16 (&sc)[kNB], f32x16 (&sn)[kNB],
                                         f32x16 (&o)[kNB][2], BlockState (&st)[kNB], float c, const float (&off)[kNB], bf16x8 (&kf)[4],
@@ -343,7 +368,7 @@ __device__ __forceinline__ bool x4_step(const char* v_lds, const char* k_nxt, in
 {
     X4Ctx x{ones_a, qf, sc, sn, o, st, off, kf, lm, c, k_nxt, kb_n2, k_row_off, k_g, (unsigned)(size_t)(lds_s16x4_t*)(v_lds + v_lane_off)};
     x.need = false;
-    x4_slots<KB_C, ABL, OPT>(x, std::make_integer_sequence<int, kX4Slots>{});
+    x4_slots<KB_C, ABL, OPT, PF>(x, std::make_integer_sequence<int, kX4Slots>{});
     // the K reads of slots 28..31 are eight MFMA slots old: this wait is free, and it keeps every asm-issued load inside the
     // basic block that issued it (hipcc may move or spill a register across a branch without knowing a load is in flight)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]));
@@ -351,11 +376,11 @@ __device__ __forceinline__ bool x4_step(const char* v_lds, const char* k_nxt, in
 }
 
 // One 512-row tile.  OPT: optimistic mix; returns false (nothing stored) when some row of the workgroup left the safe range.
-template <int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL, bool OPT>
+template <int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL, bool OPT, bool PF = false>
 __device__ __forceinline__ bool x4_tile(const FwdParams& p, char* smem)
 {
     constexpr int D = 64, KS = 4, DB = 2;
-    constexpr float kBias = OPT ? kOptBias : kLazyThr;
+    constexpr float kBias = X4Soft<OPT, PF>::kBias;
     using C = Bf16Cfg<D, NWAVES>;
     constexpr int BM = NWAVES * 32 * kNB;
     constexpr int KR = 2 * G, VR = 2 * G;
@@ -409,7 +434,7 @@ __device__ __forceinline__ bool x4_tile(const FwdParams& p, char* smem)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[blk][ks] = *(const bf16x8*)(qr + ks * 16);
     }
-    const bf16x8 ones_a = rowsum_a_operand(lane);
+    const bf16x8 ones_a = rowsum_a_operand<PF>(lane);
 
     f32x16 o[kNB][DB], s0[kNB], s1[kNB];
     BlockState st[kNB];
@@ -480,7 +505,7 @@ __device__ __forceinline__ bool x4_tile(const FwdParams& p, char* smem)
                 off[blk] = st[blk].m + kBias;
             }
         } else if (!OPT) {
-            x4_rescale(mx, c, st, o, off);
+            x4_rescale<PF>(mx, c, st, o, off);
         }
     };
     // exp, pack, P.V and row sums of sub-tile t for all blocks, phase-structured (tail)
@@ -492,16 +517,16 @@ __device__ __forceinline__ bool x4_tile(const FwdParams& p, char* smem)
 #pragma unroll
         for (int blk = 0; blk < kNB; ++blk) {
             bf16x8 pf[2];
-            exp_range(s[blk], pf, c, off[blk], 0, 8, !OPT);
-            exp_range(s[blk], pf, c, off[blk], 8, 16, !OPT);
+            exp_range<PF>(s[blk], pf, c, off[blk], 0, 8, !OPT && !PF);
+            exp_range<PF>(s[blk], pf, c, off[blk], 8, 16, !OPT && !PF);
             // a VALU result needs two wait states before an MFMA may read it; hipcc counts them for its own MFMAs, not
             // for an asm one (the pipelined loop packs P at least one whole slot ahead of its first use)
             asm volatile("s_nop 1" : "+v"(pf[0]), "+v"(pf[1]));
 #pragma unroll
-            for (int v = 0; v < 2 * DB; ++v) mfma_o(o[blk][v % DB], vf[v], pf[v / DB]);
-            mfma_l(st[blk].lacc, ones_a, pf[0]);
+            for (int v = 0; v < 2 * DB; ++v) mfma_o<PF>(o[blk][v % DB], vf[v], pf[v / DB]);
+            mfma_l<PF>(st[blk].lacc, ones_a, pf[0]);
             asm volatile("s_nop 7");  // dependent row-sum MFMAs back to back: the hazard is ours
-            mfma_l(st[blk].lacc, ones_a, pf[1]);
+            mfma_l<PF>(st[blk].lacc, ones_a, pf[1]);
         }
     };
 
@@ -526,19 +551,19 @@ __device__ __forceinline__ bool x4_tile(const FwdParams& p, char* smem)
         for (int g = 0; g < G; ++g) {
             const char* v_lds = v_slot(j + g);
             const char* k_nxt = k_slot(j + g + 1);
-            bool need = x4_step<0, ABL, OPT>(v_lds, k_nxt, 0, k_row_off, k_g, v_lane_off, ones_a, qf, s0, s1, o, st, c, off, kf, lm);
+            bool need = x4_step<0, ABL, OPT, PF>(v_lds, k_nxt, 0, k_row_off, k_g, v_lane_off, ones_a, qf, s0, s1, o, st, c, off, kf, lm);
             if (!OPT && __builtin_expect(__any(need), 0)) {
                 float mx[kNB];
 #pragma unroll
                 for (int blk = 0; blk < kNB; ++blk) mx[blk] = xhalf_max(lm[blk]);
-                x4_rescale(mx, c, st, o, off);
+                x4_rescale<PF>(mx, c, st, o, off);
             }
-            need = x4_step<1, ABL, OPT>(v_lds, k_nxt, 1, k_row_off, k_g, v_lane_off, ones_a, qf, s1, s0, o, st, c, off, kf, lm);
+            need = x4_step<1, ABL, OPT, PF>(v_lds, k_nxt, 1, k_row_off, k_g, v_lane_off, ones_a, qf, s1, s0, o, st, c, off, kf, lm);
             if (!OPT && __builtin_expect(__any(need) && 2 * (j + g) + 2 < nsub, 0)) {
                 float mx[kNB];
 #pragma unroll
                 for (int blk = 0; blk < kNB; ++blk) mx[blk] = xhalf_max(lm[blk]);
-                x4_rescale(mx, c, st, o, off);
+                x4_rescale<PF>(mx, c, st, o, off);
             }
         }
     }
@@ -567,7 +592,7 @@ __device__ __forceinline__ bool x4_tile(const FwdParams& p, char* smem)
     // The optimistic tile stores its result BEFORE the workgroup votes on it: a failed tile is simply overwritten by the redo,
     // and nothing of the first attempt is live across the vote (with the store behind the vote hipcc carried the
     // accumulators of the common path through copies and 12 MB of scratch per launch).
-    mfma_drain();
+    drain_accumulators(o, st);  // tied to the accumulators: a bare drain has no data dependence and may be scheduled past
     bool bad = false;
     if (OPT) {
         // every P was exponentiated against the first sub-tile's maximum: the tile stands iff no term left the safe range,
@@ -644,6 +669,33 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdPar
         return;
     }
     (void)x4_tile<NWAVES, CAUSAL, OUT_F32, G, ABL, false>(p, smem);
+}
+
+// The accurate mode: P and V in fp16 (11 significant bits instead of 8; X4Soft<false, true>), lazily rescaled mix only.  p.v points
+// at the fp16 copy of V made by launch_cvt_v_f16 (fa_cvt.hip), whose overflow flag this kernel honours (FwdParams::flag_mode = 1).
+template <int NWAVES, bool CAUSAL, bool OUT_F32, int G>
+__global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_p16_kernel(FwdParams p)
+{
+    using C = Bf16Cfg<64, NWAVES>;
+    __shared__ __attribute__((aligned(1024))) char smem[4 * G * C::kTileBytes];
+    if (flag_says_skip(p)) return;
+    (void)x4_tile<NWAVES, CAUSAL, OUT_F32, G, 0, false, true>(p, smem);
+}
+
+template <bool CAUSAL>
+static hipError_t launch_x4_p16(const FwdParams& p0, int out_f32, hipStream_t stream)
+{
+    FwdParams p = p0;
+    constexpr int NWAVES = 4, BM = NWAVES * 32 * kNB, G = 2;
+    p.q_tiles = (p.n + BM - 1) / BM;
+    const int64_t total = (int64_t)p.bh * p.q_tiles;
+    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)total), block(NWAVES * kWave);
+    if (out_f32)
+        hipLaunchKernelGGL((fa_fwd_bf16_x4_p16_kernel<NWAVES, CAUSAL, true, G>), grid, block, 0, stream, p);
+    else
+        hipLaunchKernelGGL((fa_fwd_bf16_x4_p16_kernel<NWAVES, CAUSAL, false, G>), grid, block, 0, stream, p);
+    return hipGetLastError();
 }
 
 template <int G, bool OPTIMISTIC, bool CAUSAL>

@@ -47,7 +47,22 @@ struct FwdParams {
     int64_t kv_head_stride;
     int64_t o_head_stride;
     int32_t o_is_bf16;      // split kernel only: O is bf16 (bf16 tensors); 0 = fp32
+    // Conditional launch chains (fa_api.cpp): a kernel chain shares one 32-bit device word; "set" means *flag == flag_serial
+    // (serials are unique per call, so the word never needs clearing).
+    //   flag_mode 0  ignore the word;   1  run only while the word is NOT set;   2  run only if the word IS set;
+    //   flag_mode 3  (fp32 split kernel) always run, and set the word when the logits are too wide for 16-bit operands.
+    uint32_t* flag;
+    uint32_t flag_serial;
+    int32_t flag_mode;
 };
+
+// Early exit of a conditionally launched kernel (wave-uniform scalar load; see FwdParams::flag_mode).
+__device__ __forceinline__ bool flag_says_skip(const FwdParams& p)
+{
+    if (p.flag_mode != 1 && p.flag_mode != 2) return false;
+    const uint32_t f = __hip_atomic_load(p.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (f == p.flag_serial) == (p.flag_mode == 1);
+}
 
 // Map the linear workgroup id onto (slab, q-tile) so that each XCD owns a contiguous range of work items
 // and therefore whole (batch*head) slabs: the dispatcher places workgroup b on XCD b % 8 (observed, used for

@@ -528,7 +528,9 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
                 case 2: return launch_cfg<64, 4, 2, 2>(p, causal, out_f32, stream);   // phase-structured, 64 rows/wave
                 case 7: return launch_bf16_pipelined(p, 64, 4, causal, out_f32, 0, stream);
                 case 24: return launch_bf16_pipelined(p, 64, 2, causal, out_f32, 0, stream);
-                case 22: return launch_bf16_pipelined(p, 64, 4, 0, 0, 1, stream);
+#if FA_ABLATION
+                case 22: return launch_bf16_pipelined(p, 64, 4, 0, 0, 1, stream);   // in-kernel phase timers (written over the lse buffer)
+#endif
                 case 25: return launch_bf16_pipelined(p, 64, 4, causal, out_f32, 3, stream);  // lazily rescaled mix only
                 case 26: return launch_bf16_pipelined(p, 64, 2, causal, out_f32, 3, stream);  // same, 2-wave workgroups
                 case 30: return launch_bf16_x4(p, causal, out_f32, 2, stream);
@@ -537,7 +539,8 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
                 case 50: return launch_bf16_x2(p, 64, causal, out_f32, 0, stream);   // one wave per SIMD, 64 rows per wave, 256-row tiles
                 case 51: return launch_bf16_x2(p, 64, causal, out_f32, 1, stream);
                 case 52: return launch_bf16_x2(p, 64, causal, out_f32, 3, stream);
-                case 33: return launch_bf16_x4(p, causal, out_f32, 11, stream);  // x4 timing ablations
+#if FA_ABLATION
+                case 33: return launch_bf16_x4(p, causal, out_f32, 11, stream);  // x4 timing ablations (results are garbage)
                 case 34: return launch_bf16_x4(p, causal, out_f32, 12, stream);
                 case 35: return launch_bf16_x4(p, causal, out_f32, 13, stream);
                 case 36: return launch_bf16_x4(p, causal, out_f32, 14, stream);
@@ -549,14 +552,21 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
                 case 43: return launch_bf16_x4(p, causal, out_f32, 20, stream);
                 case 44: return launch_bf16_x4(p, causal, out_f32, 21, stream);
                 case 45: return launch_bf16_x4(p, causal, out_f32, 22, stream);
+#endif
                 case 10: return launch_w4<64, 4, 4>(p, causal, out_f32, stream);       // 4 waves/SIMD on the VALU diet
-                default: return launch_bf16_pp2(p, causal, out_f32, variant, stream);  // 9 = pp2, 6, 11..21 = its ablations
+#if FA_ABLATION
+                default: return launch_bf16_pp2(p, causal, out_f32, variant, stream);  // 9 = pp2 (previous generation), 6, 11..21 = its ablations
+#else
+                default: return hipErrorInvalidValue;   // not a shipped tiling (timing-only ablations live in the ablation build)
+#endif
             }
         case 128:
             if (variant == 50) return launch_bf16_x2(p, 128, causal, out_f32, 0, stream);   // one wave per SIMD, explicit register files
             if (variant == 51) return launch_bf16_x2(p, 128, causal, out_f32, 1, stream);
             if (variant == 52) return launch_bf16_x2(p, 128, causal, out_f32, 3, stream);
+#if FA_ABLATION
             if (variant == 53) return launch_bf16_x2(p, 128, causal, out_f32, 12, stream);
+#endif
             if (variant == 10) return launch_w4<128, 4, 2>(p, causal, out_f32, stream);
             if (variant == 23) return launch_w4<128, 4, 3>(p, causal, out_f32, stream);
             return launch_cfg<128, 4, 1, 2>(p, causal, out_f32, stream);  // the pipelined kernel needs > 256 VGPRs at D = 128

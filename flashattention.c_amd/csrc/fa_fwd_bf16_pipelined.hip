@@ -468,6 +468,7 @@ static bool pp3_addressable(const FwdParams& p, int d)
     return ((int64_t)(p.n - 1) * p.kv_row_stride + d) * 2 < (int64_t)0xffffffffLL;
 }
 
+#if FA_ABLATION
 static hipError_t launch_pp3_prof(const FwdParams& p0, hipStream_t stream)
 {
     FwdParams p = p0;
@@ -476,6 +477,7 @@ static hipError_t launch_pp3_prof(const FwdParams& p0, hipStream_t stream)
     hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<64, 4, false, false, true, 2>), grid, block, 0, stream, p);
     return hipGetLastError();
 }
+#endif
 
 template <int D, int NWAVES, int G, bool OPTIMISTIC = true>
 static hipError_t launch_pp3(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
@@ -507,7 +509,11 @@ bool bf16_pipelined_supported(const FwdParams& p, int d) { return (d == 64 || d 
 hipError_t launch_bf16_pipelined(const FwdParams& p, int d, int nwaves, int causal, int out_f32, int mode, hipStream_t stream)
 {
     if (!bf16_pipelined_supported(p, d)) return hipErrorInvalidValue;
+#if FA_ABLATION
     if (mode == 1) return d == 64 ? launch_pp3_prof(p, stream) : hipErrorInvalidValue;
+#else
+    if (mode == 1) return hipErrorInvalidValue;
+#endif
     if (d == 64) {
         if (nwaves == 2) return mode == 3 ? launch_pp3<64, 2, 1, false>(p, causal, out_f32, stream) : launch_pp3<64, 2, 1>(p, causal, out_f32, stream);
         return mode == 3 ? launch_pp3<64, 4, 2, false>(p, causal, out_f32, stream) : launch_pp3<64, 4, 2>(p, causal, out_f32, stream);

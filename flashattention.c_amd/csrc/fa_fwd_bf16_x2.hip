@@ -582,7 +582,7 @@ __device__ __forceinline__ bool x2_tile(const FwdParams& p, char* smem)
     // The optimistic tile stores its result BEFORE the workgroup votes on it: a failed tile is simply overwritten by the redo,
     // and nothing of the first attempt is live across the vote (with the store behind the vote hipcc carried the
     // accumulators of the common path through copies and 12 MB of scratch per launch).
-    mfma_drain();
+    x2_drain_accumulators<DB>(o, st);  // tied to the accumulators: a bare drain has no data dependence and may be scheduled past
     bool bad = false;
     if (OPT) {
         // every P was exponentiated against the first sub-tile's maximum: the tile stands iff no term left the safe range,
@@ -702,6 +702,7 @@ hipError_t launch_bf16_x2(const FwdParams& p, int d, int causal, int out_f32, in
     }
     if (mode == 1) return launch_x2<128, 1>(p, causal, out_f32, stream);
     if (mode == 3) return launch_x2<128, 2, false>(p, causal, out_f32, stream);
+#if FA_ABLATION
     if (mode == 12) {
         FwdParams q = p;
         q.q_tiles = (p.n + 255) / 256;
@@ -709,6 +710,7 @@ hipError_t launch_bf16_x2(const FwdParams& p, int d, int causal, int out_f32, in
         hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<128, 4, false, false, 2, 2>), grid, block, 0, stream, q);
         return hipGetLastError();
     }
+#endif
     return launch_x2<128, 2>(p, causal, out_f32, stream);
 }
 

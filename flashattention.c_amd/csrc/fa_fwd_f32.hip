@@ -78,6 +78,8 @@ __global__ __launch_bounds__(NWAVES* kWave, MINWAVES) void fa_fwd_f32_kernel(Fwd
 
     __shared__ __attribute__((aligned(1024))) char smem[2 * C::kStageBytes];
 
+    if (flag_says_skip(p)) return;   // conditional fallback behind the guarded split kernel (FA_KERNEL_AUTO, fa_api.cpp)
+
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lq = lane & 31, hi = lane >> 5;

@@ -12,8 +12,12 @@
 // with fp32 accumulation in the matrix core.  The bf16 pipe is 16x the fp32 one on this chip (2.5 PF vs 157 TF dense), so
 // three products still beat v_mfma_f32_32x32x2_f32 by 5x on the matrix pipe, and the result stays within ~2e-4 of the fp64
 // oracle on unit-variance data at scale 1 (~1e-5 at 1/sqrt(d)) -- inside the 1e-3 fp32 tolerance of the path, two orders of
-// magnitude tighter than bf16 tensors.  The error of a score is ~2^-17.6 * sqrt(sum (q_i k_i)^2) <= 5e-6 |q||k| scale; callers
-// whose logits need more than that select the exact kernel (FA_KERNEL_MFMA).  fp32 range is kept (bf16 exponent).
+// magnitude tighter than bf16 tensors.  The error of a score is ~2^-17.6 * sqrt(sum (q_i k_i)^2) <= 5e-6 |q|_2 |k|_inf scale.
+// LOGIT-WIDTH GUARD (fp32 tensors under FA_KERNEL_AUTO, FwdParams::flag_mode = 3): every workgroup sees all keys of its slab and
+// its own query rows; it tracks max |k| element-wise while converting K (one v_max3_f32 per four values) and the 2-norms of its
+// Q rows, and when  max_rows |q|_2 * max |k|_inf * scale  exceeds kGuardLimit (= 100: twice what unit-variance data reach at
+// d = 64, scale 1) it raises the chain's flag word -- the exact fp32 kernel queued behind this one then recomputes the launch
+// (fa_api.cpp).  Callers who know better select FA_KERNEL_SPLIT (no guard) or FA_KERNEL_MFMA.  fp32 range is kept (bf16 exponent).
 //
 //   workgroup   NWAVES waves x QB blocks of 32 query rows; K/V tiles of 32 keys.
 //   HBM -> LDS  fp32 K/V rows are loaded into registers (two 16-byte loads per 8 values), split there, and written as FOUR
@@ -42,6 +46,13 @@ namespace fa {
 
 constexpr int kKvSplit = 32;         // keys per tile
 constexpr float kSplitLimit = 0x1p100f;  // optimistic pass: a row sum below this proves that no term overflowed
+constexpr float kGuardLimit = 100.0f;    // |q|_2 * |k|_inf * scale above which 16-bit operand terms no longer hold 1e-3 (see header)
+
+// running maximum of |a|, |b|: one instruction (abs as source modifiers)
+__device__ __forceinline__ void absmax2(float& m, float a, float b)
+{
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b));
+}
 
 template <int D>
 struct SplitCfg {
@@ -162,11 +173,17 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     constexpr int GPT = (C::kGroups + NT - 1) / NT;  // groups per thread and tile
 
     __shared__ __attribute__((aligned(1024))) char smem[2 * C::kStageBytes];
+    __shared__ unsigned s_kmax;   // logit-width guard: max |k| over the slab, as the bits of a non-negative float
+
+    if (flag_says_skip(p)) return;   // conditional fallback of a launch chain (bf16 tensors behind the fp16-P kernel)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 31, hi = lane >> 5;
+    constexpr bool GUARD = !IN_BF16;   // tracked for every fp32 launch (4 VALU per K piece), acted upon under flag_mode 3 only
+    float kmax = 0.0f;
+    if (GUARD && tid == 0) s_kmax = 0u;   // ordered before the first atomic by the barriers of the main loop
 
     const int total = p.bh * p.q_tiles;
     const int w = xcd_remap(blockIdx.x, total);
@@ -226,6 +243,10 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                 *(f32x4*)(stage + g_vdst[i]) = vst[i][0];
             } else {
                 bf16x8 h8, l8;
+                if constexpr (GUARD) {
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) absmax2(kmax, kst[i][0][e], kst[i][0][e + 1]), absmax2(kmax, kst[i][1][e], kst[i][1][e + 1]);
+                }
                 split8(kst[i][0], kst[i][1], h8, l8);
                 *(bf16x8*)(stage + g_kdst[i]) = h8;
                 *(bf16x8*)(stage + C::kImageBytes + g_kdst[i]) = l8;
@@ -238,8 +259,10 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
 
     // ---- Q' fragments (B operand of S^T = K Q'^T), hi and lo: lane (lq, hi) holds Q'[q][16*ks + 8*hi .. +7]
     bf16x8 qh[QB][KS], ql[QB][KS];
+    float qn2 = 0.0f;   // guard: largest squared 2-norm of Q' among this lane's rows (its half of each row; halves are added below)
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
+        float qs = 0.0f;
         const int qrow = min(q0 + qb * 32 + lq, n - 1);
         const T* qr = qg + (int64_t)qrow * p.q_row_stride + hi * 8;
 #pragma unroll
@@ -253,8 +276,13 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                 a = *(const f32x4*)(qr + ks * 16) * p.scale_log2e;
                 c = *(const f32x4*)(qr + ks * 16 + 4) * p.scale_log2e;
             }
+            if constexpr (GUARD) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qs = fmaf(a[e], a[e], fmaf(c[e], c[e], qs));
+            }
             split8(a, c, qh[qb][ks], ql[qb][ks]);
         }
+        if constexpr (GUARD) qn2 = fmaxf(qn2, xhalf_sum(qs));
     }
 
     const int k_row_off = lq * C::kRowBytes;
@@ -522,6 +550,10 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                     *(f32x4*)(stage + g_kdst[i]) = kst[i][0];
                 } else {
                     bf16x8 h8, l8;
+                    if constexpr (GUARD) {
+#pragma unroll
+                        for (int e = 0; e < 4; e += 2) absmax2(kmax, kst[i][0][e], kst[i][0][e + 1]), absmax2(kmax, kst[i][1][e], kst[i][1][e + 1]);
+                    }
                     split8c(kst[i][0], kst[i][1], h8, l8);
                     *(bf16x8*)(stage + g_kdst[i]) = h8;
                     *(bf16x8*)(stage + C::kImageBytes + g_kdst[i]) = l8;
@@ -713,6 +745,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                     } else {
                         constexpr int c = U - NU_S, gi = c / 4, which = (c % 4) / 2, half = c % 2;
                         const f32x4 x = which ? vst[gi][half] : kst[gi][half];
+                        if constexpr (GUARD && which == 0) absmax2(kmax, x[2 * H], x[2 * H + 1]);
                         bf16x2 h2, l2;
                         split2c(x[2 * H], x[2 * H + 1], h2, l2);
                         ch[which][gi][4 * half + 2 * H] = h2[0], ch[which][gi][4 * half + 2 * H + 1] = h2[1];
@@ -810,7 +843,16 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     bool ok;
     if constexpr (PIPE) ok = run_fast();
     else ok = run_tile(std::true_type{});
-    if (__syncthreads_or(!ok)) run_tile(std::false_type{});
+    if constexpr (GUARD) {   // every thread converted its share of every K tile: fold the shares into the workgroup's maximum
+        if (p.flag_mode == 3) atomicMax(&s_kmax, __float_as_uint(kmax));   // non-negative floats order like their bit patterns
+    }
+    const bool redo = __syncthreads_or(!ok);
+    if constexpr (GUARD) {
+        // |q'|_2 carries scale * log2(e); a NaN on either side raises the word as well (the exact kernel propagates it faithfully)
+        if (p.flag_mode == 3 && !(sqrtf(qn2) * __uint_as_float(s_kmax) <= kGuardLimit * kLog2e))
+            __hip_atomic_store(p.flag, p.flag_serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (redo) run_tile(std::false_type{});
 }
 
 template <int D, int NWAVES, int QB, int MINBLOCKS, bool PIPE, bool IN_BF16 = false>

@@ -25,12 +25,12 @@ import torch
 
 from . import _cabi
 
-__all__ = ["forward", "forward_packed_qkv", "load", "time_forward", "SUPPORTED_HEAD_DIMS"]
+__all__ = ["forward", "forward_packed_qkv", "load", "time_forward", "last_forward_route", "SUPPORTED_HEAD_DIMS"]
 
 SUPPORTED_HEAD_DIMS = (32, 64, 128)
 _DTYPES = {torch.float32: _cabi.FA_DTYPE_F32, torch.bfloat16: _cabi.FA_DTYPE_BF16}
 _KERNELS = {"auto": _cabi.FA_KERNEL_AUTO, "naive": _cabi.FA_KERNEL_NAIVE, "mfma": _cabi.FA_KERNEL_MFMA,
-            "exact": _cabi.FA_KERNEL_MFMA, "split": _cabi.FA_KERNEL_SPLIT}
+            "exact": _cabi.FA_KERNEL_MFMA, "split": _cabi.FA_KERNEL_SPLIT, "p16": _cabi.FA_KERNEL_P16}
 
 
 def _kernel_id(kernel: Union[str, int]) -> int:
@@ -71,12 +71,15 @@ def forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = Fa
 
     Returns a new tensor shaped like ``q`` (the reference allocates with ``torch::zeros``; here ``torch.empty`` is
     enough because every element is written).  ``return_lse=True`` additionally returns the (BH, N) fp32 row
-    log-sum-exp -- the quantity the reference's unused ``O_l`` buffer was reserved for.  ``out_dtype=torch.float32``
-    with bf16 inputs stores the fp32 accumulator unrounded (FA_DTYPE_BF16_OUT_F32).  fp32 tensors: ``kernel="auto"`` /
-    ``"split"`` run both contractions on the bf16 matrix pipe as three products of two-term bf16 splits (within 1e-3 of
-    the fp32 reference, see include/flashattn_amd.h), ``kernel="exact"`` (= ``"mfma"``) computes in fp32 arithmetic.
-    bf16 tensors with ``kernel="split"``: the accurate bf16 mode (P and the scaled Q carried in 16 significant bits; ~1e-4 of
-    the fp64 result at scale 1 with ``out_dtype=torch.float32``, at about twice the time of the default kernels).
+    log-sum-exp -- the quantity the reference's unused ``O_l`` buffer was reserved for.
+
+    Kernel choice (include/flashattn_amd.h has the full rules).  fp32 tensors: ``kernel="auto"`` runs both contractions on
+    the bf16 matrix pipe as three products of two-term bf16 splits (within 1e-3 of the fp32 reference) behind a device-side
+    guard that hands launches with too wide logits to the exact fp32 kernel; ``"split"`` is the same without the guard,
+    ``"exact"`` (= ``"mfma"``) computes in fp32 arithmetic.  bf16 tensors: ``out_dtype=torch.float32`` stores the fp32
+    accumulator (FA_DTYPE_BF16_OUT_F32) and, under ``"auto"``, selects the accurate P -- fp16 (``"p16"``, head dim 64) or
+    hi + lo bf16 terms (``"split"``) -- which is within 1e-3 of the fp32 reference at scale 1; a bf16 output keeps the fastest
+    kernels (bf16 P, ``"mfma"``; ~5e-3 at scale 1).  ``out`` must not overlap q, k or v.
     """
     bh, n, d = _check_qkv(q, k, v)
     kid = _kernel_id(kernel)
@@ -156,6 +159,16 @@ def time_forward(q, k, v, causal: bool = False, *, scale: float = 1.0, kernel: U
                                          int(warmup), int(iters), ctypes.byref(ms))
     _cabi.check(rc)
     return float(ms.value)
+
+
+def last_forward_route(stream: Optional[torch.cuda.Stream] = None) -> int:
+    """Which kernel of a conditional launch chain produced this thread's most recent forward (blocking; diagnostics):
+    0 = single unconditional launch, 1 = primary kernel (fp32: split products, bf16: fp16 P), 2 = fallback (fp32: the
+    logit-width guard fired and the exact kernel ran; bf16: a V value did not fit fp16 and the split kernel ran)."""
+    r = ctypes.c_int32(0)
+    s = (stream or torch.cuda.current_stream()).cuda_stream
+    _cabi.check(_cabi.lib().fa_last_forward_route(ctypes.c_void_p(s), ctypes.byref(r)))
+    return int(r.value)
 
 
 def load(name: str = "flash", sources=None, extra_cuda_cflags=None, **_ignored):

@@ -140,14 +140,15 @@ def main():
     else:
         print(f"[Correctness] attn values sanity check: FAILED (max abs err {err:.2e} >= {tol:g})")
     if args.dtype == "bf16":
-        # the accurate bf16 mode: same tensors, P and the scaled Q carried in 16 significant bits, fp32 output -- held to the fp32 bar
+        # the accurate bf16 path: same tensors, fp32 output -> FA_KERNEL_AUTO carries P in fp16 (head dim 64) or as hi + lo bf16 terms
+        # (head dims 32, 128) -- held to the fp32 bar
         o32 = torch.empty(qd.shape, dtype=torch.float32, device=qd.device)
-        acc = minimal_flash.forward(qd, kd, vd, args.masking, scale=args.scale, kernel="split", out=o32)
-        ms_acc = fa.time_forward(qd, kd, vd, args.masking, scale=args.scale, kernel="split", warmup=args.warmup, iters=args.iters, out=o32)
-        row('flashattention_c_amd.forward (bf16, kernel="split", fp32 out)', ms_acc)
+        acc = minimal_flash.forward(qd, kd, vd, args.masking, scale=args.scale, out=o32)
+        ms_acc = fa.time_forward(qd, kd, vd, args.masking, scale=args.scale, warmup=args.warmup, iters=args.iters, out=o32)
+        row("flashattention_c_amd.forward (bf16 in, fp32 out: accurate P)", ms_acc)
         err_acc = (acc - ref).abs().max().item()
         verdict = "PASSED" if err_acc < 1e-3 else "FAILED"
-        print(f"[Correctness] accurate bf16 mode: {verdict} (max abs err {err_acc:.2e} vs the fp32 bar 0.001)")
+        print(f"[Correctness] accurate bf16 path: {verdict} (max abs err {err_acc:.2e} vs the fp32 bar 0.001)")
         print(result.cpu())
         print(ref.cpu())
     return 0 if err < tol else 1

@@ -42,16 +42,22 @@ def forward_sharded(qs: Sequence[torch.Tensor], ks: Sequence[torch.Tensor], vs: 
     for q, k, v in zip(qs, ks, vs):
         if not (q.is_cuda and q.shape == k.shape == v.shape and q.dtype == k.dtype == v.dtype == dt):
             raise ValueError("every shard needs matching GPU tensors")
+        if not (q.device == k.device == v.device):
+            raise ValueError("q, k, v of one shard must live on the same device")
         if q.shape[1] != n or q.shape[2] != d:
             raise ValueError("all shards must share seq_len and head_dim")
-        outs.append(torch.empty_like(q))
+        # the kernel writes a dense row-major (bh, n, d) shard whatever the strides of q are
+        outs.append(torch.empty(q.shape, dtype=q.dtype, device=q.device))
         devs.append(q.device.index)
         streams.append(torch.cuda.current_stream(q.device).cuda_stream)
+    # contiguous copies (if any were needed) stay referenced until the launches are enqueued; torch's caching allocator keeps a
+    # block alive for work already queued on the stream it was allocated on
+    qc, kc, vc = ([t.contiguous() for t in ts] for ts in (qs, ks, vs))
     vp = ctypes.c_void_p
     arr = lambda ts: (vp * n_sh)(*[t.data_ptr() if t.shape[0] else None for t in ts])  # noqa: E731
     rc = _cabi.lib().fa_forward_sharded(
-        n_sh, (ctypes.c_int32 * n_sh)(*devs), arr([t.contiguous() for t in qs]), arr([t.contiguous() for t in ks]),
-        arr([t.contiguous() for t in vs]), arr(outs), (ctypes.c_int64 * n_sh)(*[q.shape[0] for q in qs]),
+        n_sh, (ctypes.c_int32 * n_sh)(*devs), arr(qc), arr(kc), arr(vc), arr(outs), (ctypes.c_int64 * n_sh)(*[q.shape[0] for q in qs]),
         n, d, float(scale), int(bool(causal)), {torch.float32: 0, torch.bfloat16: 1}[dt], (vp * n_sh)(*streams))
+    del qc, kc, vc
     _cabi.check(rc)
     return outs

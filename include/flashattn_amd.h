@@ -19,8 +19,11 @@
  *   scale       explicit; the reference hard-wires 1.0 (flashattention.cu:593,600) -- pass 1.0f for parity
  *   ragged N    any N >= 1 is handled exactly (tail keys are masked, not zero-filled as at
  *               flashattention.cu:224-231)
- *   ownership   the caller owns every buffer; nothing is allocated, freed or zero-filled here
- *               (the reference allocates O and a dead O_l inside forward(), :608-609)
+ *   ownership   the caller owns every tensor; no tensor is allocated, freed or zero-filled here (the reference allocates O and
+ *               a dead O_l inside forward(), :608-609).  One path needs scratch -- FA_KERNEL_P16's fp16 copy of V -- and
+ *               takes it from the device's stream-ordered pool (hipMallocAsync / hipFreeAsync on `stream`)
+ *   aliasing    o must not overlap q, k or v (a tile that fails its verification is recomputed from q, k, v after o was
+ *               written): overlapping ranges are rejected with FA_ERR_INVALID_ARGUMENT
  *   ordering    the kernel is enqueued on `stream` and the call returns without synchronising
  *               (the reference launches on the legacy stream and calls cudaDeviceSynchronize, :593-594)
  *   errors      every entry point returns FA_OK (0) or an fa_status code; fa_last_error() returns a
@@ -36,7 +39,7 @@
 extern "C" {
 #endif
 
-#define FLASHATTN_AMD_ABI_VERSION 1
+#define FLASHATTN_AMD_ABI_VERSION 2
 
 typedef enum fa_status {
     FA_OK = 0,
@@ -47,25 +50,41 @@ typedef enum fa_status {
 } fa_status;
 
 typedef enum fa_dtype {
-    FA_DTYPE_F32 = 0, /* fp32 in, fp32 out -- the reference's dtype.  FA_KERNEL_AUTO / FA_KERNEL_SPLIT compute both
-                         contractions as three bf16 MFMA products of two-term bf16 splits of the fp32 operands (16
-                         significant bits per operand, fp32 accumulate; max-abs error against fp64 ~2e-4 on unit-variance
-                         data at scale 1, ~1e-5 at 1/sqrt(d) -- inside the 1e-3 fp32 tolerance of the path, 2.6x faster);
-                         FA_KERNEL_MFMA computes in exact fp32 (v_mfma_f32_32x32x2_f32, ~2e-5 / ~1e-6); the environment variable
-                         FA_F32_AUTO=exact makes that the FA_KERNEL_AUTO choice for the whole process */
+    FA_DTYPE_F32 = 0, /* fp32 in, fp32 out -- the reference's dtype.  FA_KERNEL_AUTO: both contractions as three bf16 MFMA
+                         products of two-term bf16 splits of the fp32 operands (16 significant bits per operand, fp32
+                         accumulate; max-abs error against fp64 ~2e-4 on unit-variance data at scale 1, ~1e-5 at 1/sqrt(d),
+                         2.6x faster than fp32 arithmetic) BEHIND A GUARD: the kernel bounds the logit width of its launch,
+                         max |q|_2 * max |k|_inf * scale, and when that exceeds 100 (16-bit operand terms then no longer hold
+                         1e-3) the exact fp32 kernel enqueued behind it recomputes the launch -- on the device, no host
+                         round trip; fa_last_forward_route() tells which one produced the output.  FA_KERNEL_SPLIT: the split
+                         products without the guard.  FA_KERNEL_MFMA: exact fp32 arithmetic (v_mfma_f32_32x32x2_f32: ~2e-5 /
+                         ~1e-6), bit-for-bit an fmaf chain; FA_F32_AUTO=exact in the environment makes that the
+                         FA_KERNEL_AUTO choice for the whole process */
     FA_DTYPE_BF16 = 1,        /* bf16 in, bf16 MFMA with fp32 accumulate and fp32 softmax, bf16 out     */
-    FA_DTYPE_BF16_OUT_F32 = 2 /* same kernel, O written as fp32 (the accumulator precision)             */
+    FA_DTYPE_BF16_OUT_F32 = 2 /* bf16 in, O written as fp32 (the accumulator precision).  Under FA_KERNEL_AUTO this also selects
+                                 the ACCURATE P: a caller who wants the fp32 accumulator gets P in fp16 (11 significant bits;
+                                 head dim 64) or as hi + lo bf16 terms (head dims 32, 128) -- max-abs error below 1e-3 against
+                                 the fp32 reference at scale 1, where bf16 P (8 bits) shows ~5e-3.  A bf16 output rounds at
+                                 2^-9 |O| by itself and keeps the fastest kernels (bf16 P). */
 } fa_dtype;
 
 typedef enum fa_kernel {
-    FA_KERNEL_AUTO = 0,  /* fastest kernel instantiated for (dtype, d)                                  */
+    FA_KERNEL_AUTO = 0,  /* the documented choice per dtype (see fa_dtype)                              */
     FA_KERNEL_NAIVE = 1, /* rung-0 scalar kernel: fp32 only, any d <= 256; on-device cross-check        */
-    FA_KERNEL_MFMA = 2,  /* the tiled MFMA kernel in the arithmetic of `dtype`; d in {32, 64, 128}          */
-    FA_KERNEL_SPLIT = 3  /* split products on the bf16 matrix pipe.  fp32 tensors: see FA_DTYPE_F32 (the AUTO choice there).
-                            bf16 tensors: the ACCURATE bf16 mode -- K, V exact in one term, Q*scale*log2e and P carried as
-                            hi + lo (two products per contraction): max-abs error ~1e-4 against fp64 at scale 1 with
-                            FA_DTYPE_BF16_OUT_F32 (the AUTO kernels round P to 8 bits: ~5e-3), at ~2x their time */
+    FA_KERNEL_MFMA = 2,  /* the tiled MFMA kernel in the arithmetic of `dtype`: exact fp32 for fp32 tensors, bf16 P for bf16
+                            tensors (whatever the output type); d in {32, 64, 128}                        */
+    FA_KERNEL_SPLIT = 3, /* split products on the bf16 matrix pipe.  fp32 tensors: see FA_DTYPE_F32 (unguarded).
+                            bf16 tensors: K, V exact in one term, Q*scale*log2e and P carried as hi + lo (two products per
+                            contraction): max-abs error ~1e-4 against fp64 at scale 1 with FA_DTYPE_BF16_OUT_F32, at ~2x the
+                            time of the bf16-P kernels */
+    FA_KERNEL_P16 = 4    /* bf16 tensors, head dim 64: P and V in fp16 for the second contraction (v_mfma_f32_32x32x16_f16), Q.K^T
+                            in bf16 (exact in the fp32 accumulator): ~6e-4 at scale 1 at ~1.1x the time of the bf16-P kernels.
+                            V is copied to fp16 into stream-ordered scratch (hipMallocAsync) first; if some |v| >= 2^16 the
+                            split kernel takes the launch instead (decided on the device). */
 } fa_kernel;
+/* `kernel` arguments: bits 0..7 = fa_kernel; bits 8..15 = 0, or the number of one of the co-compiled tilings of that family
+ * (every one of them computes the same function; csrc/fa_fwd_bf16.hip and csrc/fa_split_kernel.h list them, tests/ run them
+ * all).  Numbers that are not shipped tilings are rejected with FA_ERR_UNSUPPORTED. */
 
 /*
  * fa_forward -- replaces forward() / run_flash_tiled_coarse{,_causal}
@@ -136,6 +155,15 @@ int fa_time_forward(const void* q, const void* k, const void* v, void* o,
 int fa_time_forward_graph(const void* q, const void* k, const void* v, void* o,
                           int64_t bh, int64_t n, int32_t d, float scale, int32_t causal, int32_t dtype,
                           int32_t kernel, int32_t warmup, int32_t iters, float* ms_per_forward);
+
+/*
+ * fa_last_forward_route -- which kernel of a conditional launch chain produced the output of this thread's most recent
+ *                          forward.  Blocking (waits for `stream`, reads one word back): diagnostics and benchmarks only.
+ *   *route  0 = the call was a single unconditional launch;  1 = the primary kernel (fp32: split products; bf16: fp16 P);
+ *           2 = the fallback (fp32: exact fp32 arithmetic -- the logit-width guard fired; bf16: the split kernel -- a V value
+ *           did not fit fp16)
+ */
+int fa_last_forward_route(void* stream, int32_t* route);
 
 /* Thread-local description of the last failure on this thread ("" if none). */
 const char* fa_last_error(void);

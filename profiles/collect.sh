@@ -25,6 +25,6 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_c3_write -- python3 $BENCH
 cd $R
 python3 bench.py --workload c3 --no-cpu-baseline > $OUT/bench_line_c3.json 2> $OUT/bench_c3.err
 python3 bench.py > $OUT/bench_line.json 2> $OUT/bench.err
-python3 profiles/summarize_rocpd.py $OUT $TAG --out $OUT
+python3 profiles/summarize_rocpd.py $OUT $TAG --out $OUT || echo "summarize_rocpd.py FAILED (kernel name mismatch?)"
 grep -h '"metric"' $OUT/*.log | head -3
 cat $OUT/bench_line.json

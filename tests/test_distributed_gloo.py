@@ -69,3 +69,37 @@ def test_two_rank_shard_and_timing(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_bench_self_launches_its_ranks_when_typed_directly():
+    """`python3 bench.py --gpus 2` typed without torch.distributed.run (the way the driver invokes N = 1) has to start its own
+    ranks as child processes and relay rank 0's JSON line.  Here: CPU ranks over gloo with the kernel stubbed out (--cpu-stub),
+    which exercises exactly that launcher path, the c5 shard arithmetic and the barrier / max-over-ranks protocol."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    for workload, bh_per_gpu, global_bh in (("c4", 16, 32), ("c5", 512, 1024)):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-stub",
+                            "--workload", workload], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout           # ONE JSON line, from rank 0
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+        assert line["config"]["bh_per_gpu"] == bh_per_gpu and line["config"]["global_bh"] == global_bh
+        assert line["extra"]["c5"]["slabs_covered"] == 1024       # the two ranks' c5 shards cover B*H = 64*16 exactly once
+        assert line["scaling"] == ("weak" if workload == "c4" else "strong")
+
+
+def test_bench_under_torchrun_is_one_rank_not_a_launcher():
+    """Under torch.distributed.run (RANK / WORLD_SIZE in the environment) bench.py must NOT launch again."""
+    import bench
+    os.environ.update(RANK="0", WORLD_SIZE="2")
+    try:
+        assert bench.under_launcher()
+    finally:
+        os.environ.pop("RANK"), os.environ.pop("WORLD_SIZE")
+    assert not bench.under_launcher()

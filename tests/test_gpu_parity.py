@@ -8,7 +8,11 @@ Tolerances (max-abs, stated once here; BASELINE.md section 4 gives the arithmeti
   bf16 kernel, fp32 out, scale 1.0              1.2e-2 unscaled scores: P is near one-hot, so the error tends to 2^-9 * max|v| (one bf16
                                                       rounding of the dominant P); max|v| ~ 5.4 over 8M randn -> 1.05e-2; observed <= 9.0e-3
   bf16 kernel, bf16 out                         2.5e-2 adds half a bf16 ulp of |O| (|O| < 4 -> 7.8e-3); observed <= 1.5e-2
-The bf16 kernel is always compared with the oracle evaluated on the SAME bf16-valued inputs.
+  bf16 tensors, fp32 out, ACCURATE P            1e-3  north_star bar at scale 1: FA_KERNEL_AUTO with an fp32 output = fp16 P (head dim 64,
+                                                      11 significant bits: 2^-12 * max|v| -> ~6e-4 expected at N = 8192) or hi + lo
+                                                      bf16 terms (head dims 32, 128: ~1e-4)
+"bf16 kernel" above = the bf16-P kernels (kernel="mfma"; FA_KERNEL_AUTO for a bf16 output).
+The bf16 kernels are always compared with the oracle evaluated on the SAME bf16-valued inputs.
 """
 import ctypes
 import os
@@ -101,7 +105,9 @@ def test_bf16_against_golden(name, out_f32):
     scale = float(z["scale"])
     o = fa.forward(q, k, v, bool(z["causal"]), scale=scale, out_dtype=torch.float32 if out_f32 else None)
     assert o.dtype == (torch.float32 if out_f32 else torch.bfloat16)
-    check(o, z["o"], bf16_tol(scale, out_f32, bool(z["causal"]), q.shape[1]))
+    check(o, z["o"], TOL_F32 if out_f32 else bf16_tol(scale, False), "auto")   # fp32 out: the accurate P (fp16 / hi + lo)
+    o = fa.forward(q, k, v, bool(z["causal"]), scale=scale, out_dtype=torch.float32 if out_f32 else None, kernel="mfma")
+    check(o, z["o"], bf16_tol(scale, out_f32, bool(z["causal"]), q.shape[1]), "bf16 P")
 
 
 def test_packed_qkv_against_golden():
@@ -181,8 +187,10 @@ def test_bf16_vs_oracle(bh, n, d, causal, scale):
     q, k, v = (orc.round_to_bf16(randn(s, bh, n, d)) for s in (4, 5, 6))
     ref = orc.attention_f64(q, k, v, causal=causal, scale=scale)
     qd, kd, vd = to_dev(q, k, v, dtype=torch.bfloat16)
-    check(fa.forward(qd, kd, vd, causal, scale=scale, out_dtype=torch.float32), ref, bf16_tol(scale, True, causal, n), "f32-out")
+    check(fa.forward(qd, kd, vd, causal, scale=scale, out_dtype=torch.float32, kernel="mfma"), ref, bf16_tol(scale, True, causal, n), "f32-out, bf16 P")
     check(fa.forward(qd, kd, vd, causal, scale=scale), ref, bf16_tol(scale, False), "bf16-out")
+    # FA_KERNEL_AUTO with an fp32 output: the accurate P (fp16 at d = 64, hi + lo bf16 terms at d = 32 / 128) -- the fp32 bar
+    check(fa.forward(qd, kd, vd, causal, scale=scale, out_dtype=torch.float32), ref, TOL_F32, "f32-out, auto (accurate P)")
 
 
 # 0 = product dispatch, 1 = phase-structured kernel, 7 / 24 = pipelined kernel with 4- / 2-wave workgroups (optimistic mix with
@@ -236,7 +244,8 @@ def test_forced_rescale_spike():
         check(fa.forward(*to_dev(q, k, v), causal), ref, TOL_F32)
         qb, kb, vb = (orc.round_to_bf16(t) for t in (q, k, v))
         refb = orc.attention_f64(qb, kb, vb, causal=causal)
-        check(fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, out_dtype=torch.float32), refb, 1.2e-2)
+        check(fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, out_dtype=torch.float32, kernel="mfma"), refb, 1.2e-2, "bf16 P")
+        check(fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, out_dtype=torch.float32), refb, TOL_F32, "fp16 P")
 
 
 @pytest.mark.parametrize("out_f32", [False, True])
@@ -253,8 +262,10 @@ def test_dominant_key_in_the_last_keys(n, out_f32):
     for causal in (False, True):
         check(fa.forward(*to_dev(q, k, v), causal), orc.attention_f64(q, k, v, causal=causal), TOL_F32, "fp32")
         refb = orc.attention_f64(qb, kb, vb, causal=causal)
-        ob = fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, out_dtype=torch.float32 if out_f32 else None)
+        ob = fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, out_dtype=torch.float32 if out_f32 else None, kernel="mfma")
         check(ob, refb, bf16_tol(1.0, out_f32), "bf16")
+        if out_f32:
+            check(fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, out_dtype=torch.float32), refb, TOL_F32, "fp16 P")
         _, lse_ref = orc.attention_f64(qb, kb, vb, causal=causal, return_lse=True)
         _, lse = fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, return_lse=True)
         check(lse, lse_ref, 2e-2, "bf16 lse")
@@ -315,7 +326,7 @@ def test_fuzz_shapes_through_the_dispatch_against_rung0():
     """Random (bh, n, d, causal, scale) through the product dispatch -- every kernel family and the ragged / tiny / one-round /
     many-round branches of choose_bf16() get hit -- against the rung-0 kernel on the same bf16-valued inputs."""
     rng = np.random.default_rng(2024)
-    worst = 0.0
+    worst = worst_acc = 0.0
     for case in range(48):
         d = int(rng.choice([32, 64, 128]))
         bh = int(rng.integers(1, 41))
@@ -325,12 +336,17 @@ def test_fuzz_shapes_through_the_dispatch_against_rung0():
         g = torch.Generator(device="cpu").manual_seed(1000 + case)
         q, k, v = (torch.randn(bh, n, d, generator=g).to(torch.bfloat16).to(dev()) for _ in range(3))
         ref = fa.forward(q.float(), k.float(), v.float(), causal, scale=scale, kernel="naive")
-        out = fa.forward(q, k, v, causal, scale=scale, out_dtype=torch.float32)
+        out = fa.forward(q, k, v, causal, scale=scale, out_dtype=torch.float32, kernel="mfma")   # the bf16-P dispatch (choose_bf16)
         assert not torch.isnan(out).any(), f"NaN: case {case} bh={bh} n={n} d={d} causal={causal}"
         err = float((out - ref).abs().max())
         worst = max(worst, err)
         assert err < bf16_tol(1.0, True), f"case {case} bh={bh} n={n} d={d} causal={causal} scale={scale}: {err:.3e}"
+        acc = fa.forward(q, k, v, causal, scale=scale, out_dtype=torch.float32)                    # auto: the accurate P
+        err_a = float((acc - ref).abs().max())
+        worst_acc = max(worst_acc, err_a)
+        assert err_a < TOL_F32, f"accurate P: case {case} bh={bh} n={n} d={d} causal={causal} scale={scale}: {err_a:.3e}"
     OBSERVED.append(("fuzz through dispatch, worst of 48", worst, bf16_tol(1.0, True)))
+    OBSERVED.append(("fuzz through dispatch, accurate P, worst of 48", worst_acc, TOL_F32))
 
 
 # bf16 tensors through the split machinery (kernel="split"): K and V are exact in one bf16 term, Q*scale*log2e and P are carried
@@ -409,7 +425,8 @@ def test_transpose_detecting_structured_input():
         check(fa.forward(*to_dev(q, k, v), causal), ref, 1e-4)
         qb, kb, vb = (orc.round_to_bf16(t) for t in (q, k, v))
         refb = orc.attention_f64(qb, kb, vb, causal=causal)
-        check(fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, out_dtype=torch.float32), refb, 5e-3)
+        check(fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, out_dtype=torch.float32, kernel="mfma"), refb, 5e-3)
+        check(fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, out_dtype=torch.float32), refb, 1e-3, "fp16 P")
 
 
 def test_packed_qkv_vs_oracle_random():
@@ -457,44 +474,56 @@ def test_runs_on_callers_stream_without_sync():
 # BASELINE.json full sizes: exact oracle on sampled slabs + size-independent properties on the whole tensor
 # ---------------------------------------------------------------------------------------------------------------
 FULL = [
-    ("c2", 128, 1024, 64, torch.float32),
-    ("c3", 16, 8192, 64, torch.float32),
-    ("c4", 16, 8192, 64, torch.bfloat16),
+    # name, bh, n, d, dtype, kernel, tolerance
+    ("c1-shape", 16, 1024, 32, torch.float32, "auto", TOL_F32),        # BASELINE config 1's shape through the HIP path (its CPU-SDPA leg is a CPU test)
+    ("c2", 128, 1024, 64, torch.float32, "auto", TOL_F32),
+    ("c3", 16, 8192, 64, torch.float32, "auto", TOL_F32),
+    ("c4", 16, 8192, 64, torch.bfloat16, "mfma", 1.2e-2),              # the bf16-P kernels (FA_KERNEL_AUTO for a bf16 output)
+    ("c4-accurate", 16, 8192, 64, torch.bfloat16, "auto", TOL_F32),    # fp32 output -> fp16 P: the north star's 1e-3 at scale 1
+    ("c5-shard", 128, 8192, 64, torch.bfloat16, "mfma", 1.2e-2),       # one GPU's share of B=64 H=16 split over 8 (src/flashattention.cu:144)
+    ("c5-shard-accurate", 128, 8192, 64, torch.bfloat16, "auto", TOL_F32),
+    ("c5-full", 1024, 8192, 64, torch.bfloat16, "mfma", 1.2e-2),       # all 1024 slabs on one GPU (4 x 1 GiB tensors)
 ]
 
 
-@pytest.mark.parametrize("name,bh,n,d,dtype", FULL)
-def test_full_size_configs(name, bh, n, d, dtype):
-    g = torch.Generator().manual_seed(0)
-    q, k, v = (torch.randn(bh, n, d, generator=g) for _ in range(3))
-    if dtype == torch.bfloat16:
-        q, k, v = (t.bfloat16() for t in (q, k, v))
-    qd, kd, vd = q.to(dev()), k.to(dev()), v.to(dev())
+@pytest.mark.parametrize("name,bh,n,d,dtype,kernel,tol", FULL, ids=[f[0] for f in FULL])
+def test_full_size_configs(name, bh, n, d, dtype, kernel, tol):
     bf = dtype == torch.bfloat16
-    kw = dict(out_dtype=torch.float32) if bf else {}
-    tol = 1.2e-2 if bf else TOL_F32
+    g = torch.Generator(device=dev()).manual_seed(0)
+    qd, kd, vd = (torch.randn(bh, n, d, generator=g, device=dev()).to(dtype) for _ in range(3))   # generated on the device: c5 is 3 GiB
+    kw = dict(out_dtype=torch.float32, kernel=kernel) if bf else dict(kernel=kernel)
     o = fa.forward(qd, kd, vd, False, **kw)
+    if kernel == "auto":   # which arithmetic ran: the primary kernel of the chain (split products / fp16 P), not its fallback
+        assert fa.last_forward_route() == 1
+    host = lambda t, s: t[s:s + 1].float().cpu().numpy()
     # (a) exact oracle on two slabs (first and last)
-    for s in (0, bh - 1):
-        ref = orc.attention_f64(q[s:s + 1].float().numpy(), k[s:s + 1].float().numpy(), v[s:s + 1].float().numpy())
-        check(o[s:s + 1], ref, tol)
-    # (b) every slab against the rung-0 kernel on device (independent code path, fp32 on the same values)
-    o_naive = fa.forward(qd.float(), kd.float(), vd.float(), False, kernel="naive")
-    assert float((o.float() - o_naive).abs().max()) < tol
+    for s_ in (0, bh - 1):
+        ref = orc.attention_f64(host(qd, s_), host(kd, s_), host(vd, s_))
+        check(o[s_:s_ + 1], ref, tol, f"{name} slab {s_}")
+    # (b) the rung-0 kernel on device (independent code path, fp32 on the same values): every slab, or 8 spread ones for c5-full
+    slabs = list(range(bh)) if bh <= 128 else sorted({0, 1, bh // 3, bh // 2, bh // 2 + 1, bh - 130, bh - 2, bh - 1})
+    for s0 in (range(0, bh, 16) if bh <= 128 else slabs):
+        sl = slice(s0, s0 + (16 if bh <= 128 else 1))
+        o_naive = fa.forward(qd[sl].float(), kd[sl].float(), vd[sl].float(), False, kernel="naive")
+        e = float((o[sl].float() - o_naive).abs().max())
+        assert e < tol, f"{name}: slabs {sl} differ from rung 0 by {e:.3e}"
     # (c) V == 1  =>  O == 1: every softmax row sums to 1 (checks l, m, masking and the whole write-out).  Not bitwise:
-    #     the numerator is summed by the matrix core (from bf16-rounded P on the bf16 path), the denominator by the VALU,
-    #     in different orders over up to 8192 terms (observed 1.4e-5 in fp32 at N = 8192).
+    #     the numerator is summed by the matrix core (from 16-bit-rounded P on the bf16 paths), the denominator by the VALU or by
+    #     another matrix instruction, in different orders over up to 8192 terms (observed 1.4e-5 in fp32 at N = 8192).
     ones = torch.ones_like(vd)
-    assert float((fa.forward(qd, kd, ones, False, **kw) - 1.0).abs().max()) < (4e-3 if bf else 1e-4)
+    e1 = float((fa.forward(qd, kd, ones, False, **kw) - 1.0).abs().max())
+    assert e1 < (4e-3 if bf else 1e-4), f"{name}: V == 1 gives |O - 1| = {e1:.3e}"
+    del ones
     # (d) linearity in V: O(q, k, 2 v1 - v2) == 2 O(q, k, v1) - O(q, k, v2)  (fp32 only; bf16 V rounding breaks exactness)
     if not bf:
-        v2 = torch.randn(bh, n, d, generator=g).to(dev())
+        v2 = torch.randn(bh, n, d, generator=g, device=dev())
         lhs = fa.forward(qd, kd, 2.0 * vd - v2, False)
         rhs = 2.0 * o - fa.forward(qd, kd, v2, False)
         lin_err = float((lhs - rhs).abs().max())
         assert lin_err < 2e-4, f"linearity residual {lin_err:.3e}"
-    # (e) causal: row 0 attends to key 0 only, so O[:, 0, :] == V[:, 0, :] (fp32: bitwise; bf16 path: the exponent of the
+    # (e) causal: row 0 attends to key 0 only, so O[:, 0, :] == V[:, 0, :] (fp32 exact kernel: bitwise; bf16 paths: the exponent of the
     #     row maximum is fma(m, c, -round(c*m)) = O(ulp), so p = 1 + O(1e-7) -- see fa_fwd_bf16.hip)
+    del o
     oc = fa.forward(qd, kd, vd, True, **kw)
     if bf:
         assert float((oc[:, 0, :] - vd[:, 0, :].float()).abs().max()) < 1e-5
@@ -503,8 +532,220 @@ def test_full_size_configs(name, bh, n, d, dtype):
         assert float((oc[:, 0, :] - vd[:, 0, :]).abs().max()) < 1e-4
         assert torch.equal(fa.forward(qd, kd, vd, True, kernel="exact")[:, 0, :], vd[:, 0, :])
     # (f) causal vs the oracle on one slab
-    refc = orc.attention_f64(q[:1].float().numpy(), k[:1].float().numpy(), v[:1].float().numpy(), causal=True)
-    check(oc[:1], refc, tol)
+    refc = orc.attention_f64(host(qd, 0), host(kd, 0), host(vd, 0), causal=True)
+    check(oc[:1], refc, tol, f"{name} causal")
+    # (g) the product call for a bf16 output (FA_KERNEL_AUTO, bf16 P) on the same tensors, against rung 0 on a few slabs
+    if bf and kernel == "mfma":
+        ob = fa.forward(qd, kd, vd, False)
+        assert ob.dtype == torch.bfloat16
+        for s_ in (0, bh - 1):
+            o_naive = fa.forward(qd[s_:s_ + 1].float(), kd[s_:s_ + 1].float(), vd[s_:s_ + 1].float(), False, kernel="naive")
+            assert float((ob[s_:s_ + 1].float() - o_naive).abs().max()) < 2.5e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the fp16-P kernel (FA_KERNEL_P16; FA_KERNEL_AUTO for bf16 tensors with an fp32 output at head dim 64)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("bh,n", [(3, 700), (2, 1536), (1, 1), (5, 31), (2, 513), (1, 4096)])
+def test_p16_kernel_vs_oracle(bh, n, causal):
+    q, k, v = (orc.round_to_bf16(randn(s, bh, n, 64)) for s in (51, 52, 53))
+    qd, kd, vd = to_dev(q, k, v, dtype=torch.bfloat16)
+    for scale in (1.0, 0.125):
+        ref, lse_ref = orc.attention_f64(q, k, v, causal=causal, scale=scale, return_lse=True)
+        o, lse = fa.forward(qd, kd, vd, causal, scale=scale, kernel="p16", out_dtype=torch.float32, return_lse=True)
+        assert fa.last_forward_route() == 1
+        check(o, ref, TOL_F32, f"p16 scale {scale}")
+        check(lse, lse_ref, 1e-3, f"p16 lse scale {scale}")       # row sums of fp16-rounded P: 2^-12 relative per term
+        ob = fa.forward(qd, kd, vd, causal, scale=scale, kernel="p16")   # bf16 output: its own rounding on top
+        check(ob, ref, bf16_tol(scale, False), f"p16 bf16 out scale {scale}")
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_p16_reference_moves_inside_the_pipelined_loop(causal):
+    """fp16 has 30 binades: the exponent reference of a wave has to follow its row maxima (window 2^-5 .. 2^14 around the row
+    maximum).  Keys that outgrow everything seen before by 2^20 .. 2^230, in the middle of the sequence, for single rows, a whole
+    32-row block and neighbouring blocks; then a row whose scores shrink again.  The LSE exposes a saturated or flushed P."""
+    bh, n, d = 2, 1536, 64
+    q, k, v = (randn(s, bh, n, d) for s in (41, 42, 43))
+    unit = lambda x: x / np.linalg.norm(x, axis=-1, keepdims=True)
+    for r, key, gain in ((3, 700, 14.0), (40, 701, 16.0), (200, 1100, 12.0), (1300, 900, 15.0), (1301, 650, 18.0), (1535, 333, 13.0),
+                         (5, 100, 3.0), (6, 300, 4.5), (7, 600, 6.0), (600, 64, 2.5), (601, 96, 3.5)):
+        k[:, key] = gain * unit(q[:, r])
+    k[0, 800] = 20.0 * unit(q[0, 64:96].mean(axis=0))
+    qb, kb, vb = (orc.round_to_bf16(t) for t in (q, k, v))
+    ref, lse_ref = orc.attention_f64(qb, kb, vb, causal=causal, return_lse=True)
+    o, lse = fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, kernel="p16", out_dtype=torch.float32, return_lse=True)
+    check(o, ref, TOL_F32, "p16")
+    check(lse, lse_ref, 2e-3, "p16 lse")
+
+
+def test_p16_falls_back_when_v_does_not_fit_fp16():
+    """|v| >= 2^16 (or inf) has no fp16 counterpart: the copy raises the chain's flag, the fp16-P kernel skips itself and the split
+    kernel (bf16 range) produces the output -- decided on the device, reported by fa_last_forward_route()."""
+    bh, n, d = 2, 700, 64
+    q, k, v = (orc.round_to_bf16(randn(s, bh, n, d)) for s in (61, 62, 63))
+    v[1, 333, 7] = 131072.0
+    v[0, 5, 60] = -70000.0          # bf16(-70000) = -69632: beyond fp16 as well
+    v = orc.round_to_bf16(v)
+    ref = orc.attention_f64(q, k, v, scale=0.125)
+    qd, kd, vd = to_dev(q, k, v, dtype=torch.bfloat16)
+    o = fa.forward(qd, kd, vd, False, scale=0.125, out_dtype=torch.float32)   # auto
+    assert fa.last_forward_route() == 2
+    got = o.cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    rel = np.abs(got - ref).max() / np.abs(ref).max()
+    assert rel < 1e-4, f"relative error {rel:.3e} with huge V entries"
+    # ... and the same tensors without the outliers take the fp16 path again
+    v[1, 333, 7] = 1.0
+    v[0, 5, 60] = -1.0
+    o = fa.forward(qd, kd, to_dev(v, dtype=torch.bfloat16)[0], False, scale=0.125, out_dtype=torch.float32)
+    assert fa.last_forward_route() == 1
+    check(o, orc.attention_f64(q, k, v, scale=0.125), TOL_F32)
+
+
+def test_p16_graph_capture_and_timing_entry():
+    """The chain allocates its fp16 copy of V from the stream-ordered pool: it has to survive stream capture (graph memory nodes)."""
+    q, k, v = (torch.randn(4, 1024, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
+    o = torch.empty(q.shape, dtype=torch.float32, device=dev())
+    ms_stream = fa.time_forward(q, k, v, False, warmup=1, iters=5, out=o)
+    ms_graph = fa.time_forward(q, k, v, False, warmup=1, iters=5, out=o, graph=True)
+    assert 0.0 < ms_graph < 50.0 and 0.0 < ms_stream < 50.0
+    ref = fa.forward(q.float(), k.float(), v.float(), False, kernel="naive")
+    assert float((o - ref).abs().max()) < TOL_F32
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fp32 tensors: the logit-width guard of FA_KERNEL_AUTO
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [32, 64, 128])
+@pytest.mark.parametrize("causal", [False, True])
+def test_fp32_auto_guard_routes_wide_logits_to_exact_arithmetic(d, causal):
+    """The inputs of the split kernel's redo test (scores up to 2^200 in the exp2 domain, a whole row of sigma-32 scores): with
+    16-bit operand terms they need a 3e-3 tolerance; FA_KERNEL_AUTO has to notice (|q|_2 |k|_inf scale > 100) and hand the
+    launch to the exact kernel, on the device -- 1e-3 holds without the caller knowing anything."""
+    bh, n = 2, 1536
+    q, k, v = (randn(s, bh, n, d) for s in (41, 42, 43))
+    q *= np.sqrt(64.0 / d)
+    unit = lambda x: x / np.linalg.norm(x, axis=-1, keepdims=True)
+    for r, key, gain in ((3, 700, 14.0), (40, 701, 16.0), (200, 1100, 12.0), (1300, 900, 15.0), (1301, 650, 18.0), (1535, 333, 6.0), (70, 9, 13.0)):
+        k[:, key] = gain * unit(q[:, r])
+    k[0, 800] = 20.0 * unit(q[0, 64:96].mean(axis=0))
+    q[1, 500] *= -4.0
+    ref, lse_ref = orc.attention_f64(q, k, v, causal=causal, return_lse=True)
+    o, lse = fa.forward(*to_dev(q, k, v), causal, return_lse=True)
+    assert fa.last_forward_route() == 2, "guard did not fire"
+    check(o, ref, TOL_F32, "auto")
+    check(lse, lse_ref, TOL_F32, "auto lse")
+
+
+def test_fp32_auto_guard_stays_quiet_on_the_reference_workloads():
+    for bh, n, d, scale in ((4, 1024, 64, 1.0), (2, 2048, 32, 1.0), (2, 777, 128, 128 ** -0.5), (3, 300, 64, 0.125)):
+        q, k, v = (randn(s, bh, n, d) for s in (71, 72, 73))
+        for causal in (False, True):
+            o = fa.forward(*to_dev(q, k, v), causal, scale=scale)
+            assert fa.last_forward_route() == 1, f"guard fired on unit-variance data at bh={bh} n={n} d={d} scale={scale}"
+            check(o, orc.attention_f64(q, k, v, causal=causal, scale=scale), TOL_F32)
+    # one wide key anywhere in the slab is enough, also when only the LAST q tile's rows are long
+    q, k, v = (randn(s, 2, 1024, 64) for s in (74, 75, 76))
+    k[1, 1000] *= 30.0
+    o = fa.forward(*to_dev(q, k, v), False)
+    assert fa.last_forward_route() == 2
+    check(o, orc.attention_f64(q, k, v), TOL_F32)
+    q, k, v = (randn(s, 2, 1024, 64) for s in (74, 75, 76))
+    q[0, 1023] *= 40.0
+    o = fa.forward(*to_dev(q, k, v), True)
+    assert fa.last_forward_route() == 2
+    check(o, orc.attention_f64(q, k, v, causal=True), TOL_F32)
+    # inf / NaN in K: whatever comes out, it comes out of fp32 arithmetic
+    k[0, 3, 3] = np.inf
+    fa.forward(*to_dev(q, k, v), False)
+    assert fa.last_forward_route() == 2
+
+
+def test_packed_qkv_guard_and_llmc_harness_size():
+    """attention_forward.cu:1217-1220 runs B=6 T=4096 C=768 NH=12 (hs = 64) with U(-1, 1) activations and validates at 1e-4
+    (:1255-1262): the packed-QKV entry at that size, sampled (batch, head) slabs against the fp64 oracle."""
+    B, T, C, NH = 6, 4096, 768, 12
+    g = torch.Generator(device=dev()).manual_seed(0)
+    inp = torch.rand(B, T, 3 * C, generator=g, device=dev()) * 2.0 - 1.0
+    out = fa.forward_packed_qkv(inp, NH)
+    assert fa.last_forward_route() == 1
+    hs = C // NH
+    for b, h in ((0, 0), (5, 11), (2, 7)):
+        q = inp[b, :, h * hs:(h + 1) * hs].cpu().numpy()[None]
+        k = inp[b, :, C + h * hs:C + (h + 1) * hs].cpu().numpy()[None]
+        v = inp[b, :, 2 * C + h * hs:2 * C + (h + 1) * hs].cpu().numpy()[None]
+        ref = orc.attention_f64(q, k, v, causal=True, scale=hs ** -0.5)
+        check(out[b:b + 1, :, h * hs:(h + 1) * hs], ref, 1e-4, f"llm.c size, slab ({b}, {h})")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# boundary: aliasing, tiling numbers, sharding, the compiled pybind module
+# ---------------------------------------------------------------------------------------------------------------
+def test_output_aliasing_an_input_is_rejected():
+    q, k, v = to_dev(*(randn(s, 2, 256, 64) for s in (81, 82, 83)))
+    for t in (q, k, v):
+        with pytest.raises(_cabi.FlashAttnError, match="overlaps"):
+            fa.forward(q, k, v, False, out=t)
+    check(fa.forward(q, q, q, False), orc.attention_f64(*(q.cpu().numpy(),) * 3), TOL_F32, "q = k = v is fine")
+
+
+def test_ablation_tilings_are_not_in_the_product_library():
+    """Timing-only instantiations (garbage results by design) live in libflashattn_amd_ablation.so; the product ABI rejects them."""
+    q, k, v = to_dev(*(orc.round_to_bf16(randn(s, 2, 1024, 64)) for s in (84, 85, 86)), dtype=torch.bfloat16)
+    for variant in (33, 34, 35, 39, 45, 22, 9, 6, 11, 99):
+        with pytest.raises(_cabi.FlashAttnError) as ei:
+            fa.forward(q, k, v, False, kernel=f"mfma:{variant}")
+        assert ei.value.code == 2, variant
+    with pytest.raises(_cabi.FlashAttnError):
+        fa.forward(*to_dev(*(orc.round_to_bf16(randn(s, 2, 512, 128)) for s in (84, 85, 86)), dtype=torch.bfloat16), False, kernel="mfma:53")
+
+
+def test_sharded_entry_point_noncontiguous_shards_and_every_visible_device():
+    q, k, v = (randn(s, 6, 200, 64) for s in (19, 20, 21))
+    ref = orc.attention_f64(q, k, v, causal=True)
+    ndev = torch.cuda.device_count()
+    world = max(2, ndev)
+    devs = [torch.device("cuda", i % ndev) for i in range(world)]
+    qs, ks, vs = [], [], []
+    for r in range(world):
+        b, e = fa.shard_range(6, world, r)
+        # non-contiguous views of the right values: (n, bh, d) storage, transposed
+        mk = lambda a: torch.from_numpy(np.ascontiguousarray(a[b:e].transpose(1, 0, 2))).to(devs[r]).transpose(0, 1)
+        qs.append(mk(q)), ks.append(mk(k)), vs.append(mk(v))
+    assert not qs[0].is_contiguous()
+    outs = fa.forward_sharded(qs, ks, vs, True)
+    for i in range(ndev):
+        torch.cuda.synchronize(i)
+    assert all(o.is_contiguous() for o in outs)
+    check(torch.cat([o.to(dev()) for o in outs]), ref, TOL_F32)
+
+
+def test_compiled_pybind_module_is_a_drop_in_for_the_reference_extension():
+    """bench_flashattention.py:10,70: `minimal_flash = load(name='flash', ...)`, `minimal_flash.forward(q, k, v, masking)` -- through
+    the compiled translation unit csrc/fa_torch_binding.cpp (what src/main.cpp becomes), not through ctypes."""
+    import glob
+    import importlib.util
+    paths = glob.glob(os.path.join(ROOT, "flashattention.c_amd", "flash_torch_binding*.so"))
+    assert paths, "flash_torch_binding not built (python flashattention.c_amd/build.py --torch-binding)"
+    spec = importlib.util.spec_from_file_location("flash_torch_binding", paths[0])
+    minimal_flash = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(minimal_flash)
+    batch_size, n_head, seq_len, head_embd = 2, 8, 512, 64                      # bench_flashattention.py:21-24, shorter
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn(batch_size * n_head, seq_len, head_embd, generator=g).cuda() for _ in range(3))   # :31-33
+    for masking in (False, True):
+        out = minimal_flash.forward(q, k, v, masking)
+        ref = orc.attention_f64(q.cpu().numpy(), k.cpu().numpy(), v.cpu().numpy(), causal=masking)      # manual_attention_*, :36-48
+        check(out, ref, TOL_F32, f"pybind masking={masking}")
+        assert out.dtype == torch.float32 and out.shape == q.shape and out.device == q.device
+    ob = minimal_flash.forward(q.bfloat16(), k.bfloat16(), v.bfloat16(), False)
+    assert ob.dtype == torch.bfloat16
+    with pytest.raises(RuntimeError):
+        minimal_flash.forward(q.cpu(), k.cpu(), v.cpu(), False)
+    with pytest.raises(RuntimeError):
+        minimal_flash.forward(q, k[:, :100], v, False)
 
 
 def test_c_driver_known_answer():

@@ -32,11 +32,14 @@ def test_library_exports_every_declared_symbol():
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 128, 0, 2, 300) == b"fa_fwd_bf16_w4_kernel"      # too few workgroups
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 128, 1, 2, 300) == b"fa_fwd_bf16_kernel"
     assert L.fa_kernel_name(_cabi.FA_DTYPE_F32, 48, 0) is None
+    # bf16 tensors with fp32 output: the accurate P -- fp16 at head dim 64, hi + lo bf16 terms elsewhere
+    assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0) == b"fa_fwd_bf16_x4_p16_kernel"
+    assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 128, 0) == b"fa_fwd_f32_split_kernel"
 
 
 def test_kernel_ids_match_the_header_and_the_python_names():
     hdr = open(os.path.join(ROOT, "include", "flashattn_amd.h")).read()
-    for name in ("FA_KERNEL_AUTO", "FA_KERNEL_NAIVE", "FA_KERNEL_MFMA", "FA_KERNEL_SPLIT", "FA_DTYPE_F32", "FA_DTYPE_BF16",
+    for name in ("FA_KERNEL_AUTO", "FA_KERNEL_NAIVE", "FA_KERNEL_MFMA", "FA_KERNEL_SPLIT", "FA_KERNEL_P16", "FA_DTYPE_F32", "FA_DTYPE_BF16",
                  "FA_DTYPE_BF16_OUT_F32"):
         m = re.search(name + r"\s*=\s*(\d+)", hdr)
         assert m and int(m.group(1)) == getattr(_cabi, name), name
@@ -44,6 +47,7 @@ def test_kernel_ids_match_the_header_and_the_python_names():
     assert flash._kernel_id("split:4") == _cabi.FA_KERNEL_SPLIT | (4 << 8)
     assert flash._kernel_id("exact") == flash._kernel_id("mfma") == _cabi.FA_KERNEL_MFMA
     assert flash._kernel_id("auto") == _cabi.FA_KERNEL_AUTO
+    assert flash._kernel_id("p16") == _cabi.FA_KERNEL_P16
     with pytest.raises(ValueError):
         flash._kernel_id("fast")
     L = _cabi.lib()
@@ -67,28 +71,40 @@ def test_fp32_auto_choice_follows_the_environment_switch():
 
 def test_cabi_rejects_bad_arguments_without_touching_a_device():
     L = _cabi.lib()
-    buf = ctypes.create_string_buffer(4096)
+    buf = ctypes.create_string_buffer(5 * 16384)
     base = (ctypes.addressof(buf) + 15) & ~15
-    p = ctypes.c_void_p(base)
+    p, k, v, o = (ctypes.c_void_p(base + i * 16384) for i in range(4))   # (1, 32, 64) fp32 = 8 KiB each, disjoint
     # null pointer
-    assert L.fa_forward(None, p, p, p, 1, 32, 64, 1.0, 0, 0, None) == 1
+    assert L.fa_forward(None, k, v, o, 1, 32, 64, 1.0, 0, 0, None) == 1
     assert b"null" in L.fa_last_error()
     # misaligned
-    assert L.fa_forward(ctypes.c_void_p(base + 4), p, p, p, 1, 32, 64, 1.0, 0, 0, None) == 1
+    assert L.fa_forward(ctypes.c_void_p(base + 4), k, v, o, 1, 32, 64, 1.0, 0, 0, None) == 1
     # bad sizes / scale / dtype
-    assert L.fa_forward(p, p, p, p, 0, 32, 64, 1.0, 0, 0, None) == 1
-    assert L.fa_forward(p, p, p, p, 1, 0, 64, 1.0, 0, 0, None) == 1
-    assert L.fa_forward(p, p, p, p, 1, 32, 64, 0.0, 0, 0, None) == 1
-    assert L.fa_forward(p, p, p, p, 1, 32, 64, float("nan"), 0, 0, None) == 1
-    assert L.fa_forward(p, p, p, p, 1, 32, 64, 1.0, 0, 7, None) == 2
+    assert L.fa_forward(p, k, v, o, 0, 32, 64, 1.0, 0, 0, None) == 1
+    assert L.fa_forward(p, k, v, o, 1, 0, 64, 1.0, 0, 0, None) == 1
+    assert L.fa_forward(p, k, v, o, 1, 32, 64, 0.0, 0, 0, None) == 1
+    assert L.fa_forward(p, k, v, o, 1, 32, 64, float("nan"), 0, 0, None) == 1
+    assert L.fa_forward(p, k, v, o, 1, 32, 64, 1.0, 0, 7, None) == 2
+    # the output must not overlap an input (a tile that fails its verification is recomputed after o was written)
+    for alias in (p, k, v, ctypes.c_void_p(base + 8192 - 16)):
+        assert L.fa_forward(p, k, v, alias, 1, 32, 64, 1.0, 0, 0, None) == 1
+        assert b"overlaps" in L.fa_last_error()
+    # inputs may alias each other (self-attention on one tensor: the reference's own test.cu passes Q = K)
+    assert L.fa_forward(p, p, p, o, 1, 32, 48, 1.0, 0, 0, None) == 2
     # unsupported head dim for the MFMA kernels, unknown kernel id
-    assert L.fa_forward(p, p, p, p, 1, 32, 48, 1.0, 0, 0, None) == 2
+    assert L.fa_forward(p, k, v, o, 1, 32, 48, 1.0, 0, 0, None) == 2
     assert b"48" in L.fa_last_error()
-    assert L.fa_forward_ex(p, p, p, p, None, 1, 32, 64, 1.0, 0, 0, 9, None) == 2
-    assert L.fa_forward_packed_qkv(p, p, 1, 8, 96, 5, None) == 1      # C % NH != 0
-    assert L.fa_forward_packed_qkv(p, p, 1, 8, 96, 2, None) == 2      # hs = 48 not instantiated
+    assert L.fa_forward_ex(p, k, v, o, None, 1, 32, 64, 1.0, 0, 0, 9, None) == 2
+    # the fp16-P kernel exists for bf16 tensors at head dim 64 only
+    assert L.fa_forward_ex(p, k, v, o, None, 1, 32, 64, 1.0, 0, _cabi.FA_DTYPE_F32, _cabi.FA_KERNEL_P16, None) == 2
+    assert L.fa_forward_ex(p, k, v, o, None, 1, 32, 32, 1.0, 0, _cabi.FA_DTYPE_BF16, _cabi.FA_KERNEL_P16, None) == 2
+    assert L.fa_forward_packed_qkv(p, o, 1, 8, 96, 5, None) == 1      # C % NH != 0
+    assert L.fa_forward_packed_qkv(p, o, 1, 8, 96, 2, None) == 2      # hs = 48 not instantiated
     ms = ctypes.c_float()
-    assert L.fa_time_forward(p, p, p, p, 1, 32, 64, 1.0, 0, 0, 0, None, 0, 0, ctypes.byref(ms)) == 1
+    assert L.fa_time_forward(p, k, v, o, 1, 32, 64, 1.0, 0, 0, 0, None, 0, 0, ctypes.byref(ms)) == 1
+    r = ctypes.c_int32(7)
+    assert L.fa_last_forward_route(None, ctypes.byref(r)) == 0 and r.value == 0   # no chain launched on this thread
+    assert L.fa_last_forward_route(None, None) == 1
 
 
 def test_python_surface_validates_like_the_reference_signature():
