@@ -10,6 +10,12 @@
 //   fa_driver --mode kat  [--bh 8] [--n 8192] [--d 64] [--dtype f32|bf16] [--causal 1]
 //   fa_driver --mode rand [--bh 16] [--n 8192] [--d 64] [--dtype bf16] [--causal 0] [--scale 1.0] [--iters 20] [--variant 0]
 //   fa_driver --mode sweep ...
+//   fa_driver --mode llmc [--B 6] [--T 4096] [--C 768] [--NH 12] [--iters 100]
+//       the llm.c dev harness (/root/reference/src/llm.c/attention_forward.cu:1209-1295) at its own size: srand(0)-style U(-1, 1)
+//       activations in the packed (B, T, 3C) layout, fa_forward_packed_qkv, every output element checked against the rung-0 kernel
+//       ON THE DEVICE at the harness' own 1e-4 (validate_result, :1255-1262), then the mean of `iters` launches between two events on
+//       the null stream (benchmark_kernel, src/llm.c/common.h:108-124).
+//   --kernel auto|mfma|split|p16 and --out_f32 1 choose the kernel family / an fp32 output for bf16 tensors in rand and sweep mode.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -65,9 +71,11 @@ struct Rng {  // xorshift64* + Box-Muller: deterministic N(0,1) without libc ran
 };
 
 struct Args {
-    std::string mode = "rand", dtype = "bf16";
+    std::string mode = "rand", dtype = "bf16", kernel = "";
     long bh = 16, n = 8192;
-    int d = 64, causal = 0, iters = 20, warmup = 3, variant = 0, check = 1;
+    int d = 64, causal = 0, iters = 20, warmup = 3, variant = 0, check = 1, out_f32 = 0;
+    int B = 6, T = 4096, C = 768, NH = 12;   // llmc mode: the harness' own size (attention_forward.cu:1217-1220)
+    bool iters_given = false;
     float scale = 1.0f;
 };
 
@@ -89,7 +97,13 @@ static Args parse(int argc, char** argv)
         else if (k == "--n") a.n = atol(val());
         else if (k == "--d") a.d = atoi(val());
         else if (k == "--causal") a.causal = atoi(val());
-        else if (k == "--iters") a.iters = atoi(val());
+        else if (k == "--iters") a.iters = atoi(val()), a.iters_given = true;
+        else if (k == "--kernel") a.kernel = val();
+        else if (k == "--out_f32") a.out_f32 = atoi(val());
+        else if (k == "--B") a.B = atoi(val());
+        else if (k == "--T") a.T = atoi(val());
+        else if (k == "--C") a.C = atoi(val());
+        else if (k == "--NH") a.NH = atoi(val());
         else if (k == "--warmup") a.warmup = atoi(val());
         else if (k == "--variant") a.variant = atoi(val());
         else if (k == "--check") a.check = atoi(val());
@@ -117,8 +131,8 @@ static void upload(const Args& a, const std::vector<float>& hq, const std::vecto
     HIP_OK(hipMalloc(&b.q, b.ne * esz));
     HIP_OK(hipMalloc(&b.k, b.ne * esz));
     HIP_OK(hipMalloc(&b.v, b.ne * esz));
-    HIP_OK(hipMalloc(&b.o, b.ne * esz));
-    HIP_OK(hipMemset(b.o, 0xff, b.ne * esz));  // poison: unwritten output shows up as NaN
+    HIP_OK(hipMalloc(&b.o, b.ne * 4));         // large enough for an fp32 output of bf16 tensors (--out_f32)
+    HIP_OK(hipMemset(b.o, 0xff, b.ne * 4));    // poison: unwritten output shows up as NaN
     std::vector<float> rq(hq), rk(hk), rv(hv);  // values as the kernel sees them
     if (bf) {
         std::vector<uint16_t> t(b.ne);
@@ -151,7 +165,7 @@ static void upload(const Args& a, const std::vector<float>& hq, const std::vecto
 static std::vector<float> download(const Args& a, const void* dev, size_t ne)
 {
     std::vector<float> out(ne);
-    if (a.dtype == "bf16") {
+    if (a.dtype == "bf16" && !a.out_f32) {
         std::vector<uint16_t> t(ne);
         HIP_OK(hipMemcpy(t.data(), dev, ne * 2, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < ne; ++i) out[i] = bf16_to_f32(t[i]);
@@ -174,11 +188,20 @@ static double peak_tflops(const std::string& dtype) { return dtype == "bf16" ? 2
 
 static void run_one(const Args& a, Buffers& b, int variant, const std::vector<float>* ref)
 {
-    const int dt = a.dtype == "bf16" ? FA_DTYPE_BF16 : FA_DTYPE_F32;
-    // --dtype f32: the exact fp32 kernel; --dtype f32s: fp32 tensors through the split kernel (variant = its tiling mode)
-    const int kernel = (a.dtype == "f32s" ? FA_KERNEL_SPLIT : FA_KERNEL_MFMA) | (variant << 8);
-    const size_t esz = dt == FA_DTYPE_BF16 ? 2 : 4;
-    HIP_OK(hipMemset(b.o, 0xff, b.ne * esz));
+    const int dt = a.dtype == "bf16" ? (a.out_f32 ? FA_DTYPE_BF16_OUT_F32 : FA_DTYPE_BF16) : FA_DTYPE_F32;
+    // --dtype f32: the exact fp32 kernel; --dtype f32s: fp32 tensors through the split kernel (variant = its tiling mode);
+    // --kernel overrides the family
+    int family = a.dtype == "f32s" ? FA_KERNEL_SPLIT : FA_KERNEL_MFMA;
+    if (a.kernel == "auto") family = FA_KERNEL_AUTO;
+    else if (a.kernel == "mfma") family = FA_KERNEL_MFMA;
+    else if (a.kernel == "split") family = FA_KERNEL_SPLIT;
+    else if (a.kernel == "p16") family = FA_KERNEL_P16;
+    else if (!a.kernel.empty()) {
+        fprintf(stderr, "unknown --kernel %s\n", a.kernel.c_str());
+        exit(2);
+    }
+    const int kernel = family | (variant << 8);
+    HIP_OK(hipMemset(b.o, 0xff, b.ne * 4));
     fa_ok(fa_forward_ex(b.q, b.k, b.v, b.o, nullptr, a.bh, a.n, a.d, a.scale, a.causal, dt, kernel, nullptr), "fa_forward_ex");
     HIP_OK(hipDeviceSynchronize());
     double max_err = -1.0;
@@ -200,12 +223,96 @@ static void run_one(const Args& a, Buffers& b, int variant, const std::vector<fl
           "fa_time_forward");
     const double flop = (a.causal ? 2.0 : 4.0) * (double)a.bh * (double)a.n * (double)a.n * (double)a.d;
     const double tf = flop / (ms * 1e-3) / 1e12;
-    printf("{\"mode\": \"%s\", \"dtype\": \"%s\", \"variant\": %d, \"bh\": %ld, \"n\": %ld, \"d\": %d, \"causal\": %d, "
+    int32_t route = 0;
+    fa_ok(fa_last_forward_route(nullptr, &route), "fa_last_forward_route");
+    printf("{\"mode\": \"%s\", \"dtype\": \"%s\", \"kernel\": \"%s\", \"out_f32\": %d, \"route\": %d, \"variant\": %d, \"bh\": %ld, \"n\": %ld, \"d\": %d, \"causal\": %d, "
            "\"scale\": %g, \"ms\": %.4f, \"tflops\": %.2f, \"frac_mfma_peak\": %.4f, \"max_abs_err_vs_naive\": %.3e, "
            "\"nan\": %zu, \"iters\": %d}\n",
-           a.mode.c_str(), a.dtype.c_str(), variant, a.bh, a.n, a.d, a.causal, (double)a.scale, ms, tf,
+           a.mode.c_str(), a.dtype.c_str(), a.kernel.empty() ? "default" : a.kernel.c_str(), a.out_f32, (int)route, variant, a.bh, a.n, a.d, a.causal,
+           (double)a.scale, ms, tf,
            tf / peak_tflops(a.dtype), max_err, n_nan, a.iters);
     fflush(stdout);
+}
+
+// llm.c's make_random_float (src/llm.c/common.h): rand() / RAND_MAX * 2 - 1 after srand(0)
+static int run_llmc(const Args& a)
+{
+    const int B = a.B, T = a.T, C = a.C, NH = a.NH;
+    if (B < 1 || T < 1 || C < 1 || NH < 1 || C % NH != 0) {
+        fprintf(stderr, "bad llmc shape\n");
+        return 2;
+    }
+    const int hs = C / NH;
+    const size_t n_inp = (size_t)B * T * 3 * C, n_out = (size_t)B * T * C;
+    std::vector<float> inp(n_inp);
+    srand(0);
+    for (size_t i = 0; i < n_inp; ++i) inp[i] = ((float)rand() / (float)RAND_MAX) * 2.0f - 1.0f;
+    float *d_inp = nullptr, *d_out = nullptr;
+    HIP_OK(hipMalloc(&d_inp, n_inp * 4));
+    HIP_OK(hipMalloc(&d_out, n_out * 4));
+    HIP_OK(hipMemcpy(d_inp, inp.data(), n_inp * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(d_out, 0xff, n_out * 4));
+    fa_ok(fa_forward_packed_qkv(d_inp, d_out, B, T, C, NH, nullptr), "fa_forward_packed_qkv");
+    HIP_OK(hipDeviceSynchronize());
+    int32_t route = 0;
+    fa_ok(fa_last_forward_route(nullptr, &route), "fa_last_forward_route");
+    std::vector<float> got(n_out);
+    HIP_OK(hipMemcpy(got.data(), d_out, n_out * 4, hipMemcpyDeviceToHost));
+
+    // rung 0 on the same values, plain (B*NH, T, hs) layout (the permute_kernel of the reference, :519-545, done on the host)
+    const size_t ne = (size_t)B * NH * T * hs;
+    std::vector<float> q(ne), k(ne), v(ne);
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < T; ++t)
+            for (int h = 0; h < NH; ++h) {
+                const float* row = inp.data() + ((size_t)b * T + t) * 3 * C + (size_t)h * hs;
+                const size_t dst = (((size_t)b * NH + h) * T + t) * hs;
+                memcpy(&q[dst], row, hs * 4);
+                memcpy(&k[dst], row + C, hs * 4);
+                memcpy(&v[dst], row + 2 * C, hs * 4);
+            }
+    float *dq, *dk, *dv, *dref;
+    HIP_OK(hipMalloc(&dq, ne * 4));
+    HIP_OK(hipMalloc(&dk, ne * 4));
+    HIP_OK(hipMalloc(&dv, ne * 4));
+    HIP_OK(hipMalloc(&dref, ne * 4));
+    HIP_OK(hipMemcpy(dq, q.data(), ne * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dk, k.data(), ne * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dv, v.data(), ne * 4, hipMemcpyHostToDevice));
+    fa_ok(fa_forward_ex(dq, dk, dv, dref, nullptr, (int64_t)B * NH, T, hs, 1.0f / sqrtf((float)hs), 1, FA_DTYPE_F32, FA_KERNEL_NAIVE, nullptr), "naive");
+    HIP_OK(hipDeviceSynchronize());
+    std::vector<float> ref(ne);
+    HIP_OK(hipMemcpy(ref.data(), dref, ne * 4, hipMemcpyDeviceToHost));
+    double max_err = 0.0;
+    size_t n_bad = 0;
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < T; ++t)
+            for (int h = 0; h < NH; ++h)
+                for (int c = 0; c < hs; ++c) {
+                    const float g = got[((size_t)b * T + t) * C + (size_t)h * hs + c];
+                    const float r = ref[(((size_t)b * NH + h) * T + t) * hs + c];
+                    const double e = fabs((double)g - (double)r);
+                    if (!(e <= 1e-4)) ++n_bad;   // validate_result tolerance (:1262); NaN counts as bad
+                    if (e > max_err) max_err = e;
+                }
+    // benchmark_kernel: `repeats` launches between two events on the null stream, mean
+    const int repeats = a.iters_given ? a.iters : 100;
+    for (int i = 0; i < 10; ++i) fa_ok(fa_forward_packed_qkv(d_inp, d_out, B, T, C, NH, nullptr), "warm-up");
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0));
+    HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < repeats; ++i) fa_ok(fa_forward_packed_qkv(d_inp, d_out, B, T, C, NH, nullptr), "fa_forward_packed_qkv");
+    HIP_OK(hipEventRecord(e1, nullptr));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= (float)repeats;
+    const double flop = 2.0 * (double)B * NH * (double)T * (double)T * hs;   // causal
+    printf("{\"mode\": \"llmc\", \"B\": %d, \"T\": %d, \"C\": %d, \"NH\": %d, \"route\": %d, \"max_abs_err_vs_naive\": %.3e, \"tol\": 1e-4, "
+           "\"not_within_tol\": %zu, \"pass\": %s, \"repeats\": %d, \"ms\": %.4f, \"tflops\": %.2f}\n",
+           B, T, C, NH, (int)route, max_err, n_bad, n_bad == 0 ? "true" : "false", repeats, ms, flop / (ms * 1e-3) / 1e12);
+    return n_bad == 0 ? 0 : 1;
 }
 
 int main(int argc, char** argv)
@@ -216,6 +323,7 @@ int main(int argc, char** argv)
         return 4;
     }
     HIP_OK(hipSetDevice(0));
+    if (a.mode == "llmc") return run_llmc(a);
     const size_t ne = (size_t)a.bh * a.n * a.d;
     std::vector<float> hq(ne), hk(ne), hv(ne);
 

@@ -521,7 +521,8 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
             // lockstep/pipelined kernel for the non-causal case; its 256-row workgroups waste more of the causal
             // triangle than the 128-row phase-structured kernel recovers at D = 32
             if (variant == 7) return launch_bf16_pipelined(p, 32, 4, causal, out_f32, 0, stream);
-            return launch_cfg<32, 4, 1, 4>(p, causal, out_f32, stream);
+            if (variant == 1) return launch_cfg<32, 4, 1, 4>(p, causal, out_f32, stream);   // phase-structured
+            return hipErrorInvalidValue;
         case 64:
             switch (variant) {
                 case 1: return launch_cfg<64, 4, 1, 4>(p, causal, out_f32, stream);   // phase-structured, 4 waves/SIMD
@@ -569,7 +570,8 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
 #endif
             if (variant == 10) return launch_w4<128, 4, 2>(p, causal, out_f32, stream);
             if (variant == 23) return launch_w4<128, 4, 3>(p, causal, out_f32, stream);
-            return launch_cfg<128, 4, 1, 2>(p, causal, out_f32, stream);  // the pipelined kernel needs > 256 VGPRs at D = 128
+            if (variant == 1) return launch_cfg<128, 4, 1, 2>(p, causal, out_f32, stream);  // phase-structured (the pipelined kernel needs > 256 VGPRs at D = 128)
+            return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }
