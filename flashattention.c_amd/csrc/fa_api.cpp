@@ -178,7 +178,7 @@ int launch_p16_chain(const fa::FwdParams& p0, int32_t d, int32_t causal, int32_t
         p.flag = f.word;
         p.flag_serial = f.serial;
         p.flag_mode = 1;   // skip if the copy found a value fp16 cannot hold
-        e = fa::launch_bf16_x4_p16(p, causal ? 1 : 0, out_f32, stream);
+        e = fa::launch_bf16_p16(p, d, causal ? 1 : 0, out_f32, stream);
     }
     if (e == hipSuccess) {
         fa::FwdParams p = p0;
@@ -215,7 +215,7 @@ int launch_f32_guarded(const fa::FwdParams& p0, int32_t d, int32_t causal, hipSt
     return FA_OK;
 }
 
-bool p16_available(const fa::FwdParams& p, int32_t d) { return d == 64 && fa::bf16_pipelined_supported(p, 64); }
+bool p16_available(const fa::FwdParams& p, int32_t d) { return fa::bf16_p16_supported(p, d); }
 
 int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int32_t kernel, hipStream_t stream)
 {
@@ -235,7 +235,7 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
             // bf16 terms elsewhere: within 1e-3 of the fp32 reference at scale 1); a bf16 output rounds at 2^-9 of |O| anyway
             // and takes the fastest kernels (bf16 P).  MFMA / SPLIT / P16 force one family.
             if (sel.kind == FA_KERNEL_P16 && !p16_available(p, d))
-                return fail(FA_ERR_UNSUPPORTED, "the fp16-P kernel is instantiated for head dim 64 and slabs below 4 GiB (got d = %d)", d);
+                return fail(FA_ERR_UNSUPPORTED, "the fp16-P kernels address a slab with 32-bit byte offsets (slabs below 4 GiB; got n = %d, d = %d)", p.n, d);
             if (sel.kind == FA_KERNEL_P16 || (sel.kind == FA_KERNEL_AUTO && out_f32 && sel.variant == 0 && p16_available(p, d)))
                 return launch_p16_chain(p, d, causal, out_f32, stream);
             if (sel.kind == FA_KERNEL_SPLIT || (sel.kind == FA_KERNEL_AUTO && out_f32 && sel.variant == 0))
@@ -455,8 +455,10 @@ const char* fa_kernel_name_for(int32_t dtype, int32_t d, int32_t causal, int64_t
     if (!head_dim_supported(d) || bh < 1 || n < 1) return nullptr;
     if (dtype == FA_DTYPE_F32) return f32_auto_is_exact() ? "fa_fwd_f32_kernel" : "fa_fwd_f32_split_kernel";
     if (dtype == FA_DTYPE_BF16) return fa::bf16_kernel_name(bh, n, d, causal);
-    if (dtype == FA_DTYPE_BF16_OUT_F32)   // the accurate P (see fa_dtype): fp16 at head dim 64 (slabs below 4 GiB), hi + lo bf16 terms elsewhere
-        return (d == 64 && ((n - 1) * 64 + 64) * 2 < 0xffffffffLL) ? "fa_fwd_bf16_x4_p16_kernel" : "fa_fwd_f32_split_kernel";
+    if (dtype == FA_DTYPE_BF16_OUT_F32) {   // the accurate P (see fa_dtype): fp16 (slabs below 4 GiB), hi + lo bf16 terms beyond
+        if (((n - 1) * d + d) * 2 >= 0xffffffffLL) return "fa_fwd_f32_split_kernel";
+        return (d == 64 && strcmp(fa::bf16_kernel_name(bh, n, d, causal), "fa_fwd_bf16_x4_kernel") == 0) ? "fa_fwd_bf16_x4_p16_kernel" : "fa_fwd_bf16_x2_p16_kernel";
+    }
     return nullptr;
 }
 

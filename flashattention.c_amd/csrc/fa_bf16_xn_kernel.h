@@ -1,0 +1,911 @@
+// fa_bf16_xn_kernel.h -- the one-wave-per-SIMD bf16 kernel with explicit register files, templated on the head dimension D and on
+// the number NB of 32-row blocks a wave owns.  ONE source for what used to be two near-copies:
+//     NB = 4, D = 64          "x4": 128 query rows per wave, 512-row workgroups   (fa_fwd_bf16_x4*.hip: large non-causal grids, c4 / c5)
+//     NB = 2, D = 32/64/128   "x2":  64 query rows per wave, 256-row workgroups   (fa_fwd_bf16_x2.hip: d = 128, d = 32, causal and small grids)
+// and, through the PF switch, the fp16-P ("accurate") forms of both (fa_fwd_bf16_x4_p16*.hip, fa_fwd_bf16_x2_p16.hip).
+// Replaces the hot loop of flash_tiled_coarse{,_causal} (/root/reference/src/flashattention.cu:214-354, :434,480-484).
+//
+// Why one wave per SIMD: on gfx950 two waves of a SIMD do not issue VALU work side by side once matrix instructions are in their
+// streams (a wave parked on the busy matrix pipe holds the vector issue port; measured in profiles/ubench), so the loop is bound
+// by the number of instructions issued per MFMA, and both the chip's power budget and that issue budget are spent best by the
+// stream with the fewest instructions per FLOP.  More blocks per wave share every K / V^T fragment read, barrier, DMA and piece of
+// per-step bookkeeping among more FLOP; the single resident wave needs every latency hidden by the software pipeline itself:
+//
+//   step t (32 keys), NB = 4:   K.Q^T of sub-tile t+1 for blocks A,B | P.V + row sums of A | K.Q^T (t+1) for C,D, first half
+//                               | P.V B | K.Q^T C,D second half | P.V C | P.V D                                  (40 MFMA slots)
+//   step t (32 keys), NB = 2:   K.Q^T of sub-tile t+1 for A and B (2 KS slots) | P.V + row sums of A (NV + 2) | P.V + row sums of B
+//   VALU work (exp + pack of every block for sub-tile t; rescaled mixes: the lane maxima of sub-tile t+1 and the rescale test) is
+//   cut into ~4-instruction units and dealt out over the MFMA slots by measured issue cost, which by construction finishes exp(X)
+//   before P.V(X) and starts max(X) only after K.Q^T(X) has retired (profiles/r01_x4_schedule_check.py re-derives the tables and
+//   checks every dependency offline).  V^T fragments of the step are read in its first NV slots, the K fragments of the next step
+//   right after the step's last K.Q^T slot.
+//
+// D = 128 (NB = 2): a 32x32-key block has 18 MFMAs for the same 40 (48) VALU instructions as at D = 64 -- the step is bound by the
+//   matrix pipe, not by instruction issue (1254 TFLOP/s at BH = 16, N = 8192; registers: O 128 + Q 64 + row sums in AGPRs).
+// D = 64, NB = 2: fewer rows per wave than NB = 4 (more LDS reads and bookkeeping per FLOP), but 256-row tiles that run as two
+//   rounds of workgroups per CU, heavy tiles first: the causal case is no longer bound by its heaviest tile.
+#pragma once
+#include <utility>
+#include "fa_bf16_step.h"
+#include "fa_kernels.h"
+
+namespace fa {
+
+template <int D, int NB>
+struct XShape {
+    static_assert((NB == 4 && D == 64) || (NB == 2 && (D == 32 || D == 64 || D == 128)), "instantiated shapes");
+    static constexpr int KS = D / 16;          // k-steps of K.Q^T
+    static constexpr int DB = D / 32;          // 32-column blocks of O
+    static constexpr int NV = 2 * DB;          // V^T fragments per 32-key sub-tile
+    static constexpr int GRP = NV + 2;         // slots of one P.V + row-sum group
+    static constexpr int kSlots = NB * (KS + GRP);
+    static constexpr int kFirstPv = 2 * KS;    // first slot that needs the V^T fragments (both layouts start with K.Q^T of A, B)
+    // NB = 4: the V^T fragments are waited for one by one in the P.V slots of block A that consume them (the youngest read gets
+    // nine slots instead of five to land); NB = 2: one wait in front of the first P.V slot
+    static constexpr bool kVWaitPerFrag = NB == 4;
+    // K fragments of the next step: KS slots starting here (after the step's last K.Q^T slot)
+    static constexpr int kKLoad = NB == 4 ? 28 : 2 * KS + 1;
+    static constexpr int kUnitsOpt = NB * 18, kUnitsRsc = NB * 21 + 1;
+    // NB = 2: VALU units are dealt out over the first kWend half-slots of the step (largest values that put every pack in front of
+    // the first MFMA reading it, found offline); NB = 4: see weight_end()
+    static constexpr int kWendOpt2 = D == 128 ? 58 : D == 64 ? 30 : 16;
+    static constexpr int kWendRsc2 = D == 128 ? 64 : D == 64 ? 34 : 18;
+};
+// ---- matrix instructions with explicit register files ------------------------------------------------------------------
+// With one wave per SIMD the wave owns 256 architectural VGPRs and 256 accumulation registers (AGPRs).  VALU instructions
+// only reach the former, MFMA operands may sit in either.  hipcc picks ONE form for every MFMA of a function (all
+// accumulators in AGPRs: the scores then need a v_accvgpr_read per element; or all in VGPRs: the Q fragments and
+// output accumulators are shuttled through v_accvgpr copies) -- either way hundreds of extra issue slots per step.  So
+// the placement is stated per instruction:   scores S -> VGPRs (the softmax reads them),   O, row sums -> AGPRs
+// (only MFMAs touch them in the loop),   Q fragments -> AGPRs (B operand),   K / V^T / P fragments -> VGPRs.
+// The price: hipcc does not see an MFMA inside an asm statement, so the hazards are ours --
+//   * MFMA result -> VALU read: the static schedule reads scores >= 7 slots after their last MFMA; every cold path
+//     (tail, rescale branch, epilogue) drains the matrix pipe first, with the registers concerned tied to the drain;
+//   * MFMA -> dependent MFMA (same accumulator): at least one independent 32x32x16 MFMA (32 cycles) sits between them;
+//   * VALU result -> MFMA operand: two wait states, ours as well (the loop packs P a whole slot ahead; the tail pads);
+//     LDS result -> MFMA operand: the explicit lgkmcnt waits.
+__device__ __forceinline__ void mfma_s_first(f32x16& s, const bf16x8& kf, const bf16x8& q)
+{
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s) : "v"(kf), "a"(q));
+}
+__device__ __forceinline__ void mfma_s(f32x16& s, const bf16x8& kf, const bf16x8& q)
+{
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(kf), "a"(q));
+}
+// PF (here and below): P and the V image are fp16 instead of bf16 (the accurate mode, see XSoft); the 16-bit fragments travel in
+// the same register types either way.
+template <bool PF = false>
+__device__ __forceinline__ void mfma_o(f32x16& o, const bf16x8& vf, const bf16x8& pfrag)
+{
+    if constexpr (PF) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(o) : "v"(vf), "v"(pfrag));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(vf), "v"(pfrag));
+}
+template <bool PF = false>
+__device__ __forceinline__ void mfma_l(f32x4_t& l, const bf16x8& ones, const bf16x8& pfrag)
+{
+    if constexpr (PF) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(pfrag));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(pfrag));
+}
+
+// Exponent bookkeeping of the three softmax mixes: p = 2^(c*s - m - kBias), and (rescaled mixes) the reference m of a wave moves
+// when some score of the next sub-tile has c*s - m - kBias > kThr.
+//   optimistic, bf16 P   m fixed after the first sub-tile, 2^100 of room either way, verified at the end (fa_bf16_common.h)
+//   rescaled,   bf16 P   p <= 1 with the row maximum anywhere in 2^-64 .. 1 between two moves of the reference
+//   rescaled,   fp16 P   fp16 spans 2^-14 .. 2^16 (normal): the row maximum is put at 2^-5 when the reference moves and may grow to
+//                        2^14 before it moves again -- entries more than 2^-9 below a row maximum at the low end of that window
+//                        become subnormal (absolute error <= 2^-25, i.e. <= 2^-20 of the maximum: below the 2^-11 rounding of P
+//                        itself).  On unit-variance data at scale 1 (N = 8192, d = 64) a 128-row wave moves its references ~4
+//                        times per tile; at 1/sqrt(d) never after the first sub-tile.
+template <bool OPT, bool PF>
+struct XSoft {
+    static_assert(!(OPT && PF), "fp16 P has no room for a fixed exponent reference");
+    static constexpr float kBias = OPT ? kOptBias : PF ? 5.0f : kLazyThr;
+    static constexpr float kThr = PF ? 14.0f : 0.0f;
+};
+
+// mfma_drain() with the registers it protects as operands: the drain is an asm statement without a data dependence of its
+// own, and hipcc is free to schedule the VALU consumers of an asm MFMA's result in front of it (it did: the optimistic
+// mix has no branch between the tail's K.Q^T and the exponentials, and they were hoisted above the bare drain).
+template <int NB>
+__device__ __forceinline__ void drain_scores(f32x16 (&s)[NB])
+{
+    if constexpr (NB == 4) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]));
+    else asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(s[0]), "+v"(s[1]));
+}
+template <int NB, int DB>
+__device__ __forceinline__ void drain_accumulators(f32x16 (&o)[NB][DB], BlockState (&st)[NB])
+{
+    if constexpr (NB == 4) {
+        static_assert(DB == 2, "four blocks per wave exist at D = 64 only");
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+                     : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[2][0]), "+a"(o[2][1]), "+a"(o[3][0]), "+a"(o[3][1]),
+                       "+a"(st[0].lacc), "+a"(st[1].lacc), "+a"(st[2].lacc), "+a"(st[3].lacc));
+    } else if constexpr (DB == 4) {
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+                     : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[1][2]), "+a"(o[1][3]),
+                       "+a"(st[0].lacc), "+a"(st[1].lacc));
+    } else if constexpr (DB == 2) {
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+                     : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(st[0].lacc), "+a"(st[1].lacc));
+    } else {
+        static_assert(DB == 1, "drain written for D = 32, 64, 128");
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+a"(o[0][0]), "+a"(o[1][0]), "+a"(st[0].lacc), "+a"(st[1].lacc));
+    }
+}
+
+// (rare, wave-uniform) move the exponent references of all blocks; everything still at the old reference is scaled once
+template <int NB, int DB, bool PF = false>
+__device__ __forceinline__ void xn_rescale(const float (&mx)[NB], float c, BlockState (&st)[NB], f32x16 (&o)[NB][DB], float (&off)[NB])
+{
+    using SM = XSoft<false, PF>;
+    bool any = false;
+    float mc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        mc[b] = mx[b] * c;
+        mc[b] = fmaf(-fabsf(mc[b]), 0x1p-23f, mc[b]);
+        any = any || (mc[b] - st[b].m > SM::kBias + SM::kThr);
+    }
+    if (__builtin_expect(__any(any), 0)) {
+        asm volatile("; lazy rescale (all blocks of the wave)" ::: "memory");
+        drain_accumulators<NB, DB>(o, st);  // the accumulators rescaled below may have an MFMA in flight (hazard not padded across the branch)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float nm = fmaxf(st[b].m, mc[b]);
+            const float a = fast_exp2(st[b].m - nm);
+            st[b].m = nm;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[b][db][r] *= a;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[b].lacc[r] *= a;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) off[b] = st[b].m + SM::kBias;
+}
+
+// ---- static schedule of one step -------------------------------------------------------------------------------------
+// MFMA slot i -> what it is
+struct XSlot {
+    int kind;  // 0 = K.Q^T, 1 = P.V, 2 = row sum
+    int blk, idx;
+};
+// P.V + row sums of one block, GRP slots, no two dependent MFMAs adjacent: P.V index p reads V^T fragment p = tt * DB + db,
+// accumulates into o[blk][p % DB] and takes P fragment p / DB
+template <int D, int NB>
+__device__ __host__ constexpr XSlot xn_pv_group(int blk, int j)
+{
+    using S = XShape<D, NB>;
+    if (j == S::DB) return {2, blk, 0};
+    if (j == S::NV + 1) return {2, blk, 1};
+    return {1, blk, j < S::DB ? j : j - 1};
+}
+template <int D, int NB>
+__device__ __host__ constexpr XSlot xn_slot(int i)
+{
+    using S = XShape<D, NB>;
+    if constexpr (NB == 4) {
+        if (i < 8) return {0, i % 2, i / 2};                                  // K.Q^T A,B   k-step i/2
+        if (i < 14) return xn_pv_group<D, NB>(0, i - 8);                      // P.V + row sums A
+        if (i < 18) return {0, 2 + (i - 14) % 2, (i - 14) / 2};               // K.Q^T C,D   k-steps 0,1
+        if (i < 24) return xn_pv_group<D, NB>(1, i - 18);                     // P.V + row sums B
+        if (i < 28) return {0, 2 + (i - 24) % 2, 2 + (i - 24) / 2};           // K.Q^T C,D   k-steps 2,3
+        if (i < 34) return xn_pv_group<D, NB>(2, i - 28);                     // P.V + row sums C
+        return xn_pv_group<D, NB>(3, i - 34);                                 // P.V + row sums D
+    } else {
+        if (i < 2 * S::KS) return {0, i % 2, i / 2};                          // K.Q^T A,B   k-step i/2
+        return xn_pv_group<D, NB>((i - 2 * S::KS) / S::GRP, (i - 2 * S::KS) % S::GRP);
+    }
+}
+// Two instruction mixes share the slot sequence:
+//   OPT = false  the lazily rescaled softmax: exp + pack of sub-tile t, lane maxima of sub-tile t+1, rescale test (21 NB + 1 units)
+//   OPT = true   the optimistic softmax: the exponent reference of a row is fixed after its first sub-tile (with 2^100 of
+//                headroom either way, see kOptBias), so the loop has no maxima, no test and no branch (18 NB units); the tile
+//                is verified at the end and redone with OPT = false if any row left the safe range.
+template <int D, int NB>
+constexpr int xn_num_units(bool opt) { return opt ? XShape<D, NB>::kUnitsOpt : XShape<D, NB>::kUnitsRsc; }
+template <int D, int NB>
+__device__ __host__ constexpr int xn_weight_before(int i)  // in half-slots: a 32x32x16 slot = 2, a 16x16x32 slot = 1
+{
+    int w = 0;
+    for (int k = 0; k < i; ++k) w += (xn_slot<D, NB>(k).kind == 2) ? 1 : 2;
+    return w;
+}
+// NB = 4: the VALU work of the optimistic mix has to be finished before the k-step-1 MFMAs of P.V D (slot 37; the fragment of its
+// k-step 0 is packed early enough by the dealing rule -- checked for every dependency by profiles/r01_x4_schedule_check.py), the
+// rescaled mix uses the whole step; NB = 2: the offline-found limits of XShape
+template <int D, int NB>
+constexpr int xn_weight_end(bool opt)
+{
+    if constexpr (NB == 4) return opt ? xn_weight_before<D, NB>(37) : xn_weight_before<D, NB>(XShape<D, NB>::kSlots);
+    else return opt ? XShape<D, NB>::kWendOpt2 : XShape<D, NB>::kWendRsc2;
+}
+// VALU units are dealt out by ISSUE COST, not by count: measured beside MFMAs (profiles/ubench/ubench_clock.hip) a plain
+// VALU instruction occupies the wave's issue for 4 cycles and a v_exp_f32 for 8, so an exp element (fma + exp) costs 12, a
+// pack (4 cvt) 16, the max micro-steps 12 / 12 / 8, the test ~20 -- 1044 (896) cycles per NB = 4 step.  Slot i receives the units
+// whose cumulative cost fits its share of the step's half-slots (24..36 cycles per full slot).
+struct XTable {
+    int ub[72];  // VALU units dealt out before slot i (kSlots + 1 entries used)
+};
+// The unit sequence.  A pack (v_cvt_pk) is scheduled two exp units after the last exponential it consumes: a VALU
+// instruction that reads the result of a transcendental issued just before it costs a wait state (hipcc pads an s_nop).
+struct XUnit {
+    int kind;  // 0 = exp of one element, 1 = pack of one fragment, 2 = lane-max micro-step, 3 = rescale test
+    int blk, idx, cost;
+};
+struct XUnitList {
+    XUnit u[85];
+};
+template <int NB>
+__device__ __host__ constexpr XUnitList xn_make_units(bool opt)
+{
+    XUnitList l{};
+    int n = 0;
+    bool pending = false;
+    XUnit pend{};
+    for (int b = 0; b < NB; ++b) {
+        for (int e = 0; e < 16; ++e) {
+            l.u[n++] = {0, b, e, 12};
+            if (e == 1 && pending) {
+                l.u[n++] = pend;
+                pending = false;
+            }
+            if (e == 9) l.u[n++] = {1, b, 0, 16};
+        }
+        pend = {1, b, 1, 16};
+        pending = true;
+    }
+    if (opt) {
+        l.u[n++] = pend;
+        return l;
+    }
+    for (int b = 0; b < NB; ++b)
+        for (int m = 0; m < 3; ++m) {
+            l.u[n++] = {2, b, m, m == 2 ? 8 : 12};
+            if (b == 0 && m == 1 && pending) {
+                l.u[n++] = pend;
+                pending = false;
+            }
+        }
+    l.u[n++] = {3, 0, 0, 20};
+    return l;
+}
+template <int D, int NB>
+__device__ __host__ constexpr XTable xn_make_table(bool opt)
+{
+    constexpr int kS = XShape<D, NB>::kSlots;
+    const XUnitList l = xn_make_units<NB>(opt);
+    const int nu = xn_num_units<D, NB>(opt), wend = xn_weight_end<D, NB>(opt);
+    XTable t{};
+    int total = 0;
+    for (int u = 0; u < nu; ++u) total += l.u[u].cost;
+    int n = 0, cum_next = l.u[0].cost;  // cum_next: cost of units 0..n inclusive
+    for (int i = 0; i <= kS; ++i) {
+        const int wb = xn_weight_before<D, NB>(i) < wend ? xn_weight_before<D, NB>(i) : wend;
+        const int target = total * wb / wend + 6;
+        while (n < nu && cum_next <= target) {
+            ++n;
+            if (n < nu) cum_next += l.u[n].cost;
+        }
+        t.ub[i] = n;
+    }
+    t.ub[kS] = nu;
+    return t;
+}
+
+// A VALU result needs two wait states before an MFMA reads it, and an asm MFMA is not padded by hipcc: when the dealing rule
+// puts the pack of a P fragment into the slot right in front of the first MFMA that reads it, that MFMA gets an s_nop 1.
+template <int D, int NB>
+__device__ __host__ constexpr bool xn_needs_pad(int i, bool opt)
+{
+    const XSlot sl = xn_slot<D, NB>(i);
+    if (sl.kind == 0 || i == 0) return false;
+    const int frag = sl.kind == 1 ? sl.idx / XShape<D, NB>::DB : sl.idx;
+    const XUnitList l = xn_make_units<NB>(opt);
+    const XTable t = xn_make_table<D, NB>(opt);
+    for (int u = 0; u < xn_num_units<D, NB>(opt); ++u)
+        if (l.u[u].kind == 1 && l.u[u].blk == sl.blk && l.u[u].idx == frag) return u >= t.ub[i - 1];
+    return false;
+}
+
+// One step.  sc: scores of sub-tile t (consumed), sn: scores of sub-tile t+1 (produced); kf: K fragments of sub-tile t+1 on
+// entry, of sub-tile t+2 (read from k_nxt / block kb_n2) on exit.  Returns the lane's rescale test for sub-tile t+1.
+// Every slot / unit index is a template parameter (fold expressions over integer sequences): nothing here relies on the
+// optimiser unrolling a 40 x 53 loop nest to resolve the register arrays.
+template <int D, int NB>
+struct XCtx {
+    using S = XShape<D, NB>;
+    const bf16x8& ones_a;
+    const bf16x8 (&qf)[NB][S::KS];
+    f32x16 (&sc)[NB];
+    f32x16 (&sn)[NB];
+    f32x16 (&o)[NB][S::DB];
+    BlockState (&st)[NB];
+    const float (&off)[NB];
+    bf16x8 (&kf)[S::KS];
+    float (&lm)[NB];
+    float c;
+    const char* k_nxt;
+    int kb_n2, k_row_off, k_g;
+    unsigned v_addr;
+    s16x4 vlo[S::NV], vhi[S::NV];
+    bf16x8 vf[S::NV];
+    bf16x8 pf[NB][2];
+    float pm[4];
+    bool need;
+};
+
+template <int D, int NB, bool OPT, int U, int ABL = 0, bool PF = false>
+__device__ __forceinline__ void xn_unit(XCtx<D, NB>& x)
+{
+    constexpr XUnit un = xn_make_units<NB>(OPT).u[U];
+    if constexpr (un.kind == 0 && (ABL & 256)) {
+        // timing-only ablation: the exponential replaced by a plain VALU instruction of the same data flow
+        const float t = fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]);
+        float r;
+        asm volatile("v_mul_f32 %0, %1, %1" : "=v"(r) : "v"(t));
+        x.sc[un.blk][un.idx] = r;
+    } else if constexpr (un.kind == 0) {
+        // optimistic mix: no clamp -- an overflow has to reach the row sum (as a huge value or +inf): that is what the final
+        // check reads.  fp16 P: no clamp either -- p ranges up to 2^kThr by design
+        if constexpr (OPT || PF) x.sc[un.blk][un.idx] = fast_exp2(fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]));
+        else x.sc[un.blk][un.idx] = exp2_clamp01(fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]));
+    } else if constexpr (un.kind == 1) {
+        x.pf[un.blk][un.idx] = pack_p16x8<PF>(x.sc[un.blk], 8 * un.idx);
+        asm volatile("" : "+v"(x.pf[un.blk][un.idx]));
+    } else if constexpr (un.kind == 2) {
+        lanemax_step(un.idx, x.sn[un.blk], x.pm, x.lm[un.blk]);
+    } else {
+        float t = fmaf(x.lm[0], x.c, -x.off[0]);
+#pragma unroll
+        for (int b = 1; b < NB; ++b) t = fmaxf(t, fmaf(x.lm[b], x.c, -x.off[b]));
+        x.need = t > XSoft<false, PF>::kThr;  // off = m + kBias
+    }
+}
+template <int D, int NB, bool OPT, int ABL, bool PF, int U0, int... Us>
+__device__ __forceinline__ void xn_units(XCtx<D, NB>& x, std::integer_sequence<int, Us...>)
+{
+    (xn_unit<D, NB, OPT, U0 + Us, ABL, PF>(x), ...);
+}
+
+// wait for the asm-issued V^T reads (two ds_read per fragment, LDS returns in order) and hand the fragments to the MFMA operands
+template <int D, int NB, int I, int ABL>
+__device__ __forceinline__ void xn_wait_v_frags(XCtx<D, NB>& x)
+{
+    using S = XShape<D, NB>;
+    if constexpr (S::kVWaitPerFrag) {
+        // slots of block A's P.V group that consume fragment v first: kFirstPv + {0, 1, 3, 4} at D = 64 (the row-sum slot sits between)
+        static_assert(S::NV == 4, "per-fragment waits written for D = 64");
+        if constexpr (I == S::kFirstPv || I == S::kFirstPv + 1 || I == S::kFirstPv + 3 || I == S::kFirstPv + 4) {
+            constexpr int v = I == S::kFirstPv ? 0 : I == S::kFirstPv + 1 ? 1 : I == S::kFirstPv + 3 ? 2 : 3;
+            if constexpr (ABL & 32) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x.vlo[v]), "+v"(x.vhi[v]));
+            else if constexpr (ABL & 4) asm volatile("" : "+v"(x.vlo[v]), "+v"(x.vhi[v]));  // timing-only ablation: no wait
+            else if constexpr (v == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(x.vlo[0]), "+v"(x.vhi[0]));
+            else if constexpr (v == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x.vlo[1]), "+v"(x.vhi[1]));
+            else if constexpr (v == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(x.vlo[2]), "+v"(x.vhi[2]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x.vlo[3]), "+v"(x.vhi[3]));
+            __builtin_amdgcn_sched_barrier(0);
+            x.vf[v] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(x.vlo[v], x.vhi[v], 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    } else if constexpr (I == S::kFirstPv) {
+        // the reads were started in slots 0 .. NV-1, at least KS slots ago: one wait in front of the first P.V slot orders them all
+        // (the K reads of the next step start after it)
+        if constexpr (S::NV == 8) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(x.vlo[0]), "+v"(x.vhi[0]), "+v"(x.vlo[1]), "+v"(x.vhi[1]), "+v"(x.vlo[2]), "+v"(x.vhi[2]), "+v"(x.vlo[3]), "+v"(x.vhi[3]));
+            asm volatile("" : "+v"(x.vlo[4]), "+v"(x.vhi[4]), "+v"(x.vlo[5]), "+v"(x.vhi[5]), "+v"(x.vlo[6]), "+v"(x.vhi[6]), "+v"(x.vlo[7]), "+v"(x.vhi[7]));
+        } else if constexpr (S::NV == 4) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(x.vlo[0]), "+v"(x.vhi[0]), "+v"(x.vlo[1]), "+v"(x.vhi[1]), "+v"(x.vlo[2]), "+v"(x.vhi[2]), "+v"(x.vlo[3]), "+v"(x.vhi[3]));
+        } else {
+            static_assert(S::NV == 2, "fragment wait written for D = 32, 64, 128");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x.vlo[0]), "+v"(x.vhi[0]), "+v"(x.vlo[1]), "+v"(x.vhi[1]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < S::NV; ++v) x.vf[v] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(x.vlo[v], x.vhi[v], 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+}
+
+template <int D, int NB, int KB_C, int I, int ABL, bool OPT, bool PF>
+__device__ __forceinline__ void xn_slot_body(XCtx<D, NB>& x)
+{
+    using S = XShape<D, NB>;
+    constexpr XSlot sl = xn_slot<D, NB>(I);
+    constexpr XTable tab = xn_make_table<D, NB>(OPT);
+    xn_wait_v_frags<D, NB, I, ABL>(x);
+    if constexpr (I < S::NV && !(ABL & 16)) load_v_frag_asm<D, KB_C, I>(x.v_addr, x.vlo[I], x.vhi[I]);  // ABL & 16: no LDS fragment reads
+    if constexpr (I < S::NV && (ABL & 16)) asm volatile("" : "=v"(x.vlo[I]), "=v"(x.vhi[I]));
+    if constexpr (I < S::NV && (ABL & 32)) load_v_frag_asm<D, KB_C, I>(x.v_addr, x.vlo[I], x.vhi[I]);  // ABL & 32: every fragment read issued twice
+    if constexpr (xn_needs_pad<D, NB>(I, OPT)) asm volatile("s_nop 1");
+    if constexpr (ABL & 1) {
+        // timing-only ablation: no matrix instructions
+    } else if constexpr (sl.kind == 0) {
+        if constexpr (sl.idx == 0) mfma_s_first(x.sn[sl.blk], x.kf[sl.idx], x.qf[sl.blk][sl.idx]);
+        else mfma_s(x.sn[sl.blk], x.kf[sl.idx], x.qf[sl.blk][sl.idx]);
+    } else if constexpr (sl.kind == 1) {
+        mfma_o<PF>(x.o[sl.blk][sl.idx % S::DB], x.vf[sl.idx], x.pf[sl.blk][sl.idx / S::DB]);
+    } else {
+        mfma_l<PF>(x.st[sl.blk].lacc, x.ones_a, x.pf[sl.blk][sl.idx]);
+    }
+    if constexpr (I >= S::kKLoad && I < S::kKLoad + S::KS) {  // K fragments of the next step (this step's last K.Q^T slot lies behind)
+        // asm, like the V^T reads: a compiler-visible LDS load would make hipcc put its own lgkmcnt waits in front of the
+        // next step's K.Q^T MFMAs, and those waits -- counted without the asm reads in flight -- drain the V^T reads too
+        constexpr int ks = I - S::kKLoad;
+        const unsigned a = (unsigned)(size_t)(lds_s16x4_t*)(x.k_nxt + x.k_row_off + x.kb_n2 * 32 * (2 * D) + (((2 * ks) ^ x.k_g) * 16));
+        if constexpr (ABL & 16) asm volatile("" : "=v"(x.kf[ks]) : "v"(a));
+        else if constexpr (ABL & 64) asm volatile("" : "+v"(x.kf[ks]) : "v"(a));  // timing-only: keep the previous step's (random) fragments
+        else asm volatile("ds_read_b128 %0, %1" : "=v"(x.kf[ks]) : "v"(a));
+        if constexpr (ABL & 32) asm volatile("ds_read_b128 %0, %1" : "=v"(x.kf[ks]) : "v"(a));
+    }
+    if constexpr (!(ABL & 2))   // ABL & 2: no VALU work
+        xn_units<D, NB, OPT, ABL, PF, tab.ub[I]>(x, std::make_integer_sequence<int, tab.ub[I + 1] - tab.ub[I]>{});
+    if constexpr (!(ABL & 128)) __builtin_amdgcn_sched_barrier(0);  // ABL & 128: slots not pinned (hipcc schedules the step)
+}
+template <int D, int NB, int KB_C, int ABL, bool OPT, bool PF, int... Is>
+__device__ __forceinline__ void xn_slots(XCtx<D, NB>& x, std::integer_sequence<int, Is...>)
+{
+    (xn_slot_body<D, NB, KB_C, Is, ABL, OPT, PF>(x), ...);
+}
+
+template <int D, int NB, int KB_C, int ABL = 0, bool OPT = false, bool PF = false>
+__device__ __forceinline__ bool xn_step(const char* v_lds, const char* k_nxt, int kb_n2, int k_row_off, int k_g, int v_lane_off,
+                                        const bf16x8& ones_a, const bf16x8 (&qf)[NB][XShape<D, NB>::KS], f32x16 (&sc)[NB], f32x16 (&sn)[NB],
+                                        f32x16 (&o)[NB][XShape<D, NB>::DB], BlockState (&st)[NB], float c, const float (&off)[NB],
+                                        bf16x8 (&kf)[XShape<D, NB>::KS], float (&lm)[NB])
+{
+    XCtx<D, NB> x{ones_a, qf, sc, sn, o, st, off, kf, lm, c, k_nxt, kb_n2, k_row_off, k_g, (unsigned)(size_t)(lds_s16x4_t*)(v_lds + v_lane_off)};
+    x.need = false;
+    xn_slots<D, NB, KB_C, ABL, OPT, PF>(x, std::make_integer_sequence<int, XShape<D, NB>::kSlots>{});
+    // the K reads are at least a P.V group old: this wait is free, and it keeps every asm-issued load inside the basic block that
+    // issued it (hipcc may move or spill a register across a branch without knowing a load is in flight)
+    if constexpr (XShape<D, NB>::KS == 8)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]), "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7]));
+    else if constexpr (XShape<D, NB>::KS == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]));
+    return x.need;
+}
+
+// One (NWAVES * 32 * NB)-row tile.  OPT: optimistic mix; returns false when some row of the workgroup left the safe range (its
+// results were stored and are overwritten by the redo).
+template <int D, int NB, int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL, bool OPT, bool PF = false>
+__device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
+{
+    constexpr int KS = XShape<D, NB>::KS, DB = XShape<D, NB>::DB;
+    constexpr float kBias = XSoft<OPT, PF>::kBias;
+    using C = Bf16Cfg<D, NWAVES>;
+    constexpr int BM = NWAVES * 32 * NB;
+    constexpr int KR = 2 * G, VR = 2 * G;
+    static_assert(G == 1 || G == 2, "ring index arithmetic written for G = 1, 2");
+    constexpr int T = C::kTileBytes;
+
+    char* const k_ring = smem;  // K ring, then V ring
+    char* const v_ring = smem + KR * T;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lq = lane & 31, hi = lane >> 5;
+
+    const int total = p.bh * p.q_tiles;
+    const int w = xcd_remap(blockIdx.x, total);
+    const int slab = w / p.q_tiles;
+    int qt = w % p.q_tiles;
+    if (CAUSAL) qt = p.q_tiles - 1 - qt;
+    const int n = p.n;
+    const int q0 = qt * BM + wave * 32 * NB;  // first row of block 0; block b starts at q0 + 32 b
+
+    const int b = slab / p.heads, h = slab % p.heads;
+    const __bf16* qg = (const __bf16*)p.q + b * p.q_batch_stride + h * p.q_head_stride;
+    const __bf16* kg = (const __bf16*)p.k + b * p.kv_batch_stride + h * p.kv_head_stride;
+    const __bf16* vg = (const __bf16*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
+    const int64_t o_slab_off = b * p.o_batch_stride + h * p.o_head_stride;
+
+    int kv_end = n;
+    if (CAUSAL) kv_end = min(n, qt * BM + BM);
+    const int nst = (kv_end + kKvBlk - 1) / kKvBlk;  // 64-key stages
+    const int nsub = (kv_end + 31) / 32;             // 32-key sub-tiles
+
+    auto k_slot = [&](int j) { return k_ring + (j & (KR - 1)) * T; };
+    auto v_slot = [&](int j) { return v_ring + (j & (VR - 1)) * T; };
+
+    TileDma<D, NWAVES> dma;
+    dma.init(kg, vg, n, p.kv_row_stride, wave, lane);
+    dma.issue_k(0u, k_slot(0), wave);
+    // every tile the first barrier group needs is requested before anything is waited for: one memory round trip, not two
+#pragma unroll
+    for (int g = 1; g <= G; ++g)
+        if (g < nst) dma.issue_k((unsigned)g * dma.stage_step, k_slot(g), wave);
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+        if (g < nst) dma.issue_v((unsigned)g * dma.stage_step, v_slot(g), wave);
+
+    bf16x8 qf[NB][KS];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+        const __bf16* qr = qg + (int64_t)min(q0 + 32 * blk + lq, n - 1) * p.q_row_stride + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[blk][ks] = *(const bf16x8*)(qr + ks * 16);
+    }
+    const bf16x8 ones_a = rowsum_a_operand<PF>(lane);
+
+    f32x16 o[NB][DB], s0[NB], s1[NB];
+    BlockState st[NB];
+    float off[NB], lm[NB];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+        st[blk].m = -INFINITY;
+        lm[blk] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[blk].lacc[r] = 0.0f;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[blk][db][r] = 0.0f;
+    }
+
+    const int k_row_off = lq * C::kRowBytes;
+    const int k_g = hi ^ k_swizzle<D>(lq);
+    const int li = lane & 15;
+    const int v_lane_off = (hi * (D / 16) + ((lane >> 4) & 1)) * 128 + (li >> 2) * 32 + (li & 3) * 8;
+    const float c = p.scale_log2e;
+
+    // sub-tile t needs a mask for the block whose first row is qb?
+    auto needs_mask = [&](int t, int qb) { return (t * 32 + 32 > n) || (CAUSAL && (t * 32 + 31 > qb)); };
+
+    // Top of stage j, j a multiple of G: K(j+1 .. j+G), V(j .. j+G-1) visible; K(j+G+1 .. j+2G), V(j+G .. j+2G-1) enqueued into the
+    // ring slots nobody reads any more (K tiles are only read into kf one step ahead of their use, and every LDS read of
+    // a wave has returned before it arrives at the barrier).
+    auto sync_top = [&](int j) {
+        if (!(ABL & 8)) {  // ABL & 8: timing-only ablation without the wait + barrier
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+#pragma unroll
+        for (int g = 1; g <= G; ++g)
+            if (__builtin_expect(j + G + g < nst, 1)) dma.issue_k((unsigned)(j + G + g) * dma.stage_step, k_slot(j + G + g), wave);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (__builtin_expect(j + G + g < nst, 1)) dma.issue_v((unsigned)(j + G + g) * dma.stage_step, v_slot(j + G + g), wave);
+    };
+    bf16x8 kf[KS];
+    auto load_kf = [&](int t) {
+        const char* k_lds = k_slot(t >> 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[ks] = load_k_frag<D>(k_lds, k_row_off, k_g, t & 1, ks);
+    };
+    // scores of sub-tile t for all blocks from the fragments in kf, phase-structured (prologue and tail)
+    auto qk_regs = [&](int t, f32x16 (&s)[NB], bool first = false) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                if (ks == 0) mfma_s_first(s[blk], kf[ks], qf[blk][ks]);
+                else mfma_s(s[blk], kf[ks], qf[blk][ks]);
+            }
+        drain_scores<NB>(s);  // cold path: let the scores retire before the VALU reads them
+        float mx[NB];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            if (needs_mask(t, q0 + 32 * blk)) mask16(s[blk], t * 32, q0 + 32 * blk + lq, n, hi, CAUSAL);
+            mx[blk] = rowmax16(s[blk]);
+        }
+        if (first) {  // nothing accumulated yet: set the references, leave the (zero) accumulators alone
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                const float mc = mx[blk] * c;
+                st[blk].m = fmaf(-fabsf(mc), 0x1p-23f, mc);
+                off[blk] = st[blk].m + kBias;
+            }
+        } else if (!OPT) {
+            xn_rescale<NB, DB, PF>(mx, c, st, o, off);
+        }
+    };
+    // exp, pack, P.V and row sums of sub-tile t for all blocks, phase-structured (tail)
+    auto finish_sub = [&](int t, f32x16 (&s)[NB]) {
+        const char* v_lds = v_slot(t >> 1);
+        bf16x8 vf[2 * DB];
+#pragma unroll
+        for (int v = 0; v < 2 * DB; ++v) vf[v] = load_v_frag<D>(v_lds, v_lane_off, t & 1, v);
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            bf16x8 pf[2];
+            exp_range<PF>(s[blk], pf, c, off[blk], 0, 8, !OPT && !PF);
+            exp_range<PF>(s[blk], pf, c, off[blk], 8, 16, !OPT && !PF);
+            // a VALU result needs two wait states before an MFMA may read it; hipcc counts them for its own MFMAs, not
+            // for an asm one (the pipelined loop packs P at least one whole slot ahead of its first use)
+            asm volatile("s_nop 1" : "+v"(pf[0]), "+v"(pf[1]));
+#pragma unroll
+            for (int v = 0; v < 2 * DB; ++v) mfma_o<PF>(o[blk][v % DB], vf[v], pf[v / DB]);
+            mfma_l<PF>(st[blk].lacc, ones_a, pf[0]);
+            asm volatile("s_nop 7");  // dependent row-sum MFMAs back to back: the hazard is ours
+            mfma_l<PF>(st[blk].lacc, ones_a, pf[1]);
+        }
+    };
+
+    // ---------------- prologue: K(0) landed -> scores of sub-tile 0, fragments of sub-tile 1 ----------------
+    wait_lds_dma();
+    __syncthreads();
+    load_kf(0);
+    qk_regs(0, s0, true);
+    load_kf(1);
+
+    // ---------------- fast loop: groups of G whole stages whose sub-tiles 2j .. 2j+2 are in range and mask-free ----------------
+    int jf = 0;
+    while ((2 * jf + 3) * 32 <= kv_end && !needs_mask(2 * jf + 2, q0) && !needs_mask(0, q0)) ++jf;
+    // The last stage may run in the fast loop too when its own two sub-tiles are whole and mask-free: its second step then
+    // computes scores of a sub-tile that does not exist (from whatever the ring slot holds) and nobody consumes them --
+    // the rescale test of that step is ignored.  Without this the final 128 keys of every slab took the slow tail path.
+    if (jf == nst - 1 && (2 * jf + 2) * 32 <= kv_end && !needs_mask(2 * jf + 1, q0) && !needs_mask(0, q0)) jf = nst;
+    jf -= jf % G;
+    for (int j = 0; j < jf; j += G) {
+        sync_top(j);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const char* v_lds = v_slot(j + g);
+            const char* k_nxt = k_slot(j + g + 1);
+            bool need = xn_step<D, NB, 0, ABL, OPT, PF>(v_lds, k_nxt, 0, k_row_off, k_g, v_lane_off, ones_a, qf, s0, s1, o, st, c, off, kf, lm);
+            if (!OPT && __builtin_expect(__any(need), 0)) {
+                float mx[NB];
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk) mx[blk] = xhalf_max(lm[blk]);
+                xn_rescale<NB, DB, PF>(mx, c, st, o, off);
+            }
+            need = xn_step<D, NB, 1, ABL, OPT, PF>(v_lds, k_nxt, 1, k_row_off, k_g, v_lane_off, ones_a, qf, s1, s0, o, st, c, off, kf, lm);
+            if (!OPT && __builtin_expect(__any(need) && 2 * (j + g) + 2 < nsub, 0)) {
+                float mx[NB];
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk) mx[blk] = xhalf_max(lm[blk]);
+                xn_rescale<NB, DB, PF>(mx, c, st, o, off);
+            }
+        }
+    }
+
+    // ---------------- tail: remaining stages, phase-structured, masks applied where needed ----------------
+    // Invariant at the top of stage j: scores of sub-tile 2j in s0 with the rescale decision taken, kf = fragments of sub-tile 2j+1.
+    const int nsub_w = CAUSAL ? min(nsub, (q0 + 32 * (NB - 1) + 31) / 32 + 1) : nsub;
+    for (int j = jf; j < nst; ++j) {
+        if (j % G == 0) sync_top(j);
+        const int t0 = 2 * j, t1 = 2 * j + 1;
+        if (t0 < nsub_w) {
+            finish_sub(t0, s0);
+            if (t1 < nsub_w) {
+                qk_regs(t1, s1);
+                load_kf(t1 + 1);
+                finish_sub(t1, s1);
+                if (t1 + 1 < nsub_w) {
+                    qk_regs(t1 + 1, s0);
+                    load_kf(t1 + 2);
+                }
+            }
+        }
+    }
+
+    // ---------------- store; verify (optimistic mix) ----------------
+    // The optimistic tile stores its result BEFORE the workgroup votes on it: a failed tile is simply overwritten by the redo,
+    // and nothing of the first attempt is live across the vote (with the store behind the vote hipcc carried the
+    // accumulators of the common path through copies and 12 MB of scratch per launch).
+    drain_accumulators<NB, DB>(o, st);  // tied to the accumulators: a bare drain has no data dependence and may be scheduled past
+    bool bad = false;
+    if (OPT) {
+        // every P was exponentiated against the first sub-tile's maximum: the tile stands iff no term left the safe range,
+        // which the row sums prove (a term > 2^100, +inf or NaN makes its row sum fail this test)
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) bad = bad || !(st[blk].lacc[0] < kOptLimit);
+    }
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+        // (distinct text per mix: identical store code of the two inlined tiles gets tail-merged by hipcc, which then shuffles
+        // the accumulators of the common path through copies and 12 MB of scratch per launch)
+        if constexpr (OPT) asm volatile("; store, optimistic mix");
+        else asm volatile("; store, rescaled mix");
+        const float lt = st[blk].lacc[0];
+        const float inv = 1.0f / lt;
+        const int qi = q0 + 32 * blk + lq;
+        if (qi < n) {
+            if constexpr (OPT) asm volatile("; rows, optimistic mix");
+            else asm volatile("; rows, rescaled mix");
+            const int64_t o_off = o_slab_off + (int64_t)qi * p.o_row_stride + 4 * hi;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (OUT_F32) {
+                        f32x4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = o[blk][db][4 * g + e] * inv;
+                        *(f32x4*)((float*)p.o + o_off + db * 32 + 8 * g) = pk;
+                    } else if ((g & 1) == 0) {
+                        // 16-byte stores: the two lanes of a row (hi = 0 / 1) hold alternate 4-column groups; one
+                        // v_permlane32_swap per dword hands lane hi = 0 both halves of column group g and lane hi = 1 both
+                        // halves of group g + 1 (the epilogue is store-issue bound: half as many, twice as wide)
+                        bf16x4 pe, po;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            pe[e] = (__bf16)(o[blk][db][4 * g + e] * inv);
+                            po[e] = (__bf16)(o[blk][db][4 * (g + 1) + e] * inv);
+                        }
+                        const u32x2 ue = __builtin_bit_cast(u32x2, pe), uo = __builtin_bit_cast(u32x2, po);
+                        const auto r0 = __builtin_amdgcn_permlane32_swap(ue[0], uo[0], false, false);
+                        const auto r1 = __builtin_amdgcn_permlane32_swap(ue[1], uo[1], false, false);
+                        // lanes 0..31: r[0] = own group g, r[1] = partner's group g;  lanes 32..63: r[0] = partner's group g+1, r[1] = own
+                        u32x4 w;
+                        w[0] = r0[0];
+                        w[1] = r1[0];
+                        w[2] = r0[1];
+                        w[3] = r1[1];
+                        // hi = 0: columns 8g .. 8g+7;  hi = 1: columns 8(g+1) .. 8(g+1)+7  (o_off already carries + 4 hi)
+                        *(u32x4*)((__bf16*)p.o + o_off - 4 * hi + db * 32 + 8 * (g + hi)) = w;
+                    }
+                }
+            if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (st[blk].m + kBias + __builtin_amdgcn_logf(lt)) * kLn2;
+        }
+    }
+    if (OPT) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // stores and DMA of this attempt done before a redo starts
+        if (__syncthreads_or(bad ? 1 : 0)) return false;             // workgroup-wide: the redo shares tiles and barriers
+    }
+    return true;
+}
+
+// ---- kernels -----------------------------------------------------------------------------------------------------------
+// OPTIMISTIC: try the fixed-reference mix first, redo the tile with the rescaling mix if its verification fails.  ABL != 0: the
+// timing-only ablations of DESIGN.md section 4 (results are garbage; instantiated in the ablation library only).
+template <int D, int NB, int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL, bool OPTIMISTIC>
+__device__ __forceinline__ void xn_kernel_body(const FwdParams& p, char* smem)
+{
+    if (OPTIMISTIC && ABL == 0) {
+        if (xn_tile<D, NB, NWAVES, CAUSAL, OUT_F32, G, 0, true>(p, smem)) return;
+    }
+    if (ABL != 0 && OPTIMISTIC) {
+        (void)xn_tile<D, NB, NWAVES, CAUSAL, OUT_F32, G, ABL, true>(p, smem);
+        return;
+    }
+    (void)xn_tile<D, NB, NWAVES, CAUSAL, OUT_F32, G, ABL, false>(p, smem);
+}
+
+template <int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL = 0, bool OPTIMISTIC = true>
+__global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_kernel(FwdParams p)
+{
+    __shared__ __attribute__((aligned(1024))) char smem[4 * G * Bf16Cfg<64, NWAVES>::kTileBytes];
+    xn_kernel_body<64, 4, NWAVES, CAUSAL, OUT_F32, G, ABL, OPTIMISTIC>(p, smem);
+}
+template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL = 0, bool OPTIMISTIC = true>
+__global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x2_kernel(FwdParams p)
+{
+    __shared__ __attribute__((aligned(1024))) char smem[4 * G * Bf16Cfg<D, NWAVES>::kTileBytes];
+    xn_kernel_body<D, 2, NWAVES, CAUSAL, OUT_F32, G, ABL, OPTIMISTIC>(p, smem);
+}
+
+// The accurate mode: P and V in fp16 (11 significant bits instead of 8; XSoft<false, true>), lazily rescaled mix only.  p.v points
+// at the fp16 copy of V made by launch_cvt_v_f16 (fa_cvt.hip), whose overflow flag these kernels honour (FwdParams::flag_mode = 1).
+template <int NWAVES, bool CAUSAL, bool OUT_F32, int G>
+__global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_p16_kernel(FwdParams p)
+{
+    __shared__ __attribute__((aligned(1024))) char smem[4 * G * Bf16Cfg<64, NWAVES>::kTileBytes];
+    if (flag_says_skip(p)) return;
+    (void)xn_tile<64, 4, NWAVES, CAUSAL, OUT_F32, G, 0, false, true>(p, smem);
+}
+template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, int G>
+__global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x2_p16_kernel(FwdParams p)
+{
+    __shared__ __attribute__((aligned(1024))) char smem[4 * G * Bf16Cfg<D, NWAVES>::kTileBytes];
+    if (flag_says_skip(p)) return;
+    (void)xn_tile<D, 2, NWAVES, CAUSAL, OUT_F32, G, 0, false, true>(p, smem);
+}
+
+// ---- launch helpers ----------------------------------------------------------------------------------------------------
+// grid: one workgroup per (slab, q tile) of NWAVES * 32 * NB rows; the K / V tiles are addressed with 32-bit byte offsets
+template <int NB>
+static bool xn_grid(const FwdParams& p0, FwdParams& p, dim3& grid, dim3& block)
+{
+    constexpr int NWAVES = 4, BM = NWAVES * 32 * NB;
+    p = p0;
+    p.q_tiles = (p.n + BM - 1) / BM;
+    const int64_t total = (int64_t)p.bh * p.q_tiles;
+    if (total > 0x7fffffffLL) return false;
+    grid = dim3((unsigned)total);
+    block = dim3(NWAVES * kWave);
+    return true;
+}
+
+template <int G, bool OPTIMISTIC, bool CAUSAL>
+static hipError_t launch_x4(const FwdParams& p0, int out_f32, hipStream_t stream)
+{
+    FwdParams p;
+    dim3 grid, block;
+    if (!xn_grid<4>(p0, p, grid, block)) return hipErrorInvalidValue;
+    if (out_f32)
+        hipLaunchKernelGGL((fa_fwd_bf16_x4_kernel<4, CAUSAL, true, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
+    else
+        hipLaunchKernelGGL((fa_fwd_bf16_x4_kernel<4, CAUSAL, false, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+// mode 1: barrier every stage; 3: rescaling mix only (no optimistic attempt); otherwise the product tiling
+template <bool CAUSAL>
+static hipError_t launch_x4_modes(const FwdParams& p, int out_f32, int mode, hipStream_t stream)
+{
+    if (mode == 1) return launch_x4<1, true, CAUSAL>(p, out_f32, stream);
+    if (mode == 3) return launch_x4<2, false, CAUSAL>(p, out_f32, stream);
+    return launch_x4<2, true, CAUSAL>(p, out_f32, stream);
+}
+
+template <bool CAUSAL>
+static hipError_t launch_x4_p16(const FwdParams& p0, int out_f32, hipStream_t stream)
+{
+    FwdParams p;
+    dim3 grid, block;
+    if (!xn_grid<4>(p0, p, grid, block)) return hipErrorInvalidValue;
+    if (out_f32)
+        hipLaunchKernelGGL((fa_fwd_bf16_x4_p16_kernel<4, CAUSAL, true, 2>), grid, block, 0, stream, p);
+    else
+        hipLaunchKernelGGL((fa_fwd_bf16_x4_p16_kernel<4, CAUSAL, false, 2>), grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+template <int D, int G, bool OPTIMISTIC = true>
+static hipError_t launch_x2(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
+{
+    FwdParams p;
+    dim3 grid, block;
+    if (!xn_grid<2>(p0, p, grid, block)) return hipErrorInvalidValue;
+    if (causal) {
+        if (out_f32)
+            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, 4, true, true, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, 4, true, false, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
+    } else {
+        if (out_f32)
+            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, 4, false, true, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, 4, false, false, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
+template <int D>
+static hipError_t launch_x2_p16(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
+{
+    FwdParams p;
+    dim3 grid, block;
+    if (!xn_grid<2>(p0, p, grid, block)) return hipErrorInvalidValue;
+    if (causal) {
+        if (out_f32)
+            hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, true, true, 2>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, true, false, 2>), grid, block, 0, stream, p);
+    } else {
+        if (out_f32)
+            hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, false, true, 2>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, false, false, 2>), grid, block, 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
+template <int ABL>
+static hipError_t launch_x4_ablation(const FwdParams& p0, hipStream_t stream)
+{
+    FwdParams p;
+    dim3 grid, block;
+    if (!xn_grid<4>(p0, p, grid, block)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((fa_fwd_bf16_x4_kernel<4, false, false, 2, ABL>), grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+// the 32-bit slab addressing of the LDS-DMA descriptors (TileDma)
+static inline bool xn_addressable(const FwdParams& p, int d)
+{
+    return ((int64_t)(p.n - 1) * p.kv_row_stride + d) * 2 < (int64_t)0xffffffffLL;
+}
+
+// timing-only ablations (results are garbage), defined in fa_fwd_bf16_x4_ablation.hip (ablation library only)
+hipError_t launch_bf16_x4_ablation(const FwdParams& p, int mode, hipStream_t stream);
+// the causal instantiations, defined in fa_fwd_bf16_x4_causal.hip
+hipError_t launch_bf16_x4_causal(const FwdParams& p, int out_f32, int mode, hipStream_t stream);
+
+}  // namespace fa

@@ -414,7 +414,8 @@ static hipError_t launch_w4(const FwdParams& p0, int causal, int out_f32, hipStr
     return hipGetLastError();
 }
 
-template <int D, int NWAVES, int QB, int MINWAVES>
+// MINWAVES_C: occupancy hint of the causal instantiations (D = 64 at 4 waves per SIMD spilled 40 bytes per lane in the mask code)
+template <int D, int NWAVES, int QB, int MINWAVES, int MINWAVES_C = MINWAVES>
 static hipError_t launch_cfg(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
 {
     FwdParams p = p0;
@@ -425,9 +426,9 @@ static hipError_t launch_cfg(const FwdParams& p0, int causal, int out_f32, hipSt
     dim3 grid((unsigned)total), block(NWAVES * kWave);
     if (causal) {
         if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_kernel<D, NWAVES, QB, true, true, MINWAVES>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_kernel<D, NWAVES, QB, true, true, MINWAVES_C>), grid, block, 0, stream, p);
         else
-            hipLaunchKernelGGL((fa_fwd_bf16_kernel<D, NWAVES, QB, true, false, MINWAVES>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_kernel<D, NWAVES, QB, true, false, MINWAVES_C>), grid, block, 0, stream, p);
     } else {
         if (out_f32)
             hipLaunchKernelGGL((fa_fwd_bf16_kernel<D, NWAVES, QB, false, true, MINWAVES>), grid, block, 0, stream, p);
@@ -494,6 +495,22 @@ const char* bf16_kernel_name(int64_t bh, int64_t n, int d, int causal)
     }
 }
 
+// the fp16-P kernels exist in the one-wave-per-SIMD family only: NB = 4 where the bf16-P dispatch would take it too (large non-causal
+// d = 64 grids), NB = 2 everywhere else
+bool bf16_p16_supported(const FwdParams& p, int d)
+{
+    return (d == 32 || d == 64 || d == 128) && ((int64_t)(p.n - 1) * p.kv_row_stride + d) * 2 < (int64_t)0xffffffffLL;
+}
+
+hipError_t launch_bf16_p16(const FwdParams& p, int d, int causal, int out_f32, hipStream_t stream)
+{
+    if (!bf16_p16_supported(p, d)) return hipErrorInvalidValue;
+    if (d == 32) return launch_bf16_x2_p16_d32(p, causal, out_f32, stream);
+    if (d == 128) return launch_bf16_x2_p16_d128(p, causal, out_f32, stream);
+    if (choose_bf16(p.bh, p.n, 64, causal, true) == kChooseX4) return launch_bf16_x4_p16(p, causal, out_f32, stream);
+    return launch_bf16_x2_p16_d64(p, causal, out_f32, stream);
+}
+
 hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, int variant, hipStream_t stream)
 {
     if (variant == 0) {
@@ -508,7 +525,7 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
             case kChooseX2D32: return launch_bf16_x2(p, 32, causal, out_f32, 0, stream);
             default:
                 if (d == 32) return launch_cfg<32, 4, 1, 4>(p, causal, out_f32, stream);
-                if (d == 64) return launch_cfg<64, 4, 1, 4>(p, causal, out_f32, stream);
+                if (d == 64) return launch_cfg<64, 4, 1, 4, 3>(p, causal, out_f32, stream);
                 return launch_cfg<128, 4, 1, 2>(p, causal, out_f32, stream);
         }
     }
@@ -525,7 +542,7 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
             return hipErrorInvalidValue;
         case 64:
             switch (variant) {
-                case 1: return launch_cfg<64, 4, 1, 4>(p, causal, out_f32, stream);   // phase-structured, 4 waves/SIMD
+                case 1: return launch_cfg<64, 4, 1, 4, 3>(p, causal, out_f32, stream);   // phase-structured, 4 waves/SIMD
                 case 2: return launch_cfg<64, 4, 2, 2>(p, causal, out_f32, stream);   // phase-structured, 64 rows/wave
                 case 7: return launch_bf16_pipelined(p, 64, 4, causal, out_f32, 0, stream);
                 case 24: return launch_bf16_pipelined(p, 64, 2, causal, out_f32, 0, stream);
@@ -554,7 +571,9 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
                 case 44: return launch_bf16_x4(p, causal, out_f32, 21, stream);
                 case 45: return launch_bf16_x4(p, causal, out_f32, 22, stream);
 #endif
-                case 10: return launch_w4<64, 4, 4>(p, causal, out_f32, stream);       // 4 waves/SIMD on the VALU diet
+#if FA_ABLATION
+                case 10: return launch_w4<64, 4, 4>(p, causal, out_f32, stream);       // 4 waves/SIMD on the VALU diet (a null result of DESIGN.md section 4; its causal form spills)
+#endif
 #if FA_ABLATION
                 default: return launch_bf16_pp2(p, causal, out_f32, variant, stream);  // 9 = pp2 (previous generation), 6, 11..21 = its ablations
 #else

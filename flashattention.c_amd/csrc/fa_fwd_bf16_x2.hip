@@ -1,695 +1,16 @@
-// fa_fwd_bf16_x2.hip -- the one-wave-per-SIMD, explicit-register-file kernel of fa_bf16_x4_kernel.h with TWO 32-row blocks per wave
-// (64 query rows), 256-row workgroups, one workgroup per CU; instantiated for D = 128 and D = 64.
-//
-//   step t (32 keys):   K.Q^T of sub-tile t+1 for A and B (2 KS slots)  |  P.V + row sums of A (NV + 2)  |  P.V + row sums of B (NV + 2)
-//   VALU units (exp + pack of A, B for sub-tile t; rescaled mix: lane maxima of t+1, test) dealt out by issue cost over the
-//   leading part of the step's half-slots so that every pack precedes the first MFMA reading it (same rule and offline check as
-//   profiles/r01_x4_schedule_check.py).  V^T fragments are read in slots 0 .. NV-1 and waited for once, before the first P.V
-//   slot; the K fragments of the next step are read in the KS slots after it.
-//
-// D = 128: a 32x32-key block has 18 MFMAs for the same 40 (48) VALU instructions as at D = 64 -- the step is bound by the matrix
-//   pipe, not by instruction issue (1254 TFLOP/s at BH = 16, N = 8192; registers: O 128 + Q 64 + row sums in AGPRs).
-// D = 64: fewer rows per wave than x4 (more LDS reads and bookkeeping per FLOP), but 256-row tiles that run as two rounds of
-//   workgroups per CU, heavy tiles first: the causal case is no longer bound by its heaviest tile.
-// See fa_bf16_x4_kernel.h for the hazards that come with asm MFMAs and for the optimistic / lazily rescaled instruction mixes.
-#include <utility>
-#include "fa_bf16_step.h"
-#include "fa_kernels.h"
+// fa_fwd_bf16_x2.hip -- the NB = 2 instantiations of the one-wave-per-SIMD kernel (fa_bf16_xn_kernel.h): 64 query rows per wave,
+// 256-row workgroups, one workgroup per CU; D = 32, 64, 128.  Replaces the hot loop of flash_tiled_coarse{,_causal}
+// (/root/reference/src/flashattention.cu:214-354, :434,480-484) for d = 128, d = 32 and the causal / small d = 64 grids.
+#include "fa_bf16_xn_kernel.h"
 
 namespace fa {
 
-constexpr int kNB2 = 2;  // 32-row blocks per wave
-template <int D>
-struct X2Shape {
-    static constexpr int KS = D / 16;          // k-steps of K.Q^T
-    static constexpr int DB = D / 32;          // 32-column blocks of O
-    static constexpr int NV = 2 * DB;          // V^T fragments per 32-key sub-tile
-    static constexpr int GRP = NV + 2;         // slots of one P.V + row-sum group
-    static constexpr int kSlots = 2 * KS + 2 * GRP;
-    static constexpr int kFirstPv = 2 * KS;    // first slot that needs the V^T fragments
-    static constexpr int kKLoad = 2 * KS + 1;  // K fragments of the next step: slots kKLoad .. kKLoad + KS - 1
-    static constexpr int kUnitsOpt = 36, kUnitsRsc = 43;
-    // VALU units are dealt out over the first kWendOpt (kWendRsc) half-slots of the step (largest values that put every pack
-    // in front of the first MFMA reading it, found offline)
-    static constexpr int kWendOpt = D == 128 ? 58 : D == 64 ? 30 : 16;
-    static constexpr int kWendRsc = D == 128 ? 64 : D == 64 ? 34 : 18;
-};
-
-// ---- matrix instructions with explicit register files ------------------------------------------------------------------
-// With one wave per SIMD the wave owns 256 architectural VGPRs and 256 accumulation registers (AGPRs).  VALU instructions
-// only reach the former, MFMA operands may sit in either.  hipcc picks ONE form for every MFMA of a function (all
-// accumulators in AGPRs: the scores then need a v_accvgpr_read per element; or all in VGPRs: the Q fragments and
-// output accumulators are shuttled through v_accvgpr copies) -- either way hundreds of extra issue slots per step.  So
-// the placement is stated per instruction:   scores S -> VGPRs (the softmax reads them),   O, row sums -> AGPRs
-// (only MFMAs touch them in the loop),   Q fragments -> AGPRs (B operand),   K / V^T / P fragments -> VGPRs.
-// The price: hipcc does not see an MFMA inside an asm statement, so the hazards are ours --
-//   * MFMA result -> VALU read: the static schedule reads scores >= 7 slots after their last MFMA; every cold path
-//     (tail, rescale branch, epilogue) drains the matrix pipe first, with the registers concerned tied to the drain;
-//   * MFMA -> dependent MFMA (same accumulator): at least one independent 32x32x16 MFMA (32 cycles) sits between them;
-//   * VALU result -> MFMA operand: two wait states, ours as well (the loop packs P a whole slot ahead; the tail pads);
-//     LDS result -> MFMA operand: the explicit lgkmcnt waits.
-__device__ __forceinline__ void x2_mfma_s_first(f32x16& s, const bf16x8& kf, const bf16x8& q)
-{
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s) : "v"(kf), "a"(q));
-}
-__device__ __forceinline__ void x2_mfma_s(f32x16& s, const bf16x8& kf, const bf16x8& q)
-{
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(kf), "a"(q));
-}
-__device__ __forceinline__ void x2_mfma_o(f32x16& o, const bf16x8& vf, const bf16x8& pfrag)
-{
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(vf), "v"(pfrag));
-}
-__device__ __forceinline__ void x2_mfma_l(f32x4_t& l, const bf16x8& ones, const bf16x8& pfrag)
-{
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(pfrag));
-}
-
-// mfma_drain() with the registers it protects as operands: the drain is an asm statement without a data dependence of its
-// own, and hipcc is free to schedule the VALU consumers of an asm MFMA's result in front of it (it did: the optimistic
-// mix has no branch between the tail's K.Q^T and the exponentials, and they were hoisted above the bare drain).
-__device__ __forceinline__ void x2_drain_scores(f32x16 (&s)[kNB2])
-{
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(s[0]), "+v"(s[1]));
-}
-template <int DB>
-__device__ __forceinline__ void x2_drain_accumulators(f32x16 (&o)[kNB2][DB], BlockState (&st)[kNB2])
-{
-    if constexpr (DB == 4) {
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
-                     : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[1][2]), "+a"(o[1][3]),
-                       "+a"(st[0].lacc), "+a"(st[1].lacc));
-    } else if constexpr (DB == 2) {
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
-                     : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(st[0].lacc), "+a"(st[1].lacc));
-    } else {
-        static_assert(DB == 1, "drain written for D = 32, 64, 128");
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+a"(o[0][0]), "+a"(o[1][0]), "+a"(st[0].lacc), "+a"(st[1].lacc));
-    }
-}
-
-// (rare, wave-uniform) move the exponent references of all blocks; everything still at the old reference is scaled once
-template <int DB>
-__device__ __forceinline__ void x2_rescale(const float (&mx)[kNB2], float c, BlockState (&st)[kNB2], f32x16 (&o)[kNB2][DB], float (&off)[kNB2])
-{
-    bool any = false;
-    float mc[kNB2];
-#pragma unroll
-    for (int b = 0; b < kNB2; ++b) {
-        mc[b] = mx[b] * c;
-        mc[b] = fmaf(-fabsf(mc[b]), 0x1p-23f, mc[b]);
-        any = any || (mc[b] - st[b].m > kLazyThr);
-    }
-    if (__builtin_expect(__any(any), 0)) {
-        asm volatile("; lazy rescale (two blocks)" ::: "memory");
-        x2_drain_accumulators<DB>(o, st);  // the accumulators rescaled below may have an MFMA in flight (hazard not padded across the branch)
-#pragma unroll
-        for (int b = 0; b < kNB2; ++b) {
-            const float nm = fmaxf(st[b].m, mc[b]);
-            const float a = fast_exp2(st[b].m - nm);
-            st[b].m = nm;
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[b][db][r] *= a;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) st[b].lacc[r] *= a;
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < kNB2; ++b) off[b] = st[b].m + kLazyThr;
-}
-
-// ---- static schedule of one step -------------------------------------------------------------------------------------
-// MFMA slot i -> what it is
-struct X2Slot {
-    int kind;  // 0 = K.Q^T, 1 = P.V, 2 = row sum
-    int blk, idx;
-};
-template <int D>
-__device__ __host__ constexpr X2Slot x2_slot(int i)
-{
-    using S = X2Shape<D>;
-    if (i < 2 * S::KS) return {0, i % 2, i / 2};  // K.Q^T A,B   k-step i/2
-    const int blk = (i - 2 * S::KS) / S::GRP, j = (i - 2 * S::KS) % S::GRP;
-    // P.V + row sums of one block, no two dependent MFMAs adjacent: P.V index p reads V^T fragment p = tt * DB + db, accumulates
-    // into o[blk][p % DB] and takes P fragment p / DB
-    if (j == S::DB) return {2, blk, 0};
-    if (j == S::NV + 1) return {2, blk, 1};
-    return {1, blk, j < S::DB ? j : j - 1};
-}
-// Two instruction mixes share the slot sequence:
-//   OPT = false  the lazily rescaled softmax: exp + pack of sub-tile t, lane maxima of sub-tile t+1, rescale test (43 units)
-//   OPT = true   the optimistic softmax (fa_bf16_common.h): no maxima, no test, no branch in the loop (36 units); the tile is
-//                verified at the end and redone with OPT = false if any row left the safe range.
-template <int D>
-constexpr int x2_num_units(bool opt) { return opt ? X2Shape<D>::kUnitsOpt : X2Shape<D>::kUnitsRsc; }
-template <int D>
-__device__ __host__ constexpr int x2_weight_before(int i)  // in half-slots: a 32x32x16 slot = 2, a 16x16x32 slot = 1
-{
-    int w = 0;
-    for (int k = 0; k < i; ++k) w += (x2_slot<D>(k).kind == 2) ? 1 : 2;
-    return w;
-}
-template <int D>
-constexpr int x2_weight_end(bool opt) { return opt ? X2Shape<D>::kWendOpt : X2Shape<D>::kWendRsc; }
-// VALU units are dealt out by ISSUE COST, not by count: measured beside MFMAs (profiles/ubench/ubench_clock.hip) a plain
-// VALU instruction occupies the wave's issue for 4 cycles and a v_exp_f32 for 8, so an exp element (fma + exp) costs 12, a
-// pack (4 cvt) 16, the max micro-steps 12 / 12 / 8, the test ~20 -- 1044 (896) cycles per step.  Slot i receives the units
-// whose cumulative cost fits its share of the step's half-slots (24..36 cycles per full slot).
-struct X2Table {
-    int ub[64];  // VALU units dealt out before slot i (36 + 1 entries used at D = 128, 20 + 1 at D = 64)
-};
-// The unit sequence.  A pack (v_cvt_pk) is scheduled two exp units after the last exponential it consumes: a VALU
-// instruction that reads the result of a transcendental issued just before it costs a wait state (hipcc pads an s_nop).
-struct X2Unit {
-    int kind;  // 0 = exp of one element, 1 = pack of one fragment, 2 = lane-max micro-step, 3 = rescale test
-    int blk, idx, cost;
-};
-struct X2UnitList {
-    X2Unit u[43];
-};
-__device__ __host__ constexpr X2UnitList x2_make_units(bool opt)
-{
-    X2UnitList l{};
-    int n = 0;
-    bool pending = false;
-    X2Unit pend{};
-    for (int b = 0; b < kNB2; ++b) {
-        for (int e = 0; e < 16; ++e) {
-            l.u[n++] = {0, b, e, 12};
-            if (e == 1 && pending) {
-                l.u[n++] = pend;
-                pending = false;
-            }
-            if (e == 9) l.u[n++] = {1, b, 0, 16};
-        }
-        pend = {1, b, 1, 16};
-        pending = true;
-    }
-    if (opt) {
-        l.u[n++] = pend;
-        return l;
-    }
-    for (int b = 0; b < kNB2; ++b)
-        for (int m = 0; m < 3; ++m) {
-            l.u[n++] = {2, b, m, m == 2 ? 8 : 12};
-            if (b == 0 && m == 1 && pending) {
-                l.u[n++] = pend;
-                pending = false;
-            }
-        }
-    l.u[n++] = {3, 0, 0, 20};
-    return l;
-}
-template <int D>
-__device__ __host__ constexpr X2Table x2_make_table(bool opt)
-{
-    constexpr int kX2Slots = X2Shape<D>::kSlots;
-    const X2UnitList l = x2_make_units(opt);
-    const int nu = x2_num_units<D>(opt), wend = x2_weight_end<D>(opt);
-    X2Table t{};
-    int total = 0;
-    for (int u = 0; u < nu; ++u) total += l.u[u].cost;
-    int n = 0, cum_next = l.u[0].cost;  // cum_next: cost of units 0..n inclusive
-    for (int i = 0; i <= kX2Slots; ++i) {
-        const int wb = x2_weight_before<D>(i) < wend ? x2_weight_before<D>(i) : wend;
-        const int target = total * wb / wend + 6;
-        while (n < nu && cum_next <= target) {
-            ++n;
-            if (n < nu) cum_next += l.u[n].cost;
-        }
-        t.ub[i] = n;
-    }
-    t.ub[kX2Slots] = nu;
-    return t;
-}
-
-// A VALU result needs two wait states before an MFMA reads it, and an asm MFMA is not padded by hipcc: when the dealing rule
-// puts the pack of a P fragment into the slot right in front of the first MFMA that reads it, that MFMA gets an s_nop 1.
-template <int D>
-__device__ __host__ constexpr bool x2_needs_pad(int i, bool opt)
-{
-    const X2Slot sl = x2_slot<D>(i);
-    if (sl.kind == 0 || i == 0) return false;
-    const int frag = sl.kind == 1 ? sl.idx / X2Shape<D>::DB : sl.idx;
-    const X2UnitList l = x2_make_units(opt);
-    const X2Table t = x2_make_table<D>(opt);
-    for (int u = 0; u < x2_num_units<D>(opt); ++u)
-        if (l.u[u].kind == 1 && l.u[u].blk == sl.blk && l.u[u].idx == frag) return u >= t.ub[i - 1];
-    return false;
-}
-
-// One step.  sc: scores of sub-tile t (consumed), sn: scores of sub-tile t+1 (produced); kf: K fragments of sub-tile t+1 on
-// entry, of sub-tile t+2 (read from k_nxt / block kb_n2) on exit.  Returns the lane's rescale test for sub-tile t+1.
-// Every slot / unit index is a template parameter (fold expressions over integer sequences): nothing here relies on the
-// optimiser unrolling a 40 x 53 loop nest to resolve the register arrays.
-template <int D>
-struct X2Ctx {
-    const bf16x8& ones_a;
-    const bf16x8 (&qf)[kNB2][X2Shape<D>::KS];
-    f32x16 (&sc)[kNB2];
-    f32x16 (&sn)[kNB2];
-    f32x16 (&o)[kNB2][X2Shape<D>::DB];
-    BlockState (&st)[kNB2];
-    const float (&off)[kNB2];
-    bf16x8 (&kf)[X2Shape<D>::KS];
-    float (&lm)[kNB2];
-    float c;
-    const char* k_nxt;
-    int kb_n2, k_row_off, k_g;
-    unsigned v_addr;
-    s16x4 vlo[X2Shape<D>::NV], vhi[X2Shape<D>::NV];
-    bf16x8 vf[X2Shape<D>::NV];
-    bf16x8 pf[kNB2][2];
-    float pm[4];
-    bool need;
-};
-
-template <int D, bool OPT, int U>
-__device__ __forceinline__ void x2_unit(X2Ctx<D>& x)
-{
-    constexpr X2Unit un = x2_make_units(OPT).u[U];
-    if constexpr (un.kind == 0) {
-        // optimistic mix: no clamp -- an overflow has to reach the row sum (as a huge value or +inf): that is what the final
-        // check reads
-        if constexpr (OPT) x.sc[un.blk][un.idx] = fast_exp2(fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]));
-        else x.sc[un.blk][un.idx] = exp2_clamp01(fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]));
-    } else if constexpr (un.kind == 1) {
-        x.pf[un.blk][un.idx] = pack_bf16x8(x.sc[un.blk], 8 * un.idx);
-        asm volatile("" : "+v"(x.pf[un.blk][un.idx]));
-    } else if constexpr (un.kind == 2) {
-        lanemax_step(un.idx, x.sn[un.blk], x.pm, x.lm[un.blk]);
-    } else {
-        float t = fmaf(x.lm[0], x.c, -x.off[0]);
-#pragma unroll
-        for (int b = 1; b < kNB2; ++b) t = fmaxf(t, fmaf(x.lm[b], x.c, -x.off[b]));
-        x.need = t > 0.0f;  // off = m + kLazyThr
-    }
-}
-template <int D, bool OPT, int U0, int... Us>
-__device__ __forceinline__ void x2_units(X2Ctx<D>& x, std::integer_sequence<int, Us...>)
-{
-    (x2_unit<D, OPT, U0 + Us>(x), ...);
-}
-
-template <int D, int KB_C, int I, int ABL, bool OPT>
-__device__ __forceinline__ void x2_slot_body(X2Ctx<D>& x)
-{
-    using S = X2Shape<D>;
-    constexpr X2Slot sl = x2_slot<D>(I);
-    constexpr X2Table tab = x2_make_table<D>(OPT);
-    // The asm-issued V^T reads were started in slots 0 .. NV-1 (two ds_read per fragment), at least KS slots ago: one wait in
-    // front of the first P.V slot orders them all (the K reads of the next step start after it, see below).
-    if constexpr (I == S::kFirstPv) {
-        if constexpr (S::NV == 8) {
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(x.vlo[0]), "+v"(x.vhi[0]), "+v"(x.vlo[1]), "+v"(x.vhi[1]), "+v"(x.vlo[2]), "+v"(x.vhi[2]), "+v"(x.vlo[3]), "+v"(x.vhi[3]));
-            asm volatile("" : "+v"(x.vlo[4]), "+v"(x.vhi[4]), "+v"(x.vlo[5]), "+v"(x.vhi[5]), "+v"(x.vlo[6]), "+v"(x.vhi[6]), "+v"(x.vlo[7]), "+v"(x.vhi[7]));
-        } else if constexpr (S::NV == 4) {
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(x.vlo[0]), "+v"(x.vhi[0]), "+v"(x.vlo[1]), "+v"(x.vhi[1]), "+v"(x.vlo[2]), "+v"(x.vhi[2]), "+v"(x.vlo[3]), "+v"(x.vhi[3]));
-        } else {
-            static_assert(S::NV == 2, "fragment wait written for D = 32, 64, 128");
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x.vlo[0]), "+v"(x.vhi[0]), "+v"(x.vlo[1]), "+v"(x.vhi[1]));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int v = 0; v < S::NV; ++v) x.vf[v] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(x.vlo[v], x.vhi[v], 0, 1, 2, 3, 4, 5, 6, 7));
-    }
-    if constexpr (I < S::NV) load_v_frag_asm<D, KB_C, I>(x.v_addr, x.vlo[I], x.vhi[I]);
-    if constexpr (x2_needs_pad<D>(I, OPT)) asm volatile("s_nop 1");
-    if constexpr (ABL & 1) {
-        // timing-only ablation: no matrix instructions
-    } else if constexpr (sl.kind == 0) {
-        if constexpr (sl.idx == 0) x2_mfma_s_first(x.sn[sl.blk], x.kf[sl.idx], x.qf[sl.blk][sl.idx]);
-        else x2_mfma_s(x.sn[sl.blk], x.kf[sl.idx], x.qf[sl.blk][sl.idx]);
-    } else if constexpr (sl.kind == 1) {
-        x2_mfma_o(x.o[sl.blk][sl.idx % S::DB], x.vf[sl.idx], x.pf[sl.blk][sl.idx / S::DB]);
-    } else {
-        x2_mfma_l(x.st[sl.blk].lacc, x.ones_a, x.pf[sl.blk][sl.idx]);
-    }
-    if constexpr (I >= S::kKLoad && I < S::kKLoad + S::KS) {  // K fragments of the next step (its last K.Q^T was slot 2 KS - 1)
-        // asm, like the V^T reads: a compiler-visible LDS load would make hipcc put its own lgkmcnt waits in front of the
-        // next step's K.Q^T MFMAs
-        constexpr int ks = I - S::kKLoad;
-        const unsigned a = (unsigned)(size_t)(lds_s16x4_t*)(x.k_nxt + x.k_row_off + x.kb_n2 * 32 * (2 * D) + (((2 * ks) ^ x.k_g) * 16));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(x.kf[ks]) : "v"(a));
-    }
-    if constexpr (!(ABL & 2)) x2_units<D, OPT, tab.ub[I]>(x, std::make_integer_sequence<int, tab.ub[I + 1] - tab.ub[I]>{});  // ABL & 2: no VALU work
-    __builtin_amdgcn_sched_barrier(0);
-}
-template <int D, int KB_C, int ABL, bool OPT, int... Is>
-__device__ __forceinline__ void x2_slots(X2Ctx<D>& x, std::integer_sequence<int, Is...>)
-{
-    (x2_slot_body<D, KB_C, Is, ABL, OPT>(x), ...);
-}
-
-template <int D, int KB_C, int ABL = 0, bool OPT = false>
-__device__ __forceinline__ bool x2_step(const char* v_lds, const char* k_nxt, int kb_n2, int k_row_off, int k_g, int v_lane_off,
-                                        const bf16x8& ones_a, const bf16x8 (&qf)[kNB2][X2Shape<D>::KS], f32x16 (&sc)[kNB2], f32x16 (&sn)[kNB2],
-                                        f32x16 (&o)[kNB2][X2Shape<D>::DB], BlockState (&st)[kNB2], float c, const float (&off)[kNB2],
-                                        bf16x8 (&kf)[X2Shape<D>::KS], float (&lm)[kNB2])
-{
-    X2Ctx<D> x{ones_a, qf, sc, sn, o, st, off, kf, lm, c, k_nxt, kb_n2, k_row_off, k_g, (unsigned)(size_t)(lds_s16x4_t*)(v_lds + v_lane_off)};
-    x.need = false;
-    x2_slots<D, KB_C, ABL, OPT>(x, std::make_integer_sequence<int, X2Shape<D>::kSlots>{});
-    // the K reads are at least GRP slots old: this wait is free, and it keeps every asm-issued load inside the basic block that
-    // issued it (hipcc may move or spill a register across a branch without knowing a load is in flight)
-    if constexpr (X2Shape<D>::KS == 8)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]), "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7]));
-    else if constexpr (X2Shape<D>::KS == 4)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]));
-    else
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]));
-    return x.need;
-}
-
-// One 256-row tile.  OPT: optimistic mix; returns false (nothing stored) when some row of the workgroup left the safe range.
-template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL, bool OPT>
-__device__ __forceinline__ bool x2_tile(const FwdParams& p, char* smem)
-{
-    constexpr int KS = X2Shape<D>::KS, DB = X2Shape<D>::DB;
-    constexpr float kBias = OPT ? kOptBias : kLazyThr;
-    using C = Bf16Cfg<D, NWAVES>;
-    constexpr int BM = NWAVES * 32 * kNB2;
-    constexpr int KR = 2 * G, VR = 2 * G;
-    static_assert(G == 1 || G == 2, "ring index arithmetic written for G = 1, 2");
-    constexpr int T = C::kTileBytes;
-
-    char* const k_ring = smem;  // K ring, then V ring
-    char* const v_ring = smem + KR * T;
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lq = lane & 31, hi = lane >> 5;
-
-    const int total = p.bh * p.q_tiles;
-    const int w = xcd_remap(blockIdx.x, total);
-    const int slab = w / p.q_tiles;
-    int qt = w % p.q_tiles;
-    if (CAUSAL) qt = p.q_tiles - 1 - qt;
-    const int n = p.n;
-    const int q0 = qt * BM + wave * 32 * kNB2;  // first row of block 0; block b starts at q0 + 32 b
-
-    const int b = slab / p.heads, h = slab % p.heads;
-    const __bf16* qg = (const __bf16*)p.q + b * p.q_batch_stride + h * p.q_head_stride;
-    const __bf16* kg = (const __bf16*)p.k + b * p.kv_batch_stride + h * p.kv_head_stride;
-    const __bf16* vg = (const __bf16*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
-    const int64_t o_slab_off = b * p.o_batch_stride + h * p.o_head_stride;
-
-    int kv_end = n;
-    if (CAUSAL) kv_end = min(n, qt * BM + BM);
-    const int nst = (kv_end + kKvBlk - 1) / kKvBlk;  // 64-key stages
-    const int nsub = (kv_end + 31) / 32;             // 32-key sub-tiles
-
-    auto k_slot = [&](int j) { return k_ring + (j & (KR - 1)) * T; };
-    auto v_slot = [&](int j) { return v_ring + (j & (VR - 1)) * T; };
-
-    TileDma<D, NWAVES> dma;
-    dma.init(kg, vg, n, p.kv_row_stride, wave, lane);
-    dma.issue_k(0u, k_slot(0), wave);
-    // every tile the first barrier group needs is requested before anything is waited for: one memory round trip, not two
-#pragma unroll
-    for (int g = 1; g <= G; ++g)
-        if (g < nst) dma.issue_k((unsigned)g * dma.stage_step, k_slot(g), wave);
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-        if (g < nst) dma.issue_v((unsigned)g * dma.stage_step, v_slot(g), wave);
-
-    bf16x8 qf[kNB2][KS];
-#pragma unroll
-    for (int blk = 0; blk < kNB2; ++blk) {
-        const __bf16* qr = qg + (int64_t)min(q0 + 32 * blk + lq, n - 1) * p.q_row_stride + hi * 8;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[blk][ks] = *(const bf16x8*)(qr + ks * 16);
-    }
-    const bf16x8 ones_a = rowsum_a_operand(lane);
-
-    f32x16 o[kNB2][DB], s0[kNB2], s1[kNB2];
-    BlockState st[kNB2];
-    float off[kNB2], lm[kNB2];
-#pragma unroll
-    for (int blk = 0; blk < kNB2; ++blk) {
-        st[blk].m = -INFINITY;
-        lm[blk] = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) st[blk].lacc[r] = 0.0f;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[blk][db][r] = 0.0f;
-    }
-
-    const int k_row_off = lq * C::kRowBytes;
-    const int k_g = hi ^ k_swizzle<D>(lq);
-    const int li = lane & 15;
-    const int v_lane_off = (hi * (D / 16) + ((lane >> 4) & 1)) * 128 + (li >> 2) * 32 + (li & 3) * 8;
-    const float c = p.scale_log2e;
-
-    // sub-tile t needs a mask for the block whose first row is qb?
-    auto needs_mask = [&](int t, int qb) { return (t * 32 + 32 > n) || (CAUSAL && (t * 32 + 31 > qb)); };
-
-    // Top of stage j, j a multiple of G: K(j+1 .. j+G), V(j .. j+G-1) visible; K(j+G+1 .. j+2G), V(j+G .. j+2G-1) enqueued into the
-    // ring slots nobody reads any more (K tiles are only read into kf one step ahead of their use, and every LDS read of
-    // a wave has returned before it arrives at the barrier).
-    auto sync_top = [&](int j) {
-        if (!(ABL & 8)) {  // ABL & 8: timing-only ablation without the wait + barrier
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-#pragma unroll
-        for (int g = 1; g <= G; ++g)
-            if (__builtin_expect(j + G + g < nst, 1)) dma.issue_k((unsigned)(j + G + g) * dma.stage_step, k_slot(j + G + g), wave);
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-            if (__builtin_expect(j + G + g < nst, 1)) dma.issue_v((unsigned)(j + G + g) * dma.stage_step, v_slot(j + G + g), wave);
-    };
-    bf16x8 kf[KS];
-    auto load_kf = [&](int t) {
-        const char* k_lds = k_slot(t >> 1);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) kf[ks] = load_k_frag<D>(k_lds, k_row_off, k_g, t & 1, ks);
-    };
-    // scores of sub-tile t for all blocks from the fragments in kf, phase-structured (prologue and tail)
-    auto qk_regs = [&](int t, f32x16 (&s)[kNB2], bool first = false) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int blk = 0; blk < kNB2; ++blk) {
-                if (ks == 0) x2_mfma_s_first(s[blk], kf[ks], qf[blk][ks]);
-                else x2_mfma_s(s[blk], kf[ks], qf[blk][ks]);
-            }
-        x2_drain_scores(s);  // cold path: let the scores retire before the VALU reads them
-        float mx[kNB2];
-#pragma unroll
-        for (int blk = 0; blk < kNB2; ++blk) {
-            if (needs_mask(t, q0 + 32 * blk)) mask16(s[blk], t * 32, q0 + 32 * blk + lq, n, hi, CAUSAL);
-            mx[blk] = rowmax16(s[blk]);
-        }
-        if (first) {  // nothing accumulated yet: set the references, leave the (zero) accumulators alone
-#pragma unroll
-            for (int blk = 0; blk < kNB2; ++blk) {
-                const float mc = mx[blk] * c;
-                st[blk].m = fmaf(-fabsf(mc), 0x1p-23f, mc);
-                off[blk] = st[blk].m + kBias;
-            }
-        } else if (!OPT) {
-            x2_rescale<DB>(mx, c, st, o, off);
-        }
-    };
-    // exp, pack, P.V and row sums of sub-tile t for all blocks, phase-structured (tail)
-    auto finish_sub = [&](int t, f32x16 (&s)[kNB2]) {
-        const char* v_lds = v_slot(t >> 1);
-        bf16x8 vf[2 * DB];
-#pragma unroll
-        for (int v = 0; v < 2 * DB; ++v) vf[v] = load_v_frag<D>(v_lds, v_lane_off, t & 1, v);
-#pragma unroll
-        for (int blk = 0; blk < kNB2; ++blk) {
-            bf16x8 pf[2];
-            exp_range(s[blk], pf, c, off[blk], 0, 8, !OPT);
-            exp_range(s[blk], pf, c, off[blk], 8, 16, !OPT);
-            // a VALU result needs two wait states before an MFMA may read it; hipcc counts them for its own MFMAs, not
-            // for an asm one (the pipelined loop packs P at least one whole slot ahead of its first use)
-            asm volatile("s_nop 1" : "+v"(pf[0]), "+v"(pf[1]));
-#pragma unroll
-            for (int v = 0; v < 2 * DB; ++v) x2_mfma_o(o[blk][v % DB], vf[v], pf[v / DB]);
-            x2_mfma_l(st[blk].lacc, ones_a, pf[0]);
-            asm volatile("s_nop 7");  // dependent row-sum MFMAs back to back: the hazard is ours
-            x2_mfma_l(st[blk].lacc, ones_a, pf[1]);
-        }
-    };
-
-    // ---------------- prologue: K(0) landed -> scores of sub-tile 0, fragments of sub-tile 1 ----------------
-    wait_lds_dma();
-    __syncthreads();
-    load_kf(0);
-    qk_regs(0, s0, true);
-    load_kf(1);
-
-    // ---------------- fast loop: groups of G whole stages whose sub-tiles 2j .. 2j+2 are in range and mask-free ----------------
-    int jf = 0;
-    while ((2 * jf + 3) * 32 <= kv_end && !needs_mask(2 * jf + 2, q0) && !needs_mask(0, q0)) ++jf;
-    // The last stage may run in the fast loop too when its own two sub-tiles are whole and mask-free: its second step then
-    // computes scores of a sub-tile that does not exist (from whatever the ring slot holds) and nobody consumes them --
-    // the rescale test of that step is ignored.  Without this the final 128 keys of every slab took the slow tail path.
-    if (jf == nst - 1 && (2 * jf + 2) * 32 <= kv_end && !needs_mask(2 * jf + 1, q0) && !needs_mask(0, q0)) jf = nst;
-    jf -= jf % G;
-    for (int j = 0; j < jf; j += G) {
-        sync_top(j);
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const char* v_lds = v_slot(j + g);
-            const char* k_nxt = k_slot(j + g + 1);
-            bool need = x2_step<D, 0, ABL, OPT>(v_lds, k_nxt, 0, k_row_off, k_g, v_lane_off, ones_a, qf, s0, s1, o, st, c, off, kf, lm);
-            if (!OPT && __builtin_expect(__any(need), 0)) {
-                float mx[kNB2];
-#pragma unroll
-                for (int blk = 0; blk < kNB2; ++blk) mx[blk] = xhalf_max(lm[blk]);
-                x2_rescale<DB>(mx, c, st, o, off);
-            }
-            need = x2_step<D, 1, ABL, OPT>(v_lds, k_nxt, 1, k_row_off, k_g, v_lane_off, ones_a, qf, s1, s0, o, st, c, off, kf, lm);
-            if (!OPT && __builtin_expect(__any(need) && 2 * (j + g) + 2 < nsub, 0)) {
-                float mx[kNB2];
-#pragma unroll
-                for (int blk = 0; blk < kNB2; ++blk) mx[blk] = xhalf_max(lm[blk]);
-                x2_rescale<DB>(mx, c, st, o, off);
-            }
-        }
-    }
-
-    // ---------------- tail: remaining stages, phase-structured, masks applied where needed ----------------
-    // Invariant at the top of stage j: scores of sub-tile 2j in s0 with the rescale decision taken, kf = fragments of sub-tile 2j+1.
-    const int nsub_w = CAUSAL ? min(nsub, (q0 + 32 * (kNB2 - 1) + 31) / 32 + 1) : nsub;
-    for (int j = jf; j < nst; ++j) {
-        if (j % G == 0) sync_top(j);
-        const int t0 = 2 * j, t1 = 2 * j + 1;
-        if (t0 < nsub_w) {
-            finish_sub(t0, s0);
-            if (t1 < nsub_w) {
-                qk_regs(t1, s1);
-                load_kf(t1 + 1);
-                finish_sub(t1, s1);
-                if (t1 + 1 < nsub_w) {
-                    qk_regs(t1 + 1, s0);
-                    load_kf(t1 + 2);
-                }
-            }
-        }
-    }
-
-    // ---------------- store; verify (optimistic mix) ----------------
-    // The optimistic tile stores its result BEFORE the workgroup votes on it: a failed tile is simply overwritten by the redo,
-    // and nothing of the first attempt is live across the vote (with the store behind the vote hipcc carried the
-    // accumulators of the common path through copies and 12 MB of scratch per launch).
-    x2_drain_accumulators<DB>(o, st);  // tied to the accumulators: a bare drain has no data dependence and may be scheduled past
-    bool bad = false;
-    if (OPT) {
-        // every P was exponentiated against the first sub-tile's maximum: the tile stands iff no term left the safe range,
-        // which the row sums prove (a term > 2^100, +inf or NaN makes its row sum fail this test)
-#pragma unroll
-        for (int blk = 0; blk < kNB2; ++blk) bad = bad || !(st[blk].lacc[0] < kOptLimit);
-    }
-#pragma unroll
-    for (int blk = 0; blk < kNB2; ++blk) {
-        // (distinct text per mix: identical store code of the two inlined tiles gets tail-merged by hipcc, which then shuffles
-        // the accumulators of the common path through copies and 12 MB of scratch per launch)
-        if constexpr (OPT) asm volatile("; store, optimistic mix");
-        else asm volatile("; store, rescaled mix");
-        const float lt = st[blk].lacc[0];
-        const float inv = 1.0f / lt;
-        const int qi = q0 + 32 * blk + lq;
-        if (qi < n) {
-            if constexpr (OPT) asm volatile("; rows, optimistic mix");
-            else asm volatile("; rows, rescaled mix");
-            const int64_t o_off = o_slab_off + (int64_t)qi * p.o_row_stride + 4 * hi;
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (OUT_F32) {
-                        f32x4 pk;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) pk[e] = o[blk][db][4 * g + e] * inv;
-                        *(f32x4*)((float*)p.o + o_off + db * 32 + 8 * g) = pk;
-                    } else if ((g & 1) == 0) {
-                        // 16-byte stores: the two lanes of a row (hi = 0 / 1) hold alternate 4-column groups; one
-                        // v_permlane32_swap per dword hands lane hi = 0 both halves of column group g and lane hi = 1 both
-                        // halves of group g + 1 (the epilogue is store-issue bound: half as many, twice as wide)
-                        bf16x4 pe, po;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            pe[e] = (__bf16)(o[blk][db][4 * g + e] * inv);
-                            po[e] = (__bf16)(o[blk][db][4 * (g + 1) + e] * inv);
-                        }
-                        const u32x2 ue = __builtin_bit_cast(u32x2, pe), uo = __builtin_bit_cast(u32x2, po);
-                        const auto r0 = __builtin_amdgcn_permlane32_swap(ue[0], uo[0], false, false);
-                        const auto r1 = __builtin_amdgcn_permlane32_swap(ue[1], uo[1], false, false);
-                        // lanes 0..31: r[0] = own group g, r[1] = partner's group g;  lanes 32..63: r[0] = partner's group g+1, r[1] = own
-                        u32x4 w;
-                        w[0] = r0[0];
-                        w[1] = r1[0];
-                        w[2] = r0[1];
-                        w[3] = r1[1];
-                        // hi = 0: columns 8g .. 8g+7;  hi = 1: columns 8(g+1) .. 8(g+1)+7  (o_off already carries + 4 hi)
-                        *(u32x4*)((__bf16*)p.o + o_off - 4 * hi + db * 32 + 8 * (g + hi)) = w;
-                    }
-                }
-            if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (st[blk].m + kBias + __builtin_amdgcn_logf(lt)) * kLn2;
-        }
-    }
-    if (OPT) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // stores and DMA of this attempt done before a redo starts
-        if (__syncthreads_or(bad ? 1 : 0)) return false;             // workgroup-wide: the redo shares tiles and barriers
-    }
-    return true;
-}
-
-// OPTIMISTIC: try the fixed-reference mix first, redo the tile with the rescaling mix if its verification fails
-template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL = 0, bool OPTIMISTIC = true>
-__global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x2_kernel(FwdParams p)
-{
-    using C = Bf16Cfg<D, NWAVES>;
-    __shared__ __attribute__((aligned(1024))) char smem[4 * G * C::kTileBytes];
-    if (OPTIMISTIC && ABL == 0) {
-        if (x2_tile<D, NWAVES, CAUSAL, OUT_F32, G, 0, true>(p, smem)) return;
-    }
-    if (ABL != 0 && OPTIMISTIC) {  // timing-only ablations of the optimistic mix (results are garbage)
-        (void)x2_tile<D, NWAVES, CAUSAL, OUT_F32, G, ABL, true>(p, smem);
-        return;
-    }
-    (void)x2_tile<D, NWAVES, CAUSAL, OUT_F32, G, ABL, false>(p, smem);
-}
-
-template <int D, int G, bool OPTIMISTIC = true>
-static hipError_t launch_x2(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
-{
-    FwdParams p = p0;
-    constexpr int NWAVES = 4, BM = NWAVES * 32 * kNB2;
-    p.q_tiles = (p.n + BM - 1) / BM;
-    const int64_t total = (int64_t)p.bh * p.q_tiles;
-    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
-    dim3 grid((unsigned)total), block(NWAVES * kWave);
-    if (causal) {
-        if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, NWAVES, true, true, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
-        else
-            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, NWAVES, true, false, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
-    } else {
-        if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, NWAVES, false, true, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
-        else
-            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, NWAVES, false, false, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
-    }
-    return hipGetLastError();
-}
-
 // d in {32, 64, 128}.  mode: 0 = product configuration (optimistic mix first, barrier every 2 stages), 1 = barrier every stage,
-// 3 = lazily rescaled mix only, 12 = timing-only ablation without the VALU units (D = 128)
+// 3 = lazily rescaled mix only, 12 = timing-only ablation without the VALU units (D = 128; ablation library only)
 hipError_t launch_bf16_x2(const FwdParams& p, int d, int causal, int out_f32, int mode, hipStream_t stream)
 {
     if (d != 32 && d != 64 && d != 128) return hipErrorInvalidValue;
-    if (!(((int64_t)(p.n - 1) * p.kv_row_stride + d) * 2 < (int64_t)0xffffffffLL)) return hipErrorInvalidValue;
+    if (!xn_addressable(p, d)) return hipErrorInvalidValue;
     if (d == 32) {
         if (mode == 1) return launch_x2<32, 1>(p, causal, out_f32, stream);
         if (mode == 3) return launch_x2<32, 2, false>(p, causal, out_f32, stream);
@@ -704,9 +25,9 @@ hipError_t launch_bf16_x2(const FwdParams& p, int d, int causal, int out_f32, in
     if (mode == 3) return launch_x2<128, 2, false>(p, causal, out_f32, stream);
 #if FA_ABLATION
     if (mode == 12) {
-        FwdParams q = p;
-        q.q_tiles = (p.n + 255) / 256;
-        dim3 grid((unsigned)(q.bh * q.q_tiles)), block(256);
+        FwdParams q;
+        dim3 grid, block;
+        if (!xn_grid<2>(p, q, grid, block)) return hipErrorInvalidValue;
         hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<128, 4, false, false, 2, 2>), grid, block, 0, stream, q);
         return hipGetLastError();
     }

@@ -1,7 +1,7 @@
-// fa_fwd_bf16_x4.hip -- the product tilings of the x4 kernel (fa_bf16_x4_kernel.h): D = 64, 128 query rows per wave, one wave
-// per SIMD.  Replaces the hot loop of flash_tiled_coarse{,_causal} (/root/reference/src/flashattention.cu:214-354, :434,480-484).
+// fa_fwd_bf16_x4.hip -- the product tilings of the NB = 4 form of the one-wave-per-SIMD kernel (fa_bf16_xn_kernel.h): D = 64, 128 query
+// rows per wave.  Replaces the hot loop of flash_tiled_coarse{,_causal} (/root/reference/src/flashattention.cu:214-354, :434,480-484).
 // Non-causal instantiations here, causal ones in fa_fwd_bf16_x4_causal.hip, ablations in fa_fwd_bf16_x4_ablation.hip.
-#include "fa_bf16_x4_kernel.h"
+#include "fa_bf16_xn_kernel.h"
 
 namespace fa {
 

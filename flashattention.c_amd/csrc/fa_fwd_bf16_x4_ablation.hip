@@ -1,7 +1,7 @@
-// fa_fwd_bf16_x4_ablation.hip -- timing-only ablation instantiations of the x4 kernel (fa_bf16_x4_kernel.h): each switches one
+// fa_fwd_bf16_x4_ablation.hip -- timing-only ablation instantiations of the x4 kernel (fa_bf16_xn_kernel.h): each switches one
 // ingredient of the main loop off (or doubles it) to price it; results are garbage by design.  Used by `fa_driver --variant 33..45`
 // and quoted in DESIGN.md section 4.
-#include "fa_bf16_x4_kernel.h"
+#include "fa_bf16_xn_kernel.h"
 
 namespace fa {
 

@@ -1,8 +1,8 @@
-// fa_fwd_bf16_x4_p16.hip -- the fp16-P ("accurate") instantiations of the x4 kernel (fa_bf16_x4_kernel.h), D = 64: bf16 Q, K; P and V
+// fa_fwd_bf16_x4_p16.hip -- the fp16-P ("accurate") instantiations of the x4 kernel (fa_bf16_xn_kernel.h), D = 64: bf16 Q, K; P and V
 // in fp16 (v_mfma_f32_32x32x16_f16 for the second contraction), 11 significant bits of P instead of 8 -- the bf16 path that
 // meets the 1e-3 bar of the reference comparison (bench_flashattention.py:36-40,74) at scale 1.  Non-causal here, causal in
 // fa_fwd_bf16_x4_p16_causal.hip (parallel compilation).
-#include "fa_bf16_x4_kernel.h"
+#include "fa_bf16_xn_kernel.h"
 
 namespace fa {
 

@@ -1,5 +1,5 @@
 // fa_fwd_bf16_x4_p16_causal.hip -- the causal fp16-P instantiations of the x4 kernel; see fa_fwd_bf16_x4_p16.hip.
-#include "fa_bf16_x4_kernel.h"
+#include "fa_bf16_xn_kernel.h"
 
 namespace fa {
 

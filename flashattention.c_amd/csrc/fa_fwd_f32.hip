@@ -210,7 +210,9 @@ __global__ __launch_bounds__(NWAVES* kWave, MINWAVES) void fa_fwd_f32_kernel(Fwd
     }
 }
 
-template <int D, int NWAVES, int MINWAVES>
+// MINWAVES_C: the occupancy hint of the causal instantiation (the mask code needs a few registers more: at 4 waves per SIMD, i.e.
+// 128 registers, the D = 64 causal kernel spilled 56 bytes per lane)
+template <int D, int NWAVES, int MINWAVES, int MINWAVES_C = MINWAVES>
 static hipError_t launch_cfg_f32(const FwdParams& p0, int causal, hipStream_t stream)
 {
     FwdParams p = p0;
@@ -220,7 +222,7 @@ static hipError_t launch_cfg_f32(const FwdParams& p0, int causal, hipStream_t st
     if (total > 0x7fffffffLL) return hipErrorInvalidValue;
     dim3 grid((unsigned)total), block(NWAVES * kWave);
     if (causal)
-        hipLaunchKernelGGL((fa_fwd_f32_kernel<D, NWAVES, true, MINWAVES>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((fa_fwd_f32_kernel<D, NWAVES, true, MINWAVES_C>), grid, block, 0, stream, p);
     else
         hipLaunchKernelGGL((fa_fwd_f32_kernel<D, NWAVES, false, MINWAVES>), grid, block, 0, stream, p);
     return hipGetLastError();
@@ -231,7 +233,7 @@ hipError_t launch_fwd_f32(const FwdParams& p, int d, int causal, int variant, hi
     (void)variant;
     switch (d) {
         case 32: return launch_cfg_f32<32, 4, 4>(p, causal, stream);
-        case 64: return launch_cfg_f32<64, 4, 4>(p, causal, stream);
+        case 64: return launch_cfg_f32<64, 4, 4, 3>(p, causal, stream);
         case 128: return launch_cfg_f32<128, 4, 2>(p, causal, stream);
         default: return hipErrorInvalidValue;
     }

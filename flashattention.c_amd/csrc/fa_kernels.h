@@ -21,8 +21,13 @@ const char* bf16_kernel_name(int64_t bh, int64_t n, int d, int causal);  // the 
 bool bf16_pipelined_supported(const FwdParams& p, int d);  // d in {32, 64} and the slab addressable with 32-bit byte offsets
 hipError_t launch_bf16_x4(const FwdParams& p, int causal, int out_f32, int mode, hipStream_t stream);  // D = 64, 128 rows/wave
 hipError_t launch_bf16_x2(const FwdParams& p, int d, int causal, int out_f32, int mode, hipStream_t stream);  // D = 64 / 128, 64 rows/wave, one wave per SIMD
-// fp16-P ("accurate") kernels: D = 64; p.v = the fp16 copy of V made by launch_cvt_v_f16
+// fp16-P ("accurate") kernels; p.v = the fp16 copy of V made by launch_cvt_v_f16.  launch_bf16_p16 picks the tiling (NB = 4 / NB = 2)
+hipError_t launch_bf16_p16(const FwdParams& p, int d, int causal, int out_f32, hipStream_t stream);
+bool bf16_p16_supported(const FwdParams& p, int d);   // d in {32, 64, 128} and the slab addressable with 32-bit byte offsets
 hipError_t launch_bf16_x4_p16(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
+hipError_t launch_bf16_x2_p16_d32(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
+hipError_t launch_bf16_x2_p16_d64(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
+hipError_t launch_bf16_x2_p16_d128(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
 hipError_t launch_cvt_v_f16(const void* src, void* dst, int64_t count, uint32_t* flag, uint32_t serial, hipStream_t stream);
 hipError_t launch_bf16_pp2(const FwdParams& p, int causal, int out_f32, int variant, hipStream_t stream);
 

@@ -139,6 +139,10 @@ __device__ __forceinline__ void mfma_from(f32x16& d, const bf16x8& a, const bf16
 {
     asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
 }
+__device__ __forceinline__ void mfma_from_zero(f32x16& d, const bf16x8& a, const bf16x8& b)
+{
+    asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+}
 __device__ __forceinline__ void mfma_acc(f32x16& d, const bf16x8& a, const bf16x8& b)
 {
     asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
@@ -297,15 +301,22 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     // came out inside the range the optimistic pass can prove.
     auto run_tile = [&](auto opt_c) -> bool {
         constexpr bool OPT = decltype(opt_c)::value;
+        // MREG: -m_ref of a row lives in a 16-register tuple, the accumulator the first product of every tile starts from (the
+        // subtraction is free).  The eight-wave D = 128 tiling has no 16 registers to spare (it spilled 16-24 bytes per lane): there
+        // the first product starts from zero and m_ref is subtracted by the VALU -- 16 instructions per tile in a loop that is
+        // bound by its 48 matrix instructions per tile.
+        constexpr bool MREG = !(D == 128 && NWAVES == 8);
         f32x16 o[QB][DB];
-        f32x16 minit[QB];   // -m_ref of this lane's row in all 16 registers: the accumulator the first product starts from
+        f32x16 minit[MREG ? QB : 1];   // -m_ref of this lane's row in all 16 registers
         float m[QB], l[QB];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             m[qb] = 0.0f;
             l[qb] = 0.0f;
+            if constexpr (MREG) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) minit[qb][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) minit[qb][r] = 0.0f;
+            }
 #pragma unroll
             for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -320,16 +331,24 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                 if constexpr (IN_BF16) {
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) {
-                        if (ks == 0) mfma_from(s[qb], kfh, ql[qb][ks], minit[qb]);
-                        else mfma_acc(s[qb], kfh, ql[qb][ks]);
+                        if (ks == 0) {
+                            if constexpr (MREG) mfma_from(s[qb], kfh, ql[qb][ks], minit[qb]);
+                            else mfma_from_zero(s[qb], kfh, ql[qb][ks]);
+                        } else {
+                            mfma_acc(s[qb], kfh, ql[qb][ks]);
+                        }
                         mfma_acc(s[qb], kfh, qh[qb][ks]);
                     }
                 } else {
                     const bf16x8 kfl = *(const bf16x8*)(kh_lds + C::kImageBytes + k_off[ks]);
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) {
-                        if (ks == 0) mfma_from(s[qb], kfl, qh[qb][ks], minit[qb]);
-                        else mfma_acc(s[qb], kfl, qh[qb][ks]);
+                        if (ks == 0) {
+                            if constexpr (MREG) mfma_from(s[qb], kfl, qh[qb][ks], minit[qb]);
+                            else mfma_from_zero(s[qb], kfl, qh[qb][ks]);
+                        } else {
+                            mfma_acc(s[qb], kfl, qh[qb][ks]);
+                        }
                         mfma_acc(s[qb], kfh, ql[qb][ks]);
                         mfma_acc(s[qb], kfh, qh[qb][ks]);
                     }
@@ -338,6 +357,12 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
             // let the last product retire (19 wait states cover its 8 passes), tied to the registers the chain writes
             if constexpr (QB == 1) asm volatile("s_nop 15\n\ts_nop 2" : "+v"(s[0]));
             else asm volatile("s_nop 15\n\ts_nop 2" : "+v"(s[0]), "+v"(s[QB - 1]));
+            if constexpr (!MREG) {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[qb][r] -= m[qb];
+            }
         };
         auto mask = [&](f32x16& sq, int kv0, int qi) {
             asm volatile("; mask" ::: "memory");  // not speculatable: keeps the caller's wave-uniform `if` a real branch
@@ -367,8 +392,10 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
             for (int qb = 0; qb < QB; ++qb) {
                 if (need_mask) mask(s[qb], 0, q0 + qb * 32 + lq);
                 m[qb] = row_max(s[qb]);
+                if constexpr (MREG) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) minit[qb][r] = -m[qb];
+                    for (int r = 0; r < 16; ++r) minit[qb][r] = -m[qb];
+                }
             }
         }
 
@@ -403,7 +430,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 s[qb][r] -= delta;
-                                minit[qb][r] = -m[qb];
+                                if constexpr (MREG) minit[qb][r] = -m[qb];
                             }
 #pragma unroll
                             for (int db = 0; db < DB; ++db)

@@ -1,0 +1,84 @@
+"""CPU: properties of the gfx950 code objects inside the in-tree library (no GPU needed -- hipcc cross-compiles here).
+
+What DESIGN.md claims about the binaries is checked on the binaries: no kernel spills to scratch, the kernels whose matrix
+instructions are inline asm (invisible to hipcc's hazard padding) drain the matrix pipe before VALU code reads an accumulator,
+and the timing-only ablation instantiations are not part of the product library."""
+import os
+import re
+
+import pytest
+
+from tests import codeobj
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "flashattention.c_amd", "libflashattn_amd.so")
+ABL_LIB = os.path.join(ROOT, "flashattention.c_amd", "libflashattn_amd_ablation.so")
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    assert os.path.exists(LIB), "build the library first (python flashattention.c_amd/build.py)"
+    return codeobj.kernels_of(LIB, str(tmp_path_factory.mktemp("co")))
+
+
+def test_no_kernel_of_the_product_library_uses_scratch(kernels):
+    """private_segment_fixed_size == 0 for every kernel (FA_KERNEL_AUTO can pick any family): a spill inside an attention loop is
+    an HBM round trip per step, and register pressure regressions show up here before they show up in a benchmark."""
+    assert len(kernels) > 100
+    spilling = [f"{k.scratch} B: {k.name}" for k in kernels.values() if k.scratch != 0]
+    assert not spilling, "\n".join(spilling)
+
+
+def test_every_kernel_family_the_dispatch_names_is_present(kernels):
+    names = "\n".join(k.name for k in kernels.values())
+    for fam in ("fa_fwd_bf16_x4_kernel", "fa_fwd_bf16_x4_p16_kernel", "fa_fwd_bf16_x2_kernel", "fa_fwd_bf16_pp3_kernel", "fa_fwd_bf16_w4_kernel",
+                "fa_fwd_bf16_kernel", "fa_fwd_f32_split_kernel", "fa_fwd_f32_kernel", "fa_naive_f32_kernel", "fa_cvt_bf16_to_f16_kernel"):
+        assert fam + "<" in names or fam + "(" in names, fam
+
+
+def test_timing_only_ablations_are_not_in_the_product_library(kernels):
+    for k in kernels.values():
+        assert "pp2" not in k.name, k.name
+        m = re.search(r"fa_fwd_bf16_x4_kernel<(.*?)>\(", k.name)
+        if m:   # <NWAVES, CAUSAL, OUT_F32, G, ABL, OPTIMISTIC>
+            assert m.group(1).split(", ")[4] == "0", k.name
+        m = re.search(r"fa_fwd_bf16_x2_kernel<(.*?)>\(", k.name)
+        if m:   # <D, NWAVES, CAUSAL, OUT_F32, G, ABL, OPTIMISTIC>
+            assert m.group(1).split(", ")[5] == "0", k.name
+        m = re.search(r"fa_fwd_bf16_pp3_kernel<(.*?)>\(", k.name)
+        if m:   # <D, NWAVES, CAUSAL, OUT_F32, PROF, G, OPTIMISTIC>: the in-kernel phase timers overwrite the lse buffer
+            assert m.group(1).split(", ")[4] == "false", k.name
+    if os.path.exists(ABL_LIB):   # ... and they do exist in the separate ablation library
+        abl = codeobj.kernels_of(ABL_LIB)
+        assert any("pp2" in k.name for k in abl.values())
+        assert any(re.search(r"fa_fwd_bf16_x4_kernel<4, false, false, 2, [1-9]", k.name) for k in abl.values())
+
+
+def test_asm_mfma_kernels_drain_the_matrix_pipe_before_reading_accumulators(kernels):
+    """The x4 / x2 kernels issue their MFMAs from inline asm into AGPR accumulators; hipcc pads no hazard for them.  Every
+    v_accvgpr_read (epilogue, rescale branch) must sit at least 18 wait states behind the closest preceding v_mfma in program order
+    (a 32x32x16 MFMA has 16 passes); the register-tied drains provide 64.  A scheduler that hoists a read above its drain fails here."""
+    dis_cache = {}
+    checked = 0
+    for k in kernels.values():
+        if not re.search(r"fa_fwd_bf16_x[24](_p16)?_kernel<", k.name):
+            continue
+        dis = dis_cache.setdefault(k.code_object, codeobj.disassemble(k.code_object))
+        i = dis.index("<" + k.mangled + ">:")
+        body = dis[i:dis.find("\n\n", i)].splitlines()[1:]
+        wait, seen_mfma, worst, reads = 0, False, None, 0
+        for line in body:
+            ins = line.split("//")[0].split()
+            if not ins:
+                continue
+            op = ins[0]
+            if op.startswith("v_mfma"):
+                wait, seen_mfma = 0, True
+                continue
+            if op.startswith("v_accvgpr_read") and seen_mfma:
+                reads += 1
+                worst = wait if worst is None else min(worst, wait)
+            wait += int(ins[1]) + 1 if op == "s_nop" else 1
+        assert reads > 0 and worst is not None and worst >= 18, f"{k.name}: {worst} wait states between an MFMA and an accumulator read"
+        checked += 1
+    assert checked >= 40

@@ -550,10 +550,12 @@ def test_full_size_configs(name, bh, n, d, dtype, kernel, tol):
 # ---------------------------------------------------------------------------------------------------------------
 # the fp16-P kernel (FA_KERNEL_P16; FA_KERNEL_AUTO for bf16 tensors with an fp32 output at head dim 64)
 # ---------------------------------------------------------------------------------------------------------------
+# d = 64: (17, 4096) is more than one round of 256-row workgroups -> the NB = 4 tiling; everything else here takes NB = 2
 @pytest.mark.parametrize("causal", [False, True])
-@pytest.mark.parametrize("bh,n", [(3, 700), (2, 1536), (1, 1), (5, 31), (2, 513), (1, 4096)])
-def test_p16_kernel_vs_oracle(bh, n, causal):
-    q, k, v = (orc.round_to_bf16(randn(s, bh, n, 64)) for s in (51, 52, 53))
+@pytest.mark.parametrize("bh,n,d", [(3, 700, 64), (2, 1536, 64), (1, 1, 64), (5, 31, 64), (2, 513, 64), (1, 4096, 64), (17, 4096, 64),
+                                    (3, 700, 32), (2, 1537, 32), (3, 700, 128), (2, 1537, 128), (5, 31, 128), (1, 1, 32)])
+def test_p16_kernel_vs_oracle(bh, n, d, causal):
+    q, k, v = (orc.round_to_bf16(randn(s, bh, n, d)) for s in (51, 52, 53))
     qd, kd, vd = to_dev(q, k, v, dtype=torch.bfloat16)
     for scale in (1.0, 0.125):
         ref, lse_ref = orc.attention_f64(q, k, v, causal=causal, scale=scale, return_lse=True)
@@ -565,13 +567,15 @@ def test_p16_kernel_vs_oracle(bh, n, causal):
         check(ob, ref, bf16_tol(scale, False), f"p16 bf16 out scale {scale}")
 
 
+@pytest.mark.parametrize("d,bh", [(64, 2), (64, 17), (32, 2), (128, 2)])   # bh = 17 at n = 4096: the NB = 4 tiling
 @pytest.mark.parametrize("causal", [False, True])
-def test_p16_reference_moves_inside_the_pipelined_loop(causal):
+def test_p16_reference_moves_inside_the_pipelined_loop(causal, d, bh):
     """fp16 has 30 binades: the exponent reference of a wave has to follow its row maxima (window 2^-5 .. 2^14 around the row
     maximum).  Keys that outgrow everything seen before by 2^20 .. 2^230, in the middle of the sequence, for single rows, a whole
     32-row block and neighbouring blocks; then a row whose scores shrink again.  The LSE exposes a saturated or flushed P."""
-    bh, n, d = 2, 1536, 64
+    n = 1536 if bh == 2 else 4096
     q, k, v = (randn(s, bh, n, d) for s in (41, 42, 43))
+    q *= np.sqrt(64.0 / d)                         # |q| ~ 8 at every head dim (the gains below are tuned to that)
     unit = lambda x: x / np.linalg.norm(x, axis=-1, keepdims=True)
     for r, key, gain in ((3, 700, 14.0), (40, 701, 16.0), (200, 1100, 12.0), (1300, 900, 15.0), (1301, 650, 18.0), (1535, 333, 13.0),
                          (5, 100, 3.0), (6, 300, 4.5), (7, 600, 6.0), (600, 64, 2.5), (601, 96, 3.5)):

@@ -32,9 +32,11 @@ def test_library_exports_every_declared_symbol():
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 128, 0, 2, 300) == b"fa_fwd_bf16_w4_kernel"      # too few workgroups
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 128, 1, 2, 300) == b"fa_fwd_bf16_kernel"
     assert L.fa_kernel_name(_cabi.FA_DTYPE_F32, 48, 0) is None
-    # bf16 tensors with fp32 output: the accurate P -- fp16 at head dim 64, hi + lo bf16 terms elsewhere
+    # bf16 tensors with fp32 output: P in fp16 -- NB = 4 tiling where the bf16-P dispatch takes it too, NB = 2 elsewhere
     assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0) == b"fa_fwd_bf16_x4_p16_kernel"
-    assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 128, 0) == b"fa_fwd_f32_split_kernel"
+    assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 1) == b"fa_fwd_bf16_x2_p16_kernel"
+    assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 128, 0) == b"fa_fwd_bf16_x2_p16_kernel"
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 32, 0, 4, 300) == b"fa_fwd_bf16_x2_p16_kernel"
 
 
 def test_kernel_ids_match_the_header_and_the_python_names():
@@ -95,9 +97,9 @@ def test_cabi_rejects_bad_arguments_without_touching_a_device():
     assert L.fa_forward(p, k, v, o, 1, 32, 48, 1.0, 0, 0, None) == 2
     assert b"48" in L.fa_last_error()
     assert L.fa_forward_ex(p, k, v, o, None, 1, 32, 64, 1.0, 0, 0, 9, None) == 2
-    # the fp16-P kernel exists for bf16 tensors at head dim 64 only
+    # the fp16-P kernels exist for bf16 tensors only (head dims 32, 64, 128)
     assert L.fa_forward_ex(p, k, v, o, None, 1, 32, 64, 1.0, 0, _cabi.FA_DTYPE_F32, _cabi.FA_KERNEL_P16, None) == 2
-    assert L.fa_forward_ex(p, k, v, o, None, 1, 32, 32, 1.0, 0, _cabi.FA_DTYPE_BF16, _cabi.FA_KERNEL_P16, None) == 2
+    assert L.fa_forward_ex(p, k, v, o, None, 1, 32, 48, 1.0, 0, _cabi.FA_DTYPE_BF16, _cabi.FA_KERNEL_P16, None) == 2
     assert L.fa_forward_packed_qkv(p, o, 1, 8, 96, 5, None) == 1      # C % NH != 0
     assert L.fa_forward_packed_qkv(p, o, 1, 8, 96, 2, None) == 2      # hs = 48 not instantiated
     ms = ctypes.c_float()
