@@ -215,6 +215,9 @@ def main():
     ap.add_argument("--prewarm-ms", type=float, default=200.0,
                     help="untimed device warm-up before the W warm-up steps: an idle MI355X needs ~100 ms of load before its "
                          "clocks settle (the first ~100 launches of a 0.3 ms kernel run ~10 %% slow)")
+    ap.add_argument("--accurate", action="store_true",
+                    help="bf16 workloads: ask for the fp32 accumulator as output -- FA_KERNEL_AUTO then carries P in fp16 (the accurate path); "
+                         "used by profiles/collect.sh to profile that kernel chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL)")
@@ -252,7 +255,7 @@ def main():
         global_bh = total_bh * world
     causal = bool(args.causal)
     q, k, v = make_inputs(bh, n, d, dtype, device, seed=rank)
-    out = torch.empty_like(q)
+    out = torch.empty(q.shape, dtype=torch.float32, device=device) if (args.accurate and dtype == "bf16") else torch.empty_like(q)
 
     def step():
         fa.forward(q, k, v, causal, scale=args.scale, out=out)
@@ -293,7 +296,7 @@ def main():
     roof = None
     if rank == 0:
         L = _cabi.lib()
-        dt_id = _cabi.FA_DTYPE_BF16 if dtype == "bf16" else _cabi.FA_DTYPE_F32
+        dt_id = (_cabi.FA_DTYPE_BF16_OUT_F32 if args.accurate else _cabi.FA_DTYPE_BF16) if dtype == "bf16" else _cabi.FA_DTYPE_F32
         kname = L.fa_kernel_name_for(dt_id, d, int(causal), bh, n).decode()
         if dtype == "f32" and route == 2:
             kname = "fa_fwd_f32_kernel"   # the logit-width guard sent this workload to the exact kernel
@@ -347,7 +350,8 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": dtype, "data": "synthetic randn (seeded), resident in HBM",
             "config": {"workload": f"{args.workload}: B={B} H={H} d={d} N={n} {dtype}, {'causal' if causal else 'non-causal'}, "
-                                   f"scale={args.scale:g}" + (" per GPU" if scaling == "weak" and world > 1 else ""),
+                                   f"scale={args.scale:g}" + (", fp32 output (accurate P)" if args.accurate and dtype == "bf16" else "")
+                                   + (" per GPU" if scaling == "weak" and world > 1 else ""),
                        "global_bh": global_bh, "bh_per_gpu": bh, "seq_len": n, "head_dim": d,
                        "parallelism": f"batch*head sharded x{world}, no collective"},
             "roofline": roof, "cpu_baseline": cpu, "extra": extras,

@@ -387,6 +387,28 @@ int main(int argc, char** argv)
         printf("  whole kernel per wave: min %.0f mean %.0f max %.0f cycles\n", mn, av, mx);
         return 0;
     }
+    if (a.mode == "prof4") {
+        // cycle stamps around the fast loop of the NB = 4 kernel (ablation library; variants 60..68 write 4 floats per wave to the lse buffer)
+        float* lse = nullptr;
+        HIP_OK(hipMalloc(&lse, (size_t)a.bh * a.n * 4));
+        for (int rep = 0; rep < 30; ++rep)   // warm clocks
+            fa_ok(fa_forward_ex(b.q, b.k, b.v, b.o, lse, a.bh, a.n, a.d, a.scale, 0, FA_DTYPE_BF16, FA_KERNEL_MFMA | (a.variant << 8), nullptr), "prof4");
+        HIP_OK(hipMemset(lse, 0, (size_t)a.bh * a.n * 4));
+        fa_ok(fa_forward_ex(b.q, b.k, b.v, b.o, lse, a.bh, a.n, a.d, a.scale, 0, FA_DTYPE_BF16, FA_KERNEL_MFMA | (a.variant << 8), nullptr), "prof4");
+        HIP_OK(hipDeviceSynchronize());
+        const size_t nw = (size_t)a.bh * ((a.n + 511) / 512) * 4;
+        std::vector<float> h(nw * 4);
+        HIP_OK(hipMemcpy(h.data(), lse, h.size() * 4, hipMemcpyDeviceToHost));
+        double cyc = 0, real = 0, steps = 0, mx = 0, whole = 0, whole_mx = 0;
+        for (size_t w = 0; w < nw; ++w) {
+            cyc += h[w * 4]; real += h[w * 4 + 1]; steps += h[w * 4 + 2]; mx = h[w * 4] > mx ? h[w * 4] : mx;
+            whole += h[w * 4 + 3]; whole_mx = h[w * 4 + 3] > whole_mx ? h[w * 4 + 3] : whole_mx;
+        }
+        printf("{\"mode\": \"prof4\", \"variant\": %d, \"waves\": %zu, \"steps_per_wave\": %.0f, \"cycles_per_step\": %.1f, \"max_wave_cycles_per_step\": %.1f, "
+               "\"loop_us\": %.2f, \"shader_mhz\": %.0f, \"tile_cycles_mean\": %.0f, \"tile_cycles_max\": %.0f, \"outside_loop_cycles_mean\": %.0f}\n", a.variant, nw, steps / nw,
+               cyc / steps, mx / (steps / nw), real / nw / 100.0, cyc / real * 100.0, whole / nw, whole_mx, (whole - cyc) / nw);
+        return 0;
+    }
     if (a.mode == "sweep") {
         const int nvar = a.dtype == "bf16" ? 9 : 1;
         for (int v = 0; v < nvar; ++v) run_one(a, b, v, a.check ? &ref : nullptr);

@@ -570,6 +570,10 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
                 case 43: return launch_bf16_x4(p, causal, out_f32, 20, stream);
                 case 44: return launch_bf16_x4(p, causal, out_f32, 21, stream);
                 case 45: return launch_bf16_x4(p, causal, out_f32, 22, stream);
+                case 46: return launch_bf16_x4(p, causal, out_f32, 23, stream);
+                case 47: return launch_bf16_x4(p, causal, out_f32, 24, stream);
+                case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69:
+                    return launch_bf16_x4(p, causal, out_f32, variant - 30, stream);   // cycle-stamped forms (fa_driver_ablation --mode prof4)
 #endif
 #if FA_ABLATION
                 case 10: return launch_w4<64, 4, 4>(p, causal, out_f32, stream);       // 4 waves/SIMD on the VALU diet (a null result of DESIGN.md section 4; its causal form spills)

@@ -10,7 +10,7 @@ hipError_t launch_bf16_x4(const FwdParams& p, int causal, int out_f32, int mode,
 {
     if (!bf16_pipelined_supported(p, 64)) return hipErrorInvalidValue;
 #if FA_ABLATION
-    if (mode >= 11 && mode <= 22) return launch_bf16_x4_ablation(p, mode, stream);
+    if (mode >= 11 && mode <= 40) return launch_bf16_x4_ablation(p, mode, stream);
 #endif
     if (causal) return launch_bf16_x4_causal(p, out_f32, mode, stream);
     return launch_x4_modes<false>(p, out_f32, mode, stream);

@@ -19,6 +19,19 @@ hipError_t launch_bf16_x4_ablation(const FwdParams& p, int mode, hipStream_t str
     if (mode == 20) return launch_x4_ablation<64>(p, stream);  // K fragments not re-read
     if (mode == 21) return launch_x4_ablation<128>(p, stream); // slots not pinned by sched_barrier
     if (mode == 22) return launch_x4_ablation<256>(p, stream); // v_exp_f32 replaced by v_mul_f32
+    if (mode == 23) return launch_x4_ablation<512>(p, stream); // no LDS-DMA issue in the loop
+    if (mode == 24) return launch_x4_ablation<520>(p, stream); // no LDS-DMA issue, no DMA wait + barrier
+    // 30 + k: in-kernel cycle stamps around the fast loop (written to the lse buffer, 4 floats per wave) on top of ablation k
+    if (mode == 30) return launch_x4_ablation<1024>(p, stream);
+    if (mode == 31) return launch_x4_ablation<1024 + 16>(p, stream);    // no LDS fragment reads
+    if (mode == 32) return launch_x4_ablation<1024 + 512>(p, stream);   // no LDS-DMA issue
+    if (mode == 33) return launch_x4_ablation<1024 + 2>(p, stream);     // no VALU units
+    if (mode == 34) return launch_x4_ablation<1024 + 1>(p, stream);     // no MFMA
+    if (mode == 35) return launch_x4_ablation<1024 + 64>(p, stream);    // K fragments not re-read
+    if (mode == 36) return launch_x4_ablation<1024 + 8>(p, stream);     // no DMA wait + barrier
+    if (mode == 37) return launch_x4_ablation<1024 + 4>(p, stream);     // no waits for the V^T fragments
+    if (mode == 39) return launch_x4_ablation<1024 + 2048>(p, stream);  // LDS-DMA bunched behind the barrier (the round-1 form)
+    if (mode == 38) return launch_x4_ablation<1024 + 512 + 16 + 8>(p, stream);   // no DMA, no LDS reads, no barrier: MFMA + VALU only
     return hipErrorInvalidValue;
 }
 

@@ -208,33 +208,42 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     const int nt = (kv_end + kKvSplit - 1) / kKvSplit;
 
     // ---- this thread's pieces of a tile: group g = tid + i * NT -> (row, 8-column slot) of K and of V
-    int g_row[GPT], g_src[GPT], g_kdst[GPT], g_vdst[GPT];
+    // The K piece and the V piece of a thread are DIFFERENT (row, slot) pairs: each image wants the eight lanes of one ds_write_b128
+    // group on eight different 16-byte bank groups.  K image (row-major, slots swizzled): consecutive lanes take consecutive slots
+    // of one row (128 contiguous bytes).  V image ([key/4][col/16][4][16] sub-tiles of 128 bytes): consecutive lanes take the four
+    // rows of a sub-tile and its two 8-column halves -- with the K mapping the four lanes of a row that share (col/8) & 1 landed on the
+    // same banks (4-way conflicts on every V write: SQ_LDS_BANK_CONFLICT 25 M against 14.7 M LDS instructions in round 1).
+    int g_krow[GPT], g_vrow[GPT], g_ksrc[GPT], g_vsrc[GPT], g_kdst[GPT], g_vdst[GPT];
     bool g_on[GPT];
 #pragma unroll
     for (int i = 0; i < GPT; ++i) {
         const int g = (tid + i * NT) % C::kGroups;   // d = 32: the upper half of the workgroup duplicates the lower half's pieces
         g_on[i] = true;
         const int row = g / (D / 8), c8 = g % (D / 8);
-        g_row[i] = row;
-        g_src[i] = row * p.kv_row_stride + c8 * 8;
+        g_krow[i] = row;
+        g_ksrc[i] = row * p.kv_row_stride + c8 * 8;
         g_kdst[i] = row * C::kRowBytes + ((c8 ^ k_swizzle<D>(row)) * 16);
-        g_vdst[i] = 2 * C::kImageBytes + ((row / 4) * (D / 16) + c8 / 2) * 128 + (row % 4) * 32 + (c8 & 1) * 16;
+        const int r4 = g & 3, half = (g >> 2) & 1, c16 = (g >> 3) % (D / 16), rq = g / (4 * (D / 8));
+        const int vrow = rq * 4 + r4, vc8 = c16 * 2 + half;
+        g_vrow[i] = vrow;
+        g_vsrc[i] = vrow * p.kv_row_stride + vc8 * 8;
+        g_vdst[i] = 2 * C::kImageBytes + (rq * (D / 16) + c16) * 128 + r4 * 32 + half * 16;
     }
     f32x4 kst[GPT][2], vst[GPT][2];
     auto load_tile = [&](int kv0) {
 #pragma unroll
         for (int i = 0; i < GPT; ++i) {
-            const bool ok = g_on[i] && (kv0 + g_row[i] < n);
-            const int64_t off = (int64_t)kv0 * p.kv_row_stride + g_src[i];
+            const bool kok = g_on[i] && (kv0 + g_krow[i] < n), vok = g_on[i] && (kv0 + g_vrow[i] < n);
+            const int64_t koff = (int64_t)kv0 * p.kv_row_stride + g_ksrc[i], voff = (int64_t)kv0 * p.kv_row_stride + g_vsrc[i];
             const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
             if constexpr (IN_BF16) {   // eight bf16 values = one 16-byte register group, passed through unchanged
-                kst[i][0] = ok ? *(const f32x4*)(kg + off) : z;
-                vst[i][0] = ok ? *(const f32x4*)(vg + off) : z;
+                kst[i][0] = kok ? *(const f32x4*)(kg + koff) : z;
+                vst[i][0] = vok ? *(const f32x4*)(vg + voff) : z;
             } else {
-                kst[i][0] = ok ? *(const f32x4*)(kg + off) : z;
-                kst[i][1] = ok ? *(const f32x4*)(kg + off + 4) : z;
-                vst[i][0] = ok ? *(const f32x4*)(vg + off) : z;
-                vst[i][1] = ok ? *(const f32x4*)(vg + off + 4) : z;
+                kst[i][0] = kok ? *(const f32x4*)(kg + koff) : z;
+                kst[i][1] = kok ? *(const f32x4*)(kg + koff + 4) : z;
+                vst[i][0] = vok ? *(const f32x4*)(vg + voff) : z;
+                vst[i][1] = vok ? *(const f32x4*)(vg + voff + 4) : z;
             }
         }
     };
@@ -555,18 +564,18 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
             const unsigned soff = (unsigned)t * tile_step;
 #pragma unroll
             for (int i = 0; i < GPT; ++i) {
-                kst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, g_src[i] * ES, soff, 0));
+                kst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, g_ksrc[i] * ES, soff, 0));
                 if constexpr (!IN_BF16)
-                    kst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, g_src[i] * ES + 16, soff, 0));
+                    kst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, g_ksrc[i] * ES + 16, soff, 0));
             }
         };
         auto load_v = [&](int t) {
             const unsigned soff = (unsigned)t * tile_step;
 #pragma unroll
             for (int i = 0; i < GPT; ++i) {
-                vst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, g_src[i] * ES, soff, 0));
+                vst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, g_vsrc[i] * ES, soff, 0));
                 if constexpr (!IN_BF16)
-                    vst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, g_src[i] * ES + 16, soff, 0));
+                    vst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, g_vsrc[i] * ES + 16, soff, 0));
             }
         };
         auto store_k = [&](char* stage) {

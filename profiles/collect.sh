@@ -22,7 +22,13 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_
     --kernel-trace -d $OUT/pmc_c3_sq -- python3 $BENCH3 > $OUT/pmc_c3_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_c3_fetch -- python3 $BENCH3 > $OUT/pmc_c3_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_c3_write -- python3 $BENCH3 > $OUT/pmc_c3_write.log 2>&1
+# the accurate bf16 path (fp32 output: V -> fp16 copy, fp16-P kernel, conditional split kernel): durations and matrix-pipe counters
+BENCHA="$R/bench.py --accurate --steps 20 --warmup 3 --no-cpu-baseline --no-extras"
+rocprofv3 --kernel-trace --stats -d $OUT/stats_acc -- python3 $BENCHA > $OUT/stats_acc.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES \
+    --kernel-trace -d $OUT/pmc_acc_sq -- python3 $BENCHA > $OUT/pmc_acc_sq.log 2>&1
 cd $R
+python3 bench.py --accurate --no-cpu-baseline --no-extras > $OUT/bench_line_accurate.json 2> $OUT/bench_acc.err
 python3 bench.py --workload c3 --no-cpu-baseline > $OUT/bench_line_c3.json 2> $OUT/bench_c3.err
 python3 bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 python3 profiles/summarize_rocpd.py $OUT $TAG --out $OUT || echo "summarize_rocpd.py FAILED (kernel name mismatch?)"
