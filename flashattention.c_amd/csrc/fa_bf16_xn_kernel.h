@@ -686,13 +686,21 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
     // ---------------- prologue: K(0) landed -> scores of sub-tile 0, fragments of sub-tile 1 ----------------
     wait_lds_dma();
     __syncthreads();
+    unsigned long long prof_landed = 0;
+    if constexpr ((ABL & 1024) != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0][0]), "+v"(qf[NB - 1][KS - 1]));   // Q fragments have arrived as well
+        prof_landed = stamp();
+    }
     load_kf(0);
     qk_regs(0, s0, true);
     load_kf(1);
 
     // ---------------- fast loop: groups of G whole stages whose sub-tiles 2j .. 2j+2 are in range and mask-free ----------------
-    int jf = 0;
-    while ((2 * jf + 3) * 32 <= kv_end && !needs_mask(2 * jf + 2, q0) && !needs_mask(0, q0)) ++jf;
+    // (closed form of: jf = 0; while ((2 jf + 3) 32 <= kv_end && !needs_mask(2 jf + 2, q0) && !needs_mask(0, q0)) ++jf; -- the loop was
+    // O(N / 64) scalar iterations per wave, ~2.5k cycles at N = 8192)
+    int jf = kv_end >= 96 ? (kv_end / 32 - 3) / 2 + 1 : 0;                    // (2 jf + 3) * 32 <= kv_end; kv_end <= n covers the ragged tail
+    if (CAUSAL) jf = q0 >= 95 ? min(jf, (q0 - 95) / 64 + 1) : 0;             // 64 j + 95 <= q0: sub-tile 2 j + 2 lies below the first row's diagonal
+    if (n < 32) jf = 0;
     // The last stage may run in the fast loop too when its own two sub-tiles are whole and mask-free: its second step then
     // computes scores of a sub-tile that does not exist (from whatever the ring slot holds) and nobody consumes them --
     // the rescale test of that step is ignored.  Without this the final 128 keys of every slab took the slow tail path.
@@ -784,6 +792,8 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
         }
     }
 
+    unsigned long long prof_tail = 0;
+    if constexpr ((ABL & 1024) != 0) prof_tail = stamp();
     // ---------------- store; verify (optimistic mix) ----------------
     // The optimistic tile stores its result BEFORE the workgroup votes on it: a failed tile is simply overwritten by the redo,
     // and nothing of the first attempt is live across the vote (with the store behind the vote hipcc carried the
@@ -845,14 +855,19 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
         }
     }
     if constexpr ((ABL & 1024) != 0) {
+        const unsigned long long t_issued = stamp();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the output stores have left
         const unsigned long long t2 = stamp();
         if (lane == 0 && p.lse != nullptr) {
-            float* dst = p.lse + ((int64_t)blockIdx.x * NWAVES + wave) * 4;
+            float* dst = p.lse + ((int64_t)blockIdx.x * NWAVES + wave) * 8;
             dst[0] = (float)(prof_t1 - prof_t0);      // shader cycles in the fast loop
             dst[1] = (float)(prof_r1 - prof_r0);      // 10 ns ticks in the fast loop
             dst[2] = (float)(2 * jf);                 // steps executed there
             dst[3] = (float)(t2 - prof_entry);        // shader cycles from the first instruction of the tile to its last store
+            dst[4] = (float)(prof_landed - prof_entry);   // entry -> Q, K(0..2), V(0..1) landed (issue + HBM round trip, all CUs at once)
+            dst[5] = (float)(prof_t0 - prof_landed);      // first scores: K fragments, K.Q^T of sub-tile 0, row maxima, references
+            dst[6] = (float)(prof_tail - prof_t1);        // tail stages outside the fast loop
+            dst[7] = (float)(t_issued - prof_tail);       // drain, O / l, packing, store issue (t2 - t_issued: stores landing)
         }
     }
     if (OPT) {

@@ -397,16 +397,19 @@ int main(int argc, char** argv)
         fa_ok(fa_forward_ex(b.q, b.k, b.v, b.o, lse, a.bh, a.n, a.d, a.scale, 0, FA_DTYPE_BF16, FA_KERNEL_MFMA | (a.variant << 8), nullptr), "prof4");
         HIP_OK(hipDeviceSynchronize());
         const size_t nw = (size_t)a.bh * ((a.n + 511) / 512) * 4;
-        std::vector<float> h(nw * 4);
+        std::vector<float> h(nw * 8);
         HIP_OK(hipMemcpy(h.data(), lse, h.size() * 4, hipMemcpyDeviceToHost));
-        double cyc = 0, real = 0, steps = 0, mx = 0, whole = 0, whole_mx = 0;
+        double cyc = 0, real = 0, steps = 0, mx = 0, whole = 0, whole_mx = 0, ph[4] = {0, 0, 0, 0};
         for (size_t w = 0; w < nw; ++w) {
-            cyc += h[w * 4]; real += h[w * 4 + 1]; steps += h[w * 4 + 2]; mx = h[w * 4] > mx ? h[w * 4] : mx;
-            whole += h[w * 4 + 3]; whole_mx = h[w * 4 + 3] > whole_mx ? h[w * 4 + 3] : whole_mx;
+            cyc += h[w * 8]; real += h[w * 8 + 1]; steps += h[w * 8 + 2]; mx = h[w * 8] > mx ? h[w * 8] : mx;
+            whole += h[w * 8 + 3]; whole_mx = h[w * 8 + 3] > whole_mx ? h[w * 8 + 3] : whole_mx;
+            for (int i = 0; i < 4; ++i) ph[i] += h[w * 8 + 4 + i];
         }
         printf("{\"mode\": \"prof4\", \"variant\": %d, \"waves\": %zu, \"steps_per_wave\": %.0f, \"cycles_per_step\": %.1f, \"max_wave_cycles_per_step\": %.1f, "
-               "\"loop_us\": %.2f, \"shader_mhz\": %.0f, \"tile_cycles_mean\": %.0f, \"tile_cycles_max\": %.0f, \"outside_loop_cycles_mean\": %.0f}\n", a.variant, nw, steps / nw,
-               cyc / steps, mx / (steps / nw), real / nw / 100.0, cyc / real * 100.0, whole / nw, whole_mx, (whole - cyc) / nw);
+               "\"loop_us\": %.2f, \"shader_mhz\": %.0f, \"tile_cycles_mean\": %.0f, \"tile_cycles_max\": %.0f, \"outside_loop_cycles_mean\": %.0f, "
+               "\"inputs_landed\": %.0f, \"first_scores\": %.0f, \"tail_stages\": %.0f, \"epilogue_issue\": %.0f, \"stores_landing\": %.0f}\n", a.variant, nw, steps / nw,
+               cyc / steps, mx / (steps / nw), real / nw / 100.0, cyc / real * 100.0, whole / nw, whole_mx, (whole - cyc) / nw,
+               ph[0] / nw, ph[1] / nw, ph[2] / nw, ph[3] / nw, (whole - cyc - ph[0] - ph[1] - ph[2] - ph[3]) / nw);
         return 0;
     }
     if (a.mode == "sweep") {

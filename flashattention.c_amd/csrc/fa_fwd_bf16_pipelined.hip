@@ -332,8 +332,11 @@ __device__ __forceinline__ bool pp3_tile(const FwdParams& p, char* smem)
     load_kf(1);
 
     // ---------------- fast loop: groups of G whole stages whose sub-tiles 2j .. 2j+2 are in range and mask-free ----------------
-    int jf = 0;
-    while ((2 * jf + 3) * 32 <= kv_end && !needs_mask(2 * jf + 2, q0a) && !needs_mask(2 * jf + 2, q0b) && !needs_mask(0, q0a)) ++jf;
+    // closed form of the obvious scan over j (which was O(N / 64) scalar iterations per wave): (2 jf + 3) * 32 <= kv_end, and for a
+    // causal tile sub-tile 2 j + 2 below the diagonal of the first row of both blocks (q0a < q0b)
+    int jf = kv_end >= 96 ? (kv_end / 32 - 3) / 2 + 1 : 0;
+    if (CAUSAL) jf = min(q0a, q0b) >= 95 ? min(jf, (min(q0a, q0b) - 95) / 64 + 1) : 0;
+    if (n < 32) jf = 0;
     // The last stage may run in the fast loop too when its own two sub-tiles are whole and mask-free: its second step then
     // computes scores of a sub-tile that does not exist (from whatever the ring slot holds) and nobody consumes them --
     // the rescale test of that step is ignored.  Without this the final 128 keys of every slab took the slow tail path.
