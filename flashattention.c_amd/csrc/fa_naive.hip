@@ -30,8 +30,10 @@ __global__ __launch_bounds__(kNaiveWaves * kWave) void fa_naive_f32_kernel(FwdPa
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * kNaiveWaves + wave;
-    const int slab = blockIdx.y;
+    // one linear grid: slab-major (grid.y stops at 65 535, the ABI admits 2^31 - 1 slabs)
+    const int row_blocks = (p.n + kNaiveWaves - 1) / kNaiveWaves;
+    const int row = (int)(blockIdx.x % (unsigned)row_blocks) * kNaiveWaves + wave;
+    const int slab = (int)(blockIdx.x / (unsigned)row_blocks);
     if (row >= p.n) return;
 
     const int b = slab / p.heads, h = slab % p.heads;
@@ -82,8 +84,9 @@ __global__ __launch_bounds__(kNaiveWaves * kWave) void fa_naive_f32_kernel(FwdPa
 
 hipError_t launch_naive_f32(const FwdParams& p, int d, int causal, hipStream_t stream)
 {
-    dim3 grid((p.n + kNaiveWaves - 1) / kNaiveWaves, p.bh);
-    hipLaunchKernelGGL(fa_naive_f32_kernel, grid, dim3(kNaiveWaves * kWave), 0, stream, p, d, causal);
+    const int64_t blocks = (int64_t)((p.n + kNaiveWaves - 1) / kNaiveWaves) * p.bh;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fa_naive_f32_kernel, dim3((unsigned)blocks), dim3(kNaiveWaves * kWave), 0, stream, p, d, causal);
     return hipGetLastError();
 }
 
