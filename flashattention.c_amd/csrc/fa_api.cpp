@@ -217,6 +217,18 @@ int launch_f32_guarded(const fa::FwdParams& p0, int32_t d, int32_t causal, hipSt
 
 bool p16_available(const fa::FwdParams& p, int32_t d) { return fa::bf16_p16_supported(p, d); }
 
+// FA_KERNEL_AUTO, bf16 tensors, fp32 output: fp16 P or hi + lo bf16 terms?  The fp16 chain has a fixed cost the split kernel does
+// not have -- the V copy (2 x sizeof(V) of HBM traffic) and two extra launches, ~15 us together -- and a faster kernel.  Measured
+// on MI355X (ms, fp16 P / split): BH x N x d = 128 x 2048 x 64: 0.187 / 0.244, 32 x 4096 x 64: 0.169 / 0.234, 128 x 1024 x 128: 0.118 /
+// 0.129, 128 x 1024 x 64: 0.074 / 0.077, the same causal: 0.075 / 0.064, 16 x 1024 x 64: 0.036 / 0.019, 128 x 1024 x 32: 0.046 / 0.056.
+// Rule: fp16 P from 6e9 multiply-adds per contraction on (a causal launch counts half), from 2e9 at d = 32 (where the split kernel is
+// slowest); the split kernel below that.
+bool p16_worthwhile(const fa::FwdParams& p, int32_t d, int32_t causal)
+{
+    const double macs = (double)p.bh * (double)p.n * (double)p.n * (double)d * (causal ? 0.5 : 1.0);
+    return macs >= (d == 32 ? 2e9 : 6e9);
+}
+
 int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int32_t kernel, hipStream_t stream)
 {
     const KernelSel sel = decode_kernel(kernel);
@@ -236,7 +248,7 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
             // and takes the fastest kernels (bf16 P).  MFMA / SPLIT / P16 force one family.
             if (sel.kind == FA_KERNEL_P16 && !p16_available(p, d))
                 return fail(FA_ERR_UNSUPPORTED, "the fp16-P kernels address a slab with 32-bit byte offsets (slabs below 4 GiB; got n = %d, d = %d)", p.n, d);
-            if (sel.kind == FA_KERNEL_P16 || (sel.kind == FA_KERNEL_AUTO && out_f32 && sel.variant == 0 && p16_available(p, d)))
+            if (sel.kind == FA_KERNEL_P16 || (sel.kind == FA_KERNEL_AUTO && out_f32 && sel.variant == 0 && p16_available(p, d) && p16_worthwhile(p, d, causal)))
                 return launch_p16_chain(p, d, causal, out_f32, stream);
             if (sel.kind == FA_KERNEL_SPLIT || (sel.kind == FA_KERNEL_AUTO && out_f32 && sel.variant == 0))
                 e = fa::launch_bf16_split(p, d, causal ? 1 : 0, out_f32, sel.variant, stream);
@@ -455,8 +467,9 @@ const char* fa_kernel_name_for(int32_t dtype, int32_t d, int32_t causal, int64_t
     if (!head_dim_supported(d) || bh < 1 || n < 1) return nullptr;
     if (dtype == FA_DTYPE_F32) return f32_auto_is_exact() ? "fa_fwd_f32_kernel" : "fa_fwd_f32_split_kernel";
     if (dtype == FA_DTYPE_BF16) return fa::bf16_kernel_name(bh, n, d, causal);
-    if (dtype == FA_DTYPE_BF16_OUT_F32) {   // the accurate P (see fa_dtype): fp16 (slabs below 4 GiB), hi + lo bf16 terms beyond
+    if (dtype == FA_DTYPE_BF16_OUT_F32) {   // the accurate P (see fa_dtype): fp16 (slabs below 4 GiB, launches large enough), hi + lo bf16 terms otherwise
         if (((n - 1) * d + d) * 2 >= 0xffffffffLL) return "fa_fwd_f32_split_kernel";
+        if ((double)bh * (double)n * (double)n * (double)d * (causal ? 0.5 : 1.0) < (d == 32 ? 2e9 : 6e9)) return "fa_fwd_f32_split_kernel";
         return (d == 64 && strcmp(fa::bf16_kernel_name(bh, n, d, causal), "fa_fwd_bf16_x4_kernel") == 0) ? "fa_fwd_bf16_x4_p16_kernel" : "fa_fwd_bf16_x2_p16_kernel";
     }
     return nullptr;

@@ -100,7 +100,7 @@ template <bool OPT, bool PF>
 struct XSoft {
     static_assert(!(OPT && PF), "fp16 P has no room for a fixed exponent reference");
     static constexpr float kBias = OPT ? kOptBias : PF ? 5.0f : kLazyThr;
-    static constexpr float kThr = PF ? 14.0f : 0.0f;
+    static constexpr float kThr = PF ? 14.0f : 0.0f;   // fp16: p < 2^14 (fp16 ends at 65 504; a wider window -- 15.5 -- measured no faster)
 };
 
 // mfma_drain() with the registers it protects as operands: the drain is an asm statement without a data dependence of its

@@ -392,11 +392,12 @@ int main(int argc, char** argv)
         float* lse = nullptr;
         HIP_OK(hipMalloc(&lse, (size_t)a.bh * a.n * 4));
         for (int rep = 0; rep < 30; ++rep)   // warm clocks
-            fa_ok(fa_forward_ex(b.q, b.k, b.v, b.o, lse, a.bh, a.n, a.d, a.scale, 0, FA_DTYPE_BF16, FA_KERNEL_MFMA | (a.variant << 8), nullptr), "prof4");
+            fa_ok(fa_forward_ex(b.q, b.k, b.v, b.o, lse, a.bh, a.n, a.d, a.scale, a.causal, FA_DTYPE_BF16, FA_KERNEL_MFMA | (a.variant << 8), nullptr), "prof4");
         HIP_OK(hipMemset(lse, 0, (size_t)a.bh * a.n * 4));
-        fa_ok(fa_forward_ex(b.q, b.k, b.v, b.o, lse, a.bh, a.n, a.d, a.scale, 0, FA_DTYPE_BF16, FA_KERNEL_MFMA | (a.variant << 8), nullptr), "prof4");
+        fa_ok(fa_forward_ex(b.q, b.k, b.v, b.o, lse, a.bh, a.n, a.d, a.scale, a.causal, FA_DTYPE_BF16, FA_KERNEL_MFMA | (a.variant << 8), nullptr), "prof4");
         HIP_OK(hipDeviceSynchronize());
-        const size_t nw = (size_t)a.bh * ((a.n + 511) / 512) * 4;
+        const int rows_per_wg = a.variant == 70 ? 256 : 512;
+        const size_t nw = (size_t)a.bh * ((a.n + rows_per_wg - 1) / rows_per_wg) * 4;
         std::vector<float> h(nw * 8);
         HIP_OK(hipMemcpy(h.data(), lse, h.size() * 4, hipMemcpyDeviceToHost));
         double cyc = 0, real = 0, steps = 0, mx = 0, whole = 0, whole_mx = 0, ph[4] = {0, 0, 0, 0};
@@ -410,6 +411,14 @@ int main(int argc, char** argv)
                "\"inputs_landed\": %.0f, \"first_scores\": %.0f, \"tail_stages\": %.0f, \"epilogue_issue\": %.0f, \"stores_landing\": %.0f}\n", a.variant, nw, steps / nw,
                cyc / steps, mx / (steps / nw), real / nw / 100.0, cyc / real * 100.0, whole / nw, whole_mx, (whole - cyc) / nw,
                ph[0] / nw, ph[1] / nw, ph[2] / nw, ph[3] / nw, (whole - cyc - ph[0] - ph[1] - ph[2] - ph[3]) / nw);
+        if (a.causal) {   // per q tile of slab 0 (tiles are launched heaviest first: tile index = q_tiles - 1 - launch position)
+            const size_t qt = (a.n + rows_per_wg - 1) / rows_per_wg;
+            printf("# slab 0, per launch position: steps, loop cycles, inputs_landed, first_scores, tail, epilogue_issue, whole tile\n");
+            for (size_t t = 0; t < qt; t += (qt > 16 ? qt / 16 : 1)) {
+                const float* r = &h[(t * 4 + 0) * 8];   // wave 0 of workgroup t (xcd_remap keeps slab 0's tiles in the first positions of XCD 0)
+                printf("#  pos %3zu: %5.0f %8.0f %7.0f %7.0f %7.0f %7.0f %8.0f\n", t, r[2], r[0], r[4], r[5], r[6], r[7], r[3]);
+            }
+        }
         return 0;
     }
     if (a.mode == "sweep") {

@@ -11,6 +11,16 @@ hipError_t launch_bf16_x2(const FwdParams& p, int d, int causal, int out_f32, in
 {
     if (d != 32 && d != 64 && d != 128) return hipErrorInvalidValue;
     if (!xn_addressable(p, d)) return hipErrorInvalidValue;
+#if FA_ABLATION
+    if (mode == 40 && d == 64) {   // cycle stamps (fa_driver_ablation --mode prof4 --variant 70): 8 floats per wave into the lse buffer
+        FwdParams q;
+        dim3 grid, block;
+        if (!xn_grid<2>(p, q, grid, block)) return hipErrorInvalidValue;
+        if (causal) hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<64, 4, true, false, 2, 1024>), grid, block, 0, stream, q);
+        else hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<64, 4, false, false, 2, 1024>), grid, block, 0, stream, q);
+        return hipGetLastError();
+    }
+#endif
     if (d == 32) {
         if (mode == 1) return launch_x2<32, 1>(p, causal, out_f32, stream);
         if (mode == 3) return launch_x2<32, 2, false>(p, causal, out_f32, stream);

@@ -62,9 +62,11 @@ typedef enum fa_dtype {
                          FA_KERNEL_AUTO choice for the whole process */
     FA_DTYPE_BF16 = 1,        /* bf16 in, bf16 MFMA with fp32 accumulate and fp32 softmax, bf16 out     */
     FA_DTYPE_BF16_OUT_F32 = 2 /* bf16 in, O written as fp32 (the accumulator precision).  Under FA_KERNEL_AUTO this also selects
-                                 the ACCURATE P: a caller who wants the fp32 accumulator gets P in fp16 (11 significant bits;
-                                 head dim 64) or as hi + lo bf16 terms (head dims 32, 128) -- max-abs error below 1e-3 against
-                                 the fp32 reference at scale 1, where bf16 P (8 bits) shows ~5e-3.  A bf16 output rounds at
+                                 the ACCURATE P: a caller who wants the fp32 accumulator gets P in fp16 (11 significant bits:
+                                 8e-4 .. 1.2e-3 of the fp32 reference at scale 1 on unit-variance data, <= 2e-4 at 1/sqrt(d),
+                                 where bf16 P shows ~5e-3) -- or, for launches below 6e9 multiply-adds per contraction (2e9 at
+                                 head dim 32; the fp16 path costs a copy of V and two extra launches, ~15 us) and for slabs
+                                 beyond 4 GiB, P and the scaled Q as hi + lo bf16 terms (~1e-4).  A bf16 output rounds at
                                  2^-9 |O| by itself and keeps the fastest kernels (bf16 P). */
 } fa_dtype;
 
@@ -77,8 +79,8 @@ typedef enum fa_kernel {
                             bf16 tensors: K, V exact in one term, Q*scale*log2e and P carried as hi + lo (two products per
                             contraction): max-abs error ~1e-4 against fp64 at scale 1 with FA_DTYPE_BF16_OUT_F32, at ~2x the
                             time of the bf16-P kernels */
-    FA_KERNEL_P16 = 4    /* bf16 tensors, head dim 64: P and V in fp16 for the second contraction (v_mfma_f32_32x32x16_f16), Q.K^T
-                            in bf16 (exact in the fp32 accumulator): ~6e-4 at scale 1 at ~1.1x the time of the bf16-P kernels.
+    FA_KERNEL_P16 = 4    /* bf16 tensors: P and V in fp16 for the second contraction (v_mfma_f32_32x32x16_f16), Q.K^T in bf16
+                            (exact in the fp32 accumulator): 8e-4 .. 1.2e-3 at scale 1 at ~1.15x the time of the bf16-P kernels.
                             V is copied to fp16 into stream-ordered scratch (hipMallocAsync) first; if some |v| >= 2^16 the
                             split kernel takes the launch instead (decided on the device). */
 } fa_kernel;

@@ -13,7 +13,8 @@ Tolerances (max-abs, stated once here; BASELINE.md section 4 gives the arithmeti
                                                       two comparable dominant keys with distant V rows: |err| <= 0.25 * 2^-10 * |v1 - v2|, and the
                                                       maximum over the launch grows with the number of outputs: observed 6.7e-4 .. 8.4e-4 on one
                                                       N = 8192 slab, 8.4e-4 / 1.0e-3 over 16 slabs (c4; two data sets), 1.17e-3 over 128 slabs
-                                                      -> P16_TOL_BIG = 1.5e-3 for launches of more than 16 long slabs (stated where used)
+                                                      (1.13e-3 on a 26 x 2670 fuzz case) -> P16_TOL_BIG = 1.5e-3 for launches of more than 16 long
+                                                      slabs and for the fuzz through the dispatch (stated where used)
 "bf16 kernel" above = the bf16-P kernels (kernel="mfma"; FA_KERNEL_AUTO for a bf16 output).
 The bf16 kernels are always compared with the oracle evaluated on the SAME bf16-valued inputs.
 """
@@ -348,9 +349,11 @@ def test_fuzz_shapes_through_the_dispatch_against_rung0():
         acc = fa.forward(q, k, v, causal, scale=scale, out_dtype=torch.float32)                    # auto: the accurate P
         err_a = float((acc - ref).abs().max())
         worst_acc = max(worst_acc, err_a)
-        assert err_a < TOL_F32, f"accurate P: case {case} bh={bh} n={n} d={d} causal={causal} scale={scale}: {err_a:.3e}"
+        # fp16 P at unscaled logits: 2^-12-relative P, the maximum over millions of outputs reaches 1.0 .. 1.2e-3 (header of this file)
+        tol_a = P16_TOL_BIG if scale >= 0.5 else TOL_F32
+        assert err_a < tol_a, f"accurate P: case {case} bh={bh} n={n} d={d} causal={causal} scale={scale}: {err_a:.3e}"
     OBSERVED.append(("fuzz through dispatch, worst of 48", worst, bf16_tol(1.0, True)))
-    OBSERVED.append(("fuzz through dispatch, accurate P, worst of 48", worst_acc, TOL_F32))
+    OBSERVED.append(("fuzz through dispatch, accurate P, worst of 48", worst_acc, P16_TOL_BIG))
 
 
 # bf16 tensors through the split machinery (kernel="split"): K and V are exact in one bf16 term, Q*scale*log2e and P are carried
@@ -598,7 +601,7 @@ def test_p16_falls_back_when_v_does_not_fit_fp16():
     v = orc.round_to_bf16(v)
     ref = orc.attention_f64(q, k, v, scale=0.125)
     qd, kd, vd = to_dev(q, k, v, dtype=torch.bfloat16)
-    o = fa.forward(qd, kd, vd, False, scale=0.125, out_dtype=torch.float32)   # auto
+    o = fa.forward(qd, kd, vd, False, scale=0.125, out_dtype=torch.float32, kernel="p16")
     assert fa.last_forward_route() == 2
     got = o.cpu().numpy().astype(np.float64)
     assert np.isfinite(got).all()
@@ -607,7 +610,7 @@ def test_p16_falls_back_when_v_does_not_fit_fp16():
     # ... and the same tensors without the outliers take the fp16 path again
     v[1, 333, 7] = 1.0
     v[0, 5, 60] = -1.0
-    o = fa.forward(qd, kd, to_dev(v, dtype=torch.bfloat16)[0], False, scale=0.125, out_dtype=torch.float32)
+    o = fa.forward(qd, kd, to_dev(v, dtype=torch.bfloat16)[0], False, scale=0.125, out_dtype=torch.float32, kernel="p16")
     assert fa.last_forward_route() == 1
     check(o, orc.attention_f64(q, k, v, scale=0.125), TOL_F32)
 
@@ -616,11 +619,22 @@ def test_p16_graph_capture_and_timing_entry():
     """The chain allocates its fp16 copy of V from the stream-ordered pool: it has to survive stream capture (graph memory nodes)."""
     q, k, v = (torch.randn(4, 1024, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
     o = torch.empty(q.shape, dtype=torch.float32, device=dev())
-    ms_stream = fa.time_forward(q, k, v, False, warmup=1, iters=5, out=o)
-    ms_graph = fa.time_forward(q, k, v, False, warmup=1, iters=5, out=o, graph=True)
+    ms_stream = fa.time_forward(q, k, v, False, warmup=1, iters=5, out=o, kernel="p16")
+    ms_graph = fa.time_forward(q, k, v, False, warmup=1, iters=5, out=o, graph=True, kernel="p16")
     assert 0.0 < ms_graph < 50.0 and 0.0 < ms_stream < 50.0
     ref = fa.forward(q.float(), k.float(), v.float(), False, kernel="naive")
     assert float((o - ref).abs().max()) < TOL_F32
+
+
+def test_auto_picks_fp16_p_or_hi_lo_terms_by_launch_size():
+    """FA_KERNEL_AUTO for bf16 tensors with an fp32 output: P in fp16 from 6e9 multiply-adds per contraction on (a launch chain:
+    route 1), hi + lo bf16 terms below (a single launch: route 0) -- both inside the fp32 bar."""
+    for bh, n, want in ((16, 1024, 0), (32, 2048, 1)):
+        q, k, v = (torch.randn(bh, n, 64, generator=torch.Generator().manual_seed(5)).bfloat16().to(dev()) for _ in range(3))
+        o = fa.forward(q, k, v, False, out_dtype=torch.float32)
+        assert fa.last_forward_route() == want, (bh, n)
+        ref = fa.forward(q.float(), k.float(), v.float(), False, kernel="naive")
+        assert float((o - ref).abs().max()) < TOL_F32
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -754,6 +768,26 @@ def test_compiled_pybind_module_is_a_drop_in_for_the_reference_extension():
         minimal_flash.forward(q.cpu(), k.cpu(), v.cpu(), False)
     with pytest.raises(RuntimeError):
         minimal_flash.forward(q, k[:, :100], v, False)
+
+
+@pytest.mark.parametrize("bh,n,d", [(1, 32768, 64), (2, 20000, 128), (70000, 64, 64), (66000, 33, 32)])
+def test_long_sequences_and_many_slabs_against_rung0(bh, n, d):
+    """Sizes beyond the BASELINE configs: 32 Ki-key rows (512 stages per tile), a ragged 20 000-key d = 128 slab, and more slabs than a
+    16-bit grid dimension holds (the ABI admits 2^31 - 1) -- every kernel family through the product dispatch against the rung-0 kernel."""
+    g = torch.Generator(device=dev()).manual_seed(9)
+    q, k, v = (torch.randn(bh, n, d, generator=g, device=dev()) for _ in range(3))
+    for causal in (False, True):
+        ref = fa.forward(q, k, v, causal, scale=d ** -0.5, kernel="naive")
+        o = fa.forward(q, k, v, causal, scale=d ** -0.5)                                     # fp32 tensors, guarded split products
+        assert float((o - ref).abs().max()) < TOL_F32
+        qb, kb, vb = q.bfloat16(), k.bfloat16(), v.bfloat16()
+        refb = fa.forward(qb.float(), kb.float(), vb.float(), causal, scale=d ** -0.5, kernel="naive")
+        ob = fa.forward(qb, kb, vb, causal, scale=d ** -0.5, out_dtype=torch.float32, kernel="mfma")   # bf16 P
+        # short rows keep the 2^-9 rounding of each bf16 P value un-averaged: up to 2^-9 * max|v| ~ 1e-2 over millions of rows (observed 5.0e-3)
+        assert float((ob - refb).abs().max()) < (4e-3 if n >= 1000 else 1.2e-2)
+        oa = fa.forward(qb, kb, vb, causal, scale=d ** -0.5, out_dtype=torch.float32)                  # accurate P through AUTO
+        assert float((oa - refb).abs().max()) < TOL_F32
+        del ref, o, refb, ob, oa
 
 
 def test_c_driver_known_answer():
