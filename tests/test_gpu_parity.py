@@ -626,6 +626,32 @@ def test_p16_graph_capture_and_timing_entry():
     assert float((o - ref).abs().max()) < TOL_F32
 
 
+def test_guarded_fp32_chain_survives_graph_capture_and_other_streams():
+    """The fp32 AUTO chain (split kernel + conditional exact kernel) replayed from a hipGraph, and two chains in flight on two streams
+    with opposite verdicts: each call's flag word is its own (ring slot + serial number), so neither sees the other's."""
+    q, k, v = (torch.randn(8, 1024, 64, device=dev()) for _ in range(3))
+    o = torch.empty_like(q)
+    ms = fa.time_forward(q, k, v, False, warmup=1, iters=4, out=o, graph=True)
+    assert 0.0 < ms < 50.0
+    ref = fa.forward(q, k, v, False, kernel="exact")
+    assert float((o - ref).abs().max()) < TOL_F32
+    kw = k.clone()
+    kw[3, 77] *= 40.0                                   # wide logits: this launch must be handed to the exact kernel
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            o1 = fa.forward(q, k, v, False)
+            r1 = fa.last_forward_route(s1)
+        with torch.cuda.stream(s2):
+            o2 = fa.forward(q, kw, v, False)
+            r2 = fa.last_forward_route(s2)
+        assert (r1, r2) == (1, 2)
+    torch.cuda.synchronize()
+    assert float((o1 - ref).abs().max()) < TOL_F32
+    assert float((o2 - fa.forward(q, kw, v, False, kernel="exact")).abs().max()) < 1e-4
+
+
 def test_auto_picks_fp16_p_or_hi_lo_terms_by_launch_size():
     """FA_KERNEL_AUTO for bf16 tensors with an fp32 output: P in fp16 from 6e9 multiply-adds per contraction on (a launch chain:
     route 1), hi + lo bf16 terms below (a single launch: route 0) -- both inside the fp32 bar."""
