@@ -335,26 +335,6 @@ struct XCtx {
     bf16x8 pf[NB][2];
     float pm[4];
     bool need;
-    // LDS-DMA pieces this step issues between its MFMA slots (see XDmaPlan): descriptor, per-lane offset, scalar offset, LDS address
-    const TileDma<D, 4>* dma;
-    unsigned dma_soff[3];
-    char* dma_dst[3];
-};
-
-// LDS-DMA spread over the steps.  A barrier group of G = 2 stages (four steps) has to enqueue the tiles K(j+3), K(j+4), V(j+2),
-// V(j+3): 16 KiB-pieces per workgroup, 8 DMA instructions per wave at D = 64.  Issued back to back behind the barrier they cost the
-// wave ~50 issue cycles each (the memory pipeline's queue fills: measured 103 cycles per step of 1626, fa_driver_ablation --mode
-// prof4); issued one at a time between MFMA slots of the first three steps they cost what an LDS read costs.  Every piece goes to a
-// ring slot whose tile died before the group's barrier, so WHERE in the group it is issued does not matter for correctness; it has
-// to land before the next group's barrier (vmcnt(0) there), which is why the fourth step issues nothing.  Pieces of stages past the
-// end of the slab are answered with zeros by the descriptor's bounds check and land in slots nobody reads.
-template <int D, int NB>
-struct XDmaPlan {
-    static constexpr bool kSpread = (NB == 4 && D == 64);
-    // step s of the group issues pieces [first(s), first(s + 1)) of the list K(j+3)c0 K(j+3)c1 V(j+2)c0 V(j+2)c1 K(j+4)c0 K(j+4)c1 V(j+3)c0 V(j+3)c1
-    __device__ __host__ static constexpr int first(int s) { return s <= 0 ? 0 : s == 1 ? 3 : s == 2 ? 6 : 8; }
-    // MFMA slots behind which the (up to three) pieces of a step are issued: clear of the V^T reads (slots 0..3) and K reads (28..31)
-    __device__ __host__ static constexpr int slot(int k) { return k == 0 ? 10 : k == 1 ? 18 : 24; }
 };
 
 template <int D, int NB, bool OPT, int U, int ABL = 0, bool PF = false>
@@ -429,7 +409,7 @@ __device__ __forceinline__ void xn_wait_v_frags(XCtx<D, NB>& x)
     }
 }
 
-template <int D, int NB, int KB_C, int I, int ABL, bool OPT, bool PF, int DSTEP>
+template <int D, int NB, int KB_C, int I, int ABL, bool OPT, bool PF>
 __device__ __forceinline__ void xn_slot_body(XCtx<D, NB>& x)
 {
     using S = XShape<D, NB>;
@@ -460,55 +440,25 @@ __device__ __forceinline__ void xn_slot_body(XCtx<D, NB>& x)
         else asm volatile("ds_read_b128 %0, %1" : "=v"(x.kf[ks]) : "v"(a));
         if constexpr (ABL & 32) asm volatile("ds_read_b128 %0, %1" : "=v"(x.kf[ks]) : "v"(a));
     }
-    if constexpr (DSTEP >= 0 && XDmaPlan<D, NB>::kSpread) {
-        using PL = XDmaPlan<D, NB>;
-        constexpr int npieces = PL::first(DSTEP + 1) - PL::first(DSTEP);
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (k < npieces && I == PL::slot(k)) {
-                const int piece = PL::first(DSTEP) + k;             // 0,1 K(j+3)  2,3 V(j+2)  4,5 K(j+4)  6,7 V(j+3)
-                const bool is_v = (piece >> 1) & 1;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(is_v ? x.dma->v_rsrc : x.dma->k_rsrc, (lds_void_t*)x.dma_dst[k], 16,
-                                                         is_v ? x.dma->v_voff : x.dma->k_voff, x.dma_soff[k], 0, 0);
-            }
-    }
     if constexpr (!(ABL & 2))   // ABL & 2: no VALU work
         xn_units<D, NB, OPT, ABL, PF, tab.ub[I]>(x, std::make_integer_sequence<int, tab.ub[I + 1] - tab.ub[I]>{});
     if constexpr (!(ABL & 128)) __builtin_amdgcn_sched_barrier(0);  // ABL & 128: slots not pinned (hipcc schedules the step)
 }
-template <int D, int NB, int KB_C, int ABL, bool OPT, bool PF, int DSTEP, int... Is>
+template <int D, int NB, int KB_C, int ABL, bool OPT, bool PF, int... Is>
 __device__ __forceinline__ void xn_slots(XCtx<D, NB>& x, std::integer_sequence<int, Is...>)
 {
-    (xn_slot_body<D, NB, KB_C, Is, ABL, OPT, PF, DSTEP>(x), ...);
+    (xn_slot_body<D, NB, KB_C, Is, ABL, OPT, PF>(x), ...);
 }
 
-// DSTEP: -1, or the index of this step in its barrier group when the group's LDS-DMA is spread over the steps (XDmaPlan); then
-// dma / gj describe the group: the pieces go to the ring slots of stages gj + 2 .. gj + 4
-template <int D, int NB, int KB_C, int ABL = 0, bool OPT = false, bool PF = false, int DSTEP = -1>
+template <int D, int NB, int KB_C, int ABL = 0, bool OPT = false, bool PF = false>
 __device__ __forceinline__ bool xn_step(const char* v_lds, const char* k_nxt, int kb_n2, int k_row_off, int k_g, int v_lane_off,
                                         const bf16x8& ones_a, const bf16x8 (&qf)[NB][XShape<D, NB>::KS], f32x16 (&sc)[NB], f32x16 (&sn)[NB],
                                         f32x16 (&o)[NB][XShape<D, NB>::DB], BlockState (&st)[NB], float c, const float (&off)[NB],
-                                        bf16x8 (&kf)[XShape<D, NB>::KS], float (&lm)[NB], const TileDma<D, 4>* dma = nullptr, int gj = 0,
-                                        char* k_ring = nullptr, char* v_ring = nullptr)
+                                        bf16x8 (&kf)[XShape<D, NB>::KS], float (&lm)[NB])
 {
     XCtx<D, NB> x{ones_a, qf, sc, sn, o, st, off, kf, lm, c, k_nxt, kb_n2, k_row_off, k_g, (unsigned)(size_t)(lds_s16x4_t*)(v_lds + v_lane_off)};
     x.need = false;
-    if constexpr (DSTEP >= 0 && XDmaPlan<D, NB>::kSpread) {
-        using PL = XDmaPlan<D, NB>;
-        constexpr int T = Bf16Cfg<D, 4>::kTileBytes;
-        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        x.dma = dma;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int piece = PL::first(DSTEP) + k;
-            const int stage = gj + ((piece >> 1) == 0 ? 3 : (piece >> 1) == 1 ? 2 : (piece >> 1) == 2 ? 4 : 3);
-            const bool is_v = (piece >> 1) & 1;
-            const int chunk = piece & 1;   // chunk i of a wave is chunk (wave + 4 i) of the tile
-            x.dma_soff[k] = (unsigned)stage * dma->stage_step + (unsigned)chunk * dma->chunk_step;
-            x.dma_dst[k] = (is_v ? v_ring : k_ring) + (stage & 3) * T + (wave + chunk * 4) * 1024;
-        }
-    }
-    xn_slots<D, NB, KB_C, ABL, OPT, PF, DSTEP>(x, std::make_integer_sequence<int, XShape<D, NB>::kSlots>{});
+    xn_slots<D, NB, KB_C, ABL, OPT, PF>(x, std::make_integer_sequence<int, XShape<D, NB>::kSlots>{});
     // the K reads are at least a P.V group old: this wait is free, and it keeps every asm-issued load inside the basic block that
     // issued it (hipcc may move or spill a register across a branch without knowing a load is in flight)
     if constexpr (XShape<D, NB>::KS == 8)
@@ -610,16 +560,11 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
     // Top of stage j, j a multiple of G: K(j+1 .. j+G), V(j .. j+G-1) visible; K(j+G+1 .. j+2G), V(j+G .. j+2G-1) enqueued into the
     // ring slots nobody reads any more (K tiles are only read into kf one step ahead of their use, and every LDS read of
     // a wave has returned before it arrives at the barrier).
-    static_assert(NWAVES == 4, "XCtx carries a TileDma<D, 4>");
-    constexpr bool SPREAD = XDmaPlan<D, NB>::kSpread && G == 2 && NWAVES == 4 && !(ABL & 2048);   // ABL & 2048: the bunched form, for comparison
-    auto sync_only = [&]() {
+    auto sync_top = [&](int j) {
         if (!(ABL & 8)) {  // ABL & 8: timing-only ablation without the wait + barrier
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __syncthreads();
         }
-    };
-    auto sync_top = [&](int j) {
-        sync_only();
         if constexpr (ABL & 512) return;   // timing-only ablation: no LDS-DMA in the loop (the tiles of the prologue are reused)
 #pragma unroll
         for (int g = 1; g <= G; ++g)
@@ -711,38 +656,6 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
         prof_t0 = stamp();
         prof_r0 = __builtin_amdgcn_s_memrealtime();
     }
-    // one step of the fast loop; GS = its index in the barrier group when the group's DMA is spread over the steps
-    auto fast_step = [&](auto kb_c, auto gs_c, int j, int g, f32x16 (&sc)[NB], f32x16 (&sn)[NB]) -> bool {
-        constexpr int KB = decltype(kb_c)::value, GS = decltype(gs_c)::value;
-        const char* v_lds = v_slot(j + g);
-        const char* k_nxt = k_slot(j + g + 1);
-        if constexpr (SPREAD && !(ABL & 512))
-            return xn_step<D, NB, KB, ABL, OPT, PF, GS>(v_lds, k_nxt, KB, k_row_off, k_g, v_lane_off, ones_a, qf, sc, sn, o, st, c, off, kf, lm, &dma, j,
-                                                        k_ring, v_ring);
-        else
-            return xn_step<D, NB, KB, ABL, OPT, PF>(v_lds, k_nxt, KB, k_row_off, k_g, v_lane_off, ones_a, qf, sc, sn, o, st, c, off, kf, lm);
-    };
-    auto maybe_rescale = [&](bool need, bool live) {
-        if (!OPT && __builtin_expect(__any(need) && live, 0)) {
-            float mx[NB];
-#pragma unroll
-            for (int blk = 0; blk < NB; ++blk) mx[blk] = xhalf_max(lm[blk]);
-            xn_rescale<NB, DB, PF>(mx, c, st, o, off);
-        }
-    };
-    constexpr std::integral_constant<int, 0> I0{};
-    constexpr std::integral_constant<int, 1> I1{};
-    constexpr std::integral_constant<int, 2> I2{};
-    constexpr std::integral_constant<int, 3> I3{};
-    if constexpr (SPREAD) {
-        for (int j = 0; j < jf; j += 2) {
-            sync_only();
-            maybe_rescale(fast_step(I0, I0, j, 0, s0, s1), true);
-            maybe_rescale(fast_step(I1, I1, j, 0, s1, s0), 2 * j + 2 < nsub);
-            maybe_rescale(fast_step(I0, I2, j, 1, s0, s1), true);
-            maybe_rescale(fast_step(I1, I3, j, 1, s1, s0), 2 * (j + 1) + 2 < nsub);
-        }
-    } else
     for (int j = 0; j < jf; j += G) {
         sync_top(j);
 #pragma unroll

@@ -575,7 +575,7 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
                 case 45: return launch_bf16_x4(p, causal, out_f32, 22, stream);
                 case 46: return launch_bf16_x4(p, causal, out_f32, 23, stream);
                 case 47: return launch_bf16_x4(p, causal, out_f32, 24, stream);
-                case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69:
+                case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68:
                     return launch_bf16_x4(p, causal, out_f32, variant - 30, stream);   // cycle-stamped forms (fa_driver_ablation --mode prof4)
 #endif
 #if FA_ABLATION

@@ -30,7 +30,6 @@ hipError_t launch_bf16_x4_ablation(const FwdParams& p, int mode, hipStream_t str
     if (mode == 35) return launch_x4_ablation<1024 + 64>(p, stream);    // K fragments not re-read
     if (mode == 36) return launch_x4_ablation<1024 + 8>(p, stream);     // no DMA wait + barrier
     if (mode == 37) return launch_x4_ablation<1024 + 4>(p, stream);     // no waits for the V^T fragments
-    if (mode == 39) return launch_x4_ablation<1024 + 2048>(p, stream);  // LDS-DMA bunched behind the barrier (the round-1 form)
     if (mode == 38) return launch_x4_ablation<1024 + 512 + 16 + 8>(p, stream);   // no DMA, no LDS reads, no barrier: MFMA + VALU only
     return hipErrorInvalidValue;
 }
