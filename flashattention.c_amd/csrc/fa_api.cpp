@@ -98,14 +98,17 @@ fa::FwdParams make_params(const void* q, const void* k, const void* v, void* o, 
 // captured slot and serial: a verdict left by an earlier replay can only send a later one down the slower, more careful kernel.
 constexpr int kFlagSlots = 4096;
 __device__ uint32_t g_flag_ring[kFlagSlots];
+__device__ unsigned long long g_stat_ring[kFlagSlots][2];   // pre-pass maxima of the t3 chain, tagged with the call's serial (fa_cvt.hip)
 constexpr int kMaxDevices = 64;
 std::atomic<uint32_t*> g_ring_base[kMaxDevices];
+std::atomic<unsigned long long*> g_stat_base[kMaxDevices];
 std::atomic<bool> g_pool_tuned[kMaxDevices];
 std::atomic<uint32_t> g_serial{1};
 
 struct FlagRef {
     uint32_t* word = nullptr;
     uint32_t serial = 0;
+    unsigned long long* stats = nullptr;   // two 64-bit words of the same slot
 };
 thread_local FlagRef t_last_flag;   // chain state of this thread's most recent forward (fa_last_forward_route)
 thread_local int t_last_chain = 0;  // 0 = no chain, 1 = fp32 guard, 2 = fp16-P
@@ -126,12 +129,16 @@ bool next_flag(FlagRef& f)
         void* sym = nullptr;
         if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_flag_ring)) != hipSuccess || sym == nullptr) return false;
         base = static_cast<uint32_t*>(sym);
+        void* sym2 = nullptr;
+        if (hipGetSymbolAddress(&sym2, HIP_SYMBOL(g_stat_ring)) != hipSuccess || sym2 == nullptr) return false;
+        g_stat_base[dev].store(static_cast<unsigned long long*>(sym2), std::memory_order_release);
         g_ring_base[dev].store(base, std::memory_order_release);
     }
     uint32_t serial = g_serial.fetch_add(1, std::memory_order_relaxed);
     if (serial == 0) serial = g_serial.fetch_add(1, std::memory_order_relaxed);   // 0 is the ring's initial content
     f.word = base + serial % kFlagSlots;
     f.serial = serial;
+    f.stats = g_stat_base[dev].load(std::memory_order_acquire) + 2 * (size_t)(serial % kFlagSlots);
     return true;
 }
 
@@ -194,6 +201,51 @@ int launch_p16_chain(const fa::FwdParams& p0, int32_t d, int32_t causal, int32_t
     t_last_chain = 2;
     return FA_OK;
 }
+
+#if FA_ABLATION
+// fp32 tensors, long non-causal rows at head dim 64: K / V split once per launch into stream-ordered scratch (the same pass bounds the
+// logit width), then the static-slot three-product kernel; guard, range or finiteness trouble raises the flag -> exact kernel.
+// The pre-pass moves 2.5 x sizeof(K + V) + sizeof(Q) through HBM (~40 us at c3).
+// The experimental three-product kernel of fa_f32_t3_kernel.h (ablation library only; FA_KERNEL_SPLIT tilings 8 = guarded chain with the exact
+// kernel as fallback, 9 = the kernel alone, 16 + a = timing-only ablation a of the kernel alone)
+int launch_f32_t3_chain(const fa::FwdParams& p0, int32_t d, hipStream_t stream, bool guarded, int abl)
+{
+    FlagRef f;
+    if (!next_flag(f)) return fail(FA_ERR_HIP, "no device flag ring (hipGetSymbolAddress failed)");
+    const int64_t count = (int64_t)p0.bh * p0.n * d;
+    void* scratch = nullptr;
+    hipError_t e = scratch_alloc(&scratch, (size_t)count * 8u, stream);   // four bf16 arrays
+    if (e != hipSuccess) return fail(FA_ERR_HIP, "hipMallocAsync(%zu bytes) for the split K / V failed: %s", (size_t)count * 8u, hipGetErrorString(e));
+    e = fa::launch_t3_prepass(p0.q, p0.k, p0.v, scratch, count, p0.scale_log2e, f.stats, f.serial, stream);
+    if (e == hipSuccess) {
+        fa::FwdParams p = p0;
+        char* s = static_cast<char*>(scratch);
+        p.k = s;
+        p.k_lo = s + count * 2;
+        p.v = s + count * 4;
+        p.v_lo = s + count * 6;
+        p.stats = f.stats;
+        p.flag = f.word;
+        p.flag_serial = f.serial;
+        p.flag_mode = guarded ? 3 : 0;
+        e = fa::launch_f32_t3(p, abl, stream);
+    }
+    if (e == hipSuccess && guarded) {
+        fa::FwdParams p = p0;
+        p.flag = f.word;
+        p.flag_serial = f.serial;
+        p.flag_mode = 2;
+        e = fa::launch_fwd_f32(p, d, 0, 0, stream);
+    }
+    const hipError_t ef = hipFreeAsync(scratch, stream);
+    if (e == hipSuccess) e = ef;
+    if (e != hipSuccess) return fail(FA_ERR_HIP, "fp32 three-product launch chain failed: %s", hipGetErrorString(e));
+    t_last_flag = f;
+    t_last_chain = 1;
+    return FA_OK;
+}
+
+#endif
 
 // fp32 tensors, FA_KERNEL_AUTO: split kernel with the logit-width guard, exact kernel as the conditional fallback
 int launch_f32_guarded(const fa::FwdParams& p0, int32_t d, int32_t causal, hipStream_t stream)
@@ -260,6 +312,12 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
             e = fa::launch_fwd_f32(p, d, causal ? 1 : 0, sel.variant, stream);       // exact fp32 arithmetic
         } else if (sel.kind == FA_KERNEL_AUTO && sel.variant == 0) {
             return launch_f32_guarded(p, d, causal, stream);                         // split products behind the logit-width guard
+#if FA_ABLATION
+        } else if (sel.kind == FA_KERNEL_SPLIT && sel.variant >= 8 && sel.variant < 32) {   // the experimental three-product kernel
+            if (!fa::f32_t3_supported(p, d, causal))
+                return fail(FA_ERR_UNSUPPORTED, "fa_fwd_f32_t3_kernel covers head dim 64, non-causal, N a multiple of 64, plain layout");
+            return launch_f32_t3_chain(p, d, stream, sel.variant == 8, sel.variant >= 16 ? sel.variant - 16 : 0);
+#endif
         } else {
             e = fa::launch_f32_split(p, d, causal ? 1 : 0, sel.variant, stream);     // SPLIT: fp32 tensors on the bf16 pipe, unguarded
         }
@@ -465,7 +523,10 @@ const char* fa_version(void)
 const char* fa_kernel_name_for(int32_t dtype, int32_t d, int32_t causal, int64_t bh, int64_t n)
 {
     if (!head_dim_supported(d) || bh < 1 || n < 1) return nullptr;
-    if (dtype == FA_DTYPE_F32) return f32_auto_is_exact() ? "fa_fwd_f32_kernel" : "fa_fwd_f32_split_kernel";
+    if (dtype == FA_DTYPE_F32) {
+        if (f32_auto_is_exact()) return "fa_fwd_f32_kernel";
+        return "fa_fwd_f32_split_kernel";
+    }
     if (dtype == FA_DTYPE_BF16) return fa::bf16_kernel_name(bh, n, d, causal);
     if (dtype == FA_DTYPE_BF16_OUT_F32) {   // the accurate P (see fa_dtype): fp16 (slabs below 4 GiB, launches large enough), hi + lo bf16 terms otherwise
         if (((n - 1) * d + d) * 2 >= 0xffffffffLL) return "fa_fwd_f32_split_kernel";

@@ -54,6 +54,10 @@ struct FwdParams {
     uint32_t* flag;
     uint32_t flag_serial;
     int32_t flag_mode;
+    // fa_fwd_f32_t3_kernel only: the low bf16 terms of the pre-split K and V (p.k / p.v hold the high terms) and the pre-pass maxima
+    const void* k_lo;
+    const void* v_lo;
+    const unsigned long long* stats;   // [0] (serial << 32) | bits of max |k|,  [1] (serial << 32) | bits of max |q * scale * log2 e|_2^2
 };
 
 // Early exit of a conditionally launched kernel (wave-uniform scalar load; see FwdParams::flag_mode).

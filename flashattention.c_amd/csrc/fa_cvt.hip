@@ -41,4 +41,98 @@ hipError_t launch_cvt_v_f16(const void* src, void* dst, int64_t count, uint32_t*
     return hipGetLastError();
 }
 
+#if FA_ABLATION
+// ---- pre-pass of fa_fwd_f32_t3_kernel (fa_f32_t3_kernel.h, ablation library only): fp32 K, V -> two-term bf16 splits, once per launch ----
+// x_hi = bf16(x) (round to nearest even), x_lo = bf16(x - x_hi): 16 significant bits, fp32 exponent range.  Dense (bh, n, d) outputs.
+// The same pass bounds what the logit-width guard needs: max |k| over the launch and max |q * scale * log2 e|_2^2 over all query rows,
+// each folded into one 64-bit word by atomicMax with this call's serial number in the upper half (a word of the per-device ring never
+// needs clearing: a newer call's values always compare greater than an older call's).
+__device__ __forceinline__ void split_store8(const f32x4& a, const f32x4& b, u32x4* hi_dst, u32x4* lo_dst)
+{
+    bf16x8 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = (__bf16)a[i];
+        h[i + 4] = (__bf16)b[i];
+        l[i] = (__bf16)(a[i] - (float)h[i]);
+        l[i + 4] = (__bf16)(b[i] - (float)h[i + 4]);
+    }
+    *hi_dst = __builtin_bit_cast(u32x4, h);
+    *lo_dst = __builtin_bit_cast(u32x4, l);
+}
+__device__ __forceinline__ float wave_max_f(float x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, 64));
+    return x;
+}
+// fmaxf drops a NaN operand: fold |x| through its bit pattern instead (NaN and inf compare above every finite value)
+__device__ __forceinline__ unsigned absbits_max(unsigned m, float x) { const unsigned b = __float_as_uint(x) & 0x7fffffffu; return b > m ? b : m; }
+
+// one device atomic per WORKGROUP (every wave's own atomic on one word serialises at ~12 ns each: 8192 waves = 100 us)
+__device__ __forceinline__ void block_max_to(unsigned long long* word, uint32_t serial, unsigned m)
+{
+    __shared__ unsigned s_m;
+    if (threadIdx.x == 0) s_m = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(&s_m, m);
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(word, ((unsigned long long)serial << 32) | s_m);
+}
+
+__global__ __launch_bounds__(256) void fa_split_kv_kernel(const f32x4* __restrict__ k, const f32x4* __restrict__ v, u32x4* __restrict__ khi,
+                                                          u32x4* __restrict__ klo, u32x4* __restrict__ vhi, u32x4* __restrict__ vlo, int64_t groups,
+                                                          unsigned long long* stats, uint32_t serial)
+{
+    unsigned kmax = 0u;   // bits of max |k|
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 k0 = __builtin_nontemporal_load(k + 2 * i), k1 = __builtin_nontemporal_load(k + 2 * i + 1);
+        const f32x4 v0 = __builtin_nontemporal_load(v + 2 * i), v1 = __builtin_nontemporal_load(v + 2 * i + 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) kmax = absbits_max(absbits_max(kmax, k0[e]), k1[e]);
+        split_store8(k0, k1, khi + i, klo + i);
+        split_store8(v0, v1, vhi + i, vlo + i);
+    }
+    block_max_to(stats, serial, kmax);
+}
+
+// max over all query rows of |q * c|_2^2, d = 64: sixteen consecutive lanes hold one row (a float4 each)
+__global__ __launch_bounds__(256) void fa_qnorm_d64_kernel(const f32x4* __restrict__ q, int64_t quads, float c, unsigned long long* stats, uint32_t serial)
+{
+    unsigned best = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 x = __builtin_nontemporal_load(q + i) * c;
+        float s = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);   // quads is a multiple of 16 and the stride a multiple of 64: rows never straddle
+        best = absbits_max(best, s);
+    }
+    block_max_to(stats + 1, serial, best);
+}
+
+// k, v: (bh, n, 64) fp32 contiguous; scratch: 4 * count bf16 elements (K_hi | K_lo | V_hi | V_lo); q: (bh, n, 64) fp32 contiguous
+hipError_t launch_t3_prepass(const void* q, const void* k, const void* v, void* scratch, int64_t count, float scale_log2e, unsigned long long* stats,
+                             uint32_t serial, hipStream_t stream)
+{
+    const int64_t groups = count / 8;
+    if (groups < 1 || count % 64 != 0) return hipErrorInvalidValue;
+    __bf16* s = static_cast<__bf16*>(scratch);
+    const int64_t want = (groups + 255) / 256;
+    const unsigned grid = (unsigned)(want < 1024 ? want : 1024);
+    hipLaunchKernelGGL(fa_split_kv_kernel, dim3(grid), dim3(256), 0, stream, (const f32x4*)k, (const f32x4*)v, (u32x4*)s, (u32x4*)(s + count),
+                       (u32x4*)(s + 2 * count), (u32x4*)(s + 3 * count), groups, stats, serial);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int64_t quads = count / 4, wantq = (quads + 255) / 256;
+    hipLaunchKernelGGL(fa_qnorm_d64_kernel, dim3((unsigned)(wantq < 1024 ? wantq : 1024)), dim3(256), 0, stream, (const f32x4*)q, quads, scale_log2e, stats, serial);
+    return hipGetLastError();
+}
+
+#endif   // FA_ABLATION
+
 }  // namespace fa

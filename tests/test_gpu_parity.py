@@ -816,6 +816,21 @@ def test_long_sequences_and_many_slabs_against_rung0(bh, n, d):
         del ref, o, refb, ob, oa
 
 
+def test_experimental_three_product_kernel_in_the_ablation_library():
+    """fa_fwd_f32_t3_kernel (pre-split K / V + static-slot three-product kernel; no faster than the split kernel yet,
+    so it lives in the ablation library): its guarded chain and the kernel alone against the rung-0 kernel, through the C driver."""
+    import json
+    drv = os.path.join(ROOT, "flashattention.c_amd", "fa_driver_ablation")
+    if not os.path.exists(drv):
+        pytest.skip("ablation library not built (python flashattention.c_amd/build.py --ablation)")
+    for variant in (8, 9):
+        r = subprocess.run([drv, "--mode", "rand", "--bh", "3", "--n", "4160", "--d", "64", "--dtype", "f32s", "--variant", str(variant), "--iters", "2"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        assert j["nan"] == 0 and j["max_abs_err_vs_naive"] < TOL_F32, j
+
+
 def test_c_driver_known_answer():
     """The torch-less driver (test.cu counterpart) on its iota/ones workload."""
     drv = os.path.join(ROOT, "flashattention.c_amd", "fa_driver")
