@@ -9,14 +9,15 @@
 //     bf16 kernels -- no VALU, no VGPR round trip;
 //   * every MFMA is asm with its register files chosen (scores -> VGPRs, O and the Q' fragments -> AGPRs) and sits in a static slot
 //     with its share of the VALU work: per 32-key step and wave 48 MFMAs (24 K.Q'^T, 24 P.V) against 32 exp + 32 adds + 16
-//     hi/lo splits of P -- the loop is bound by the matrix pipe, not by instruction issue;
+//     hi/lo splits of P -- the intent was a loop bound by the matrix pipe; measured, it is bound by instruction issue (see below);
 //   * the softmax is the reference-free optimistic one of the split kernel's fast pass: p = exp2(s) with s already in the exp2
 //     domain (Q' = Q * scale * log2 e), fp32 row sums on the VALU.  A row sum outside (2^-100, 2^100) or a non-finite output RAISES
 //     THE LAUNCH CHAIN'S FLAG instead of being redone here: the exact fp32 kernel queued behind recomputes the launch (fa_api.cpp).
 // Scope (everything else stays with fa_split_kernel.h): head dim 64, non-causal, N a multiple of 64, plain (BH, N, d) layout.
 //
 //   step t (32 keys, 48 MFMA slots):  K.Q'^T of sub-tile t+1: 4 k-steps x 3 terms x blocks A, B (24)  |  P.V of A: 12  |  P.V of B: 12
-//   V^T fragments (hi and lo) read in slots 0..7, waited for in front of slot 24; K fragments (hi and lo) of step t+1 read in slots 24..31.
+//   V^T fragments (hi and lo) read in slots 0..7, waited for in front of slot 24; K_lo fragments of THIS step's scores read in slots 0..3
+//   (waited for in front of slot 4), K_hi fragments of step t+1 in slots 24..27.
 #pragma once
 #include "fa_bf16_xn_kernel.h"
 #include "fa_split_kernel.h"   // split2 / split8: the two-term bf16 split
@@ -28,7 +29,7 @@ constexpr float kT3Limit = 0x1p100f;
 // ---- static schedule ---------------------------------------------------------------------------------------------------------
 struct T3Slot {
     int kind;  // 0 = K.Q'^T, 1 = P.V
-    int blk, idx, term;   // K.Q'^T: idx = k-step;  P.V: idx = V^T fragment v = tt * 2 + db.   term 0: lo.hi, 1: hi.lo, 2: hi.hi
+    int blk, idx, term;   // K.Q'^T: idx = k-step, term 0: K_hi.Q_lo, 1: K_hi.Q_hi, 2: K_lo.Q_hi;  P.V: idx = V^T fragment v = tt * 2 + db, term 0: V_lo.P_hi, 1: V_hi.P_lo, 2: V_hi.P_hi
 };
 __device__ __host__ constexpr T3Slot t3_slot(int i)
 {
@@ -38,29 +39,59 @@ __device__ __host__ constexpr T3Slot t3_slot(int i)
     return {1, blk, pair * 2 + r % 2, r / 2};
 }
 constexpr int kT3Slots = 48;
-// VALU units: kind 0 = exp2 + row-sum add of one score, kind 1 = hi/lo split of one pair of P values.  Block A first, then B; a split
-// follows its second exponential two units later (the transcendental's result needs a wait state before a plain VALU reads it).
+// VALU work as single instructions ("micro-ops"), dealt over the MFMA slots by issue cost.  Per pair q of P values of a block (scores
+// 2q, 2q+1 -> p0, p1 -> hi / lo bf16 pairs): E0 E1 (v_exp_f32), A0 A1 (row-sum adds), H (v_cvt_pk_bf16_f32: the hi pair), U0 U1 (hi back
+// to fp32: shift / mask), D0 D1 (p - hi), L (v_cvt_pk_bf16_f32: the lo pair).  Software-pipelined over the pairs so that no instruction
+// but L follows its producer directly:
+//     E0(q) E1(q) U0(q-1) U1(q-1) A0(q) A1(q) H(q) D0(q-1) D1(q-1) L(q-1)
+// Each is one asm volatile statement: the order below IS the issue order.
+//
+// What this construction showed (profiles/ubench/ubench_valu_mix.hip, profiles/r02_ubench_valu_mix.txt): with one wave per SIMD an
+// instruction of any kind issues every ~5.3 cycles (v_exp_f32 9.1, v_cvt_pk_bf16_f32 8.1, even s_nop 4.7), an MFMA costs ~11 cycles of
+// issue on top of its 32 cycles of pipe, and packed fp32 adds do not overlap an MFMA at all (4 v_pk_add_f32 beside one MFMA: 62 cycles).
+// Per step that is 16 pairs x 67 cycles of split/exp work + 48 x 11 cycles of MFMA issue + ~240 cycles of LDS reads and addresses + the
+// s_nop hipcc pads between dependent asm statements (~40 x 4.7) ~= 2000-2100 cycles against 1536 cycles of matrix pipe: THE LOOP IS
+// BOUND BY INSTRUCTION ISSUE, NOT BY THE PIPE, and lands where the compiler-scheduled split kernel (several waves per SIMD) already
+// is.  Variants measured on the way, all correct (2.4e-4 at c3), relative to the split kernel on the same box: units of 12-24 cycles
+// as builtins 1.04x its time; this form 0.98x; score blocks pinned to fixed registers with packed adds in two-instruction chunks
+// 1.07x; the same in four-instruction chunks 1.07x.
+enum T3Op { kE0, kE1, kA0, kA1, kH, kU0, kU1, kD0, kD1, kL };
 struct T3Unit {
-    int kind, blk, idx, cost;
+    int op, blk, q, cost;
 };
+constexpr int kT3Units = 2 * 8 * 10;
 struct T3UnitList {
-    T3Unit u[48];
+    T3Unit u[kT3Units];
 };
 __device__ __host__ constexpr T3UnitList t3_make_units()
 {
     T3UnitList l{};
     int n = 0;
     for (int b = 0; b < 2; ++b) {
-        for (int e = 0; e < 16; ++e) {
-            l.u[n++] = {0, b, e, 12};
-            if ((e & 1) == 1 && e >= 3) l.u[n++] = {1, b, (e - 3) / 2, 24};   // pair q is split behind the exponential of element 2 q + 3
+        for (int q = 0; q <= 8; ++q) {
+            if (q < 8) {
+                l.u[n++] = {kE0, b, q, 9};
+                l.u[n++] = {kE1, b, q, 9};
+            }
+            if (q > 0) {
+                l.u[n++] = {kU0, b, q - 1, 5};
+                l.u[n++] = {kU1, b, q - 1, 5};
+            }
+            if (q < 8) {
+                l.u[n++] = {kA0, b, q, 5};
+                l.u[n++] = {kA1, b, q, 5};
+                l.u[n++] = {kH, b, q, 8};
+            }
+            if (q > 0) {
+                l.u[n++] = {kD0, b, q - 1, 5};
+                l.u[n++] = {kD1, b, q - 1, 5};
+                l.u[n++] = {kL, b, q - 1, 8};
+            }
         }
-        l.u[n++] = {1, b, 7, 24};   // the last pair: one unit behind its second exponential
     }
     return l;
 }
-constexpr int kT3Units = 48;
-constexpr int kT3Wend = 34;   // all VALU work is dealt out over the first 34 slots: block B's P is complete before its first P.V slot (36)
+constexpr int kT3Wend = 40;   // block B's second P fragment is first read in slot 42, its first in slot 36 (checked below)
 struct T3Table {
     int ub[kT3Slots + 1];
 };
@@ -73,7 +104,7 @@ __device__ __host__ constexpr T3Table t3_make_table()
     int n = 0, cum_next = l.u[0].cost;
     for (int i = 0; i <= kT3Slots; ++i) {
         const int wb = i < kT3Wend ? i : kT3Wend;
-        const int target = total * wb / kT3Wend + 6;
+        const int target = total * wb / kT3Wend + 2;
         while (n < kT3Units && cum_next <= target) {
             ++n;
             if (n < kT3Units) cum_next += l.u[n].cost;
@@ -83,61 +114,72 @@ __device__ __host__ constexpr T3Table t3_make_table()
     t.ub[kT3Slots] = kT3Units;
     return t;
 }
-// the unit that completes P fragment f (8 values = pairs 4f .. 4f+3) of block b
+// the micro-op that completes P fragment f (8 values = pairs 4f .. 4f+3) of block b: the L of its last pair
 __device__ __host__ constexpr int t3_frag_done_unit(int b, int f)
 {
     const T3UnitList l = t3_make_units();
     int last = -1;
     for (int u = 0; u < kT3Units; ++u)
-        if (l.u[u].kind == 1 && l.u[u].blk == b && l.u[u].idx / 4 == f) last = u;
+        if (l.u[u].op == kL && l.u[u].blk == b && l.u[u].q / 4 == f) last = u;
     return last;
 }
-// static checks of the schedule: every P fragment is complete at least one whole slot before the first MFMA that reads it
+// static check of the schedule: every P fragment is complete at least one whole slot before the first MFMA that reads it (a VALU result
+// needs two wait states before an MFMA may read it, and hipcc pads nothing in front of an asm MFMA)
 __device__ __host__ constexpr bool t3_schedule_ok()
 {
     const T3Table t = t3_make_table();
     for (int i = 24; i < kT3Slots; ++i) {
         const T3Slot s = t3_slot(i);
-        const int f = s.idx / 2;
-        if (t3_frag_done_unit(s.blk, f) >= t.ub[i - 1]) return false;   // must have been issued before slot i - 1 ends ... i.e. in slots < i - 1
+        if (t3_frag_done_unit(s.blk, s.idx / 2) >= t.ub[i - 1]) return false;
     }
     return true;
 }
-static_assert(t3_schedule_ok(), "a P fragment is split too late for its first P.V slot");
+static_assert(t3_schedule_ok(), "a P fragment is completed too late for its first P.V slot");
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 struct T3Ctx {
     const bf16x8 (&qh)[2][4];
     const bf16x8 (&ql)[2][4];
     f32x16 (&sc)[2];
     f32x16 (&sn)[2];
     f32x16 (&o)[2][2];
-    float (&la)[2];
-    float (&lb)[2];
+    f32x2_t (&lsum)[2];   // the two running row sums of a block (even / odd scores), as one packed pair
     bf16x8 (&kfh)[4];
     bf16x8 (&kfl)[4];
-    const char* kh_nxt;   // K_hi tile the fragments of the step after next come from (K_lo at + lo_off)
-    int kb_n2, k_row_off, k_g, lo_off_k;
+    const char* kh_nxt;   // K_hi tile the (hi) fragments of the step after next come from
+    const char* kl_cur;   // K_lo tile of the sub-tile whose scores THIS step produces (its fragments are read in slots 0..3, used from slot 4 on)
+    int kb_n2, kb_cur, k_row_off, k_g;
     unsigned vh_addr, vl_addr;
     s16x4 vlo[8], vhi[8];   // fragments 0..3: V_hi, 4..7: V_lo
     bf16x8 vf[8];
-    bf16x8 ph[2][2], pl[2][2];
+    u32x4_t ph[2][2], pl[2][2];   // P_hi / P_lo fragments, one packed bf16 pair per element
+    // vector types, not arrays: element access at a constant index is then a register by construction (arrays of a struct that is
+    // passed by reference through the fold expressions were left in scratch memory)
+    f32x16 t[2];          // hi back in fp32, then p - hi (between U and L): elements 2q, 2q+1
 };
 
 template <int U>
 __device__ __forceinline__ void t3_unit(T3Ctx& x)
 {
     constexpr T3Unit un = t3_make_units().u[U];
-    if constexpr (un.kind == 0) {
-        const float pv = fast_exp2(x.sc[un.blk][un.idx]);
-        x.sc[un.blk][un.idx] = pv;
-        if constexpr ((un.idx & 1) == 0) x.la[un.blk] += pv;
-        else x.lb[un.blk] += pv;
-    } else {
-        constexpr int q = un.idx, f = q / 4, pos = (2 * q) % 8;
-        bf16x2 h2, l2;
-        split2(x.sc[un.blk][2 * q], x.sc[un.blk][2 * q + 1], h2, l2);
-        x.ph[un.blk][f][pos] = h2[0], x.ph[un.blk][f][pos + 1] = h2[1];
-        x.pl[un.blk][f][pos] = l2[0], x.pl[un.blk][f][pos + 1] = l2[1];
+    constexpr int b = un.blk, q = un.q, f = q / 4, e = q % 4;
+    if constexpr (un.op == kE0) asm volatile("v_exp_f32 %0, %0" : "+v"(x.sc[b][2 * q]));
+    else if constexpr (un.op == kE1) asm volatile("v_exp_f32 %0, %0" : "+v"(x.sc[b][2 * q + 1]));
+    else if constexpr (un.op == kA0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x.lsum[b][0]) : "v"(x.sc[b][2 * q]));
+    else if constexpr (un.op == kA1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x.lsum[b][1]) : "v"(x.sc[b][2 * q + 1]));
+    else if constexpr (un.op == kH) {
+        unsigned h;
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h) : "v"(x.sc[b][2 * q]), "v"(x.sc[b][2 * q + 1]));
+        x.ph[b][f][e] = h;
+    } else if constexpr (un.op == kU0) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(x.t[b][2 * q]) : "v"(x.ph[b][f][e]));
+    else if constexpr (un.op == kU1) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(x.t[b][2 * q + 1]) : "v"(x.ph[b][f][e]));
+    else if constexpr (un.op == kD0) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(x.t[b][2 * q]) : "v"(x.sc[b][2 * q]));
+    else if constexpr (un.op == kD1) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(x.t[b][2 * q + 1]) : "v"(x.sc[b][2 * q + 1]));
+    else {
+        unsigned l;
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l) : "v"(x.t[b][2 * q]), "v"(x.t[b][2 * q + 1]));
+        x.pl[b][f][e] = l;
     }
 }
 template <int U0, int... Us>
@@ -161,28 +203,33 @@ __device__ __forceinline__ void t3_slot_body(T3Ctx& x)
         for (int v = 0; v < 8; ++v) x.vf[v] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(x.vlo[v], x.vhi[v], 0, 1, 2, 3, 4, 5, 6, 7));
     }
     if constexpr (ABL & 4) { if constexpr (I < 8) asm volatile("" : "=v"(x.vlo[I]), "=v"(x.vhi[I])); }
-    else if constexpr (I < 4) load_v_frag_asm<D, KB_C, I>(x.vh_addr, x.vlo[I], x.vhi[I]);
-    else if constexpr (I < 8) load_v_frag_asm<D, KB_C, I - 4>(x.vl_addr, x.vlo[I], x.vhi[I]);
+    else if constexpr (I < 4) {
+        load_v_frag_asm<D, KB_C, I>(x.vh_addr, x.vlo[I], x.vhi[I]);
+        const unsigned a = (unsigned)(size_t)(lds_s16x4_t*)(x.kl_cur + x.k_row_off + x.kb_cur * 32 * (2 * D) + (((2 * I) ^ x.k_g) * 16));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(x.kfl[I]) : "v"(a));
+    } else if constexpr (I < 8) {
+        load_v_frag_asm<D, KB_C, I - 4>(x.vl_addr, x.vlo[I], x.vhi[I]);
+    }
     // a VALU result needs two wait states before an MFMA reads it; the schedule check above keeps a whole slot between a split and its
     // first reader, so no padding is needed here
     if constexpr (ABL & 1) {
     } else if constexpr (sl.kind == 0) {
-        const bf16x8& a = sl.term == 0 ? x.kfl[sl.idx] : x.kfh[sl.idx];
-        const bf16x8& b = sl.term == 1 ? x.ql[sl.blk][sl.idx] : x.qh[sl.blk][sl.idx];
+        const bf16x8& a = sl.term == 2 ? x.kfl[sl.idx] : x.kfh[sl.idx];
+        const bf16x8& b = sl.term == 0 ? x.ql[sl.blk][sl.idx] : x.qh[sl.blk][sl.idx];
+        if constexpr (I == 4 && !(ABL & 4))   // the K_lo fragments were read in slots 0..3 (LDS returns in order; this slot's two V^T reads are behind them)
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(x.kfl[0]), "+v"(x.kfl[1]), "+v"(x.kfl[2]), "+v"(x.kfl[3]));
         if constexpr (sl.idx == 0 && sl.term == 0) mfma_s_first(x.sn[sl.blk], a, b);
         else mfma_s(x.sn[sl.blk], a, b);
     } else {
         constexpr int v = sl.idx, f = v / 2, db = v % 2;
         const bf16x8& a = sl.term == 0 ? x.vf[4 + v] : x.vf[v];
-        const bf16x8& b = sl.term == 1 ? x.pl[sl.blk][f] : x.ph[sl.blk][f];
+        const bf16x8 b = __builtin_bit_cast(bf16x8, sl.term == 1 ? x.pl[sl.blk][f] : x.ph[sl.blk][f]);
         mfma_o<false>(x.o[sl.blk][db], a, b);
     }
-    if constexpr (I >= 24 && I < 32) {   // K fragments of the step after next: hi in slots 24..27, lo in 28..31
-        constexpr int ks = (I - 24) % 4;
-        constexpr bool lo = I >= 28;
-        const unsigned a = (unsigned)(size_t)(lds_s16x4_t*)(x.kh_nxt + (lo ? x.lo_off_k : 0) + x.k_row_off + x.kb_n2 * 32 * (2 * D) + (((2 * ks) ^ x.k_g) * 16));
-        if constexpr (ABL & 4) { if constexpr (lo) asm volatile("" : "+v"(x.kfl[ks]) : "v"(a)); else asm volatile("" : "+v"(x.kfh[ks]) : "v"(a)); }
-        else if constexpr (lo) asm volatile("ds_read_b128 %0, %1" : "=v"(x.kfl[ks]) : "v"(a));
+    if constexpr (I >= 24 && I < 28) {   // K_hi fragments of the step after next (K_lo: read by that step itself, slots 0..3)
+        constexpr int ks = I - 24;
+        const unsigned a = (unsigned)(size_t)(lds_s16x4_t*)(x.kh_nxt + x.k_row_off + x.kb_n2 * 32 * (2 * D) + (((2 * ks) ^ x.k_g) * 16));
+        if constexpr (ABL & 4) asm volatile("" : "+v"(x.kfh[ks]) : "v"(a));
         else asm volatile("ds_read_b128 %0, %1" : "=v"(x.kfh[ks]) : "v"(a));
     }
     if constexpr (!(ABL & 2)) t3_units<tab.ub[I]>(x, std::make_integer_sequence<int, tab.ub[I + 1] - tab.ub[I]>{});
@@ -196,15 +243,15 @@ __device__ __forceinline__ void t3_slots(T3Ctx& x, std::integer_sequence<int, Is
 
 // lo_off_k / lo_off_v: byte distance from the K_hi (V_hi) ring to the K_lo (V_lo) ring
 template <int KB_C, int ABL = 0>
-__device__ __forceinline__ void t3_step(const char* vh_lds, int lo_off_v, const char* kh_nxt, int lo_off_k, int kb_n2, int k_row_off, int k_g, int v_lane_off,
+__device__ __forceinline__ void t3_step(const char* vh_lds, int lo_off_v, const char* kh_nxt, const char* kl_cur, int kb_cur, int kb_n2, int k_row_off, int k_g, int v_lane_off,
                                         const bf16x8 (&qh)[2][4], const bf16x8 (&ql)[2][4], f32x16 (&sc)[2], f32x16 (&sn)[2], f32x16 (&o)[2][2],
-                                        float (&la)[2], float (&lb)[2], bf16x8 (&kfh)[4], bf16x8 (&kfl)[4])
+                                        f32x2_t (&lsum)[2], bf16x8 (&kfh)[4], bf16x8 (&kfl)[4])
 {
-    T3Ctx x{qh, ql, sc, sn, o, la, lb, kfh, kfl, kh_nxt, kb_n2, k_row_off, k_g, lo_off_k,
+    T3Ctx x{qh, ql, sc, sn, o, lsum, kfh, kfl, kh_nxt, kl_cur, kb_n2, kb_cur, k_row_off, k_g,
             (unsigned)(size_t)(lds_s16x4_t*)(vh_lds + v_lane_off), (unsigned)(size_t)(lds_s16x4_t*)(vh_lds + lo_off_v + v_lane_off)};
     t3_slots<KB_C, ABL>(x, std::make_integer_sequence<int, kT3Slots>{});
     // the K reads are sixteen slots old: this wait is free, and it keeps every asm-issued load inside the basic block that issued it
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kfh[0]), "+v"(kfh[1]), "+v"(kfh[2]), "+v"(kfh[3]), "+v"(kfl[0]), "+v"(kfl[1]), "+v"(kfl[2]), "+v"(kfl[3]));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kfh[0]), "+v"(kfh[1]), "+v"(kfh[2]), "+v"(kfh[3]));
 }
 
 // p.k / p.v: K_hi / V_hi (dense (bh, n, 64) bf16); p.k_lo / p.v_lo: the low terms; p.stats: {max |k| word, max |q'|^2 word} of the pre-pass
@@ -215,7 +262,10 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_f32_t3_kernel(FwdParams p)
     using C = Bf16Cfg<D, NWAVES>;
     constexpr int T = C::kTileBytes, R = 2 * G, BM = NWAVES * 32 * NB;
     static_assert(G == 2, "ring arithmetic written for a barrier every two stages");
-    __shared__ __attribute__((aligned(1024))) char smem[4 * R * T];   // K_hi | K_lo | V_hi | V_lo rings of R stages
+    // K_hi | K_lo | V_hi | V_lo rings.  The K_lo fragments are read by the step that uses them (sixteen VGPRs less across the P.V phase), so a
+    // K_lo tile lives one step longer than its K_hi tile -- into the stage at whose top the DMA of the tile 2G stages ahead is enqueued:
+    // the K_lo ring has 2R slots.  5 R T = 160 KiB: the whole LDS of the CU.
+    __shared__ __attribute__((aligned(1024))) char smem[5 * R * T];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -248,9 +298,11 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_f32_t3_kernel(FwdParams p)
     const int nst = n / kKvBlk;   // n is a multiple of 64 (checked by the launcher)
 
     char* const kh_ring = smem;
-    constexpr int LO_K = R * T, LO_V = R * T;   // K_lo ring right behind K_hi, V_lo right behind V_hi
-    char* const vh_ring = smem + 2 * R * T;
+    char* const kl_ring = smem + R * T;
+    constexpr int LO_V = R * T;   // V_lo ring right behind V_hi
+    char* const vh_ring = smem + 3 * R * T;
     auto kh_slot = [&](int j) { return kh_ring + (j & (R - 1)) * T; };
+    auto kl_slot = [&](int j) { return kl_ring + (j & (2 * R - 1)) * T; };
     auto vh_slot = [&](int j) { return vh_ring + (j & (R - 1)) * T; };
 
     TileDma<D, NWAVES> dh, dl;
@@ -258,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_f32_t3_kernel(FwdParams p)
     dl.init(klg, vlg, n, D, wave, lane);
     auto issue_k = [&](int j) {
         dh.issue_k((unsigned)j * dh.stage_step, kh_slot(j), wave);
-        dl.issue_k((unsigned)j * dl.stage_step, kh_slot(j) + LO_K, wave);
+        dl.issue_k((unsigned)j * dl.stage_step, kl_slot(j), wave);
     };
     auto issue_v = [&](int j) {
         dh.issue_v((unsigned)j * dh.stage_step, vh_slot(j), wave);
@@ -291,10 +343,10 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_f32_t3_kernel(FwdParams p)
     asm volatile("s_nop 4" : "+a"(ql[0][0]), "+a"(ql[0][1]), "+a"(ql[0][2]), "+a"(ql[0][3]), "+a"(ql[1][0]), "+a"(ql[1][1]), "+a"(ql[1][2]), "+a"(ql[1][3]));
 
     f32x16 o[NB][2], s0[NB], s1[NB];
-    float la[NB], lb[NB];
+    f32x2_t lsum[NB];
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
-        la[blk] = lb[blk] = 0.0f;
+        lsum[blk] = f32x2_t{0.0f, 0.0f};
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -318,45 +370,53 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_f32_t3_kernel(FwdParams p)
             if (__builtin_expect(j + G + g < nst, 1)) issue_v(j + G + g);
     };
     bf16x8 kfh[KS], kfl[KS];
-    auto load_kf = [&](int t) {
+    auto load_kf = [&](int t, bool with_lo) {
         const char* k_lds = kh_slot(t >> 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             kfh[ks] = load_k_frag<D>(k_lds, k_row_off, k_g, t & 1, ks);
-            kfl[ks] = load_k_frag<D>(k_lds + LO_K, k_row_off, k_g, t & 1, ks);
+            if (with_lo) kfl[ks] = load_k_frag<D>(kl_slot(t >> 1), k_row_off, k_g, t & 1, ks);
         }
     };
 
     // ---------------- prologue: K(0) landed -> scores of sub-tile 0, fragments of sub-tile 1 ----------------
     wait_lds_dma();
     __syncthreads();
-    load_kf(0);
+    load_kf(0, true);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int term = 0; term < 3; ++term)
 #pragma unroll
             for (int blk = 0; blk < NB; ++blk) {
-                const bf16x8& a = term == 0 ? kfl[ks] : kfh[ks];
-                const bf16x8& b = term == 1 ? ql[blk][ks] : qh[blk][ks];
+                const bf16x8& a = term == 2 ? kfl[ks] : kfh[ks];
+                const bf16x8& b = term == 0 ? ql[blk][ks] : qh[blk][ks];
                 if (ks == 0 && term == 0) mfma_s_first(s0[blk], a, b);
                 else mfma_s(s0[blk], a, b);
             }
     drain_scores<NB>(s0);
-    load_kf(1);
+    load_kf(1, false);   // K_hi of sub-tile 1; the first step reads its K_lo itself
 
     // ---------------- main loop: groups of G stages, no masks (N is a multiple of 64, non-causal) ----------------
-    for (int j = 0; j < nst; j += G) {
+    // Whole groups first, without a branch around the steps: a conditional step puts a second phi between the accumulators' asm
+    // definitions and the loop-header phi, the header phi then stays a VGPR phi and the compiler copies all 64 accumulators out of
+    // and back into AGPRs every iteration (128 v_accvgpr moves per four steps).
+    auto stage = [&](int jg) {
+        const char* vh_lds = vh_slot(jg);
+        const char* kh_nxt = kh_slot(jg + 1);
+        // step 2 jg scores sub-tile 2 jg + 1 (this stage, second half), step 2 jg + 1 scores the first half of the next stage
+        t3_step<0, ABL>(vh_lds, LO_V, kh_nxt, kl_slot(jg), 1, 0, k_row_off, k_g, v_lane_off, qh, ql, s0, s1, o, lsum, kfh, kfl);
+        t3_step<1, ABL>(vh_lds, LO_V, kh_nxt, kl_slot(jg + 1), 0, 1, k_row_off, k_g, v_lane_off, qh, ql, s1, s0, o, lsum, kfh, kfl);
+    };
+    int j = 0;
+    for (; j + G <= nst; j += G) {
         sync_top(j);
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            if (j + g < nst) {   // wave-uniform; an odd stage count leaves the last group half empty
-                const char* vh_lds = vh_slot(j + g);
-                const char* kh_nxt = kh_slot(j + g + 1);
-                t3_step<0, ABL>(vh_lds, LO_V, kh_nxt, LO_K, 0, k_row_off, k_g, v_lane_off, qh, ql, s0, s1, o, la, lb, kfh, kfl);
-                t3_step<1, ABL>(vh_lds, LO_V, kh_nxt, LO_K, 1, k_row_off, k_g, v_lane_off, qh, ql, s1, s0, o, la, lb, kfh, kfl);
-            }
-        }
+        for (int g = 0; g < G; ++g) stage(j + g);
+    }
+    if (j < nst) {   // an odd stage count: one more stage (G = 2)
+        sync_top(j);
+        stage(j);
     }
 
     // ---------------- epilogue: O / l, store; a row outside the provable range raises the chain's flag ----------------
@@ -364,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_f32_t3_kernel(FwdParams p)
     bool ok = true;
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
-        const float lt = xhalf_sum(la[blk] + lb[blk]);
+        const float lt = xhalf_sum(lsum[blk][0] + lsum[blk][1]);
         const float inv = 1.0f / lt;
         const int qi = q0 + 32 * blk + lq;
         float mag = 0.0f;
