@@ -47,6 +47,20 @@ __global__ __launch_bounds__(256, 1) void kmix(float* out, unsigned long long* c
                 else if constexpr (KIND == 7) asm volatile("s_nop 0");
                 else if constexpr (KIND == 8) asm volatile("v_add_f32 %0, %0, %1" : "+v"(r[k]) : "v"(r[(k + 5) % 16]));
                 else if constexpr (KIND == 9) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(r[k]) : "v"(r[(k + 5) % 16]));
+                else if constexpr (KIND == 12) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(u[i]) : "v"(r[k]), "v"(r[(k + 5) % 16]), "s"(0x07060302u));
+                else if constexpr (KIND == 13) asm volatile("v_pack_b32_f16 %0, %1, %2 op_sel:[1,1,0]" : "=v"(u[i]) : "v"(r[k]), "v"(r[(k + 5) % 16]));
+                else if constexpr (KIND == 14) asm volatile("v_exp_f16 %0, %0" : "+v"(r[k]));
+                else if constexpr (KIND == 15) asm volatile("v_exp_legacy_f32 %0, %0" : "+v"(r[k]));
+                else if constexpr (KIND == 16) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(u[i]) : "v"(r[k]), "v"(r[(k + 5) % 16]));
+                else if constexpr (KIND == 17) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u[i]) : "v"(r[k]), "v"(r[(k + 5) % 16]));
+                else if constexpr (KIND == 18) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(p[i2]));
+                else if constexpr (KIND == 19) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p[i]) : "v"(p[i2]));
+                else if constexpr (KIND == 20) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(r[k]) : "v"(r[(k + 5) % 16]), "v"(r[(k + 9) % 16]));
+                else if constexpr (KIND == 21) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(u[i]) : "v"(u[i2]));
+                else if constexpr (KIND == 22) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(r[k]) : "v"(k0));
+                else if constexpr (KIND == 23) asm volatile("v_mov_b32 %0, %1" : "=v"(u[i]) : "v"(u[i2]));
+                else if constexpr (KIND == 24) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(u[i]) : "v"(r[k]));
+                else if constexpr (KIND == 25) asm volatile("v_exp_f32 %0, %0 mul:2" : "+v"(r[k]));
                 // dependent pairs: the second instruction reads what the first wrote
                 else if constexpr (KIND == 10) { if (v & 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(u[i]) : "v"(r[(k + 15) % 16])); else asm volatile("v_sub_f32 %0, %1, %0" : "+v"(r[k]) : "v"(r[(k + 5) % 16])); }
                 else if constexpr (KIND == 11) { if (v & 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(r[(k + 7) % 16]) : "v"(r[(k + 15) % 16])); else asm volatile("v_exp_f32 %0, %0" : "+v"(r[k])); }
@@ -102,6 +116,20 @@ int main()
     run<5>("v_and_b32 literal", out, cyc, seed);
     run<6>("v_lshlrev_b32", out, cyc, seed);
     run<7>("s_nop 0", out, cyc, seed);
+    run<12>("v_perm_b32", out, cyc, seed);
+    run<13>("v_pack_b32_f16 op_sel:[1,1,0]", out, cyc, seed);
+    run<14>("v_exp_f16", out, cyc, seed);
+    run<15>("v_exp_legacy_f32", out, cyc, seed);
+    run<25>("v_exp_f32 mul:2", out, cyc, seed);
+    run<16>("v_cvt_pkrtz_f16_f32", out, cyc, seed);
+    run<17>("v_cvt_pk_f16_f32", out, cyc, seed);
+    run<18>("v_pk_mul_f32", out, cyc, seed);
+    run<19>("v_pk_fma_f32", out, cyc, seed);
+    run<21>("v_pk_mul_f16", out, cyc, seed);
+    run<20>("v_max3_f32", out, cyc, seed);
+    run<22>("v_mul_f32", out, cyc, seed);
+    run<23>("v_mov_b32", out, cyc, seed);
+    run<24>("v_accvgpr_write_b32", out, cyc, seed);
     run<10>("(v_sub_f32 -> v_cvt_pk dependent) / 2", out, cyc, seed);
     run<11>("(v_exp_f32 -> v_add_f32 dependent) / 2", out, cyc, seed);
     return 0;
