@@ -91,16 +91,20 @@ __device__ __forceinline__ void mfma_l(f32x4_t& l, const bf16x8& ones, const bf1
 // when some score of the next sub-tile has c*s - m - kBias > kThr.
 //   optimistic, bf16 P   m fixed after the first sub-tile, 2^100 of room either way, verified at the end (fa_bf16_common.h)
 //   rescaled,   bf16 P   p <= 1 with the row maximum anywhere in 2^-64 .. 1 between two moves of the reference
-//   rescaled,   fp16 P   fp16 spans 2^-14 .. 2^16 (normal): the row maximum is put at 2^-5 when the reference moves and may grow to
-//                        2^14 before it moves again -- entries more than 2^-9 below a row maximum at the low end of that window
-//                        become subnormal (absolute error <= 2^-25, i.e. <= 2^-20 of the maximum: below the 2^-11 rounding of P
-//                        itself).  On unit-variance data at scale 1 (N = 8192, d = 64) a 128-row wave moves its references ~4
-//                        times per tile; at 1/sqrt(d) never after the first sub-tile.
+//   rescaled,   fp16 P   fp16 spans 2^-14 .. 2^16 (normal): the row maximum is put at 2^0 when the reference moves and may grow to
+//                        2^15.9 before it moves again.  The LOW end of the window is what decides the accuracy: below 2^-14 an fp16
+//                        carries an absolute error of 2^-25, and on a long flat row (N = 16 384, scale 0.5) most of the weight sits
+//                        in thousands of entries 2^-10 .. 2^-20 below the maximum.  With the maximum at 2^-5 (the first choice, 19
+//                        bits of headroom) those were subnormal and the output error reached 1.9e-3 (a CPU simulation of the
+//                        rounding alone: 2.6e-3 at 2^-5, 7.7e-4 at 2^-3, flat from 2^-1 upwards); with the maximum at 2^0 the
+//                        same launch is at 6.2e-4.  The price is headroom, i.e. more moves of the reference on unit-variance
+//                        data at scale 1 (c4, same box: 2^-5 0.327 ms, 2^-1 0.334, 2^0 ~0.338, 2^2 0.344, 2^6 0.373); at 1/sqrt(d)
+//                        the reference never moves after the first sub-tile and the time is the same.
 template <bool OPT, bool PF>
 struct XSoft {
     static_assert(!(OPT && PF), "fp16 P has no room for a fixed exponent reference");
-    static constexpr float kBias = OPT ? kOptBias : PF ? 5.0f : kLazyThr;
-    static constexpr float kThr = PF ? 14.0f : 0.0f;   // fp16: p < 2^14 (fp16 ends at 65 504; a wider window -- 15.5 -- measured no faster)
+    static constexpr float kBias = OPT ? kOptBias : PF ? 0.0f : kLazyThr;
+    static constexpr float kThr = PF ? 15.9f : 0.0f;   // fp16: p < 2^15.9 = 61 147 (fp16 ends at 65 504)
 };
 
 // mfma_drain() with the registers it protects as operands: the drain is an asm statement without a data dependence of its

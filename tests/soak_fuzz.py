@@ -1,0 +1,137 @@
+"""Long randomized soak of the product dispatch on one GPU -- not collected by pytest (minutes, not seconds); run by hand:
+
+    python tests/soak_fuzz.py --cases 800 --seed 7 [--out gpurun_out/soak.txt]
+
+Every case draws (bh, n, d, causal, scale, dtype, data shape) and compares FA_KERNEL_AUTO -- bf16 tensors with bf16 and with fp32
+output, fp32 tensors -- with the rung-0 kernel (one thread per query row, fp32) on the same inputs, with the tolerances of
+tests/test_gpu_parity.py.  Lengths are drawn around the tiling boundaries (multiples of 32 .. 512, +-1), the data from several
+families: N(0,1); wide logits (x3: the fp32 guard hands the launch to the exact kernel, the bf16 kernels rescale); planted dominant
+keys; a constant V; zero Q; values at the bf16 / fp16 range ends for V.  Exit code 1 on the first mismatch or NaN.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import flashattention_c_amd as fa  # noqa: E402
+
+TOL_F32 = 1e-3
+P16_TOL_BIG = 1.5e-3
+
+
+def bf16_tol(scale, out_f32, causal, n):
+    if not out_f32:
+        return 2.5e-2
+    if scale >= 0.5:
+        return 1.2e-2
+    return 1e-3 if (not causal and n >= 1000) else 4e-3
+
+
+def draw_n(rng):
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        return int(rng.integers(1, 200))
+    if kind == 1:
+        base = int(rng.choice([32, 64, 128, 256, 512, 1024, 2048, 4096]))
+        return max(1, base * int(rng.integers(1, 5)) + int(rng.integers(-1, 2)))
+    if kind == 2:
+        return int(rng.integers(200, 3000))
+    return int(rng.integers(3000, 9000))
+
+
+def make_data(rng, g, family, bh, n, d):
+    q, k, v = (torch.randn(bh, n, d, generator=g) for _ in range(3))
+    vmag = 1.0
+    if family == 1:      # wide logits
+        q *= 3.0
+    elif family == 2:    # planted dominant keys
+        for _ in range(min(8, n)):
+            b, r, c = int(rng.integers(0, bh)), int(rng.integers(0, n)), int(rng.integers(0, n))
+            k[b, c] = float(rng.uniform(8.0, 16.0)) * q[b, r] / q[b, r].norm()
+    elif family == 3:    # constant V: the output is that constant whatever the weights
+        v[:] = 1.25
+    elif family == 4:    # zero Q: uniform weights
+        q.zero_()
+    elif family == 5:    # large V (the fp16-P chain must hand |v| >= 2^16 to the split kernel)
+        vmag = float(rng.choice([300.0, 7.0e4]))
+        v *= vmag
+    return q, k, v, vmag
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=400)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(a.seed)
+    worst = {}
+    routes = {}
+    lines = []
+
+    def note(key, err, tol, desc):
+        if err > worst.get(key, (0.0, ""))[0]:
+            worst[key] = (err, desc)
+        if not (err < tol):
+            print(f"FAIL {key}: {err:.3e} >= {tol:.1e}  {desc}", flush=True)
+            sys.exit(1)
+
+    for case in range(a.cases):
+        d = int(rng.choice([32, 64, 128]))
+        n = draw_n(rng)
+        bh = int(rng.integers(1, 9)) if n > 3000 else int(rng.integers(1, 49))
+        causal = bool(rng.integers(0, 2))
+        scale = float(rng.choice([1.0, 0.5, d ** -0.5]))
+        family = int(rng.integers(0, 6))
+        g = torch.Generator(device="cpu").manual_seed(a.seed * 100003 + case)
+        q, k, v, vmag = make_data(rng, g, family, bh, n, d)
+        desc = f"case {case} bh={bh} n={n} d={d} causal={int(causal)} scale={scale:.4g} family={family}"
+        # ---- fp32 tensors
+        qd, kd, vd = (t.to(dev) for t in (q, k, v))
+        ref = fa.forward(qd, kd, vd, causal, scale=scale, kernel="naive")
+        out = fa.forward(qd, kd, vd, causal, scale=scale)
+        r = fa.last_forward_route()
+        routes[("f32", r)] = routes.get(("f32", r), 0) + 1
+        if torch.isnan(out).any() or torch.isnan(ref).any():
+            print("FAIL NaN fp32 " + desc, flush=True)
+            sys.exit(1)
+        note("fp32 tensors", float((out - ref).abs().max()) / vmag, TOL_F32, desc)
+        # ---- bf16 tensors
+        qb, kb, vb = (t.to(torch.bfloat16).to(dev) for t in (q, k, v))
+        refb = fa.forward(qb.float(), kb.float(), vb.float(), causal, scale=scale, kernel="naive")
+        ob = fa.forward(qb, kb, vb, causal, scale=scale)                                  # bf16 out
+        of = fa.forward(qb, kb, vb, causal, scale=scale, out_dtype=torch.float32)          # fp32 out: accurate P
+        r = fa.last_forward_route()
+        routes[("bf16->f32", r)] = routes.get(("bf16->f32", r), 0) + 1
+        if torch.isnan(ob.float()).any() or torch.isnan(of).any():
+            print("FAIL NaN bf16 " + desc, flush=True)
+            sys.exit(1)
+        # wide logits sharpen the softmax: the bf16-P bound is the scale-1 one whatever the nominal scale
+        eff_scale = 1.0 if family in (1, 2) else scale
+        note("bf16 tensors, bf16 out", float((ob.float() - refb).abs().max()) / vmag, bf16_tol(eff_scale, False, causal, n), desc)
+        # fp16 P: every weight carries a relative error <= 2^-11, so |o - o_exact| <= 2^-11 * max_i |v_i - o| <= 2^-10 * max |v| to first
+        # order.  N(0,1) logits stay far below that (1.5e-3 observed at most); planted dominant keys and x3 logits put two comparable
+        # dominant keys with distant V rows into many rows (2-5e-3 while the fp16 window kept the row maximum at 2^-5 and the tail of
+        # the row was subnormal; <= 1.1e-3 since it sits at 2^0) -- those families are held to the bound itself.
+        vmax = float(vb.float().abs().max()) / vmag
+        tol_a = 2.0 ** -10 * vmax if family in (1, 2) else (P16_TOL_BIG if eff_scale >= 0.5 else TOL_F32)
+        note("bf16 tensors, fp32 out", float((of - refb).abs().max()) / vmag, tol_a, desc)
+        if case % 50 == 49:
+            print(f"{case + 1} cases ok", flush=True)
+    lines.append(f"soak: {a.cases} cases, seed {a.seed}: all within tolerance")
+    for key, (err, desc) in worst.items():
+        lines.append(f"  worst {key}: {err:.3e}   ({desc})")
+    lines.append("  routes (tensor kind, fa_last_forward_route): " + ", ".join(f"{k[0]}/{k[1]}: {v}" for k, v in sorted(routes.items())))
+    text = "\n".join(lines)
+    print(text)
+    if a.out:
+        with open(a.out, "a") as f:
+            f.write(text + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -13,8 +13,11 @@ Tolerances (max-abs, stated once here; BASELINE.md section 4 gives the arithmeti
                                                       two comparable dominant keys with distant V rows: |err| <= 0.25 * 2^-10 * |v1 - v2|, and the
                                                       maximum over the launch grows with the number of outputs: observed 6.7e-4 .. 8.4e-4 on one
                                                       N = 8192 slab, 8.4e-4 / 1.0e-3 over 16 slabs (c4; two data sets), 1.17e-3 over 128 slabs
-                                                      (1.13e-3 on a 26 x 2670 fuzz case) -> P16_TOL_BIG = 1.5e-3 for launches of more than 16 long
-                                                      slabs and for the fuzz through the dispatch (stated where used)
+                                                      (1.13e-3 on a 26 x 2670 fuzz case, 1.09e-3 on 17 x 4096) -> P16_TOL_BIG = 1.5e-3 for launches
+                                                      of more than ~4 M outputs and for the fuzz through the dispatch (stated where used).
+                                                      Long flat rows (N = 16 384, scale 0.5) were at 1.9e-3 while the row maximum sat at 2^-5 of
+                                                      the fp16 range (subnormal tail); at 2^0 they are at 6e-4 (tests/soak_fuzz.py found it).
+                                                      Hostile data (planted dominant keys, x3 logits): first-order bound 2^-10 * max|v|.
 "bf16 kernel" above = the bf16-P kernels (kernel="mfma"; FA_KERNEL_AUTO for a bf16 output).
 The bf16 kernels are always compared with the oracle evaluated on the SAME bf16-valued inputs.
 """
@@ -564,7 +567,8 @@ def test_p16_kernel_vs_oracle(bh, n, d, causal):
         ref, lse_ref = orc.attention_f64(q, k, v, causal=causal, scale=scale, return_lse=True)
         o, lse = fa.forward(qd, kd, vd, causal, scale=scale, kernel="p16", out_dtype=torch.float32, return_lse=True)
         assert fa.last_forward_route() == 1
-        check(o, ref, TOL_F32, f"p16 scale {scale}")
+        # unscaled logits over 4.5 M outputs (17 x 4096 x 64): the maximum of the 11-bit rounding of P sits at 1.0 .. 1.1e-3 (header)
+        check(o, ref, P16_TOL_BIG if (scale >= 0.5 and bh * n > 60000) else TOL_F32, f"p16 scale {scale}")
         check(lse, lse_ref, 1e-3, f"p16 lse scale {scale}")       # row sums of fp16-rounded P: 2^-12 relative per term
         ob = fa.forward(qd, kd, vd, causal, scale=scale, kernel="p16")   # bf16 output: its own rounding on top
         check(ob, ref, bf16_tol(scale, False), f"p16 bf16 out scale {scale}")
@@ -573,8 +577,8 @@ def test_p16_kernel_vs_oracle(bh, n, d, causal):
 @pytest.mark.parametrize("d,bh", [(64, 2), (64, 17), (32, 2), (128, 2)])   # bh = 17 at n = 4096: the NB = 4 tiling
 @pytest.mark.parametrize("causal", [False, True])
 def test_p16_reference_moves_inside_the_pipelined_loop(causal, d, bh):
-    """fp16 has 30 binades: the exponent reference of a wave has to follow its row maxima (window 2^-5 .. 2^14 around the row
-    maximum).  Keys that outgrow everything seen before by 2^20 .. 2^230, in the middle of the sequence, for single rows, a whole
+    """fp16 has 30 binades: the exponent reference of a wave has to follow its row maxima (the row maximum sits in 2^0 .. 2^15.9
+    of the fp16 range).  Keys that outgrow everything seen before by 2^20 .. 2^230, in the middle of the sequence, for single rows, a whole
     32-row block and neighbouring blocks; then a row whose scores shrink again.  The LSE exposes a saturated or flushed P."""
     n = 1536 if bh == 2 else 4096
     q, k, v = (randn(s, bh, n, d) for s in (41, 42, 43))
