@@ -92,19 +92,28 @@ def main():
         desc = f"case {case} bh={bh} n={n} d={d} causal={int(causal)} scale={scale:.4g} family={family}"
         # ---- fp32 tensors
         qd, kd, vd = (t.to(dev) for t in (q, k, v))
-        ref = fa.forward(qd, kd, vd, causal, scale=scale, kernel="naive")
-        out = fa.forward(qd, kd, vd, causal, scale=scale)
+        ref, lse_ref = fa.forward(qd, kd, vd, causal, scale=scale, kernel="naive", return_lse=True)
+        out, lse = fa.forward(qd, kd, vd, causal, scale=scale, return_lse=True)
         r = fa.last_forward_route()
         routes[("f32", r)] = routes.get(("f32", r), 0) + 1
         if torch.isnan(out).any() or torch.isnan(ref).any():
             print("FAIL NaN fp32 " + desc, flush=True)
             sys.exit(1)
         note("fp32 tensors", float((out - ref).abs().max()) / vmag, TOL_F32, desc)
+        note("fp32 tensors, LSE", float((lse - lse_ref).abs().max()), TOL_F32, desc)
+        if case % 8 == 0 and d in (32, 64, 128):    # the llm.c entry: packed (B, T, 3C) fp32, causal, 1/sqrt(d)
+            nh = int(rng.integers(1, 5))
+            B, T = max(1, bh // nh), min(n, 2048)
+            inp = torch.randn(B, T, 3 * nh * d, generator=g).to(dev)
+            got = fa.forward_packed_qkv(inp, nh)
+            qq, kk, vv = (inp[:, :, i * nh * d:(i + 1) * nh * d].reshape(B, T, nh, d).permute(0, 2, 1, 3).reshape(B * nh, T, d).contiguous() for i in range(3))
+            want = fa.forward(qq, kk, vv, True, scale=d ** -0.5, kernel="naive").reshape(B, nh, T, d).permute(0, 2, 1, 3).reshape(B, T, nh * d)
+            note("packed QKV (llm.c layout)", float((got - want).abs().max()), TOL_F32, desc + f" B={B} T={T} NH={nh}")
         # ---- bf16 tensors
         qb, kb, vb = (t.to(torch.bfloat16).to(dev) for t in (q, k, v))
-        refb = fa.forward(qb.float(), kb.float(), vb.float(), causal, scale=scale, kernel="naive")
-        ob = fa.forward(qb, kb, vb, causal, scale=scale)                                  # bf16 out
-        of = fa.forward(qb, kb, vb, causal, scale=scale, out_dtype=torch.float32)          # fp32 out: accurate P
+        refb, lse_refb = fa.forward(qb.float(), kb.float(), vb.float(), causal, scale=scale, kernel="naive", return_lse=True)
+        ob, lse_b = fa.forward(qb, kb, vb, causal, scale=scale, return_lse=True)                                  # bf16 out
+        of, lse_f = fa.forward(qb, kb, vb, causal, scale=scale, out_dtype=torch.float32, return_lse=True)          # fp32 out: accurate P
         r = fa.last_forward_route()
         routes[("bf16->f32", r)] = routes.get(("bf16->f32", r), 0) + 1
         if torch.isnan(ob.float()).any() or torch.isnan(of).any():
@@ -120,6 +129,9 @@ def main():
         vmax = float(vb.float().abs().max()) / vmag
         tol_a = 2.0 ** -10 * vmax if family in (1, 2) else (P16_TOL_BIG if eff_scale >= 0.5 else TOL_F32)
         note("bf16 tensors, fp32 out", float((of - refb).abs().max()) / vmag, tol_a, desc)
+        # the LSE sees what O / l hides (a clamped or saturated P): row sums of 8-bit-rounded P stay within 2e-2, of 11-bit ones 2e-3
+        note("bf16 tensors, bf16 out, LSE", float((lse_b - lse_refb).abs().max()), 2e-2, desc)
+        note("bf16 tensors, fp32 out, LSE", float((lse_f - lse_refb).abs().max()), 2e-3, desc)
         if case % 50 == 49:
             print(f"{case + 1} cases ok", flush=True)
     lines.append(f"soak: {a.cases} cases, seed {a.seed}: all within tolerance")
