@@ -23,6 +23,17 @@ $D --mode rand --bh 16 --n 8192 --d 32 --dtype f32s --warmup 60 --iters 20 --che
 echo "== fp32 tensors, exact fp32 arithmetic: c3, c2"
 $D --mode rand --bh 16 --n 8192 --d 64 --dtype f32 --warmup 20 --iters 10 --check 0
 $D --mode rand --bh 128 --n 1024 --d 64 --dtype f32 --warmup 100 --iters 30 --check 0
+echo "== fp16-P (accurate) kernels: --kernel p16 --out_f32 1  (c4 at scale 1, 0.5, 1/sqrt(d); causal; bh=128; d=128; d=32; c2 shape)"
+P="--dtype bf16 --kernel p16 --out_f32 1 --warmup 100 --iters 30 --check 0"
+for sc in 1 0.5 0.125; do $D --mode rand --bh 16 --n 8192 --d 64 $P --scale $sc; done
+$D --mode rand --bh 16 --n 8192 --d 64 $P --causal 1
+$D --mode rand --bh 128 --n 8192 --d 64 $P --iters 10
+$D --mode rand --bh 16 --n 8192 --d 128 $P
+$D --mode rand --bh 16 --n 8192 --d 128 $P --causal 1
+$D --mode rand --bh 16 --n 8192 --d 32 $P
+$D --mode rand --bh 128 --n 1024 --d 64 $P
+echo "== llm.c harness size"
+$D --mode llmc | tail -1
 H="python3 -m flashattention_c_amd.harness.bench_flashattention --iters 50 --warmup 100"
 {
 for hd in 64 32 128; do for dt in f32 bf16; do
