@@ -1,0 +1,49 @@
+"""GPU (-m gpu): the launcher + RCCL leg of bench.py's multi-GPU protocol, as far as one GPU can show it."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def test_timing_protocol_over_rccl_with_one_rank():
+    """torch.distributed.run -> one rank -> init_process_group('nccl') -> bench.timed_region with its collectives forced on."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "nccl_one_rank_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+    assert r.returncode == 0 and "NCCL_ONE_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_under_the_drivers_launch_line_with_one_gpu():
+    """The driver's N > 1 command line with N = 1: `python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1`
+    must print exactly one JSON line carrying the contract's keys."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+           "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 5 and line["warmup"] == 2 and line["value"] > 100.0
+    assert 0.2 < line["roofline"]["frac"] < 1.0 and line["roofline"]["bound"] == "mfma"
