@@ -143,18 +143,28 @@ __device__ __forceinline__ void xn_rescale(const float (&mx)[NB], float c, Block
 {
     using SM = XSoft<false, PF>;
     bool any = false;
+    bool move[NB];   // wave-uniform.  bf16 P: all blocks move together (64 binades of slack: rare, and it spares later moves);
+                     // fp16 P (16 binades: a move every few hundred keys on unscaled unit-variance data): only the blocks that need it
     float mc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         mc[b] = mx[b] * c;
         mc[b] = fmaf(-fabsf(mc[b]), 0x1p-23f, mc[b]);
-        any = any || (mc[b] - st[b].m > SM::kBias + SM::kThr);
+        const bool need = mc[b] - st[b].m > SM::kBias + SM::kThr;
+        if constexpr (PF) {
+            move[b] = __any(need);
+            any = any || move[b];
+        } else {
+            move[b] = true;
+            any = any || need;
+        }
     }
-    if (__builtin_expect(__any(any), 0)) {
-        asm volatile("; lazy rescale (all blocks of the wave)" ::: "memory");
+    if (__builtin_expect(PF ? any : __any(any), 0)) {
+        asm volatile("; lazy rescale" ::: "memory");
         drain_accumulators<NB, DB>(o, st);  // the accumulators rescaled below may have an MFMA in flight (hazard not padded across the branch)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
+            if (!move[b]) continue;
             const float nm = fmaxf(st[b].m, mc[b]);
             const float a = fast_exp2(st[b].m - nm);
             st[b].m = nm;
@@ -832,8 +842,14 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_p16_kernel(Fw
     if (flag_says_skip(p)) return;
     (void)xn_tile<64, 4, NWAVES, CAUSAL, OUT_F32, G, 0, false, true>(p, smem);
 }
+// Causal launches rely on one workgroup per CU (heavy tiles first, light ones behind them on the same CU): when the allocation
+// happens to leave room for a second wave per SIMD the hardware co-schedules two heavy tiles and the launch gets 20-30 % slower
+// (measured twice: forced with __launch_bounds__(256, 2) on the bf16-P kernel, and by accident when this kernel dropped to 124 + 104
+// registers).  amdgpu_waves_per_eu does not change what the hardware co-schedules; an LDS allocation of more than half the CU's
+// 160 KB does: xn_solo_lds() adds unused dynamic LDS to such launches.  For large causal grids the second resident workgroup is
+// a gain (128 x 8192: 1.22 ms against 1.46), hence the bound of two for d <= 64 -- it pins what the allocation gave by accident.
 template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, int G>
-__global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x2_p16_kernel(FwdParams p)
+__global__ __launch_bounds__(NWAVES* kWave, D <= 64 ? 2 : 1) void fa_fwd_bf16_x2_p16_kernel(FwdParams p)
 {
     __shared__ __attribute__((aligned(1024))) char smem[4 * G * Bf16Cfg<D, NWAVES>::kTileBytes];
     if (flag_says_skip(p)) return;
@@ -890,17 +906,36 @@ static hipError_t launch_x4_p16(const FwdParams& p0, int out_f32, hipStream_t st
     return hipGetLastError();
 }
 
+// Unused dynamic LDS that keeps a second NB = 2 workgroup off the CU (static rings + this > half of the CU's 160 KB), for the
+// causal launches that want it.  The d = 32 kernels (181 registers) and the fp16-P d = 64 kernels (228) leave room for a second
+// wave per SIMD and the hardware uses it.  With at most two long tiles per CU the order "heavy tiles first, one per CU, light ones
+// behind them" IS the load balance and a co-resident pair of heavy tiles breaks it; with more tiles per CU, or short ones, the
+// second resident workgroup hides latency and wins.  Measured, causal, ms with two per CU / one per CU (BH x N, tiles):
+//   d = 32 bf16 P:   16 x 8192 (512)  0.159 / 0.121    32 x 8192 (1024) 0.209 / 0.223    128 x 8192 (4096) 0.740 / 0.869
+//                   128 x 1024 (512)  0.030 / 0.038
+//   d = 64 fp16 P:   16 x 8192 (512)  0.242 / 0.198    32 x 8192 (1024) 0.343 / 0.375    128 x 8192 (4096) 1.218 / 1.462
+//                   128 x 1024 (512)  0.062 / 0.076
+template <int D, int G>
+static unsigned xn_solo_lds(const FwdParams& p, const dim3& grid, int causal)
+{
+    constexpr int ring = 4 * G * Bf16Cfg<D, 4>::kTileBytes;
+    const long wgs = (long)grid.x * grid.y * grid.z;
+    if (!causal || ring >= 84 * 1024 || wgs > 2 * 256 || p.n < 4096) return 0;
+    return 84 * 1024 - ring;
+}
+
 template <int D, int G, bool OPTIMISTIC = true>
 static hipError_t launch_x2(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
 {
     FwdParams p;
     dim3 grid, block;
     if (!xn_grid<2>(p0, p, grid, block)) return hipErrorInvalidValue;
+    const unsigned solo = xn_solo_lds<D, G>(p, grid, causal);
     if (causal) {
         if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, 4, true, true, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, 4, true, true, G, 0, OPTIMISTIC>), grid, block, solo, stream, p);
         else
-            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, 4, true, false, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, 4, true, false, G, 0, OPTIMISTIC>), grid, block, solo, stream, p);
     } else {
         if (out_f32)
             hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, 4, false, true, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
@@ -916,11 +951,12 @@ static hipError_t launch_x2_p16(const FwdParams& p0, int causal, int out_f32, hi
     FwdParams p;
     dim3 grid, block;
     if (!xn_grid<2>(p0, p, grid, block)) return hipErrorInvalidValue;
+    const unsigned solo = xn_solo_lds<D, 2>(p, grid, causal);
     if (causal) {
         if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, true, true, 2>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, true, true, 2>), grid, block, solo, stream, p);
         else
-            hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, true, false, 2>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, true, false, 2>), grid, block, solo, stream, p);
     } else {
         if (out_f32)
             hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, false, true, 2>), grid, block, 0, stream, p);
