@@ -509,7 +509,20 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
     const int w = xcd_remap(blockIdx.x, total);
     const int slab = w / p.q_tiles;
     int qt = w % p.q_tiles;
-    if (CAUSAL) qt = p.q_tiles - 1 - qt;
+    if (CAUSAL) {
+        if (p.alt_order) {
+            // Two workgroups per CU, the whole grid resident at once (xn_launch_order): the dispatcher deals an XCD's workgroups over
+            // its 32 CUs in order, so position pos and pos + 32 share a CU.  Even rounds take a slab's tiles from the heavy end, odd
+            // rounds from the light end: the two tiles of a CU add up to one slab-independent amount of work.  A bijection per slab
+            // for every tile count (slabs do not straddle XCDs here: bh % 8 == 0).
+            const int pos = blockIdx.x / kNumXcd, k = pos % p.q_tiles, s0 = pos - k;
+            auto even_before = [](int x) { return (x / 64) * 32 + (x % 64 < 32 ? x % 64 : 32); };
+            const int e = even_before(pos) - even_before(s0);
+            qt = ((pos / 32) & 1) ? k - e : p.q_tiles - 1 - e;
+        } else {
+            qt = p.q_tiles - 1 - qt;
+        }
+    }
     const int n = p.n;
     const int q0 = qt * BM + wave * 32 * NB;  // first row of block 0; block b starts at q0 + 32 b
 
@@ -846,8 +859,8 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_p16_kernel(Fw
 // happens to leave room for a second wave per SIMD the hardware co-schedules two heavy tiles and the launch gets 20-30 % slower
 // (measured twice: forced with __launch_bounds__(256, 2) on the bf16-P kernel, and by accident when this kernel dropped to 124 + 104
 // registers).  amdgpu_waves_per_eu does not change what the hardware co-schedules; an LDS allocation of more than half the CU's
-// 160 KB does: xn_solo_lds() adds unused dynamic LDS to such launches.  For large causal grids the second resident workgroup is
-// a gain (128 x 8192: 1.22 ms against 1.46), hence the bound of two for d <= 64 -- it pins what the allocation gave by accident.
+// 160 KB does: see xn_launch_order().  For large causal grids the second resident workgroup is a gain (128 x 8192: 1.22 ms against
+// 1.46), hence the bound of two for d <= 64 -- it pins what the allocation gave by accident.
 template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, int G>
 __global__ __launch_bounds__(NWAVES* kWave, D <= 64 ? 2 : 1) void fa_fwd_bf16_x2_p16_kernel(FwdParams p)
 {
@@ -906,22 +919,31 @@ static hipError_t launch_x4_p16(const FwdParams& p0, int out_f32, hipStream_t st
     return hipGetLastError();
 }
 
-// Unused dynamic LDS that keeps a second NB = 2 workgroup off the CU (static rings + this > half of the CU's 160 KB), for the
-// causal launches that want it.  The d = 32 kernels (181 registers) and the fp16-P d = 64 kernels (228) leave room for a second
-// wave per SIMD and the hardware uses it.  With at most two long tiles per CU the order "heavy tiles first, one per CU, light ones
-// behind them" IS the load balance and a co-resident pair of heavy tiles breaks it; with more tiles per CU, or short ones, the
-// second resident workgroup hides latency and wins.  Measured, causal, ms with two per CU / one per CU (BH x N, tiles):
-//   d = 32 bf16 P:   16 x 8192 (512)  0.159 / 0.121    32 x 8192 (1024) 0.209 / 0.223    128 x 8192 (4096) 0.740 / 0.869
-//                   128 x 1024 (512)  0.030 / 0.038
-//   d = 64 fp16 P:   16 x 8192 (512)  0.242 / 0.198    32 x 8192 (1024) 0.343 / 0.375    128 x 8192 (4096) 1.218 / 1.462
-//                   128 x 1024 (512)  0.062 / 0.076
+// Causal launches of the NB = 2 kernels and the second workgroup of a CU.  The d = 32 kernels (181 registers) and the fp16-P d = 64
+// kernel (228) fit twice on a CU and the hardware co-schedules them; the bf16-P d = 64 kernel (264) does not -- forced to 256 it
+// spills into AGPRs inside the loop and gains nothing (0.153 ms on c4-causal either way) -- and its launches see alt_order = 0
+// and no padding because a second workgroup never fits.  With many tiles per CU, or
+// short ones, that hides latency and wins.  With at most two long tiles per CU the whole grid is resident at once and the launch
+// lasts as long as the CU with the heaviest PAIR: in slab order, heavy tiles first, that is two heavy tiles (c4-causal fp16 P:
+// 0.242 ms).  Two answers, measured on causal 16 x 8192 (ms; fp16 P d = 64 / fp16 P d = 32 / bf16 P d = 32):
+//   * one workgroup per CU -- unused dynamic LDS pushes the allocation past half of the CU's 160 KB (amdgpu_waves_per_eu does
+//     not change what the hardware co-schedules) -- and the light tiles follow the heavy ones:          0.197 / 0.154 / 0.120
+//   * two per CU, odd rounds of an XCD's workgroups walking their slab from the light end (alt_order): 0.181 / 0.140 / 0.109
+//     -- needs slabs that do not straddle XCDs (bh % 8 == 0); other grids take the first answer.
+// More than two rounds (32 x 8192: 0.343 plain, 0.370 alternating) and short rows (128 x 1024: 0.062 with two per CU, 0.076 with
+// one) keep the plain order with two per CU.
 template <int D, int G>
-static unsigned xn_solo_lds(const FwdParams& p, const dim3& grid, int causal)
+static unsigned xn_launch_order(FwdParams& p, const dim3& grid, int causal, bool co_resident)
 {
     constexpr int ring = 4 * G * Bf16Cfg<D, 4>::kTileBytes;
     const long wgs = (long)grid.x * grid.y * grid.z;
-    if (!causal || ring >= 84 * 1024 || wgs > 2 * 256 || p.n < 4096) return 0;
-    return 84 * 1024 - ring;
+    p.alt_order = 0;
+    if (!causal || !co_resident || ring >= 84 * 1024 || wgs > 2 * 256 || p.n < 4096) return 0;
+    if (p.bh % kNumXcd == 0) {   // both workgroups of a CU resident, tiles paired heavy + light (xn_tile)
+        p.alt_order = 1;
+        return 0;
+    }
+    return 84 * 1024 - ring;     // one workgroup per CU, heavy tiles first
 }
 
 template <int D, int G, bool OPTIMISTIC = true>
@@ -930,7 +952,7 @@ static hipError_t launch_x2(const FwdParams& p0, int causal, int out_f32, hipStr
     FwdParams p;
     dim3 grid, block;
     if (!xn_grid<2>(p0, p, grid, block)) return hipErrorInvalidValue;
-    const unsigned solo = xn_solo_lds<D, G>(p, grid, causal);
+    const unsigned solo = xn_launch_order<D, G>(p, grid, causal, D == 32);
     if (causal) {
         if (out_f32)
             hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, 4, true, true, G, 0, OPTIMISTIC>), grid, block, solo, stream, p);
@@ -951,7 +973,7 @@ static hipError_t launch_x2_p16(const FwdParams& p0, int causal, int out_f32, hi
     FwdParams p;
     dim3 grid, block;
     if (!xn_grid<2>(p0, p, grid, block)) return hipErrorInvalidValue;
-    const unsigned solo = xn_solo_lds<D, 2>(p, grid, causal);
+    const unsigned solo = xn_launch_order<D, 2>(p, grid, causal, D <= 64);
     if (causal) {
         if (out_f32)
             hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, true, true, 2>), grid, block, solo, stream, p);

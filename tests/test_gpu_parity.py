@@ -415,6 +415,25 @@ def test_fuzz_fp32_shapes_through_the_dispatch_against_rung0():
     OBSERVED.append(("fp32 fuzz through dispatch, worst of 40", worst, TOL_F32))
 
 
+
+@pytest.mark.parametrize("bh,n", [(8, 4096), (16, 4096), (8, 5000), (8, 6144), (16, 8192), (8, 16384), (8, 12289), (24, 4200)])
+def test_causal_paired_tile_order_covers_every_tile_once(bh, n):
+    """Causal NB = 2 launches whose whole grid is resident with two workgroups per CU (d = 32, and fp16 P at d = 64; bh % 8 == 0,
+    at most 512 tiles, N >= 4096) deal the tiles of a slab from both ends (FwdParams::alt_order).  The map has to be a bijection
+    for every tile count per slab -- 16, 20, 24, 32, 49, 64 here, slabs aligned and not aligned with the 32-position rounds -- or
+    some rows are computed twice and others never (the output buffer is poisoned with NaN first)."""
+    g = torch.Generator(device="cpu").manual_seed(n + bh)
+    for d, kernel, out_dtype, tol in ((32, "auto", torch.bfloat16, 2.5e-2), (64, "p16", torch.float32, P16_TOL_BIG), (32, "p16", torch.float32, P16_TOL_BIG)):
+        q, k, v = (torch.randn(bh, n, d, generator=g).to(torch.bfloat16).to(dev()) for _ in range(3))
+        ref = fa.forward(q.float(), k.float(), v.float(), True, kernel="naive")
+        out = torch.full((bh, n, d), float("nan"), dtype=out_dtype, device=dev())
+        fa.forward(q, k, v, True, kernel=kernel, out=out)
+        assert not torch.isnan(out.float()).any(), f"unwritten rows: d={d} kernel={kernel}"
+        err = float((out.float() - ref).abs().max())
+        OBSERVED.append((f"paired causal order bh={bh} n={n} d={d} {kernel}", err, tol))
+        assert err < tol, f"d={d} kernel={kernel}: {err:.3e}"
+
+
 def test_graph_replay_timing_entry():
     q, k, v = (torch.randn(4, 512, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
     ms_stream = fa.time_forward(q, k, v, False, warmup=1, iters=5)
