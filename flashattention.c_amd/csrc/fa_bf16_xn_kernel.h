@@ -509,20 +509,7 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
     const int w = xcd_remap(blockIdx.x, total);
     const int slab = w / p.q_tiles;
     int qt = w % p.q_tiles;
-    if (CAUSAL) {
-        if (p.alt_order) {
-            // Two workgroups per CU, the whole grid resident at once (xn_launch_order): the dispatcher deals an XCD's workgroups over
-            // its 32 CUs in order, so position pos and pos + 32 share a CU.  Even rounds take a slab's tiles from the heavy end, odd
-            // rounds from the light end: the two tiles of a CU add up to one slab-independent amount of work.  A bijection per slab
-            // for every tile count (slabs do not straddle XCDs here: bh % 8 == 0).
-            const int pos = blockIdx.x / kNumXcd, k = pos % p.q_tiles, s0 = pos - k;
-            auto even_before = [](int x) { return (x / 64) * 32 + (x % 64 < 32 ? x % 64 : 32); };
-            const int e = even_before(pos) - even_before(s0);
-            qt = ((pos / 32) & 1) ? k - e : p.q_tiles - 1 - e;
-        } else {
-            qt = p.q_tiles - 1 - qt;
-        }
-    }
+    if (CAUSAL) qt = causal_tile(p, qt);
     const int n = p.n;
     const int q0 = qt * BM + wave * 32 * NB;  // first row of block 0; block b starts at q0 + 32 b
 

@@ -80,6 +80,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int total)
     return base + idx;
 }
 
+// Tile of a causal workgroup.  Default: walk each slab from its heaviest tile (light tiles then follow heavy ones onto a CU).
+// alt_order (set by the launcher when the WHOLE grid is resident with two workgroups per CU and slabs do not straddle XCDs,
+// bh % 8 == 0): the dispatcher deals an XCD's workgroups over its 32 CUs in order, so positions pos and pos + 32 share a CU; even
+// rounds take a slab's tiles from the heavy end, odd rounds from the light end, and the two tiles of every CU add up to the same
+// work.  A bijection per slab for every tile count.
+__device__ __forceinline__ int causal_tile(const FwdParams& p, int qt)
+{
+    if (!p.alt_order) return p.q_tiles - 1 - qt;
+    const int pos = blockIdx.x / kNumXcd, k = pos % p.q_tiles, s0 = pos - k;
+    auto even_before = [](int x) { return (x / 64) * 32 + (x % 64 < 32 ? x % 64 : 32); };
+    const int e = even_before(pos) - even_before(s0);
+    return ((pos / 32) & 1) ? k - e : p.q_tiles - 1 - e;
+}
+
 // Drain this wave's outstanding LDS-DMA (global_load_lds) transfers.  LDS-DMA completion is tracked by vmcnt; a
 // barrier does not wait for it, and the compiler only inserts the wait in front of LDS reads it thinks may alias.
 __device__ __forceinline__ void wait_lds_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
