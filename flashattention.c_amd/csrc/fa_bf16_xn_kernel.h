@@ -143,23 +143,19 @@ __device__ __forceinline__ void xn_rescale(const float (&mx)[NB], float c, Block
 {
     using SM = XSoft<false, PF>;
     bool any = false;
-    bool move[NB];   // wave-uniform.  bf16 P: all blocks move together (64 binades of slack: rare, and it spares later moves);
-                     // fp16 P (16 binades: a move every few hundred keys on unscaled unit-variance data): only the blocks that need it
+    bool move[NB];   // wave-uniform: only the blocks that need it move (fp16 P, 16 binades of headroom, moves every few hundred keys on
+                     // unscaled unit-variance data: -2.5 % on c4; and the branch keeps 36 VGPRs less alive than moving all blocks did,
+                     // which is what lets the NB = 2 kernels at d = 64 fit a CU twice: 124 - 136 + 104 registers instead of 160 + 104)
     float mc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         mc[b] = mx[b] * c;
         mc[b] = fmaf(-fabsf(mc[b]), 0x1p-23f, mc[b]);
         const bool need = mc[b] - st[b].m > SM::kBias + SM::kThr;
-        if constexpr (PF) {
-            move[b] = __any(need);
-            any = any || move[b];
-        } else {
-            move[b] = true;
-            any = any || need;
-        }
+        move[b] = __any(need);
+        any = any || move[b];
     }
-    if (__builtin_expect(PF ? any : __any(any), 0)) {
+    if (__builtin_expect(any, 0)) {
         asm volatile("; lazy rescale" ::: "memory");
         drain_accumulators<NB, DB>(o, st);  // the accumulators rescaled below may have an MFMA in flight (hazard not padded across the branch)
 #pragma unroll
@@ -906,10 +902,9 @@ static hipError_t launch_x4_p16(const FwdParams& p0, int out_f32, hipStream_t st
     return hipGetLastError();
 }
 
-// Causal launches of the NB = 2 kernels and the second workgroup of a CU.  The d = 32 kernels (181 registers) and the fp16-P d = 64
-// kernel (228) fit twice on a CU and the hardware co-schedules them; the bf16-P d = 64 kernel (264) does not -- forced to 256 it
-// spills into AGPRs inside the loop and gains nothing (0.153 ms on c4-causal either way) -- and its launches see alt_order = 0
-// and no padding because a second workgroup never fits.  With many tiles per CU, or
+// Causal launches of the NB = 2 kernels and the second workgroup of a CU.  The d = 32 kernels (181 registers) and the d = 64 kernels
+// (228 - 240 since the reference moves are per block; 264 before, and forcing that version to 256 with __launch_bounds__ made it
+// spill into AGPRs inside the loop for no gain) fit twice on a CU and the hardware co-schedules them.  With many tiles per CU, or
 // short ones, that hides latency and wins.  With at most two long tiles per CU the whole grid is resident at once and the launch
 // lasts as long as the CU with the heaviest PAIR: in slab order, heavy tiles first, that is two heavy tiles (c4-causal fp16 P:
 // 0.242 ms).  Two answers, measured on causal 16 x 8192 (ms; fp16 P d = 64 / fp16 P d = 32 / bf16 P d = 32):
@@ -939,7 +934,7 @@ static hipError_t launch_x2(const FwdParams& p0, int causal, int out_f32, hipStr
     FwdParams p;
     dim3 grid, block;
     if (!xn_grid<2>(p0, p, grid, block)) return hipErrorInvalidValue;
-    const unsigned solo = xn_launch_order<D, G>(p, grid, causal, D == 32);
+    const unsigned solo = xn_launch_order<D, G>(p, grid, causal, D <= 64);
     if (causal) {
         if (out_f32)
             hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, 4, true, true, G, 0, OPTIMISTIC>), grid, block, solo, stream, p);

@@ -458,11 +458,13 @@ static Bf16Choice choose_bf16(int64_t bh, int64_t n, int d, int causal, bool add
     // d == 64
     const int64_t items256 = bh * ((n + 255) / 256), items512 = bh * ((n + 511) / 512);
     if (causal) {
-        // With every workgroup resident at once (two-wave kernel) a causal launch lasts as long as its heaviest tile.  The
-        // one-wave-per-SIMD kernel with 256-row tiles runs one workgroup per CU, heavy tiles first, so light tiles follow heavy
-        // ones on the same CU.  Measured (TFLOP/s, pipelined 4-wave / x2): BH x N = 8 x 8192: 522 / 544, 16 x 4096: 464 / 483,
-        // 16 x 8192: 642 / 884, 4 x 16384: 520 / 594;  32 x 4096: 600 / 571, 64 x 4096: 776 / 699, 128 x 8192: 1005 / 913.
-        if (items256 <= 256 || (items256 <= 512 && n >= 8192)) return kChooseX2D64;
+        // With every workgroup resident at once (two-wave kernel) a causal launch lasts as long as its heaviest pair of tiles.  The
+        // one-wave-per-SIMD kernel with 256-row tiles runs one or two workgroups per CU in an order chosen for the grid (heavy tiles
+        // first, or heavy + light pairs: xn_launch_order in fa_bf16_xn_kernel.h).  Measured (ms, two-wave / x2), BH x N:
+        // 16 x 8192: 0.206 / 0.148, 12 x 8192: 0.196 / 0.145, 8 x 16384: 0.307 / 0.279, 16 x 4096: 0.070 / 0.066, 32 x 4096:
+        // 0.113 / 0.084, 32 x 8192: 0.303 / 0.290, 64 x 4096: 0.185 / 0.184, 64 x 8192: 0.568 / 0.563, 128 x 8192: 1.078 / 1.069;
+        // short rows, 128 x 2048: 0.115 / 0.115, 128 x 1024: 0.040 / 0.040 -- those stay where they were.
+        if (items256 <= 512 || n >= 4096) return kChooseX2D64;
         return kChoosePipelined4;
     }
     // Non-causal.  Rounds of workgroups, in units of 131072 query rows of work:
