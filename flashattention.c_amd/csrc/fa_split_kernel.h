@@ -193,7 +193,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     const int w = xcd_remap(blockIdx.x, total);
     const int slab = w / p.q_tiles;
     int qt = w % p.q_tiles;
-    if (CAUSAL) qt = p.q_tiles - 1 - qt;  // longest (latest) q tiles first
+    if (CAUSAL) qt = causal_tile(p, qt);  // longest (latest) q tiles first, or heavy + light pairs (FwdParams::alt_order)
     const int n = p.n;
     const int q0 = qt * BM + wave * (QB * 32);
 
@@ -900,6 +900,11 @@ static hipError_t launch_split(const FwdParams& p0, int causal, hipStream_t stre
     const int64_t total = (int64_t)p.bh * p.q_tiles;
     if (total > 0x7fffffffLL) return hipErrorInvalidValue;
     dim3 grid((unsigned)total), block(NWAVES * kWave);
+    // The one-block-per-wave tilings at d <= 64 run two workgroups per CU.  A causal grid that is resident as a whole (at most two
+    // workgroups per CU) then lasts as long as its heaviest PAIR of tiles: deal them heavy + light (causal_tile, fa_common.h).
+    // Measured, fp32 tensors, ms: 16 x 4096 d = 64 0.162 -> 0.125, 32 x 2048 0.089 -> 0.074, 16 x 4096 d = 32 0.122 -> 0.094; the
+    // two-block tilings (one workgroup per CU, heavy tiles first) must keep their order: 16 x 8192 0.397 -> 0.531 when paired.
+    p.alt_order = (causal && QB == 1 && NWAVES == 4 && D <= 64 && total <= 2 * 256 && p.bh % kNumXcd == 0) ? 1 : 0;
     if (causal)
         hipLaunchKernelGGL((fa_fwd_f32_split_kernel<D, NWAVES, QB, true, MINBLOCKS, PIPE, IN_BF16>), grid, block, 0, stream, p);
     else

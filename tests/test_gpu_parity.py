@@ -434,6 +434,25 @@ def test_causal_paired_tile_order_covers_every_tile_once(bh, n):
         assert err < tol, f"d={d} kernel={kernel}: {err:.3e}"
 
 
+
+@pytest.mark.parametrize("bh,n,d", [(16, 4096, 64), (8, 5000, 64), (32, 2048, 64), (16, 4096, 32), (8, 7168, 32), (64, 1024, 64), (24, 2500, 64)])
+def test_causal_paired_tile_order_in_the_split_kernel(bh, n, d):
+    """fp32 tensors, causal, the one-block-per-wave tilings of the split kernel (two workgroups per CU) on grids that are resident
+    as a whole: same paired tile order, same bijection requirement (NaN-poisoned output), against the fp64 oracle on a few slabs."""
+    q, k, v = (randn(s, bh, n, d) for s in (71, 72, 73))
+    qd, kd, vd = to_dev(q, k, v)
+    out = torch.full((bh, n, d), float("nan"), dtype=torch.float32, device=dev())
+    fa.forward(qd, kd, vd, True, out=out)
+    assert not torch.isnan(out).any(), "unwritten rows"
+    ref_dev = fa.forward(qd, kd, vd, True, kernel="naive")
+    err = float((out - ref_dev).abs().max())
+    OBSERVED.append((f"split paired causal order bh={bh} n={n} d={d}", err, TOL_F32))
+    assert err < TOL_F32, f"{err:.3e}"
+    sl = [0, bh - 1]
+    ref = orc.attention_f64(q[sl], k[sl], v[sl], causal=True)
+    check(out[sl], ref, TOL_F32, "vs fp64 oracle")
+
+
 def test_graph_replay_timing_entry():
     q, k, v = (torch.randn(4, 512, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
     ms_stream = fa.time_forward(q, k, v, False, warmup=1, iters=5)
