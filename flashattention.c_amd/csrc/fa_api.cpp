@@ -531,7 +531,7 @@ const char* fa_kernel_name_for(int32_t dtype, int32_t d, int32_t causal, int64_t
     if (dtype == FA_DTYPE_BF16_OUT_F32) {   // the accurate P (see fa_dtype): fp16 (slabs below 4 GiB, launches large enough), hi + lo bf16 terms otherwise
         if (((n - 1) * d + d) * 2 >= 0xffffffffLL) return "fa_fwd_f32_split_kernel";
         if ((double)bh * (double)n * (double)n * (double)d * (causal ? 0.5 : 1.0) < (d == 32 ? 2e9 : 6e9)) return "fa_fwd_f32_split_kernel";
-        return (d == 64 && strcmp(fa::bf16_kernel_name(bh, n, d, causal), "fa_fwd_bf16_x4_kernel") == 0) ? "fa_fwd_bf16_x4_p16_kernel" : "fa_fwd_bf16_x2_p16_kernel";
+        return (d == 64 && fa::bf16_p16_uses_x4(bh, n, causal)) ? "fa_fwd_bf16_x4_p16_kernel" : "fa_fwd_bf16_x2_p16_kernel";
     }
     return nullptr;
 }

@@ -504,12 +504,21 @@ bool bf16_p16_supported(const FwdParams& p, int d)
     return (d == 32 || d == 64 || d == 128) && ((int64_t)(p.n - 1) * p.kv_row_stride + d) * 2 < (int64_t)0xffffffffLL;
 }
 
+// d = 64 fp16 P: the NB = 4 kernel (512-row workgroups, one per CU) only where it is not behind -- a single, well filled round of
+// them.  Elsewhere the NB = 2 kernel, which fits a CU twice: ms NB = 4 / NB = 2, BH x 8192: 16: 0.279 / 0.278, 12: 0.260 / 0.251,
+// 32: 0.538 / 0.530, 128: 2.122 / 2.056.
+bool bf16_p16_uses_x4(int64_t bh, int64_t n, int causal)
+{
+    const int64_t items512 = bh * ((n + 511) / 512);
+    return choose_bf16(bh, n, 64, causal, true) == kChooseX4 && items512 > 192 && items512 <= 256;
+}
+
 hipError_t launch_bf16_p16(const FwdParams& p, int d, int causal, int out_f32, hipStream_t stream)
 {
     if (!bf16_p16_supported(p, d)) return hipErrorInvalidValue;
     if (d == 32) return launch_bf16_x2_p16_d32(p, causal, out_f32, stream);
     if (d == 128) return launch_bf16_x2_p16_d128(p, causal, out_f32, stream);
-    if (choose_bf16(p.bh, p.n, 64, causal, true) == kChooseX4) return launch_bf16_x4_p16(p, causal, out_f32, stream);
+    if (bf16_p16_uses_x4(p.bh, p.n, causal)) return launch_bf16_x4_p16(p, causal, out_f32, stream);
     return launch_bf16_x2_p16_d64(p, causal, out_f32, stream);
 }
 

@@ -25,6 +25,7 @@ hipError_t launch_bf16_x2(const FwdParams& p, int d, int causal, int out_f32, in
 hipError_t launch_bf16_p16(const FwdParams& p, int d, int causal, int out_f32, hipStream_t stream);
 bool bf16_p16_supported(const FwdParams& p, int d);   // d in {32, 64, 128} and the slab addressable with 32-bit byte offsets
 hipError_t launch_bf16_x4_p16(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
+bool bf16_p16_uses_x4(int64_t bh, int64_t n, int causal);
 hipError_t launch_bf16_x2_p16_d32(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
 hipError_t launch_bf16_x2_p16_d64(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
 hipError_t launch_bf16_x2_p16_d128(const FwdParams& p, int causal, int out_f32, hipStream_t stream);

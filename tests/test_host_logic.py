@@ -42,7 +42,8 @@ def test_library_exports_every_declared_symbol():
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 32, 0, 4, 300) == b"fa_fwd_f32_split_kernel"
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 16, 1024) == b"fa_fwd_f32_split_kernel"
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 1, 128, 1024) == b"fa_fwd_f32_split_kernel"
-    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 128, 2048) == b"fa_fwd_bf16_x4_p16_kernel"
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 128, 2048) == b"fa_fwd_bf16_x2_p16_kernel"   # more than one round of 512-row tiles: NB = 2, two per CU
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 16, 8192) == b"fa_fwd_bf16_x4_p16_kernel"    # c4: one full round of NB = 4
 
 
 def test_kernel_ids_match_the_header_and_the_python_names():
