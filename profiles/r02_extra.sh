@@ -4,6 +4,8 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 $R/profiles/ubench/ubench_regfile > $OUT/r02_ubench_regfile.txt 2>&1
+# per-instruction issue costs alone and beside an MFMA (hipcc --offload-arch=gfx950 -O3 -o ubench_valu_mix ubench_valu_mix.hip)
+[ -x $R/profiles/ubench/ubench_valu_mix ] && $R/profiles/ubench/ubench_valu_mix > $OUT/r02_ubench_valu_mix.txt 2>&1
 D=$R/flashattention.c_amd/fa_driver_ablation
 {
 echo "# fa_driver_ablation --mode prof4: s_memtime stamps around the fast loop / prologue / epilogue of every wave of the NB = 4 kernel (c4 unless noted)"
