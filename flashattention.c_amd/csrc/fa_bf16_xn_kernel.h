@@ -911,7 +911,7 @@ static hipError_t launch_x4_p16(const FwdParams& p0, int out_f32, hipStream_t st
 //   * one workgroup per CU -- unused dynamic LDS pushes the allocation past half of the CU's 160 KB (amdgpu_waves_per_eu does
 //     not change what the hardware co-schedules) -- and the light tiles follow the heavy ones:          0.197 / 0.154 / 0.120
 //   * two per CU, odd rounds of an XCD's workgroups walking their slab from the light end (alt_order): 0.181 / 0.140 / 0.109
-//     -- needs slabs that do not straddle XCDs (bh % 8 == 0); other grids take the first answer.
+//     -- for grids of nearly two full rounds; emptier ones take the first answer (xn_launch_order).
 // More than two rounds (32 x 8192: 0.343 plain, 0.370 alternating) and short rows (128 x 1024: 0.062 with two per CU, 0.076 with
 // one) keep the plain order with two per CU.
 template <int D, int G>
@@ -921,8 +921,11 @@ static unsigned xn_launch_order(FwdParams& p, const dim3& grid, int causal, bool
     const long wgs = (long)grid.x * grid.y * grid.z;
     p.alt_order = 0;
     if (!causal || !co_resident || ring >= 84 * 1024 || wgs > 2 * 256 || p.n < 4096) return 0;
-    if (p.bh % kNumXcd == 0) {   // both workgroups of a CU resident, tiles paired heavy + light (xn_tile)
-        p.alt_order = 1;
+    // Nearly two full rounds: pair the tiles.  A half-filled second round leaves too many heavy tiles without a partner and the
+    // padded launch wins (ms paired / padded: 12 x 8192 d = 32 0.127 / 0.114, 5 x 16384 0.220 / 0.196, fp16 P 12 x 8192 0.202 / 0.193;
+    // against 20 x 6144 d = 32 0.117 / 0.133, fp16 P 7 x 16384 0.371 / 0.430, 20 x 5000 0.143 / 0.170, 9 x 12288 d = 64 0.249 / 0.301).
+    if (wgs > 384) {
+        p.alt_order = 1;         // both workgroups of a CU resident, tiles paired heavy + light (causal_tile)
         return 0;
     }
     return 84 * 1024 - ring;     // one workgroup per CU, heavy tiles first

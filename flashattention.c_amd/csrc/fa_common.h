@@ -81,17 +81,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int total)
 }
 
 // Tile of a causal workgroup.  Default: walk each slab from its heaviest tile (light tiles then follow heavy ones onto a CU).
-// alt_order (set by the launcher when the WHOLE grid is resident with two workgroups per CU and slabs do not straddle XCDs,
-// bh % 8 == 0): the dispatcher deals an XCD's workgroups over its 32 CUs in order, so positions pos and pos + 32 share a CU; even
-// rounds take a slab's tiles from the heavy end, odd rounds from the light end, and the two tiles of every CU add up to the same
-// work.  A bijection per slab for every tile count.
+// alt_order (set by the launcher when the WHOLE grid is resident with two workgroups per CU: at most 64 per XCD): the dispatcher
+// deals an XCD's workgroups over its 32 CUs in order, so positions pos and pos + 32 share a CU.  Within the stretch of a slab that
+// an XCD owns (xcd_remap gives every XCD a contiguous range of items; a slab may be cut by the boundary), even rounds take that
+// stretch's tiles from the heavy end, odd rounds from the light end: the two tiles of a CU add up to about the same work
+// everywhere.  Each stretch maps onto its own set of tiles, so the whole is a bijection for every bh and tile count.
 __device__ __forceinline__ int causal_tile(const FwdParams& p, int qt)
 {
     if (!p.alt_order) return p.q_tiles - 1 - qt;
-    const int pos = blockIdx.x / kNumXcd, k = pos % p.q_tiles, s0 = pos - k;
+    const int total = p.bh * p.q_tiles, q = total / kNumXcd, r = total % kNumXcd;
+    const int xcd = blockIdx.x % kNumXcd, pos = blockIdx.x / kNumXcd;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, cnt = q + (xcd < r ? 1 : 0);
+    const int w = base + pos, k = w % p.q_tiles, slab0 = w - k;
+    const int seg0 = slab0 > base ? slab0 : base;                                               // first item of this stretch
+    const int seg1 = slab0 + p.q_tiles < base + cnt ? slab0 + p.q_tiles : base + cnt;           // one past its last
+    const int k_lo = seg0 - slab0, len = seg1 - seg0, pos0 = seg0 - base, j = w - seg0;
     auto even_before = [](int x) { return (x / 64) * 32 + (x % 64 < 32 ? x % 64 : 32); };
-    const int e = even_before(pos) - even_before(s0);
-    return ((pos / 32) & 1) ? k - e : p.q_tiles - 1 - e;
+    const int e = even_before(pos) - even_before(pos0);                                         // even-round items of the stretch before this one
+    const int hi = p.q_tiles - 1 - k_lo, lo = p.q_tiles - k_lo - len;                           // the stretch's tiles: lo .. hi
+    return ((pos / 32) & 1) ? lo + (j - e) : hi - e;
 }
 
 // Drain this wave's outstanding LDS-DMA (global_load_lds) transfers.  LDS-DMA completion is tracked by vmcnt; a

@@ -416,12 +416,13 @@ def test_fuzz_fp32_shapes_through_the_dispatch_against_rung0():
 
 
 
-@pytest.mark.parametrize("bh,n", [(8, 4096), (16, 4096), (8, 5000), (8, 6144), (16, 8192), (8, 16384), (8, 12289), (24, 4200)])
+@pytest.mark.parametrize("bh,n", [(8, 4096), (16, 4096), (8, 5000), (8, 6144), (16, 8192), (8, 16384), (8, 12289), (24, 4200),
+                                  (13, 8192), (20, 5000), (7, 16384), (9, 12288), (15, 7000), (25, 4096), (11, 9000)])
 def test_causal_paired_tile_order_covers_every_tile_once(bh, n):
-    """Causal NB = 2 launches whose whole grid is resident with two workgroups per CU (d = 32, and fp16 P at d = 64; bh % 8 == 0,
-    at most 512 tiles, N >= 4096) deal the tiles of a slab from both ends (FwdParams::alt_order).  The map has to be a bijection
-    for every tile count per slab -- 16, 20, 24, 32, 49, 64 here, slabs aligned and not aligned with the 32-position rounds -- or
-    some rows are computed twice and others never (the output buffer is poisoned with NaN first)."""
+    """Causal NB = 2 launches whose whole grid is resident with two workgroups per CU (385 .. 512 tiles, N >= 4096) deal the
+    tiles of a slab from both ends (FwdParams::alt_order); emptier grids are launched with one workgroup per CU.  The map has to
+    be a bijection for every tile count per slab and every bh -- slabs aligned with the 32-position rounds, not aligned, and cut
+    by the boundary between two XCDs -- or some rows are computed twice and others never (the output is poisoned with NaN first)."""
     g = torch.Generator(device="cpu").manual_seed(n + bh)
     for d, kernel, out_dtype, tol in ((32, "auto", torch.bfloat16, 2.5e-2), (64, "p16", torch.float32, P16_TOL_BIG), (32, "p16", torch.float32, P16_TOL_BIG)):
         q, k, v = (torch.randn(bh, n, d, generator=g).to(torch.bfloat16).to(dev()) for _ in range(3))
@@ -435,7 +436,8 @@ def test_causal_paired_tile_order_covers_every_tile_once(bh, n):
 
 
 
-@pytest.mark.parametrize("bh,n,d", [(16, 4096, 64), (8, 5000, 64), (32, 2048, 64), (16, 4096, 32), (8, 7168, 32), (64, 1024, 64), (24, 2500, 64)])
+@pytest.mark.parametrize("bh,n,d", [(16, 4096, 64), (8, 5000, 64), (32, 2048, 64), (16, 4096, 32), (8, 7168, 32), (64, 1024, 64), (24, 2500, 64),
+                                    (12, 4096, 64), (20, 2048, 64), (5, 8192, 32), (9, 6000, 64), (13, 3000, 32), (3, 16384, 64)])
 def test_causal_paired_tile_order_in_the_split_kernel(bh, n, d):
     """fp32 tensors, causal, the one-block-per-wave tilings of the split kernel (two workgroups per CU) on grids that are resident
     as a whole: same paired tile order, same bijection requirement (NaN-poisoned output), against the fp64 oracle on a few slabs."""
