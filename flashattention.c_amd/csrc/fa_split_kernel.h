@@ -905,6 +905,7 @@ static hipError_t launch_split(const FwdParams& p0, int causal, hipStream_t stre
     // Measured, fp32 tensors, ms: 16 x 4096 d = 64 0.162 -> 0.125, 32 x 2048 0.089 -> 0.074, 16 x 4096 d = 32 0.122 -> 0.094, and with
     // slabs cut by XCD boundaries 12 x 4096 0.149 -> 0.134, 20 x 2048 0.079 -> 0.071, 12 x 4096 d = 32 0.119 -> 0.104; the
     // two-block tilings (one workgroup per CU, heavy tiles first) must keep their order: 16 x 8192 0.397 -> 0.531 when paired.
+    // (larger grids: +-3 % either way on seven shapes -- they keep the plain order)
     p.alt_order = (causal && QB == 1 && NWAVES == 4 && D <= 64 && total <= 2 * 256) ? 1 : 0;
     if (causal)
         hipLaunchKernelGGL((fa_fwd_f32_split_kernel<D, NWAVES, QB, true, MINBLOCKS, PIPE, IN_BF16>), grid, block, 0, stream, p);

@@ -455,6 +455,22 @@ def test_causal_paired_tile_order_in_the_split_kernel(bh, n, d):
     check(out[sl], ref, TOL_F32, "vs fp64 oracle")
 
 
+
+@pytest.mark.parametrize("bh,n,d", [(5, 3000, 64), (13, 777, 64), (16, 4096, 64), (3, 8192, 32), (7, 1300, 128), (33, 129, 32), (1, 5000, 64)])
+def test_causal_alternating_tile_order_in_the_exact_kernel(bh, n, d):
+    """kernel="exact" (fp32 arithmetic; also the fallback of the guarded fp32 chain) deals every causal slab's tiles alternately
+    from the heavy and the light end, for every grid size: a bijection or NaN-poisoned rows stay (and the values must agree)."""
+    q, k, v = (randn(s, bh, n, d) for s in (81, 82, 83))
+    qd, kd, vd = to_dev(q, k, v)
+    out = torch.full((bh, n, d), float("nan"), dtype=torch.float32, device=dev())
+    fa.forward(qd, kd, vd, True, kernel="exact", out=out)
+    assert not torch.isnan(out).any(), "unwritten rows"
+    ref = fa.forward(qd, kd, vd, True, kernel="naive")
+    err = float((out - ref).abs().max())
+    OBSERVED.append((f"exact kernel alternating causal order bh={bh} n={n} d={d}", err, 1e-4))
+    assert err < 1e-4, f"{err:.3e}"
+
+
 def test_graph_replay_timing_entry():
     q, k, v = (torch.randn(4, 512, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
     ms_stream = fa.time_forward(q, k, v, False, warmup=1, iters=5)
