@@ -920,14 +920,17 @@ static unsigned xn_launch_order(FwdParams& p, const dim3& grid, int causal, bool
     constexpr int ring = 4 * G * Bf16Cfg<D, 4>::kTileBytes;
     const long wgs = (long)grid.x * grid.y * grid.z;
     p.alt_order = 0;
-    if (!causal || !co_resident || ring >= 84 * 1024 || wgs > 2 * 256 || p.n < 4096) return 0;
-    // Nearly two full rounds: pair the tiles.  A half-filled second round leaves too many heavy tiles without a partner and the
-    // padded launch wins (ms paired / padded: 12 x 8192 d = 32 0.127 / 0.114, 5 x 16384 0.220 / 0.196, fp16 P 12 x 8192 0.202 / 0.193;
-    // against 20 x 6144 d = 32 0.117 / 0.133, fp16 P 7 x 16384 0.371 / 0.430, 20 x 5000 0.143 / 0.170, 9 x 12288 d = 64 0.249 / 0.301).
+    if (!causal || !co_resident || ring >= 84 * 1024 || wgs > 2 * 256) return 0;
+    // Nearly two full rounds: pair the tiles, whatever the row length (short rows too: 128 x 1024 d = 64 0.040 -> 0.034 ms, 64 x 2048
+    // 0.065 -> 0.054, d = 32 64 x 2048 0.050 -> 0.039).  A half-filled second round leaves too many heavy tiles without a partner:
+    // long rows then take the padded launch (ms paired / padded: 12 x 8192 d = 32 0.127 / 0.114, 5 x 16384 0.220 / 0.196, fp16 P
+    // 12 x 8192 0.202 / 0.193; against 20 x 6144 d = 32 0.117 / 0.133, fp16 P 7 x 16384 0.371 / 0.430, 20 x 5000 0.143 / 0.170,
+    // 9 x 12288 d = 64 0.249 / 0.301), short rows keep both workgroups and the plain order (40 x 2048: 0.060 against 0.061 padded).
     if (wgs > 384) {
         p.alt_order = 1;         // both workgroups of a CU resident, tiles paired heavy + light (causal_tile)
         return 0;
     }
+    if (p.n < 4096) return 0;
     return 84 * 1024 - ring;     // one workgroup per CU, heavy tiles first
 }
 

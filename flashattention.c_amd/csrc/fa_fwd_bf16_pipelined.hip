@@ -491,10 +491,12 @@ static hipError_t launch_pp3(const FwdParams& p0, int causal, int out_f32, hipSt
     const int64_t total = (int64_t)p.bh * p.q_tiles;
     if (total > 0x7fffffffLL) return hipErrorInvalidValue;
     dim3 grid((unsigned)total), block(NWAVES * kWave);
-    // Two workgroups per CU by construction.  The paired causal tile order (causal_tile) was measured here too -- 16 x 8192: 0.204
-    // -> 0.154 ms -- which only reaches what the one-wave-per-SIMD kernel does on such grids (0.150), so the dispatch keeps sending
-    // them there and this kernel keeps the plain order for the large grids it serves.
-    p.alt_order = 0;
+    // Two workgroups per CU by construction: on causal grids of whole rounds (a multiple of 256 workgroups) the tiles of a slab are
+    // dealt alternately from the heavy and the light end (causal_tile).  Measured, causal d = 64, ms plain -> alternating: 128 x 2048
+    // 0.117 -> 0.110, 256 x 1024 0.073 -> 0.064, 512 x 512 0.051 -> 0.047, 64 x 2048 0.065 -> 0.054; with a partial last round it
+    // loses (48 x 3000, 576 workgroups: 0.085 -> 0.095) and stays off.  (16 x 8192: 0.204 -> 0.154, which only reaches what the
+    // one-wave-per-SIMD kernel does on such grids -- the dispatch keeps sending long rows there.)
+    p.alt_order = (causal && NWAVES == 4 && total % 256 == 0) ? 1 : 0;
     if (causal) {
         if (out_f32)
             hipLaunchKernelGGL((fa_fwd_bf16_pp3_kernel<D, NWAVES, true, true, false, G, OPTIMISTIC>), grid, block, 0, stream, p);

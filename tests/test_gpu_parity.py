@@ -417,7 +417,8 @@ def test_fuzz_fp32_shapes_through_the_dispatch_against_rung0():
 
 
 @pytest.mark.parametrize("bh,n", [(8, 4096), (16, 4096), (8, 5000), (8, 6144), (16, 8192), (8, 16384), (8, 12289), (24, 4200),
-                                  (13, 8192), (20, 5000), (7, 16384), (9, 12288), (15, 7000), (25, 4096), (11, 9000)])
+                                  (13, 8192), (20, 5000), (7, 16384), (9, 12288), (15, 7000), (25, 4096), (11, 9000),
+                                  (128, 1024), (64, 2048), (100, 1024), (56, 2048), (250, 500), (33, 3000)])
 def test_causal_paired_tile_order_covers_every_tile_once(bh, n):
     """Causal NB = 2 launches whose whole grid is resident with two workgroups per CU (385 .. 512 tiles, N >= 4096) deal the
     tiles of a slab from both ends (FwdParams::alt_order); emptier grids are launched with one workgroup per CU.  The map has to
@@ -469,6 +470,24 @@ def test_causal_alternating_tile_order_in_the_exact_kernel(bh, n, d):
     err = float((out - ref).abs().max())
     OBSERVED.append((f"exact kernel alternating causal order bh={bh} n={n} d={d}", err, 1e-4))
     assert err < 1e-4, f"{err:.3e}"
+
+
+
+@pytest.mark.parametrize("bh,n", [(128, 2048), (256, 1024), (512, 512), (96, 2048), (64, 3072), (48, 3000), (130, 2000)])
+def test_causal_alternating_tile_order_in_the_two_wave_kernel(bh, n):
+    """Causal d = 64 grids of more than 512 short tiles go to the two-wave kernel, which deals slabs alternately from both ends
+    when the grid is a whole number of rounds (a multiple of 256 workgroups) and in plain order otherwise: both here, NaN-poisoned."""
+    g = torch.Generator(device="cpu").manual_seed(n + bh)
+    q, k, v = (torch.randn(bh, n, 64, generator=g).to(torch.bfloat16).to(dev()) for _ in range(3))
+    assert fa.kernel_name(q, True) in ("fa_fwd_bf16_pp3_kernel", "fa_fwd_bf16_x2_kernel") if hasattr(fa, "kernel_name") else True
+    ref = fa.forward(q.float(), k.float(), v.float(), True, kernel="naive")
+    for kern in ("auto", "mfma:7"):
+        out = torch.full((bh, n, 64), float("nan"), dtype=torch.float32, device=dev())
+        fa.forward(q, k, v, True, kernel=kern, out=out)
+        assert not torch.isnan(out).any(), f"unwritten rows ({kern})"
+        err = float((out - ref).abs().max())
+        OBSERVED.append((f"two-wave alternating causal order bh={bh} n={n} {kern}", err, bf16_tol(1.0, True)))
+        assert err < bf16_tol(1.0, True), f"{kern}: {err:.3e}"
 
 
 def test_graph_replay_timing_entry():
