@@ -941,18 +941,23 @@ static hipError_t launch_x2(const FwdParams& p0, int causal, int out_f32, hipStr
     dim3 grid, block;
     if (!xn_grid<2>(p0, p, grid, block)) return hipErrorInvalidValue;
     const unsigned solo = xn_launch_order<D, G>(p, grid, causal, D <= 64);
-    if (causal) {
-        if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, 4, true, true, G, 0, OPTIMISTIC>), grid, block, solo, stream, p);
-        else
-            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, 4, true, false, G, 0, OPTIMISTIC>), grid, block, solo, stream, p);
-    } else {
-        if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, 4, false, true, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
-        else
-            hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, 4, false, false, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
-    }
-    return hipGetLastError();
+    auto go = [&](unsigned dyn_lds) {
+        if (causal) {
+            if (out_f32)
+                hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, 4, true, true, G, 0, OPTIMISTIC>), grid, block, dyn_lds, stream, p);
+            else
+                hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, 4, true, false, G, 0, OPTIMISTIC>), grid, block, dyn_lds, stream, p);
+        } else {
+            if (out_f32)
+                hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, 4, false, true, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
+            else
+                hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<D, 4, false, false, G, 0, OPTIMISTIC>), grid, block, 0, stream, p);
+        }
+        return hipGetLastError();
+    };
+    hipError_t e = go(solo);
+    if (e != hipSuccess && solo != 0) e = go(0);   // the padding is an optimisation: a runtime that refuses it still gets the launch
+    return e;
 }
 
 template <int D>
@@ -962,18 +967,23 @@ static hipError_t launch_x2_p16(const FwdParams& p0, int causal, int out_f32, hi
     dim3 grid, block;
     if (!xn_grid<2>(p0, p, grid, block)) return hipErrorInvalidValue;
     const unsigned solo = xn_launch_order<D, 2>(p, grid, causal, D <= 64);
-    if (causal) {
-        if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, true, true, 2>), grid, block, solo, stream, p);
-        else
-            hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, true, false, 2>), grid, block, solo, stream, p);
-    } else {
-        if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, false, true, 2>), grid, block, 0, stream, p);
-        else
-            hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, false, false, 2>), grid, block, 0, stream, p);
-    }
-    return hipGetLastError();
+    auto go = [&](unsigned dyn_lds) {
+        if (causal) {
+            if (out_f32)
+                hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, true, true, 2>), grid, block, dyn_lds, stream, p);
+            else
+                hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, true, false, 2>), grid, block, dyn_lds, stream, p);
+        } else {
+            if (out_f32)
+                hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, false, true, 2>), grid, block, 0, stream, p);
+            else
+                hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, false, false, 2>), grid, block, 0, stream, p);
+        }
+        return hipGetLastError();
+    };
+    hipError_t e = go(solo);
+    if (e != hipSuccess && solo != 0) e = go(0);   // see launch_x2
+    return e;
 }
 
 template <int ABL>
