@@ -169,6 +169,52 @@ bool f32_auto_is_exact()
     return exact;
 }
 
+// Key-split launch for grids that leave most of the chip idle (FlashDecoding-style): bf16 tensors, bf16 P, non-causal, plain
+// (bh, n, d) layout, at most 128 tiles of 256 rows.  A lone 256-row tile over 8192 keys takes 0.108 ms whatever bh is (1, 2 or 4
+// slabs: the launch is one tile long), so S = 2 .. 8 workgroups per q-tile each take n / S keys (>= 1024) through the NB = 2
+// kernel -- the split index rides on the "head" index of FwdParams, kv_head_stride carries the key offset, the partial outputs
+// (fp32, normalised) and their log-sum-exps go to stream-ordered scratch -- and fa_combine_splits_kernel merges them.
+int keysplit_factor(const fa::FwdParams& p, int32_t d, int32_t causal)
+{
+    if (causal || p.heads != 1 || p.n < 4096) return 1;
+    if (((int64_t)(p.n - 1) * p.kv_row_stride + d) * 2 >= (int64_t)0xffffffffLL) return 1;   // the NB = 2 kernels' 32-bit slab offsets
+    const int64_t tiles = (int64_t)p.bh * ((p.n + 255) / 256);
+    if (tiles > 128) return 1;
+    int S = 1;
+    while (S < 8 && tiles * (2 * S) <= 256 && p.n / (2 * S) >= 1024) S *= 2;
+    return S;
+}
+
+int launch_bf16_keysplit(const fa::FwdParams& p0, int32_t d, int32_t out_f32, int S, hipStream_t stream)
+{
+    int n_kv = ((p0.n + S - 1) / S + 63) / 64 * 64;
+    while (S > 1 && (int64_t)(S - 1) * n_kv >= p0.n) --S;        // every split owns at least one key
+    const size_t o_bytes = (size_t)S * p0.bh * p0.n * d * 4u, l_bytes = (size_t)S * p0.bh * p0.n * 4u;
+    void* scratch = nullptr;
+    hipError_t e = scratch_alloc(&scratch, o_bytes + l_bytes, stream);
+    if (e != hipSuccess) return fail(FA_ERR_HIP, "hipMallocAsync(%zu bytes) for the key-split partials failed: %s", o_bytes + l_bytes, hipGetErrorString(e));
+    float* o_part = (float*)scratch;
+    float* lse_part = (float*)((char*)scratch + o_bytes);
+    fa::FwdParams p = p0;
+    p.bh = p0.bh * S;
+    p.heads = S;
+    p.q_head_stride = 0;
+    p.kv_head_stride = (int64_t)n_kv * p0.kv_row_stride;
+    p.o = o_part;
+    p.o_batch_stride = (int64_t)p0.n * d;
+    p.o_head_stride = (int64_t)p0.bh * p0.n * d;
+    p.o_row_stride = d;
+    p.lse = lse_part;
+    p.n_kv = n_kv;
+    p.n_kv_total = p0.n;
+    e = fa::launch_bf16_x2(p, d, 0, 1, 0, stream);
+    if (e == hipSuccess) e = fa::launch_combine_splits(p0, o_part, lse_part, S, d, out_f32, stream);
+    const hipError_t ef = hipFreeAsync(scratch, stream);
+    if (e == hipSuccess) e = ef;
+    if (e != hipSuccess) return fail(FA_ERR_HIP, "key-split launch failed: %s", hipGetErrorString(e));
+    return FA_OK;
+}
+
 // bf16 tensors, fp16 P: V -> fp16 scratch copy, fp16-P kernel, split kernel as the conditional fallback
 int launch_p16_chain(const fa::FwdParams& p0, int32_t d, int32_t causal, int32_t out_f32, hipStream_t stream)
 {
@@ -304,8 +350,11 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
                 return launch_p16_chain(p, d, causal, out_f32, stream);
             if (sel.kind == FA_KERNEL_SPLIT || (sel.kind == FA_KERNEL_AUTO && out_f32 && sel.variant == 0))
                 e = fa::launch_bf16_split(p, d, causal ? 1 : 0, out_f32, sel.variant, stream);
-            else
+            else {
+                const int S = (sel.variant == 0 && (sel.kind == FA_KERNEL_AUTO || sel.kind == FA_KERNEL_MFMA)) ? keysplit_factor(p, d, causal) : 1;
+                if (S > 1) return launch_bf16_keysplit(p, d, out_f32, S, stream);
                 e = fa::launch_fwd_bf16(p, d, causal ? 1 : 0, out_f32, sel.variant, stream);
+            }
         } else if (sel.kind == FA_KERNEL_P16) {
             return fail(FA_ERR_UNSUPPORTED, "FA_KERNEL_P16 is a bf16-tensor kernel");
         } else if (sel.kind == FA_KERNEL_MFMA || (sel.kind == FA_KERNEL_AUTO && f32_auto_is_exact())) {

@@ -515,7 +515,10 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
     const __bf16* vg = (const __bf16*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
     const int64_t o_slab_off = b * p.o_batch_stride + h * p.o_head_stride;
 
-    int kv_end = n;
+    // keys of this workgroup: all n, or its share of a key-split launch (FwdParams::n_kv; non-causal only)
+    int nk = n;
+    if (!CAUSAL && p.n_kv > 0) nk = min(p.n_kv, p.n_kv_total - h * p.n_kv);
+    int kv_end = nk;
     if (CAUSAL) kv_end = min(n, qt * BM + BM);
     const int nst = (kv_end + kKvBlk - 1) / kKvBlk;  // 64-key stages
     const int nsub = (kv_end + 31) / 32;             // 32-key sub-tiles
@@ -524,7 +527,7 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
     auto v_slot = [&](int j) { return v_ring + (j & (VR - 1)) * T; };
 
     TileDma<D, NWAVES> dma;
-    dma.init(kg, vg, n, p.kv_row_stride, wave, lane);
+    dma.init(kg, vg, nk, p.kv_row_stride, wave, lane);
     dma.issue_k(0u, k_slot(0), wave);
     // every tile the first barrier group needs is requested before anything is waited for: one memory round trip, not two
 #pragma unroll
@@ -565,7 +568,7 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
     const float c = p.scale_log2e;
 
     // sub-tile t needs a mask for the block whose first row is qb?
-    auto needs_mask = [&](int t, int qb) { return (t * 32 + 32 > n) || (CAUSAL && (t * 32 + 31 > qb)); };
+    auto needs_mask = [&](int t, int qb) { return (t * 32 + 32 > nk) || (CAUSAL && (t * 32 + 31 > qb)); };
 
     // Top of stage j, j a multiple of G: K(j+1 .. j+G), V(j .. j+G-1) visible; K(j+G+1 .. j+2G), V(j+G .. j+2G-1) enqueued into the
     // ring slots nobody reads any more (K tiles are only read into kf one step ahead of their use, and every LDS read of
@@ -602,7 +605,7 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
         float mx[NB];
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk) {
-            if (needs_mask(t, q0 + 32 * blk)) mask16(s[blk], t * 32, q0 + 32 * blk + lq, n, hi, CAUSAL);
+            if (needs_mask(t, q0 + 32 * blk)) mask16(s[blk], t * 32, q0 + 32 * blk + lq, nk, hi, CAUSAL);
             mx[blk] = rowmax16(s[blk]);
         }
         if (first) {  // nothing accumulated yet: set the references, leave the (zero) accumulators alone
@@ -655,7 +658,7 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
     // O(N / 64) scalar iterations per wave, ~2.5k cycles at N = 8192)
     int jf = kv_end >= 96 ? (kv_end / 32 - 3) / 2 + 1 : 0;                    // (2 jf + 3) * 32 <= kv_end; kv_end <= n covers the ragged tail
     if (CAUSAL) jf = q0 >= 95 ? min(jf, (q0 - 95) / 64 + 1) : 0;             // 64 j + 95 <= q0: sub-tile 2 j + 2 lies below the first row's diagonal
-    if (n < 32) jf = 0;
+    if (nk < 32) jf = 0;
     // The last stage may run in the fast loop too when its own two sub-tiles are whole and mask-free: its second step then
     // computes scores of a sub-tile that does not exist (from whatever the ring slot holds) and nobody consumes them --
     // the rescale test of that step is ignored.  Without this the final 128 keys of every slab took the slow tail path.

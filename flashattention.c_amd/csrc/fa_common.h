@@ -57,6 +57,8 @@ struct FwdParams {
     // fa_fwd_f32_t3_kernel only: the low bf16 terms of the pre-split K and V (p.k / p.v hold the high terms) and the pre-pass maxima
     const void* k_lo;
     const void* v_lo;
+    int32_t n_kv, n_kv_total;   // key-split launches (non-causal NB = 2 kernels): a workgroup whose "head" index is s reads the keys
+                                // [s * n_kv, min((s + 1) * n_kv, n_kv_total)) -- kv_head_stride carries the offset; 0 = all n keys
     int32_t alt_order;     // causal NB = 2 launches with two workgroups per CU: odd rounds of a CU's workgroups walk their slab light-to-heavy
     const unsigned long long* stats;   // [0] (serial << 32) | bits of max |k|,  [1] (serial << 32) | bits of max |q * scale * log2 e|_2^2
 };

@@ -135,4 +135,54 @@ hipError_t launch_t3_prepass(const void* q, const void* k, const void* v, void* 
 
 #endif   // FA_ABLATION
 
+
+// ---- combine of a key-split launch (fa_api.cpp: launch_bf16_keysplit) -------------------------------------------------------
+// S workgroups per q-tile each saw a share of the keys and left a normalised partial output O_s (fp32, [S][bh][n][d]) and the
+// log-sum-exp of its share (natural log, [bh][S][n]).  O = sum_s w_s O_s / sum_s w_s with w_s = exp(lse_s - max_s lse_s);
+// lse = max + log(sum w_s).  One thread per four output columns; HBM-bound and small (S * 4 bytes per output element).
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void fa_combine_splits_kernel(FwdParams p, const float* __restrict__ o_part, const float* __restrict__ lse_part,
+                                                                 int S, int d)
+{
+    const int tpr = d / 4;                                       // threads per row
+    const int64_t rows = (int64_t)p.bh * p.n;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row_id = t / tpr;
+    if (row_id >= rows) return;
+    const int c = (int)(t % tpr) * 4;
+    const int slab = (int)(row_id / p.n), row = (int)(row_id % p.n);
+    float m = -INFINITY;
+    for (int s = 0; s < S; ++s) m = fmaxf(m, lse_part[((int64_t)slab * S + s) * p.n + row]);
+    float wsum = 0.0f;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int s = 0; s < S; ++s) {
+        const float w = __expf(lse_part[((int64_t)slab * S + s) * p.n + row] - m);
+        const f32x4 x = *(const f32x4*)(o_part + (((int64_t)s * p.bh + slab) * p.n + row) * d + c);
+        acc += w * x;
+        wsum += w;
+    }
+    const float inv = 1.0f / wsum;
+    const int b = slab / p.heads, h = slab % p.heads;
+    const int64_t off = b * p.o_batch_stride + h * p.o_head_stride + (int64_t)row * p.o_row_stride + c;
+    if constexpr (OUT_F32) {
+        *(f32x4*)((float*)p.o + off) = acc * inv;
+    } else {
+        __bf16* dst = (__bf16*)p.o + off;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = (__bf16)(acc[e] * inv);
+    }
+    if (p.lse != nullptr && c == 0) p.lse[(int64_t)slab * p.n + row] = m + __logf(wsum);
+}
+
+hipError_t launch_combine_splits(const FwdParams& p, const float* o_part, const float* lse_part, int S, int d, int out_f32, hipStream_t stream)
+{
+    const int64_t threads = (int64_t)p.bh * p.n * (d / 4);
+    const unsigned blocks = (unsigned)((threads + 255) / 256);
+    if (out_f32)
+        hipLaunchKernelGGL(fa_combine_splits_kernel<true>, dim3(blocks), dim3(256), 0, stream, p, o_part, lse_part, S, d);
+    else
+        hipLaunchKernelGGL(fa_combine_splits_kernel<false>, dim3(blocks), dim3(256), 0, stream, p, o_part, lse_part, S, d);
+    return hipGetLastError();
+}
+
 }  // namespace fa

@@ -30,6 +30,8 @@ hipError_t launch_bf16_x2_p16_d32(const FwdParams& p, int causal, int out_f32, h
 hipError_t launch_bf16_x2_p16_d64(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
 hipError_t launch_bf16_x2_p16_d128(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
 hipError_t launch_cvt_v_f16(const void* src, void* dst, int64_t count, uint32_t* flag, uint32_t serial, hipStream_t stream);
+// combine of a key-split launch: partial outputs fp32 [S][bh][n][d], partial log-sum-exps [bh][S][n] -> p.o (and p.lse)
+hipError_t launch_combine_splits(const FwdParams& p, const float* o_part, const float* lse_part, int S, int d, int out_f32, hipStream_t stream);
 // fp32 tensors, head dim 64, long non-causal rows: pre-split K / V (launch_t3_prepass) + the static-slot three-product kernel
 bool f32_t3_supported(const FwdParams& p, int d, int causal);
 hipError_t launch_f32_t3(const FwdParams& p, int abl, hipStream_t stream);   // ablation library only

@@ -489,6 +489,33 @@ def test_causal_alternating_tile_order_in_the_two_wave_kernel(bh, n):
         assert err < bf16_tol(1.0, True), f"{kern}: {err:.3e}"
 
 
+
+@pytest.mark.parametrize("bh,n,d", [(1, 8192, 64), (2, 8192, 64), (4, 8192, 64), (1, 4096, 64), (3, 5000, 64), (1, 16384, 64), (2, 7777, 32),
+                                    (1, 8192, 128), (5, 4200, 128), (1, 33000, 64), (8, 4096, 64)])
+def test_key_split_launch_for_grids_that_leave_the_chip_idle(bh, n, d):
+    """bf16 tensors, bf16 P, non-causal, at most 128 tiles of 256 rows and N >= 4096: S = 2 .. 8 workgroups per q-tile take n / S
+    keys each (FwdParams::n_kv) and fa_combine_splits_kernel merges the partial outputs by their log-sum-exps.  Ragged lengths,
+    every head dim, both output types, the LSE, and a spiked key that makes one split's maximum dwarf the others'."""
+    q, k, v = (orc.round_to_bf16(randn(s, bh, n, d)) for s in (91, 92, 93))
+    k[0, n // 3] = 6.0 * q[0, 17] / np.linalg.norm(q[0, 17])          # one row's weight sits almost entirely in one split
+    qd, kd, vd = to_dev(q, k, v, dtype=torch.bfloat16)
+    ref_dev, lse_ref = fa.forward(qd.float(), kd.float(), vd.float(), False, kernel="naive", return_lse=True)
+    for out_dtype in (torch.bfloat16, torch.float32):
+        o, lse = fa.forward(qd, kd, vd, False, kernel="mfma", out_dtype=out_dtype, return_lse=True)
+        err = float((o.float() - ref_dev).abs().max())
+        tol = bf16_tol(1.0, out_dtype == torch.float32)
+        OBSERVED.append((f"key split bh={bh} n={n} d={d} {out_dtype}", err, tol))
+        assert err < tol, f"{out_dtype}: {err:.3e}"
+        assert float((lse - lse_ref).abs().max()) < 2e-2
+    out = torch.full((bh, n, d), float("nan"), dtype=torch.bfloat16, device=dev())
+    fa.forward(qd, kd, vd, False, out=out)                               # FA_KERNEL_AUTO, bf16 out
+    assert not torch.isnan(out.float()).any()
+    assert float((out.float() - ref_dev).abs().max()) < bf16_tol(1.0, False)
+    sl = [0]
+    ref = orc.attention_f64(q[sl], k[sl], v[sl], causal=False)
+    check(out[sl], ref, bf16_tol(1.0, False), "vs fp64 oracle")
+
+
 def test_graph_replay_timing_entry():
     q, k, v = (torch.randn(4, 512, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
     ms_stream = fa.time_forward(q, k, v, False, warmup=1, iters=5)
