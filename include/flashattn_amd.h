@@ -20,8 +20,10 @@
  *   ragged N    any N >= 1 is handled exactly (tail keys are masked, not zero-filled as at
  *               flashattention.cu:224-231)
  *   ownership   the caller owns every tensor; no tensor is allocated, freed or zero-filled here (the reference allocates O and
- *               a dead O_l inside forward(), :608-609).  One path needs scratch -- FA_KERNEL_P16's fp16 copy of V -- and
- *               takes it from the device's stream-ordered pool (hipMallocAsync / hipFreeAsync on `stream`)
+ *               a dead O_l inside forward(), :608-609).  Two paths need scratch -- FA_KERNEL_P16's fp16 copy of V, and the
+ *               partial outputs of a key-split launch (bf16 tensors, non-causal, grids of at most 128 256-row tiles: several
+ *               workgroups per q-tile share the keys and a combine kernel merges them) -- and take it from the device's
+ *               stream-ordered pool (hipMallocAsync / hipFreeAsync on `stream`)
  *   aliasing    o must not overlap q, k or v (a tile that fails its verification is recomputed from q, k, v after o was
  *               written): overlapping ranges are rejected with FA_ERR_INVALID_ARGUMENT
  *   ordering    the kernel is enqueued on `stream` and the call returns without synchronising
