@@ -185,7 +185,9 @@ int keysplit_factor(const fa::FwdParams& p, int32_t d, int32_t causal)
     return S;
 }
 
-int launch_bf16_keysplit(const fa::FwdParams& p0, int32_t d, int32_t out_f32, int S, hipStream_t stream)
+// p16: p0.v is the fp16 copy of V and p0 carries the chain's flag fields (the fp16-P kernel skips itself when the copy overflowed; the
+// combine then merges garbage, which the chain's fallback launch overwrites -- it runs after this function)
+int launch_bf16_keysplit(const fa::FwdParams& p0, int32_t d, int32_t out_f32, int S, hipStream_t stream, bool p16 = false)
 {
     int n_kv = ((p0.n + S - 1) / S + 63) / 64 * 64;
     while (S > 1 && (int64_t)(S - 1) * n_kv >= p0.n) --S;        // every split owns at least one key
@@ -207,8 +209,11 @@ int launch_bf16_keysplit(const fa::FwdParams& p0, int32_t d, int32_t out_f32, in
     p.lse = lse_part;
     p.n_kv = n_kv;
     p.n_kv_total = p0.n;
-    e = fa::launch_bf16_x2(p, d, 0, 1, 0, stream);
-    if (e == hipSuccess) e = fa::launch_combine_splits(p0, o_part, lse_part, S, d, out_f32, stream);
+    if (!p16) e = fa::launch_bf16_x2(p, d, 0, 1, 0, stream);
+    else e = d == 32 ? fa::launch_bf16_x2_p16_d32(p, 0, 1, stream) : d == 64 ? fa::launch_bf16_x2_p16_d64(p, 0, 1, stream) : fa::launch_bf16_x2_p16_d128(p, 0, 1, stream);
+    fa::FwdParams pc = p0;
+    pc.flag_mode = 0;
+    if (e == hipSuccess) e = fa::launch_combine_splits(pc, o_part, lse_part, S, d, out_f32, stream);
     const hipError_t ef = hipFreeAsync(scratch, stream);
     if (e == hipSuccess) e = ef;
     if (e != hipSuccess) return fail(FA_ERR_HIP, "key-split launch failed: %s", hipGetErrorString(e));
@@ -231,7 +236,12 @@ int launch_p16_chain(const fa::FwdParams& p0, int32_t d, int32_t causal, int32_t
         p.flag = f.word;
         p.flag_serial = f.serial;
         p.flag_mode = 1;   // skip if the copy found a value fp16 cannot hold
-        e = fa::launch_bf16_p16(p, d, causal ? 1 : 0, out_f32, stream);
+        const int S = keysplit_factor(p0, d, causal);
+        if (S > 1) {
+            if (launch_bf16_keysplit(p, d, out_f32, S, stream, true) != FA_OK) e = hipErrorUnknown;   // fail() has recorded the message
+        } else {
+            e = fa::launch_bf16_p16(p, d, causal ? 1 : 0, out_f32, stream);
+        }
     }
     if (e == hipSuccess) {
         fa::FwdParams p = p0;
@@ -346,7 +356,7 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
             // and takes the fastest kernels (bf16 P).  MFMA / SPLIT / P16 force one family.
             if (sel.kind == FA_KERNEL_P16 && !p16_available(p, d))
                 return fail(FA_ERR_UNSUPPORTED, "the fp16-P kernels address a slab with 32-bit byte offsets (slabs below 4 GiB; got n = %d, d = %d)", p.n, d);
-            if (sel.kind == FA_KERNEL_P16 || (sel.kind == FA_KERNEL_AUTO && out_f32 && sel.variant == 0 && p16_available(p, d) && p16_worthwhile(p, d, causal)))
+            if (sel.kind == FA_KERNEL_P16 || (sel.kind == FA_KERNEL_AUTO && out_f32 && sel.variant == 0 && p16_available(p, d) && (p16_worthwhile(p, d, causal) || keysplit_factor(p, d, causal) > 1)))
                 return launch_p16_chain(p, d, causal, out_f32, stream);
             if (sel.kind == FA_KERNEL_SPLIT || (sel.kind == FA_KERNEL_AUTO && out_f32 && sel.variant == 0))
                 e = fa::launch_bf16_split(p, d, causal ? 1 : 0, out_f32, sel.variant, stream);
@@ -576,9 +586,19 @@ const char* fa_kernel_name_for(int32_t dtype, int32_t d, int32_t causal, int64_t
         if (f32_auto_is_exact()) return "fa_fwd_f32_kernel";
         return "fa_fwd_f32_split_kernel";
     }
-    if (dtype == FA_DTYPE_BF16) return fa::bf16_kernel_name(bh, n, d, causal);
+    if (dtype == FA_DTYPE_BF16) {
+        fa::FwdParams pk{};
+        memset(&pk, 0, sizeof(pk));
+        pk.bh = (int32_t)bh, pk.n = (int32_t)n, pk.heads = 1, pk.kv_row_stride = d;
+        if (keysplit_factor(pk, d, causal) > 1) return "fa_fwd_bf16_x2_kernel";       // small grids: key-split launch of the NB = 2 kernel
+        return fa::bf16_kernel_name(bh, n, d, causal);
+    }
     if (dtype == FA_DTYPE_BF16_OUT_F32) {   // the accurate P (see fa_dtype): fp16 (slabs below 4 GiB, launches large enough), hi + lo bf16 terms otherwise
         if (((n - 1) * d + d) * 2 >= 0xffffffffLL) return "fa_fwd_f32_split_kernel";
+        fa::FwdParams pk{};
+        memset(&pk, 0, sizeof(pk));
+        pk.bh = (int32_t)bh, pk.n = (int32_t)n, pk.heads = 1, pk.kv_row_stride = d;
+        if (keysplit_factor(pk, d, causal) > 1) return "fa_fwd_bf16_x2_p16_kernel";   // small grids: key-split launch of the NB = 2 kernel
         if ((double)bh * (double)n * (double)n * (double)d * (causal ? 0.5 : 1.0) < (d == 32 ? 2e9 : 6e9)) return "fa_fwd_f32_split_kernel";
         return (d == 64 && fa::bf16_p16_uses_x4(bh, n, causal)) ? "fa_fwd_bf16_x4_p16_kernel" : "fa_fwd_bf16_x2_p16_kernel";
     }

@@ -507,6 +507,22 @@ def test_key_split_launch_for_grids_that_leave_the_chip_idle(bh, n, d):
         OBSERVED.append((f"key split bh={bh} n={n} d={d} {out_dtype}", err, tol))
         assert err < tol, f"{out_dtype}: {err:.3e}"
         assert float((lse - lse_ref).abs().max()) < 2e-2
+    # FA_KERNEL_AUTO with an fp32 output: the fp16-P chain, key-split (V copy -> S partial launches -> combine -> empty fallback)
+    oa, lsea = fa.forward(qd, kd, vd, False, out_dtype=torch.float32, return_lse=True)
+    assert fa.last_forward_route() == 1
+    erra = float((oa - ref_dev).abs().max())
+    OBSERVED.append((f"key split, fp16 P, bh={bh} n={n} d={d}", erra, P16_TOL_BIG))
+    assert erra < P16_TOL_BIG, f"fp16 P: {erra:.3e}"
+    assert float((lsea - lse_ref).abs().max()) < 2e-3
+    if bh <= 2 and d == 64:      # ... and its fallback when V does not fit fp16: the split kernel's output must win over the combine's
+        vbig = vd.clone()
+        vbig[0, 5, 3] = 7.0e4
+        ob = fa.forward(qd, kd, vbig, False, out_dtype=torch.float32)
+        assert fa.last_forward_route() == 2
+        refb = fa.forward(qd.float(), kd.float(), vbig.float(), False, kernel="naive")
+        assert not torch.isnan(ob).any()
+        rel = float((ob - refb).abs().max() / refb.abs().max())
+        assert rel < 1e-4, f"relative error {rel:.3e} with a huge V entry"
     out = torch.full((bh, n, d), float("nan"), dtype=torch.bfloat16, device=dev())
     fa.forward(qd, kd, vd, False, out=out)                               # FA_KERNEL_AUTO, bf16 out
     assert not torch.isnan(out.float()).any()
