@@ -747,6 +747,20 @@ def test_p16_graph_capture_and_timing_entry():
     assert float((o - ref).abs().max()) < TOL_F32
 
 
+
+def test_key_split_launch_survives_graph_capture():
+    """The key-split launch takes its partial outputs from the stream-ordered pool and is three launches (partials, combine, free):
+    replayed from a hipGraph, bf16 output and the fp16-P chain with an fp32 output."""
+    q, k, v = (torch.randn(2, 8192, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
+    ref = fa.forward(q.float(), k.float(), v.float(), False, kernel="naive")
+    ob = torch.empty_like(q)
+    ms = fa.time_forward(q, k, v, False, warmup=1, iters=4, out=ob, graph=True)
+    assert 0.0 < ms < 50.0 and float((ob.float() - ref).abs().max()) < bf16_tol(1.0, False)
+    of = torch.empty(q.shape, dtype=torch.float32, device=dev())
+    ms = fa.time_forward(q, k, v, False, warmup=1, iters=4, out=of, graph=True)
+    assert 0.0 < ms < 50.0 and float((of - ref).abs().max()) < P16_TOL_BIG
+
+
 def test_guarded_fp32_chain_survives_graph_capture_and_other_streams():
     """The fp32 AUTO chain (split kernel + conditional exact kernel) replayed from a hipGraph, and two chains in flight on two streams
     with opposite verdicts: each call's flag word is its own (ring slot + serial number), so neither sees the other's."""
