@@ -395,6 +395,11 @@ def c4_side_measurements(fa, _cabi, q, k, v, causal, args, device):
     # causal reported separately; 1/sqrt(d) as a second line
     timed("c4_causal", dict(causal=True, scale=args.scale, out=out), fwd_flop(bh, n, d, True), note="c4 shape, causal (algorithmic FLOP halved)")
     timed("c4_scale_rsqrt_d", dict(causal=causal, scale=d ** -0.5, out=out), flop, note="c4 shape at scale 1/sqrt(d) instead of the reference's 1.0")
+    # one slab of the same length: a grid that leaves the chip idle -> key-split launch (S workgroups per q-tile + combine)
+    q1, k1, v1 = make_inputs(1, n, d, "bf16", device, seed=3)
+    timed("bh1_n8192_bf16_keysplit", dict(causal=False, scale=args.scale), fwd_flop(1, n, d, False), tensors=(q1, k1, v1),
+          note="B*H = 1 at the c4 length, bf16 tensors: 32 q-tiles x 8 key shares + combine instead of 32 workgroups", warm=100, iters=50)
+    del q1, k1, v1
     # README rows 2 and 4 (d = 32), bf16 and fp32 tensors
     for name, (B2, H2, n2) in (("d32_n8192", (2, 8, 8192)), ("d32_n1024", (8, 16, 1024))):
         q2, k2, v2 = make_inputs(B2 * H2, n2, 32, "bf16", device, seed=2)
