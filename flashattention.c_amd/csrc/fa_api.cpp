@@ -158,6 +158,17 @@ hipError_t scratch_alloc(void** ptr, size_t bytes, hipStream_t stream)
     return hipMallocAsync(ptr, bytes, stream);
 }
 
+// Stream-ordered scratch inside a captured graph is not reliable on this runtime (ROCm 7.2, MI355X): the first kernels that touch a
+// graph allocation of more than a few MB after the graph starts did not see / keep their data (fp16-P chain at 16 x 8192: output
+// unwritten on every replay of a one-launch graph; key-split launches: intermittently; tests/ + DESIGN.md section 1.2).  So the
+// paths that need scratch are not taken while `stream` is capturing: FA_KERNEL_AUTO falls back to kernels without scratch (same or
+// better accuracy, slower), an explicit FA_KERNEL_P16 is refused.
+bool stream_is_capturing(hipStream_t stream)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+
 // FA_F32_AUTO=exact in the environment makes FA_KERNEL_AUTO compute fp32 tensors in fp32 arithmetic (FA_KERNEL_MFMA) process-wide:
 // the switch for a deployment whose logits are too wide for 16-bit operands, without touching call sites.  Read once.
 bool f32_auto_is_exact()
@@ -356,12 +367,16 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
             // and takes the fastest kernels (bf16 P).  MFMA / SPLIT / P16 force one family.
             if (sel.kind == FA_KERNEL_P16 && !p16_available(p, d))
                 return fail(FA_ERR_UNSUPPORTED, "the fp16-P kernels address a slab with 32-bit byte offsets (slabs below 4 GiB; got n = %d, d = %d)", p.n, d);
-            if (sel.kind == FA_KERNEL_P16 || (sel.kind == FA_KERNEL_AUTO && out_f32 && sel.variant == 0 && p16_available(p, d) && (p16_worthwhile(p, d, causal) || keysplit_factor(p, d, causal) > 1)))
+            const bool capturing = stream_is_capturing(stream);
+            if (sel.kind == FA_KERNEL_P16 && capturing)
+                return fail(FA_ERR_UNSUPPORTED, "FA_KERNEL_P16 needs stream-ordered scratch, which is not reliable inside a captured graph on this runtime; "
+                                                "FA_KERNEL_AUTO picks a kernel without scratch while the stream is capturing");
+            if (sel.kind == FA_KERNEL_P16 || (!capturing && sel.kind == FA_KERNEL_AUTO && out_f32 && sel.variant == 0 && p16_available(p, d) && (p16_worthwhile(p, d, causal) || keysplit_factor(p, d, causal) > 1)))
                 return launch_p16_chain(p, d, causal, out_f32, stream);
             if (sel.kind == FA_KERNEL_SPLIT || (sel.kind == FA_KERNEL_AUTO && out_f32 && sel.variant == 0))
                 e = fa::launch_bf16_split(p, d, causal ? 1 : 0, out_f32, sel.variant, stream);
             else {
-                const int S = (sel.variant == 0 && (sel.kind == FA_KERNEL_AUTO || sel.kind == FA_KERNEL_MFMA)) ? keysplit_factor(p, d, causal) : 1;
+                const int S = (!capturing && sel.variant == 0 && (sel.kind == FA_KERNEL_AUTO || sel.kind == FA_KERNEL_MFMA)) ? keysplit_factor(p, d, causal) : 1;
                 if (S > 1) return launch_bf16_keysplit(p, d, out_f32, S, stream);
                 e = fa::launch_fwd_bf16(p, d, causal ? 1 : 0, out_f32, sel.variant, stream);
             }

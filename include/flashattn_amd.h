@@ -23,7 +23,9 @@
  *               a dead O_l inside forward(), :608-609).  Two paths need scratch -- FA_KERNEL_P16's fp16 copy of V, and the
  *               partial outputs of a key-split launch (bf16 tensors, non-causal, grids of at most 128 256-row tiles: several
  *               workgroups per q-tile share the keys and a combine kernel merges them) -- and take it from the device's
- *               stream-ordered pool (hipMallocAsync / hipFreeAsync on `stream`)
+ *               stream-ordered pool (hipMallocAsync / hipFreeAsync on `stream`); neither is taken while `stream` is capturing
+ *               (graph allocations proved unreliable on ROCm 7.2): FA_KERNEL_AUTO then picks kernels without scratch, an
+ *               explicit FA_KERNEL_P16 returns FA_ERR_UNSUPPORTED
  *   aliasing    o must not overlap q, k or v (a tile that fails its verification is recomputed from q, k, v after o was
  *               written): overlapping ranges are rejected with FA_ERR_INVALID_ARGUMENT
  *   ordering    the kernel is enqueued on `stream` and the call returns without synchronising
