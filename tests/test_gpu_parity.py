@@ -781,6 +781,13 @@ def test_guarded_fp32_chain_survives_graph_capture_and_other_streams():
     assert 0.0 < ms < 50.0
     ref = fa.forward(q, k, v, False, kernel="exact")
     assert float((o - ref).abs().max()) < TOL_F32
+    # a one-launch graph at a larger size, output zeroed first (the form that exposed the scratch paths under capture)
+    qb, kb, vb = (torch.randn(16, 4096, 64, device=dev()) for _ in range(3))
+    ob = torch.zeros_like(qb)
+    torch.cuda.synchronize()
+    assert 0.0 < fa.time_forward(qb, kb, vb, False, warmup=0, iters=1, out=ob, graph=True) < 50.0
+    torch.cuda.synchronize()
+    assert float((ob - fa.forward(qb, kb, vb, False, kernel="exact")).abs().max()) < TOL_F32
     kw = k.clone()
     kw[3, 77] *= 40.0                                   # wide logits: this launch must be handed to the exact kernel
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
