@@ -772,6 +772,33 @@ def test_small_grids_under_stream_capture_take_the_plain_launch():
             assert 0.0 < ms < 50.0 and float((o.float() - ref).abs().max()) < tol, (odt, iters)
 
 
+
+def test_scratch_paths_on_concurrent_streams():
+    """Two streams, each issuing key-split launches and fp16-P chains back to back (stream-ordered scratch: hipMallocAsync /
+    hipFreeAsync per call): neither may see the other's partial outputs or V copy."""
+    qa, ka, va = (torch.randn(2, 8192, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
+    qb, kb, vb = (torch.randn(16, 4096, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
+    refa = fa.forward(qa.float(), ka.float(), va.float(), False, kernel="naive")
+    refb = fa.forward(qb.float(), kb.float(), vb.float(), False, kernel="naive")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(6):
+        with torch.cuda.stream(s1):
+            o1 = fa.forward(qa, ka, va, False)                                   # key-split, bf16 out
+            o3 = fa.forward(qa, ka, va, False, out_dtype=torch.float32)          # key-split inside the fp16-P chain
+        with torch.cuda.stream(s2):
+            o2 = fa.forward(qb, kb, vb, False, out_dtype=torch.float32)          # fp16-P chain (V copy in scratch)
+            o4 = fa.forward(qa, ka, va, False)
+        outs.append((o1, o2, o3, o4))
+    torch.cuda.synchronize()
+    for o1, o2, o3, o4 in outs:
+        assert float((o1.float() - refa).abs().max()) < bf16_tol(1.0, False)
+        assert float((o4.float() - refa).abs().max()) < bf16_tol(1.0, False)
+        assert float((o3 - refa).abs().max()) < P16_TOL_BIG
+        assert float((o2 - refb).abs().max()) < P16_TOL_BIG
+
+
 def test_guarded_fp32_chain_survives_graph_capture_and_other_streams():
     """The fp32 AUTO chain (split kernel + conditional exact kernel) replayed from a hipGraph, and two chains in flight on two streams
     with opposite verdicts: each call's flag word is its own (ring slot + serial number), so neither sees the other's."""
