@@ -9,11 +9,11 @@ LIB_PATH = os.path.join(PKG_DIR, "libflashattn_amd.so")
 
 FA_OK = 0
 FA_DTYPE_F32, FA_DTYPE_BF16, FA_DTYPE_BF16_OUT_F32 = 0, 1, 2
-FA_KERNEL_AUTO, FA_KERNEL_NAIVE, FA_KERNEL_MFMA, FA_KERNEL_SPLIT, FA_KERNEL_P16 = 0, 1, 2, 3, 4
+FA_KERNEL_AUTO, FA_KERNEL_NAIVE, FA_KERNEL_MFMA, FA_KERNEL_SPLIT, FA_KERNEL_P16, FA_KERNEL_P16X2 = 0, 1, 2, 3, 4, 5
 
 # every symbol include/flashattn_amd.h declares
 EXPORTED_SYMBOLS = (
-    "fa_forward", "fa_forward_ex", "fa_forward_sharded", "fa_forward_packed_qkv", "fa_time_forward", "fa_time_forward_graph",
+    "fa_forward", "fa_forward_ex", "fa_workspace_bytes", "fa_forward_ws", "fa_forward_sharded", "fa_forward_packed_qkv", "fa_time_forward", "fa_time_forward_graph",
     "fa_last_forward_route", "fa_last_error", "fa_device_count", "fa_version", "fa_kernel_name", "fa_kernel_name_for",
 )
 
@@ -39,6 +39,10 @@ def lib() -> ctypes.CDLL:
     L.fa_forward.restype = ctypes.c_int
     L.fa_forward_ex.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, f32, i32, i32, i32, vp]
     L.fa_forward_ex.restype = ctypes.c_int
+    L.fa_workspace_bytes.argtypes = [i64, i64, i32, i32, i32, i32]
+    L.fa_workspace_bytes.restype = ctypes.c_size_t
+    L.fa_forward_ws.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, f32, i32, i32, i32, vp, ctypes.c_size_t, vp]
+    L.fa_forward_ws.restype = ctypes.c_int
     L.fa_forward_sharded.argtypes = [i32, ctypes.POINTER(i32), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
                                      ctypes.POINTER(vp), ctypes.POINTER(i64), i64, i32, f32, i32, i32, ctypes.POINTER(vp)]
     L.fa_forward_sharded.restype = ctypes.c_int

@@ -150,10 +150,10 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(const f32x16& s, int base)
 
 // P fragment in the format of the second contraction: bf16 (default) or fp16 (round to nearest even: v_cvt_pk_f16_f32)
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-template <bool PF>
+template <int PF>   // 0 = bf16, 1 / 2 = fp16
 __device__ __forceinline__ bf16x8 pack_p16x8(const f32x16& s, int base)
 {
-    if constexpr (PF) {
+    if constexpr (PF != 0) {
         f16x8 r;
 #pragma unroll
         for (int i = 0; i < 8; ++i) r[i] = (_Float16)s[base + i];
@@ -234,11 +234,11 @@ constexpr float kOptLimit = 0x1p100f;
 
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-template <bool PF = false>
+template <int PF = 0>
 __device__ __forceinline__ bf16x8 rowsum_a_operand(int lane)
 {
     const bool one = (((lane & 15) >> 2) & 1) == ((lane >> 4) & 1);
-    if constexpr (PF) {
+    if constexpr (PF != 0) {
         f16x8 a;
 #pragma unroll
         for (int i = 0; i < 8; ++i) a[i] = one ? (_Float16)1.0f : (_Float16)0.0f;

@@ -60,7 +60,25 @@ __device__ __forceinline__ void mask16(f32x16& s, int key0, int qi, int n, int h
 
 // exp + pack of one block's 16 scores, element range [e0, e1) and pack of fragment(s) whose elements are complete
 // (clamp = false: the optimistic mix, where an overflow has to reach the row sum instead of being clamped away)
-template <bool PF = false>
+// PF = 2: half h (0 / 1) of the lo term of P fragment f -- elements 8 f + 4 h .. + 3, two packed registers.  lo = fp16(p - float(hi)):
+// one v_fma_mixlo_f16 / v_fma_mixhi_f16 per element computes hi * (-1.0) + p in fp32 (hi: an fp16 half of the packed register, picked
+// by op_sel; the difference is exact) and rounds it into the low / high half of the destination.  s holds the fp32 p the pack read.
+__device__ __forceinline__ void lo_half(const f32x16& s, int f, int h, const bf16x8& hi, bf16x8& lo)
+{
+    const u32x4 hv = __builtin_bit_cast(u32x4, hi);
+    u32x4 lv = __builtin_bit_cast(u32x4, lo);
+#pragma unroll
+    for (int r = 2 * h; r < 2 * h + 2; ++r) {
+        unsigned d;
+        asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                     : "=&v"(d)
+                     : "v"(hv[r]), "v"(s[8 * f + 2 * r]), "v"(s[8 * f + 2 * r + 1]));
+        lv[r] = d;
+    }
+    lo = __builtin_bit_cast(bf16x8, lv);
+}
+
+template <int PF = 0>
 __device__ __forceinline__ void exp_range(f32x16& s, bf16x8 (&pf)[2], float c, float off, int e0, int e1, bool clamp = true)
 {
 #pragma unroll

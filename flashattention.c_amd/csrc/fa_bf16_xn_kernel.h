@@ -31,25 +31,29 @@
 
 namespace fa {
 
-template <int D, int NB>
+// PF: the format of P (and of the V image) in the second contraction -- 0 = bf16, 1 = fp16 (11 significant bits), 2 = fp16 hi + fp16 lo
+// (two products per P.V and per row sum: P to ~22 bits; see XSoft)
+template <int D, int NB, int PF = 0>
 struct XShape {
     static_assert((NB == 4 && D == 64) || (NB == 2 && (D == 32 || D == 64 || D == 128)), "instantiated shapes");
+    static_assert(PF >= 0 && PF <= 2, "P formats");
     static constexpr int KS = D / 16;          // k-steps of K.Q^T
     static constexpr int DB = D / 32;          // 32-column blocks of O
     static constexpr int NV = 2 * DB;          // V^T fragments per 32-key sub-tile
-    static constexpr int GRP = NV + 2;         // slots of one P.V + row-sum group
+    static constexpr int NT = PF == 2 ? 2 : 1; // terms of P
+    static constexpr int GRP = NT * (NV + 2);  // slots of one P.V + row-sum group
     static constexpr int kSlots = NB * (KS + GRP);
     static constexpr int kFirstPv = 2 * KS;    // first slot that needs the V^T fragments (both layouts start with K.Q^T of A, B)
     // NB = 4: the V^T fragments are waited for one by one in the P.V slots of block A that consume them (the youngest read gets
     // nine slots instead of five to land); NB = 2: one wait in front of the first P.V slot
     static constexpr bool kVWaitPerFrag = NB == 4;
     // K fragments of the next step: KS slots starting here (after the step's last K.Q^T slot)
-    static constexpr int kKLoad = NB == 4 ? 28 : 2 * KS + 1;
-    static constexpr int kUnitsOpt = NB * 18, kUnitsRsc = NB * 21 + 1;
+    static constexpr int kKLoad = NB == 4 ? 16 + 2 * GRP : 2 * KS + 1;
+    static constexpr int kUnitsOpt = NB * 18, kUnitsRsc = NB * (21 + (PF == 2 ? 4 : 0)) + 1;
     // NB = 2: VALU units are dealt out over the first kWend half-slots of the step (largest values that put every pack in front of
-    // the first MFMA reading it, found offline); NB = 4: see weight_end()
+    // the first MFMA reading it, found offline and re-checked at compile time: xn_schedule_ok); NB = 4: see weight_end()
     static constexpr int kWendOpt2 = D == 128 ? 58 : D == 64 ? 30 : 16;
-    static constexpr int kWendRsc2 = D == 128 ? 64 : D == 64 ? 34 : 18;
+    static constexpr int kWendRsc2 = PF == 2 ? (D == 128 ? 99 : D == 64 ? 52 : 29) : (D == 128 ? 64 : D == 64 ? 34 : 18);
 };
 // ---- matrix instructions with explicit register files ------------------------------------------------------------------
 // With one wave per SIMD the wave owns 256 architectural VGPRs and 256 accumulation registers (AGPRs).  VALU instructions
@@ -74,16 +78,16 @@ __device__ __forceinline__ void mfma_s(f32x16& s, const bf16x8& kf, const bf16x8
 }
 // PF (here and below): P and the V image are fp16 instead of bf16 (the accurate mode, see XSoft); the 16-bit fragments travel in
 // the same register types either way.
-template <bool PF = false>
+template <int PF = 0>
 __device__ __forceinline__ void mfma_o(f32x16& o, const bf16x8& vf, const bf16x8& pfrag)
 {
-    if constexpr (PF) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(o) : "v"(vf), "v"(pfrag));
+    if constexpr (PF != 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(o) : "v"(vf), "v"(pfrag));
     else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(vf), "v"(pfrag));
 }
-template <bool PF = false>
+template <int PF = 0>
 __device__ __forceinline__ void mfma_l(f32x4_t& l, const bf16x8& ones, const bf16x8& pfrag)
 {
-    if constexpr (PF) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(pfrag));
+    if constexpr (PF != 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(pfrag));
     else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(pfrag));
 }
 
@@ -100,11 +104,14 @@ __device__ __forceinline__ void mfma_l(f32x4_t& l, const bf16x8& ones, const bf1
 //                        same launch is at 6.2e-4.  The price is headroom, i.e. more moves of the reference on unit-variance
 //                        data at scale 1 (c4, same box: 2^-5 0.327 ms, 2^-1 0.334, 2^0 ~0.338, 2^2 0.344, 2^6 0.373); at 1/sqrt(d)
 //                        the reference never moves after the first sub-tile and the time is the same.
-template <bool OPT, bool PF>
+//   rescaled,   fp16 hi + lo   the same window; lo = fp16(p - hi) carries the next 11 bits of p (exact difference, one
+//                        v_fma_mixlo/hi_f16 per score) while hi >= 2^-3 or so and fades out below (its own subnormals): P is good to
+//                        ~2^-22 relative at the row maximum and never worse than one-term fp16 P.  Twice the P.V and row-sum MFMAs.
+template <bool OPT, int PF>
 struct XSoft {
-    static_assert(!(OPT && PF), "fp16 P has no room for a fixed exponent reference");
-    static constexpr float kBias = OPT ? kOptBias : PF ? 0.0f : kLazyThr;
-    static constexpr float kThr = PF ? 15.9f : 0.0f;   // fp16: p < 2^15.9 = 61 147 (fp16 ends at 65 504)
+    static_assert(!(OPT && PF != 0), "fp16 P has no room for a fixed exponent reference");
+    static constexpr float kBias = OPT ? kOptBias : PF != 0 ? 0.0f : kLazyThr;
+    static constexpr float kThr = PF != 0 ? 15.9f : 0.0f;   // fp16: p < 2^15.9 = 61 147 (fp16 ends at 65 504)
 };
 
 // mfma_drain() with the registers it protects as operands: the drain is an asm statement without a data dependence of its
@@ -138,7 +145,7 @@ __device__ __forceinline__ void drain_accumulators(f32x16 (&o)[NB][DB], BlockSta
 }
 
 // (rare, wave-uniform) move the exponent references of all blocks; everything still at the old reference is scaled once
-template <int NB, int DB, bool PF = false>
+template <int NB, int DB, int PF = 0>
 __device__ __forceinline__ void xn_rescale(const float (&mx)[NB], float c, BlockState (&st)[NB], f32x16 (&o)[NB][DB], float (&off)[NB])
 {
     using SM = XSoft<false, PF>;
@@ -181,119 +188,137 @@ __device__ __forceinline__ void xn_rescale(const float (&mx)[NB], float c, Block
 struct XSlot {
     int kind;  // 0 = K.Q^T, 1 = P.V, 2 = row sum
     int blk, idx;
+    int term;  // P.V / row sum: 0 = P (hi), 1 = the lo term of P (PF = 2)
 };
 // P.V + row sums of one block, GRP slots, no two dependent MFMAs adjacent: P.V index p reads V^T fragment p = tt * DB + db,
-// accumulates into o[blk][p % DB] and takes P fragment p / DB
-template <int D, int NB>
+// accumulates into o[blk][p % DB] and takes P fragment p / DB.  One term of P: P.V(tt = 0) x DB | row sum 0 | P.V(tt = 1) x DB | row
+// sum 1.  Two terms (PF = 2): each of the two halves is run for hi, then for lo -- an accumulator is touched every DB + 1 slots.
+template <int D, int NB, int PF = 0>
 __device__ __host__ constexpr XSlot xn_pv_group(int blk, int j)
 {
-    using S = XShape<D, NB>;
-    if (j == S::DB) return {2, blk, 0};
-    if (j == S::NV + 1) return {2, blk, 1};
-    return {1, blk, j < S::DB ? j : j - 1};
+    using S = XShape<D, NB, PF>;
+    constexpr int H = S::DB + 1;                 // slots of one (term, tt) run: DB P.V + one row sum
+    const int run = j / H, w = j % H;            // run = tt * NT + term
+    const int tt = run / S::NT, term = run % S::NT;
+    if (w == S::DB) return {2, blk, tt, term};
+    return {1, blk, tt * S::DB + w, term};
 }
-template <int D, int NB>
+template <int D, int NB, int PF = 0>
 __device__ __host__ constexpr XSlot xn_slot(int i)
 {
-    using S = XShape<D, NB>;
+    using S = XShape<D, NB, PF>;
+    constexpr int G = S::GRP;
     if constexpr (NB == 4) {
-        if (i < 8) return {0, i % 2, i / 2};                                  // K.Q^T A,B   k-step i/2
-        if (i < 14) return xn_pv_group<D, NB>(0, i - 8);                      // P.V + row sums A
-        if (i < 18) return {0, 2 + (i - 14) % 2, (i - 14) / 2};               // K.Q^T C,D   k-steps 0,1
-        if (i < 24) return xn_pv_group<D, NB>(1, i - 18);                     // P.V + row sums B
-        if (i < 28) return {0, 2 + (i - 24) % 2, 2 + (i - 24) / 2};           // K.Q^T C,D   k-steps 2,3
-        if (i < 34) return xn_pv_group<D, NB>(2, i - 28);                     // P.V + row sums C
-        return xn_pv_group<D, NB>(3, i - 34);                                 // P.V + row sums D
+        if (i < 8) return {0, i % 2, i / 2, 0};                                       // K.Q^T A,B   k-step i/2
+        if (i < 8 + G) return xn_pv_group<D, NB, PF>(0, i - 8);                       // P.V + row sums A
+        if (i < 12 + G) return {0, 2 + (i - 8 - G) % 2, (i - 8 - G) / 2, 0};          // K.Q^T C,D   k-steps 0,1
+        if (i < 12 + 2 * G) return xn_pv_group<D, NB, PF>(1, i - 12 - G);             // P.V + row sums B
+        if (i < 16 + 2 * G) return {0, 2 + (i - 12 - 2 * G) % 2, 2 + (i - 12 - 2 * G) / 2, 0};   // K.Q^T C,D   k-steps 2,3
+        if (i < 16 + 3 * G) return xn_pv_group<D, NB, PF>(2, i - 16 - 2 * G);         // P.V + row sums C
+        return xn_pv_group<D, NB, PF>(3, i - 16 - 3 * G);                             // P.V + row sums D
     } else {
-        if (i < 2 * S::KS) return {0, i % 2, i / 2};                          // K.Q^T A,B   k-step i/2
-        return xn_pv_group<D, NB>((i - 2 * S::KS) / S::GRP, (i - 2 * S::KS) % S::GRP);
+        if (i < 2 * S::KS) return {0, i % 2, i / 2, 0};                               // K.Q^T A,B   k-step i/2
+        return xn_pv_group<D, NB, PF>((i - 2 * S::KS) / G, (i - 2 * S::KS) % G);
     }
 }
-// Two instruction mixes share the slot sequence:
-//   OPT = false  the lazily rescaled softmax: exp + pack of sub-tile t, lane maxima of sub-tile t+1, rescale test (21 NB + 1 units)
+// Instruction mixes that share the slot sequence:
+//   OPT = false  the lazily rescaled softmax: exp + pack of sub-tile t, lane maxima of sub-tile t+1, rescale test (21 NB + 1 units;
+//                PF = 2: four more per block for the lo term of P)
 //   OPT = true   the optimistic softmax: the exponent reference of a row is fixed after its first sub-tile (with 2^100 of
 //                headroom either way, see kOptBias), so the loop has no maxima, no test and no branch (18 NB units); the tile
 //                is verified at the end and redone with OPT = false if any row left the safe range.
-template <int D, int NB>
-constexpr int xn_num_units(bool opt) { return opt ? XShape<D, NB>::kUnitsOpt : XShape<D, NB>::kUnitsRsc; }
-template <int D, int NB>
+template <int D, int NB, int PF = 0>
+constexpr int xn_num_units(bool opt) { return opt ? XShape<D, NB, PF>::kUnitsOpt : XShape<D, NB, PF>::kUnitsRsc; }
+template <int D, int NB, int PF = 0>
 __device__ __host__ constexpr int xn_weight_before(int i)  // in half-slots: a 32x32x16 slot = 2, a 16x16x32 slot = 1
 {
     int w = 0;
-    for (int k = 0; k < i; ++k) w += (xn_slot<D, NB>(k).kind == 2) ? 1 : 2;
+    for (int k = 0; k < i; ++k) w += (xn_slot<D, NB, PF>(k).kind == 2) ? 1 : 2;
     return w;
 }
 // NB = 4: the VALU work of the optimistic mix has to be finished before the k-step-1 MFMAs of P.V D (slot 37; the fragment of its
-// k-step 0 is packed early enough by the dealing rule -- checked for every dependency by profiles/r01_x4_schedule_check.py), the
-// rescaled mix uses the whole step; NB = 2: the offline-found limits of XShape
-template <int D, int NB>
+// k-step 0 is packed early enough by the dealing rule), the rescaled mixes use the whole step; NB = 2: the offline-found limits of
+// XShape.  Every dependency of the resulting tables is checked at compile time (xn_schedule_ok).
+template <int D, int NB, int PF = 0>
 constexpr int xn_weight_end(bool opt)
 {
-    if constexpr (NB == 4) return opt ? xn_weight_before<D, NB>(37) : xn_weight_before<D, NB>(XShape<D, NB>::kSlots);
-    else return opt ? XShape<D, NB>::kWendOpt2 : XShape<D, NB>::kWendRsc2;
+    using S = XShape<D, NB, PF>;
+    if constexpr (NB == 4) return opt ? xn_weight_before<D, NB, PF>(16 + 3 * S::GRP + S::DB + 1) : xn_weight_before<D, NB, PF>(S::kSlots);
+    else return opt ? S::kWendOpt2 : S::kWendRsc2;
 }
 // VALU units are dealt out by ISSUE COST, not by count: measured beside MFMAs (profiles/ubench/ubench_clock.hip) a plain
 // VALU instruction occupies the wave's issue for 4 cycles and a v_exp_f32 for 8, so an exp element (fma + exp) costs 12, a
-// pack (4 cvt) 16, the max micro-steps 12 / 12 / 8, the test ~20 -- 1044 (896) cycles per NB = 4 step.  Slot i receives the units
-// whose cumulative cost fits its share of the step's half-slots (24..36 cycles per full slot).
+// pack (4 cvt) 16, half a lo fragment (4 v_fma_mix) 16, the max micro-steps 12 / 12 / 8, the test ~20 -- 1044 (896) cycles per
+// NB = 4 step.  Slot i receives the units whose cumulative cost fits its share of the step's half-slots (24..36 cycles per full slot).
 struct XTable {
     int ub[72];  // VALU units dealt out before slot i (kSlots + 1 entries used)
 };
 // The unit sequence.  A pack (v_cvt_pk) is scheduled two exp units after the last exponential it consumes: a VALU
 // instruction that reads the result of a transcendental issued just before it costs a wait state (hipcc pads an s_nop).
+// PF = 2: the two halves of a fragment's lo term follow its pack, one exp unit apart (they read the pack's result and the
+// exponentials the pack read).
 struct XUnit {
-    int kind;  // 0 = exp of one element, 1 = pack of one fragment, 2 = lane-max micro-step, 3 = rescale test
+    int kind;  // 0 = exp of one element, 1 = pack of one fragment, 2 = lane-max micro-step, 3 = rescale test, 4 = half a lo fragment
     int blk, idx, cost;
 };
 struct XUnitList {
-    XUnit u[85];
+    XUnit u[120];
 };
-template <int NB>
+template <int NB, int PF = 0>
 __device__ __host__ constexpr XUnitList xn_make_units(bool opt)
 {
     XUnitList l{};
     int n = 0;
-    bool pending = false;
-    XUnit pend{};
+    int npend = 0;
+    XUnit pend[3] = {};
     for (int b = 0; b < NB; ++b) {
         for (int e = 0; e < 16; ++e) {
             l.u[n++] = {0, b, e, 12};
-            if (e == 1 && pending) {
-                l.u[n++] = pend;
-                pending = false;
+            if (npend > 0 && (e == 1 || e == 2 || e == 3)) {   // the previous block's second fragment: pack, then (PF = 2) its lo halves
+                l.u[n++] = pend[0];
+                pend[0] = pend[1];
+                pend[1] = pend[2];
+                --npend;
             }
             if (e == 9) l.u[n++] = {1, b, 0, 16};
+            if (PF == 2 && e == 10) l.u[n++] = {4, b, 0, 16};
+            if (PF == 2 && e == 11) l.u[n++] = {4, b, 1, 16};
         }
-        pend = {1, b, 1, 16};
-        pending = true;
+        pend[0] = {1, b, 1, 16};
+        npend = 1;
+        if (PF == 2) {
+            pend[1] = {4, b, 2, 16};
+            pend[2] = {4, b, 3, 16};
+            npend = 3;
+        }
     }
     if (opt) {
-        l.u[n++] = pend;
+        for (int k = 0; k < npend; ++k) l.u[n++] = pend[k];
         return l;
     }
+    int used = 0;
     for (int b = 0; b < NB; ++b)
         for (int m = 0; m < 3; ++m) {
             l.u[n++] = {2, b, m, m == 2 ? 8 : 12};
-            if (b == 0 && m == 1 && pending) {
-                l.u[n++] = pend;
-                pending = false;
-            }
+            if (m >= 1 && used < npend) l.u[n++] = pend[used++];   // one term: after max(0, 1); two terms: the lo halves after max(0, 2), max(1, 1)
         }
+    for (; used < npend; ++used) l.u[n++] = pend[used];   // (not reached for NB >= 2)
     l.u[n++] = {3, 0, 0, 20};
     return l;
 }
-template <int D, int NB>
+template <int D, int NB, int PF = 0>
 __device__ __host__ constexpr XTable xn_make_table(bool opt)
 {
-    constexpr int kS = XShape<D, NB>::kSlots;
-    const XUnitList l = xn_make_units<NB>(opt);
-    const int nu = xn_num_units<D, NB>(opt), wend = xn_weight_end<D, NB>(opt);
+    constexpr int kS = XShape<D, NB, PF>::kSlots;
+    static_assert(kS + 1 <= 72, "XTable::ub");
+    const XUnitList l = xn_make_units<NB, PF>(opt);
+    const int nu = xn_num_units<D, NB, PF>(opt), wend = xn_weight_end<D, NB, PF>(opt);
     XTable t{};
     int total = 0;
     for (int u = 0; u < nu; ++u) total += l.u[u].cost;
     int n = 0, cum_next = l.u[0].cost;  // cum_next: cost of units 0..n inclusive
     for (int i = 0; i <= kS; ++i) {
-        const int wb = xn_weight_before<D, NB>(i) < wend ? xn_weight_before<D, NB>(i) : wend;
+        const int wb = xn_weight_before<D, NB, PF>(i) < wend ? xn_weight_before<D, NB, PF>(i) : wend;
         const int target = total * wb / wend + 6;
         while (n < nu && cum_next <= target) {
             ++n;
@@ -305,19 +330,72 @@ __device__ __host__ constexpr XTable xn_make_table(bool opt)
     return t;
 }
 
+// index of the unit that completes the P fragment MFMA slot sl reads: the pack of fragment tt (hi term), the second lo half (lo term)
+template <int D, int NB, int PF = 0>
+__device__ __host__ constexpr int xn_producer_unit(XSlot sl, bool opt)
+{
+    const int frag = sl.kind == 1 ? sl.idx / XShape<D, NB, PF>::DB : sl.idx;
+    const XUnitList l = xn_make_units<NB, PF>(opt);
+    for (int u = 0; u < xn_num_units<D, NB, PF>(opt); ++u) {
+        if (sl.term == 0 && l.u[u].kind == 1 && l.u[u].blk == sl.blk && l.u[u].idx == frag) return u;
+        if (sl.term == 1 && l.u[u].kind == 4 && l.u[u].blk == sl.blk && l.u[u].idx == 2 * frag + 1) return u;
+    }
+    return 1 << 20;
+}
 // A VALU result needs two wait states before an MFMA reads it, and an asm MFMA is not padded by hipcc: when the dealing rule
-// puts the pack of a P fragment into the slot right in front of the first MFMA that reads it, that MFMA gets an s_nop 1.
-template <int D, int NB>
+// puts the last VALU instruction of a P fragment into the slot right in front of the first MFMA that reads it, that MFMA gets an s_nop 1.
+template <int D, int NB, int PF = 0>
 __device__ __host__ constexpr bool xn_needs_pad(int i, bool opt)
 {
-    const XSlot sl = xn_slot<D, NB>(i);
+    const XSlot sl = xn_slot<D, NB, PF>(i);
     if (sl.kind == 0 || i == 0) return false;
-    const int frag = sl.kind == 1 ? sl.idx / XShape<D, NB>::DB : sl.idx;
-    const XUnitList l = xn_make_units<NB>(opt);
-    const XTable t = xn_make_table<D, NB>(opt);
-    for (int u = 0; u < xn_num_units<D, NB>(opt); ++u)
-        if (l.u[u].kind == 1 && l.u[u].blk == sl.blk && l.u[u].idx == frag) return u >= t.ub[i - 1];
-    return false;
+    const XTable t = xn_make_table<D, NB, PF>(opt);
+    return xn_producer_unit<D, NB, PF>(sl, opt) >= t.ub[i - 1];
+}
+// Compile-time check of every dependency of a step's static schedule (round 1 and 2 re-derived the tables offline,
+// profiles/r01_x4_schedule_check.py):
+//   * the unit that completes a P fragment is dealt out before the first MFMA slot that reads the fragment;
+//   * the lane maxima of a block's next sub-tile start at least five slots after the block's last K.Q^T slot (MFMA result -> VALU read);
+//   * the unit list has exactly the advertised number of units, and lo halves follow their pack, packs their exponentials.
+template <int D, int NB, int PF = 0>
+__device__ __host__ constexpr bool xn_schedule_ok(bool opt)
+{
+    using S = XShape<D, NB, PF>;
+    const XUnitList l = xn_make_units<NB, PF>(opt);
+    const XTable t = xn_make_table<D, NB, PF>(opt);
+    const int nu = xn_num_units<D, NB, PF>(opt);
+    // unit count: the list is zero-initialised past its end (cost 0) and every real unit has a cost
+    for (int u = 0; u < nu; ++u)
+        if (l.u[u].cost == 0) return false;
+    if (nu < 120 && l.u[nu].cost != 0) return false;
+    int last_qk[NB] = {};
+    for (int i = 0; i < S::kSlots; ++i) {
+        const XSlot sl = xn_slot<D, NB, PF>(i);
+        if (sl.kind == 0) {
+            last_qk[sl.blk] = i;
+            continue;
+        }
+        if (sl.term >= S::NT) return false;
+        if (xn_producer_unit<D, NB, PF>(sl, opt) >= t.ub[i]) return false;       // fragment not complete before its MFMA
+    }
+    int pos[NB][8] = {};   // per block: unit index of exp 7, exp 15, pack 0, pack 1, lo 0.1, lo 1.1 (order checks)
+    for (int u = 0; u < nu; ++u) {
+        const XUnit un = l.u[u];
+        if (un.kind == 0 && un.idx == 7) pos[un.blk][0] = u;
+        if (un.kind == 0 && un.idx == 15) pos[un.blk][1] = u;
+        if (un.kind == 1) pos[un.blk][2 + un.idx] = u;
+        if (un.kind == 4) {
+            if (u <= pos[un.blk][2 + un.idx / 2] || pos[un.blk][2 + un.idx / 2] == 0) return false;   // lo half in front of its pack
+        }
+        if (un.kind == 2 && un.idx == 0) {
+            int s0 = 0;
+            while (s0 < S::kSlots && !(t.ub[s0] <= u && u < t.ub[s0 + 1])) ++s0;
+            if (s0 < last_qk[un.blk] + 5) return false;                           // maxima read scores still in the matrix pipe
+        }
+    }
+    for (int b = 0; b < NB; ++b)
+        if (pos[b][2] <= pos[b][0] || pos[b][3] <= pos[b][1]) return false;        // pack in front of an exponential it consumes
+    return true;
 }
 
 // One step.  sc: scores of sub-tile t (consumed), sn: scores of sub-tile t+1 (produced); kf: K fragments of sub-tile t+1 on
@@ -326,7 +404,7 @@ __device__ __host__ constexpr bool xn_needs_pad(int i, bool opt)
 // optimiser unrolling a 40 x 53 loop nest to resolve the register arrays.
 template <int D, int NB>
 struct XCtx {
-    using S = XShape<D, NB>;
+    using S = XShape<D, NB>;   // (KS, DB, NV do not depend on the P format)
     const bf16x8& ones_a;
     const bf16x8 (&qf)[NB][S::KS];
     f32x16 (&sc)[NB];
@@ -343,14 +421,15 @@ struct XCtx {
     s16x4 vlo[S::NV], vhi[S::NV];
     bf16x8 vf[S::NV];
     bf16x8 pf[NB][2];
+    bf16x8 pl[NB][2];   // PF = 2: the lo term of P
     float pm[4];
     bool need;
 };
 
-template <int D, int NB, bool OPT, int U, int ABL = 0, bool PF = false>
+template <int D, int NB, bool OPT, int U, int ABL = 0, int PF = 0>
 __device__ __forceinline__ void xn_unit(XCtx<D, NB>& x)
 {
-    constexpr XUnit un = xn_make_units<NB>(OPT).u[U];
+    constexpr XUnit un = xn_make_units<NB, PF>(OPT).u[U];
     if constexpr (un.kind == 0 && (ABL & 256)) {
         // timing-only ablation: the exponential replaced by a plain VALU instruction of the same data flow
         const float t = fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]);
@@ -360,11 +439,13 @@ __device__ __forceinline__ void xn_unit(XCtx<D, NB>& x)
     } else if constexpr (un.kind == 0) {
         // optimistic mix: no clamp -- an overflow has to reach the row sum (as a huge value or +inf): that is what the final
         // check reads.  fp16 P: no clamp either -- p ranges up to 2^kThr by design
-        if constexpr (OPT || PF) x.sc[un.blk][un.idx] = fast_exp2(fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]));
+        if constexpr (OPT || PF != 0) x.sc[un.blk][un.idx] = fast_exp2(fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]));
         else x.sc[un.blk][un.idx] = exp2_clamp01(fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]));
     } else if constexpr (un.kind == 1) {
         x.pf[un.blk][un.idx] = pack_p16x8<PF>(x.sc[un.blk], 8 * un.idx);
         asm volatile("" : "+v"(x.pf[un.blk][un.idx]));
+    } else if constexpr (un.kind == 4) {
+        lo_half(x.sc[un.blk], un.idx / 2, un.idx % 2, x.pf[un.blk][un.idx / 2], x.pl[un.blk][un.idx / 2]);
     } else if constexpr (un.kind == 2) {
         lanemax_step(un.idx, x.sn[un.blk], x.pm, x.lm[un.blk]);
     } else {
@@ -374,22 +455,33 @@ __device__ __forceinline__ void xn_unit(XCtx<D, NB>& x)
         x.need = t > XSoft<false, PF>::kThr;  // off = m + kBias
     }
 }
-template <int D, int NB, bool OPT, int ABL, bool PF, int U0, int... Us>
+template <int D, int NB, bool OPT, int ABL, int PF, int U0, int... Us>
 __device__ __forceinline__ void xn_units(XCtx<D, NB>& x, std::integer_sequence<int, Us...>)
 {
     (xn_unit<D, NB, OPT, U0 + Us, ABL, PF>(x), ...);
 }
 
 // wait for the asm-issued V^T reads (two ds_read per fragment, LDS returns in order) and hand the fragments to the MFMA operands
-template <int D, int NB, int I, int ABL>
+// first slot of block A's P.V group that reads V^T fragment v
+template <int D, int NB, int PF>
+__device__ __host__ constexpr int xn_first_use_of_v(int v)
+{
+    for (int i = XShape<D, NB, PF>::kFirstPv; i < XShape<D, NB, PF>::kSlots; ++i)
+        if (xn_slot<D, NB, PF>(i).kind == 1 && xn_slot<D, NB, PF>(i).idx == v) return i;
+    return -1;
+}
+template <int D, int NB, int I, int ABL, int PF>
 __device__ __forceinline__ void xn_wait_v_frags(XCtx<D, NB>& x)
 {
-    using S = XShape<D, NB>;
+    using S = XShape<D, NB, PF>;
     if constexpr (S::kVWaitPerFrag) {
-        // slots of block A's P.V group that consume fragment v first: kFirstPv + {0, 1, 3, 4} at D = 64 (the row-sum slot sits between)
+        // slots of block A's P.V group that consume fragment v first: kFirstPv + {0, 1, 3, 4} at D = 64 with one term of P (the row-sum
+        // slot sits between), + {0, 1, 6, 7} with two.  Only the V^T reads are in flight here (the K reads start behind block A's group)
         static_assert(S::NV == 4, "per-fragment waits written for D = 64");
-        if constexpr (I == S::kFirstPv || I == S::kFirstPv + 1 || I == S::kFirstPv + 3 || I == S::kFirstPv + 4) {
-            constexpr int v = I == S::kFirstPv ? 0 : I == S::kFirstPv + 1 ? 1 : I == S::kFirstPv + 3 ? 2 : 3;
+        constexpr int v = I == xn_first_use_of_v<D, NB, PF>(0) ? 0 : I == xn_first_use_of_v<D, NB, PF>(1) ? 1 : I == xn_first_use_of_v<D, NB, PF>(2) ? 2
+                          : I == xn_first_use_of_v<D, NB, PF>(3) ? 3 : -1;
+        static_assert(xn_first_use_of_v<D, NB, PF>(3) < S::kKLoad, "the per-fragment lgkmcnt values assume no K read has been issued yet");
+        if constexpr (v >= 0) {
             if constexpr (ABL & 32) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x.vlo[v]), "+v"(x.vhi[v]));
             else if constexpr (ABL & 4) asm volatile("" : "+v"(x.vlo[v]), "+v"(x.vhi[v]));  // timing-only ablation: no wait
             else if constexpr (v == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(x.vlo[0]), "+v"(x.vhi[0]));
@@ -419,26 +511,28 @@ __device__ __forceinline__ void xn_wait_v_frags(XCtx<D, NB>& x)
     }
 }
 
-template <int D, int NB, int KB_C, int I, int ABL, bool OPT, bool PF>
+template <int D, int NB, int KB_C, int I, int ABL, bool OPT, int PF>
 __device__ __forceinline__ void xn_slot_body(XCtx<D, NB>& x)
 {
-    using S = XShape<D, NB>;
-    constexpr XSlot sl = xn_slot<D, NB>(I);
-    constexpr XTable tab = xn_make_table<D, NB>(OPT);
-    xn_wait_v_frags<D, NB, I, ABL>(x);
+    using S = XShape<D, NB, PF>;
+    constexpr XSlot sl = xn_slot<D, NB, PF>(I);
+    constexpr XTable tab = xn_make_table<D, NB, PF>(OPT);
+    xn_wait_v_frags<D, NB, I, ABL, PF>(x);
     if constexpr (I < S::NV && !(ABL & 16)) load_v_frag_asm<D, KB_C, I>(x.v_addr, x.vlo[I], x.vhi[I]);  // ABL & 16: no LDS fragment reads
     if constexpr (I < S::NV && (ABL & 16)) asm volatile("" : "=v"(x.vlo[I]), "=v"(x.vhi[I]));
     if constexpr (I < S::NV && (ABL & 32)) load_v_frag_asm<D, KB_C, I>(x.v_addr, x.vlo[I], x.vhi[I]);  // ABL & 32: every fragment read issued twice
-    if constexpr (xn_needs_pad<D, NB>(I, OPT)) asm volatile("s_nop 1");
+    if constexpr (xn_needs_pad<D, NB, PF>(I, OPT)) asm volatile("s_nop 1");
     if constexpr (ABL & 1) {
         // timing-only ablation: no matrix instructions
     } else if constexpr (sl.kind == 0) {
         if constexpr (sl.idx == 0) mfma_s_first(x.sn[sl.blk], x.kf[sl.idx], x.qf[sl.blk][sl.idx]);
         else mfma_s(x.sn[sl.blk], x.kf[sl.idx], x.qf[sl.blk][sl.idx]);
     } else if constexpr (sl.kind == 1) {
-        mfma_o<PF>(x.o[sl.blk][sl.idx % S::DB], x.vf[sl.idx], x.pf[sl.blk][sl.idx / S::DB]);
+        if constexpr (sl.term == 0) mfma_o<PF>(x.o[sl.blk][sl.idx % S::DB], x.vf[sl.idx], x.pf[sl.blk][sl.idx / S::DB]);
+        else mfma_o<PF>(x.o[sl.blk][sl.idx % S::DB], x.vf[sl.idx], x.pl[sl.blk][sl.idx / S::DB]);
     } else {
-        mfma_l<PF>(x.st[sl.blk].lacc, x.ones_a, x.pf[sl.blk][sl.idx]);
+        if constexpr (sl.term == 0) mfma_l<PF>(x.st[sl.blk].lacc, x.ones_a, x.pf[sl.blk][sl.idx]);
+        else mfma_l<PF>(x.st[sl.blk].lacc, x.ones_a, x.pl[sl.blk][sl.idx]);
     }
     if constexpr (I >= S::kKLoad && I < S::kKLoad + S::KS) {  // K fragments of the next step (this step's last K.Q^T slot lies behind)
         // asm, like the V^T reads: a compiler-visible LDS load would make hipcc put its own lgkmcnt waits in front of the
@@ -454,13 +548,13 @@ __device__ __forceinline__ void xn_slot_body(XCtx<D, NB>& x)
         xn_units<D, NB, OPT, ABL, PF, tab.ub[I]>(x, std::make_integer_sequence<int, tab.ub[I + 1] - tab.ub[I]>{});
     if constexpr (!(ABL & 128)) __builtin_amdgcn_sched_barrier(0);  // ABL & 128: slots not pinned (hipcc schedules the step)
 }
-template <int D, int NB, int KB_C, int ABL, bool OPT, bool PF, int... Is>
+template <int D, int NB, int KB_C, int ABL, bool OPT, int PF, int... Is>
 __device__ __forceinline__ void xn_slots(XCtx<D, NB>& x, std::integer_sequence<int, Is...>)
 {
     (xn_slot_body<D, NB, KB_C, Is, ABL, OPT, PF>(x), ...);
 }
 
-template <int D, int NB, int KB_C, int ABL = 0, bool OPT = false, bool PF = false>
+template <int D, int NB, int KB_C, int ABL = 0, bool OPT = false, int PF = 0>
 __device__ __forceinline__ bool xn_step(const char* v_lds, const char* k_nxt, int kb_n2, int k_row_off, int k_g, int v_lane_off,
                                         const bf16x8& ones_a, const bf16x8 (&qf)[NB][XShape<D, NB>::KS], f32x16 (&sc)[NB], f32x16 (&sn)[NB],
                                         f32x16 (&o)[NB][XShape<D, NB>::DB], BlockState (&st)[NB], float c, const float (&off)[NB],
@@ -468,7 +562,8 @@ __device__ __forceinline__ bool xn_step(const char* v_lds, const char* k_nxt, in
 {
     XCtx<D, NB> x{ones_a, qf, sc, sn, o, st, off, kf, lm, c, k_nxt, kb_n2, k_row_off, k_g, (unsigned)(size_t)(lds_s16x4_t*)(v_lds + v_lane_off)};
     x.need = false;
-    xn_slots<D, NB, KB_C, ABL, OPT, PF>(x, std::make_integer_sequence<int, XShape<D, NB>::kSlots>{});
+    static_assert(xn_schedule_ok<D, NB, PF>(OPT), "static schedule of the step: a P fragment is read before it is complete, or the lane maxima read scores in flight");
+    xn_slots<D, NB, KB_C, ABL, OPT, PF>(x, std::make_integer_sequence<int, XShape<D, NB, PF>::kSlots>{});
     // the K reads are at least a P.V group old: this wait is free, and it keeps every asm-issued load inside the basic block that
     // issued it (hipcc may move or spill a register across a branch without knowing a load is in flight)
     if constexpr (XShape<D, NB>::KS == 8)
@@ -482,7 +577,7 @@ __device__ __forceinline__ bool xn_step(const char* v_lds, const char* k_nxt, in
 
 // One (NWAVES * 32 * NB)-row tile.  OPT: optimistic mix; returns false when some row of the workgroup left the safe range (its
 // results were stored and are overwritten by the redo).
-template <int D, int NB, int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL, bool OPT, bool PF = false>
+template <int D, int NB, int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL, bool OPT, int PF = 0>
 __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
 {
     constexpr int KS = XShape<D, NB>::KS, DB = XShape<D, NB>::DB;
@@ -628,8 +723,15 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk) {
             bf16x8 pf[2];
-            exp_range<PF>(s[blk], pf, c, off[blk], 0, 8, !OPT && !PF);
-            exp_range<PF>(s[blk], pf, c, off[blk], 8, 16, !OPT && !PF);
+            exp_range<PF>(s[blk], pf, c, off[blk], 0, 8, !OPT && PF == 0);
+            exp_range<PF>(s[blk], pf, c, off[blk], 8, 16, !OPT && PF == 0);
+            bf16x8 pl[2];
+            if constexpr (PF == 2) {
+                asm volatile("s_nop 0" : "+v"(pf[0]), "+v"(pf[1]));   // the lo halves are asm: a transcendental's result needs a wait state
+#pragma unroll
+                for (int u = 0; u < 4; ++u) lo_half(s[blk], u / 2, u % 2, pf[u / 2], pl[u / 2]);
+                asm volatile("s_nop 1" : "+v"(pl[0]), "+v"(pl[1]));
+            }
             // a VALU result needs two wait states before an MFMA may read it; hipcc counts them for its own MFMAs, not
             // for an asm one (the pipelined loop packs P at least one whole slot ahead of its first use)
             asm volatile("s_nop 1" : "+v"(pf[0]), "+v"(pf[1]));
@@ -638,6 +740,13 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
             mfma_l<PF>(st[blk].lacc, ones_a, pf[0]);
             asm volatile("s_nop 7");  // dependent row-sum MFMAs back to back: the hazard is ours
             mfma_l<PF>(st[blk].lacc, ones_a, pf[1]);
+            if constexpr (PF == 2) {
+#pragma unroll
+                for (int v = 0; v < 2 * DB; ++v) mfma_o<PF>(o[blk][v % DB], vf[v], pl[v / DB]);
+                mfma_l<PF>(st[blk].lacc, ones_a, pl[0]);
+                asm volatile("s_nop 7");
+                mfma_l<PF>(st[blk].lacc, ones_a, pl[1]);
+            }
         }
     };
 
@@ -832,14 +941,23 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x2_kernel(FwdPar
     xn_kernel_body<D, 2, NWAVES, CAUSAL, OUT_F32, G, ABL, OPTIMISTIC>(p, smem);
 }
 
-// The accurate mode: P and V in fp16 (11 significant bits instead of 8; XSoft<false, true>), lazily rescaled mix only.  p.v points
-// at the fp16 copy of V made by launch_cvt_v_f16 (fa_cvt.hip), whose overflow flag these kernels honour (FwdParams::flag_mode = 1).
+// The accurate modes: P and V in fp16, lazily rescaled mix only (XSoft<false, PF>).  PF = 1: one fp16 term of P, 11 significant bits
+// instead of bf16's 8 ("p16": ~1e-3 of the fp32 reference at scale 1, not guaranteed inside it for large launches).  PF = 2: hi + lo
+// fp16 terms ("p16x2": ~22 bits, the kernel FA_KERNEL_AUTO gives a caller who asks for the fp32 accumulator).  p.v points at the fp16
+// copy of V made by launch_cvt_v_f16 (fa_cvt.hip), whose overflow flag these kernels honour (FwdParams::flag_mode = 1).
 template <int NWAVES, bool CAUSAL, bool OUT_F32, int G>
 __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_p16_kernel(FwdParams p)
 {
     __shared__ __attribute__((aligned(1024))) char smem[4 * G * Bf16Cfg<64, NWAVES>::kTileBytes];
     if (flag_says_skip(p)) return;
-    (void)xn_tile<64, 4, NWAVES, CAUSAL, OUT_F32, G, 0, false, true>(p, smem);
+    (void)xn_tile<64, 4, NWAVES, CAUSAL, OUT_F32, G, 0, false, 1>(p, smem);
+}
+template <int NWAVES, bool CAUSAL, bool OUT_F32, int G>
+__global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_p16x2_kernel(FwdParams p)
+{
+    __shared__ __attribute__((aligned(1024))) char smem[4 * G * Bf16Cfg<64, NWAVES>::kTileBytes];
+    if (flag_says_skip(p)) return;
+    (void)xn_tile<64, 4, NWAVES, CAUSAL, OUT_F32, G, 0, false, 2>(p, smem);
 }
 // Causal launches rely on one workgroup per CU (heavy tiles first, light ones behind them on the same CU): when the allocation
 // happens to leave room for a second wave per SIMD the hardware co-schedules two heavy tiles and the launch gets 20-30 % slower
@@ -852,7 +970,14 @@ __global__ __launch_bounds__(NWAVES* kWave, D <= 64 ? 2 : 1) void fa_fwd_bf16_x2
 {
     __shared__ __attribute__((aligned(1024))) char smem[4 * G * Bf16Cfg<D, NWAVES>::kTileBytes];
     if (flag_says_skip(p)) return;
-    (void)xn_tile<D, 2, NWAVES, CAUSAL, OUT_F32, G, 0, false, true>(p, smem);
+    (void)xn_tile<D, 2, NWAVES, CAUSAL, OUT_F32, G, 0, false, 1>(p, smem);
+}
+template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, int G>
+__global__ __launch_bounds__(NWAVES* kWave, D <= 64 ? 2 : 1) void fa_fwd_bf16_x2_p16x2_kernel(FwdParams p)
+{
+    __shared__ __attribute__((aligned(1024))) char smem[4 * G * Bf16Cfg<D, NWAVES>::kTileBytes];
+    if (flag_says_skip(p)) return;
+    (void)xn_tile<D, 2, NWAVES, CAUSAL, OUT_F32, G, 0, false, 2>(p, smem);
 }
 
 // ---- launch helpers ----------------------------------------------------------------------------------------------------
@@ -892,16 +1017,23 @@ static hipError_t launch_x4_modes(const FwdParams& p, int out_f32, int mode, hip
     return launch_x4<2, true, CAUSAL>(p, out_f32, stream);
 }
 
-template <bool CAUSAL>
+template <bool CAUSAL, int PF = 1>
 static hipError_t launch_x4_p16(const FwdParams& p0, int out_f32, hipStream_t stream)
 {
     FwdParams p;
     dim3 grid, block;
     if (!xn_grid<4>(p0, p, grid, block)) return hipErrorInvalidValue;
-    if (out_f32)
-        hipLaunchKernelGGL((fa_fwd_bf16_x4_p16_kernel<4, CAUSAL, true, 2>), grid, block, 0, stream, p);
-    else
-        hipLaunchKernelGGL((fa_fwd_bf16_x4_p16_kernel<4, CAUSAL, false, 2>), grid, block, 0, stream, p);
+    if constexpr (PF == 2) {
+        if (out_f32)
+            hipLaunchKernelGGL((fa_fwd_bf16_x4_p16x2_kernel<4, CAUSAL, true, 2>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((fa_fwd_bf16_x4_p16x2_kernel<4, CAUSAL, false, 2>), grid, block, 0, stream, p);
+    } else {
+        if (out_f32)
+            hipLaunchKernelGGL((fa_fwd_bf16_x4_p16_kernel<4, CAUSAL, true, 2>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((fa_fwd_bf16_x4_p16_kernel<4, CAUSAL, false, 2>), grid, block, 0, stream, p);
+    }
     return hipGetLastError();
 }
 
@@ -963,7 +1095,7 @@ static hipError_t launch_x2(const FwdParams& p0, int causal, int out_f32, hipStr
     return e;
 }
 
-template <int D>
+template <int D, int PF = 1>
 static hipError_t launch_x2_p16(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
 {
     FwdParams p;
@@ -971,7 +1103,19 @@ static hipError_t launch_x2_p16(const FwdParams& p0, int causal, int out_f32, hi
     if (!xn_grid<2>(p0, p, grid, block)) return hipErrorInvalidValue;
     const unsigned solo = xn_launch_order<D, 2>(p, grid, causal, D <= 64);
     auto go = [&](unsigned dyn_lds) {
-        if (causal) {
+        if constexpr (PF == 2) {
+            if (causal) {
+                if (out_f32)
+                    hipLaunchKernelGGL((fa_fwd_bf16_x2_p16x2_kernel<D, 4, true, true, 2>), grid, block, dyn_lds, stream, p);
+                else
+                    hipLaunchKernelGGL((fa_fwd_bf16_x2_p16x2_kernel<D, 4, true, false, 2>), grid, block, dyn_lds, stream, p);
+            } else {
+                if (out_f32)
+                    hipLaunchKernelGGL((fa_fwd_bf16_x2_p16x2_kernel<D, 4, false, true, 2>), grid, block, 0, stream, p);
+                else
+                    hipLaunchKernelGGL((fa_fwd_bf16_x2_p16x2_kernel<D, 4, false, false, 2>), grid, block, 0, stream, p);
+            }
+        } else if (causal) {
             if (out_f32)
                 hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, true, true, 2>), grid, block, dyn_lds, stream, p);
             else

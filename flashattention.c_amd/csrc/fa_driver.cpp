@@ -15,7 +15,12 @@
 //       activations in the packed (B, T, 3C) layout, fa_forward_packed_qkv, every output element checked against the rung-0 kernel
 //       ON THE DEVICE at the harness' own 1e-4 (validate_result, :1255-1262), then the mean of `iters` launches between two events on
 //       the null stream (benchmark_kernel, src/llm.c/common.h:108-124).
-//   --kernel auto|mfma|split|p16 and --out_f32 1 choose the kernel family / an fp32 output for bf16 tensors in rand and sweep mode.
+//   fa_driver --mode sharded [--devices N] [--bh 1024] [--n 8192] [--d 64] [--dtype bf16] [--iters 5]
+//       BASELINE config 5's arithmetic on whatever devices are visible: the batch*head axis cut into N contiguous shards (the
+//       first bh % N shards one slab longer), one fa_forward_sharded call per iteration, per-device milliseconds from events on each
+//       device's stream and their maximum (the job time: no collective on the path).  FA_ALLOW_SAME_DEVICE=1 lets N exceed the number
+//       of devices (shards then share devices round-robin): the only way to exercise N > 1 on a one-GPU box.
+//   --kernel auto|mfma|split|p16|p16x2 and --out_f32 1 choose the kernel family / an fp32 output for bf16 tensors in rand and sweep mode.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -74,6 +79,7 @@ struct Args {
     std::string mode = "rand", dtype = "bf16", kernel = "";
     long bh = 16, n = 8192;
     int d = 64, causal = 0, iters = 20, warmup = 3, variant = 0, check = 1, out_f32 = 0;
+    int devices = 0;                         // sharded mode: number of shards (0 = every visible device)
     int B = 6, T = 4096, C = 768, NH = 12;   // llmc mode: the harness' own size (attention_forward.cu:1217-1220)
     bool iters_given = false;
     float scale = 1.0f;
@@ -108,6 +114,7 @@ static Args parse(int argc, char** argv)
         else if (k == "--variant") a.variant = atoi(val());
         else if (k == "--check") a.check = atoi(val());
         else if (k == "--scale") a.scale = (float)atof(val());
+        else if (k == "--devices") a.devices = atoi(val());
         else {
             fprintf(stderr, "unknown flag %s\n", k.c_str());
             exit(2);
@@ -196,14 +203,22 @@ static void run_one(const Args& a, Buffers& b, int variant, const std::vector<fl
     else if (a.kernel == "mfma") family = FA_KERNEL_MFMA;
     else if (a.kernel == "split") family = FA_KERNEL_SPLIT;
     else if (a.kernel == "p16") family = FA_KERNEL_P16;
+    else if (a.kernel == "p16x2") family = FA_KERNEL_P16X2;
     else if (!a.kernel.empty()) {
         fprintf(stderr, "unknown --kernel %s\n", a.kernel.c_str());
         exit(2);
     }
     const int kernel = family | (variant << 8);
     HIP_OK(hipMemset(b.o, 0xff, b.ne * 4));
-    fa_ok(fa_forward_ex(b.q, b.k, b.v, b.o, nullptr, a.bh, a.n, a.d, a.scale, a.causal, dt, kernel, nullptr), "fa_forward_ex");
+    // the non-allocating form of the boundary: the caller sizes and owns the scratch (most shapes need none)
+    const size_t ws_bytes = fa_workspace_bytes(a.bh, a.n, a.d, a.causal, dt, kernel);
+    void* ws = nullptr;
+    if (ws_bytes > 0) HIP_OK(hipMalloc(&ws, ws_bytes));
+    fa_ok(fa_forward_ws(b.q, b.k, b.v, b.o, nullptr, a.bh, a.n, a.d, a.scale, a.causal, dt, kernel, ws, ws_bytes, nullptr), "fa_forward_ws");
     HIP_OK(hipDeviceSynchronize());
+    int32_t route = 0;
+    fa_ok(fa_last_forward_route(nullptr, &route), "fa_last_forward_route");
+    if (ws) HIP_OK(hipFree(ws));
     double max_err = -1.0;
     size_t n_nan = 0;
     if (ref) {
@@ -223,8 +238,6 @@ static void run_one(const Args& a, Buffers& b, int variant, const std::vector<fl
           "fa_time_forward");
     const double flop = (a.causal ? 2.0 : 4.0) * (double)a.bh * (double)a.n * (double)a.n * (double)a.d;
     const double tf = flop / (ms * 1e-3) / 1e12;
-    int32_t route = 0;
-    fa_ok(fa_last_forward_route(nullptr, &route), "fa_last_forward_route");
     printf("{\"mode\": \"%s\", \"dtype\": \"%s\", \"kernel\": \"%s\", \"out_f32\": %d, \"route\": %d, \"variant\": %d, \"bh\": %ld, \"n\": %ld, \"d\": %d, \"causal\": %d, "
            "\"scale\": %g, \"ms\": %.4f, \"tflops\": %.2f, \"frac_mfma_peak\": %.4f, \"max_abs_err_vs_naive\": %.3e, "
            "\"nan\": %zu, \"iters\": %d}\n",
@@ -315,6 +328,88 @@ static int run_llmc(const Args& a)
     return n_bad == 0 ? 0 : 1;
 }
 
+// BASELINE config 5 (B = 64, H = 16 -> 1024 slabs, bf16) over N shards: contiguous split of the batch*head axis, no collective
+static int run_sharded(const Args& a)
+{
+    int ndev = fa_device_count();
+    if (ndev < 1) {
+        fprintf(stderr, "no device\n");
+        return 4;
+    }
+    const int ns = a.devices > 0 ? a.devices : ndev;
+    const bool bf = a.dtype == "bf16";
+    const int dt = bf ? FA_DTYPE_BF16 : FA_DTYPE_F32;
+    const size_t esz = bf ? 2 : 4;
+    std::vector<int32_t> devs(ns);
+    std::vector<int64_t> bhs(ns);
+    std::vector<void*> q(ns, nullptr), k(ns, nullptr), v(ns, nullptr), o(ns, nullptr), streams(ns, nullptr);
+    std::vector<hipEvent_t> e0(ns), e1(ns);
+    const int64_t base = a.bh / ns, rem = a.bh % ns;
+    for (int i = 0; i < ns; ++i) {
+        devs[i] = i % ndev;
+        bhs[i] = base + (i < rem ? 1 : 0);
+        HIP_OK(hipSetDevice(devs[i]));
+        const size_t ne = (size_t)bhs[i] * a.n * a.d;
+        hipStream_t st;
+        HIP_OK(hipStreamCreate(&st));
+        streams[i] = st;
+        HIP_OK(hipEventCreate(&e0[i]));
+        HIP_OK(hipEventCreate(&e1[i]));
+        if (ne == 0) continue;
+        HIP_OK(hipMalloc(&q[i], ne * esz));
+        HIP_OK(hipMalloc(&k[i], ne * esz));
+        HIP_OK(hipMalloc(&v[i], ne * esz));
+        HIP_OK(hipMalloc(&o[i], ne * esz));
+        // random data of the right kind without a host pass over 1 GiB per tensor: one seeded slab, repeated
+        const size_t slab = (size_t)a.n * a.d;
+        std::vector<float> h(slab);
+        std::vector<uint16_t> hb(slab);
+        void* dst[3] = {q[i], k[i], v[i]};
+        for (int t = 0; t < 3; ++t) {
+            Rng rng(1234u + 17u * (unsigned)t + 101u * (unsigned)i);
+            for (size_t j = 0; j < slab; ++j) h[j] = rng.normal();
+            if (bf) for (size_t j = 0; j < slab; ++j) hb[j] = f32_to_bf16(h[j]);
+            for (int64_t s = 0; s < bhs[i]; ++s)
+                HIP_OK(hipMemcpy((char*)dst[t] + (size_t)s * slab * esz, bf ? (const void*)hb.data() : (const void*)h.data(), slab * esz, hipMemcpyHostToDevice));
+        }
+    }
+    auto once = [&]() {
+        fa_ok(fa_forward_sharded(ns, devs.data(), q.data(), k.data(), v.data(), o.data(), bhs.data(), a.n, a.d, a.scale, a.causal, dt, streams.data()),
+              "fa_forward_sharded");
+    };
+    for (int w = 0; w < (a.warmup > 0 ? a.warmup : 1); ++w) once();
+    for (int i = 0; i < ns; ++i) {
+        HIP_OK(hipSetDevice(devs[i]));
+        HIP_OK(hipStreamSynchronize((hipStream_t)streams[i]));
+    }
+    for (int i = 0; i < ns; ++i) {
+        HIP_OK(hipSetDevice(devs[i]));
+        HIP_OK(hipEventRecord(e0[i], (hipStream_t)streams[i]));
+    }
+    const int iters = a.iters_given ? a.iters : 5;
+    for (int it = 0; it < iters; ++it) once();
+    double worst = 0.0;
+    std::string per = "[";
+    for (int i = 0; i < ns; ++i) {
+        HIP_OK(hipSetDevice(devs[i]));
+        HIP_OK(hipEventRecord(e1[i], (hipStream_t)streams[i]));
+        HIP_OK(hipEventSynchronize(e1[i]));
+        float ms = 0.0f;
+        HIP_OK(hipEventElapsedTime(&ms, e0[i], e1[i]));
+        const double m = ms / iters;
+        worst = m > worst ? m : worst;
+        char buf[64];
+        snprintf(buf, sizeof(buf), "%s%.4f", i ? ", " : "", m);
+        per += buf;
+    }
+    per += "]";
+    const double flop = (a.causal ? 2.0 : 4.0) * (double)a.bh * (double)a.n * (double)a.n * (double)a.d;
+    printf("{\"mode\": \"sharded\", \"dtype\": \"%s\", \"shards\": %d, \"visible_devices\": %d, \"bh\": %ld, \"n\": %ld, \"d\": %d, \"causal\": %d, "
+           "\"per_shard_ms\": %s, \"ms\": %.4f, \"tflops\": %.2f, \"iters\": %d}\n",
+           a.dtype.c_str(), ns, ndev, a.bh, a.n, a.d, a.causal, per.c_str(), worst, flop / (worst * 1e-3) / 1e12, iters);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     const Args a = parse(argc, argv);
@@ -324,6 +419,7 @@ int main(int argc, char** argv)
     }
     HIP_OK(hipSetDevice(0));
     if (a.mode == "llmc") return run_llmc(a);
+    if (a.mode == "sharded") return run_sharded(a);
     const size_t ne = (size_t)a.bh * a.n * a.d;
     std::vector<float> hq(ne), hk(ne), hv(ne);
 

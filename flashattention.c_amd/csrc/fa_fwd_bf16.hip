@@ -522,6 +522,15 @@ hipError_t launch_bf16_p16(const FwdParams& p, int d, int causal, int out_f32, h
     return launch_bf16_x2_p16_d64(p, causal, out_f32, stream);
 }
 
+hipError_t launch_bf16_p16x2(const FwdParams& p, int d, int causal, int out_f32, hipStream_t stream)
+{
+    if (!bf16_p16_supported(p, d)) return hipErrorInvalidValue;
+    if (d == 32) return launch_bf16_x2_p16x2_d32(p, causal, out_f32, stream);
+    if (d == 128) return launch_bf16_x2_p16x2_d128(p, causal, out_f32, stream);
+    if (bf16_p16_uses_x4(p.bh, p.n, causal)) return launch_bf16_x4_p16x2(p, out_f32, stream);
+    return launch_bf16_x2_p16x2_d64(p, causal, out_f32, stream);
+}
+
 hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, int variant, hipStream_t stream)
 {
     if (variant == 0) {

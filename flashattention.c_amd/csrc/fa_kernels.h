@@ -29,6 +29,12 @@ bool bf16_p16_uses_x4(int64_t bh, int64_t n, int causal);
 hipError_t launch_bf16_x2_p16_d32(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
 hipError_t launch_bf16_x2_p16_d64(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
 hipError_t launch_bf16_x2_p16_d128(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
+// two-term fp16 P (hi + lo): the same chain, kernels fa_fwd_bf16_x{2,4}_p16x2_kernel
+hipError_t launch_bf16_p16x2(const FwdParams& p, int d, int causal, int out_f32, hipStream_t stream);
+hipError_t launch_bf16_x4_p16x2(const FwdParams& p, int out_f32, hipStream_t stream);   // non-causal only
+hipError_t launch_bf16_x2_p16x2_d32(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
+hipError_t launch_bf16_x2_p16x2_d64(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
+hipError_t launch_bf16_x2_p16x2_d128(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
 hipError_t launch_cvt_v_f16(const void* src, void* dst, int64_t count, uint32_t* flag, uint32_t serial, hipStream_t stream);
 // combine of a key-split launch: partial outputs fp32 [S][bh][n][d], partial log-sum-exps [bh][S][n] -> p.o (and p.lse)
 hipError_t launch_combine_splits(const FwdParams& p, const float* o_part, const float* lse_part, int S, int d, int out_f32, hipStream_t stream);

@@ -23,9 +23,13 @@ torch::Tensor forward(torch::Tensor Q, torch::Tensor K, torch::Tensor V, bool ca
     const int dtype = Q.scalar_type() == torch::kBFloat16 ? FA_DTYPE_BF16 : FA_DTYPE_F32;   // reference: fp32 only (data_ptr<float>())
     torch::Tensor O = torch::empty_like(Q);   // reference: torch::zeros + a dead O_l (flashattention.cu:608-609); every element is written
     const c10::hip::HIPStream stream = c10::hip::getCurrentHIPStream(Q.device().index());
-    const int rc = fa_forward(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), Q.size(0), Q.size(1), (int32_t)Q.size(2),
-                              /*scale=*/1.0f,   // the reference's hard-wired scale (flashattention.cu:593,600)
-                              causal ? 1 : 0, dtype, stream.stream());
+    // the non-allocating form of the boundary: scratch, when the chosen kernels want any (small bf16 grids), is a torch tensor
+    const size_t ws_bytes = fa_workspace_bytes(Q.size(0), Q.size(1), (int32_t)Q.size(2), causal ? 1 : 0, dtype, FA_KERNEL_AUTO);
+    torch::Tensor ws;
+    if (ws_bytes > 0) ws = torch::empty({(int64_t)ws_bytes}, Q.options().dtype(torch::kUInt8));
+    const int rc = fa_forward_ws(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), /*lse=*/nullptr, Q.size(0), Q.size(1),
+                                 (int32_t)Q.size(2), /*scale=*/1.0f,   // the reference's hard-wired scale (flashattention.cu:593,600)
+                                 causal ? 1 : 0, dtype, FA_KERNEL_AUTO, ws_bytes ? ws.data_ptr() : nullptr, ws_bytes, stream.stream());
     TORCH_CHECK(rc == FA_OK, "flashattn_amd: ", fa_last_error());
     return O;   // asynchronous on the current stream (the reference ends with cudaDeviceSynchronize, :594)
 }

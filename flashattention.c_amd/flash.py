@@ -25,12 +25,12 @@ import torch
 
 from . import _cabi
 
-__all__ = ["forward", "forward_packed_qkv", "load", "time_forward", "last_forward_route", "SUPPORTED_HEAD_DIMS"]
+__all__ = ["forward", "forward_packed_qkv", "load", "time_forward", "last_forward_route", "workspace_bytes", "SUPPORTED_HEAD_DIMS"]
 
 SUPPORTED_HEAD_DIMS = (32, 64, 128)
 _DTYPES = {torch.float32: _cabi.FA_DTYPE_F32, torch.bfloat16: _cabi.FA_DTYPE_BF16}
 _KERNELS = {"auto": _cabi.FA_KERNEL_AUTO, "naive": _cabi.FA_KERNEL_NAIVE, "mfma": _cabi.FA_KERNEL_MFMA,
-            "exact": _cabi.FA_KERNEL_MFMA, "split": _cabi.FA_KERNEL_SPLIT, "p16": _cabi.FA_KERNEL_P16}
+            "exact": _cabi.FA_KERNEL_MFMA, "split": _cabi.FA_KERNEL_SPLIT, "p16": _cabi.FA_KERNEL_P16, "p16x2": _cabi.FA_KERNEL_P16X2}
 
 
 def _kernel_id(kernel: Union[str, int]) -> int:
@@ -66,7 +66,8 @@ def _check_qkv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> Tuple[int, 
 
 def forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = False, *,
             scale: float = 1.0, return_lse: bool = False, kernel: Union[str, int] = "auto",
-            out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None):
+            out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None,
+            workspace: Optional[torch.Tensor] = None):
     """``O = softmax(scale * q k^T [+ causal mask]) v`` per (batch*head); drop-in for ``flash.forward(q, k, v, causal)``.
 
     Returns a new tensor shaped like ``q`` (the reference allocates with ``torch::zeros``; here ``torch.empty`` is
@@ -77,9 +78,15 @@ def forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = Fa
     the bf16 matrix pipe as three products of two-term bf16 splits (within 1e-3 of the fp32 reference) behind a device-side
     guard that hands launches with too wide logits to the exact fp32 kernel; ``"split"`` is the same without the guard,
     ``"exact"`` (= ``"mfma"``) computes in fp32 arithmetic.  bf16 tensors: ``out_dtype=torch.float32`` stores the fp32
-    accumulator (FA_DTYPE_BF16_OUT_F32) and, under ``"auto"``, selects the accurate P -- fp16 (``"p16"``, head dim 64) or
-    hi + lo bf16 terms (``"split"``) -- which is within 1e-3 of the fp32 reference at scale 1; a bf16 output keeps the fastest
-    kernels (bf16 P, ``"mfma"``; ~5e-3 at scale 1).  ``out`` must not overlap q, k or v.
+    accumulator (FA_DTYPE_BF16_OUT_F32) and, under ``"auto"``, selects the accurate P -- two fp16 terms (``"p16x2"``) or, for
+    small launches, hi + lo bf16 terms (``"split"``) -- which is within 1e-4 of the fp32 reference at scale 1; ``"p16"`` (one
+    fp16 term, ~1e-3) is an explicit choice only; a bf16 output keeps the fastest kernels (bf16 P, ``"mfma"``; ~5e-3 at scale 1).
+    ``out`` must not overlap q, k or v.
+
+    The call goes through ``fa_forward_ws``: scratch (the fp16 copy of V, key-split partials), when the chosen kernels need any,
+    is a ``torch.empty`` byte tensor from torch's caching allocator on the current stream -- the C ABI itself allocates nothing,
+    which also makes every kernel family legal under ``torch.cuda.graph`` capture.  ``workspace`` may pass a preallocated
+    ``torch.uint8`` tensor of at least ``workspace_bytes(...)`` bytes instead.
     """
     bh, n, d = _check_qkv(q, k, v)
     kid = _kernel_id(kernel)
@@ -100,12 +107,29 @@ def forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = Fa
     lse = torch.empty((bh, n), dtype=torch.float32, device=q.device) if return_lse else None
     L = _cabi.lib()
     with torch.cuda.device(q.device):
+        need = int(L.fa_workspace_bytes(bh, n, d, int(bool(causal)), dt, kid))
+        if workspace is None:
+            # 256-byte aligned by the caching allocator (its blocks are 512-byte multiples)
+            workspace = torch.empty(need, dtype=torch.uint8, device=q.device) if need else None
+        elif workspace.dtype != torch.uint8 or workspace.device != q.device or not workspace.is_contiguous() or workspace.numel() < need:
+            raise ValueError(f"workspace must be a contiguous torch.uint8 tensor of at least {need} bytes on {q.device}")
         stream = torch.cuda.current_stream().cuda_stream
-        rc = L.fa_forward_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+        rc = L.fa_forward_ws(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                              lse.data_ptr() if lse is not None else None,
-                             bh, n, d, float(scale), int(bool(causal)), dt, kid, ctypes.c_void_p(stream))
+                             bh, n, d, float(scale), int(bool(causal)), dt, kid,
+                             workspace.data_ptr() if workspace is not None else None,
+                             workspace.numel() if workspace is not None else 0, ctypes.c_void_p(stream))
     _cabi.check(rc)
     return (out, lse) if return_lse else out
+
+
+def workspace_bytes(bh: int, n: int, d: int, causal: bool = False, *, dtype: torch.dtype = torch.float32,
+                    out_dtype: Optional[torch.dtype] = None, kernel: Union[str, int] = "auto") -> int:
+    """Bytes of scratch ``forward`` needs for this call (``fa_workspace_bytes``); 0 for most shapes."""
+    dt = _DTYPES[dtype]
+    if out_dtype is not None and out_dtype != dtype:
+        dt = _cabi.FA_DTYPE_BF16_OUT_F32
+    return int(_cabi.lib().fa_workspace_bytes(int(bh), int(n), int(d), int(bool(causal)), dt, _kernel_id(kernel)))
 
 
 def forward_packed_qkv(inp: torch.Tensor, n_head: int) -> torch.Tensor:
@@ -163,7 +187,7 @@ def time_forward(q, k, v, causal: bool = False, *, scale: float = 1.0, kernel: U
 
 def last_forward_route(stream: Optional[torch.cuda.Stream] = None) -> int:
     """Which kernel of a conditional launch chain produced this thread's most recent forward (blocking; diagnostics):
-    0 = single unconditional launch, 1 = primary kernel (fp32: split products, bf16: fp16 P), 2 = fallback (fp32: the
+    0 = single unconditional launch, 1 = primary kernel (fp32: split products, bf16: fp16 P in one or two terms), 2 = fallback (fp32: the
     logit-width guard fired and the exact kernel ran; bf16: a V value did not fit fp16 and the split kernel ran)."""
     r = ctypes.c_int32(0)
     s = (stream or torch.cuda.current_stream()).cuda_stream

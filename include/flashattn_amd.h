@@ -19,13 +19,17 @@
  *   scale       explicit; the reference hard-wires 1.0 (flashattention.cu:593,600) -- pass 1.0f for parity
  *   ragged N    any N >= 1 is handled exactly (tail keys are masked, not zero-filled as at
  *               flashattention.cu:224-231)
- *   ownership   the caller owns every tensor; no tensor is allocated, freed or zero-filled here (the reference allocates O and
- *               a dead O_l inside forward(), :608-609).  Two paths need scratch -- FA_KERNEL_P16's fp16 copy of V, and the
- *               partial outputs of a key-split launch (bf16 tensors, non-causal, grids of at most 128 256-row tiles: several
- *               workgroups per q-tile share the keys and a combine kernel merges them) -- and take it from the device's
- *               stream-ordered pool (hipMallocAsync / hipFreeAsync on `stream`); neither is taken while `stream` is capturing
- *               (graph allocations proved unreliable on ROCm 7.2): FA_KERNEL_AUTO then picks kernels without scratch, an
- *               explicit FA_KERNEL_P16 returns FA_ERR_UNSUPPORTED
+ *   ownership   the caller owns every buffer; nothing is allocated, freed or zero-filled by fa_forward_ws, the entry point of this
+ *               boundary proper (the reference allocates O and a dead O_l inside forward(), :608-609).  Two paths need scratch --
+ *               the fp16 copy of V of the fp16-P kernels (FA_KERNEL_P16X2 / FA_KERNEL_P16, and FA_KERNEL_AUTO with an fp32 output),
+ *               and the partial outputs of a key-split launch (bf16 tensors, non-causal, grids of at most 128 256-row tiles: several
+ *               workgroups per q-tile share the keys and a combine kernel merges them): fa_workspace_bytes() reports the size for a
+ *               call, fa_forward_ws() takes the caller's buffer, and every path is then legal inside a captured hipGraph.
+ *               fa_forward / fa_forward_ex / fa_forward_sharded are CONVENIENCE WRAPPERS: they take the same bytes from a private
+ *               stream-ordered pool of the device (hipMemPoolCreate; hipMallocFromPoolAsync / hipFreeAsync on `stream`; the device's
+ *               default pool is never touched) -- except while `stream` is capturing (graph allocations proved unreliable on ROCm
+ *               7.2): FA_KERNEL_AUTO then picks kernels without scratch, an explicit FA_KERNEL_P16 / P16X2 returns
+ *               FA_ERR_UNSUPPORTED.  A failed pool allocation makes FA_KERNEL_AUTO fall back to those kernels as well
  *   aliasing    o must not overlap q, k or v (a tile that fails its verification is recomputed from q, k, v after o was
  *               written): overlapping ranges are rejected with FA_ERR_INVALID_ARGUMENT
  *   ordering    the kernel is enqueued on `stream` and the call returns without synchronising
@@ -37,13 +41,14 @@
 #ifndef FLASHATTN_AMD_H
 #define FLASHATTN_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define FLASHATTN_AMD_ABI_VERSION 2
+#define FLASHATTN_AMD_ABI_VERSION 3
 
 typedef enum fa_status {
     FA_OK = 0,
@@ -66,12 +71,13 @@ typedef enum fa_dtype {
                          FA_KERNEL_AUTO choice for the whole process */
     FA_DTYPE_BF16 = 1,        /* bf16 in, bf16 MFMA with fp32 accumulate and fp32 softmax, bf16 out     */
     FA_DTYPE_BF16_OUT_F32 = 2 /* bf16 in, O written as fp32 (the accumulator precision).  Under FA_KERNEL_AUTO this also selects
-                                 the ACCURATE P: a caller who wants the fp32 accumulator gets P in fp16 (11 significant bits:
-                                 8e-4 .. 1.2e-3 of the fp32 reference at scale 1 on unit-variance data, <= 2e-4 at 1/sqrt(d),
-                                 where bf16 P shows ~5e-3) -- or, for launches below 6e9 multiply-adds per contraction (2e9 at
-                                 head dim 32; the fp16 path costs a copy of V and two extra launches, ~15 us) and for slabs
-                                 beyond 4 GiB, P and the scaled Q as hi + lo bf16 terms (~1e-4).  A bf16 output rounds at
-                                 2^-9 |O| by itself and keeps the fastest kernels (bf16 P). */
+                                 the ACCURATE P: a caller who wants the fp32 accumulator gets P as two fp16 terms, hi + lo
+                                 (FA_KERNEL_P16X2: ~22 significant bits, <= 1e-4 of the fp32 reference at scale 1 on unit-variance
+                                 data where bf16 P shows ~5e-3) -- or, for launches below 6e9 multiply-adds per contraction (2e9 at
+                                 head dim 32; the fp16 path costs a copy of V and two extra launches, ~15 us), for slabs beyond
+                                 4 GiB and whenever scratch is not available, P and the scaled Q as hi + lo bf16 terms
+                                 (FA_KERNEL_SPLIT, ~1e-4).  A bf16 output rounds at 2^-9 |O| by itself and keeps the fastest
+                                 kernels (bf16 P). */
 } fa_dtype;
 
 typedef enum fa_kernel {
@@ -83,10 +89,14 @@ typedef enum fa_kernel {
                             bf16 tensors: K, V exact in one term, Q*scale*log2e and P carried as hi + lo (two products per
                             contraction): max-abs error ~1e-4 against fp64 at scale 1 with FA_DTYPE_BF16_OUT_F32, at ~2x the
                             time of the bf16-P kernels */
-    FA_KERNEL_P16 = 4    /* bf16 tensors: P and V in fp16 for the second contraction (v_mfma_f32_32x32x16_f16), Q.K^T in bf16
-                            (exact in the fp32 accumulator): 8e-4 .. 1.2e-3 at scale 1 at ~1.15x the time of the bf16-P kernels.
-                            V is copied to fp16 into stream-ordered scratch (hipMallocAsync) first; if some |v| >= 2^16 the
-                            split kernel takes the launch instead (decided on the device). */
+    FA_KERNEL_P16 = 4,   /* bf16 tensors: P and V in fp16 for the second contraction (v_mfma_f32_32x32x16_f16), ONE fp16 term of P
+                            (11 significant bits), Q.K^T in bf16 (exact in the fp32 accumulator): 8e-4 .. 1.2e-3 at scale 1 -- AT the
+                            1e-3 bar, not safely inside it (the maximum grows with the number of outputs) -- at ~1.15x the time of the
+                            bf16-P kernels.  Never chosen by FA_KERNEL_AUTO.  V is copied to fp16 into scratch first; if some
+                            |v| >= 2^16 the split kernel takes the launch instead (decided on the device). */
+    FA_KERNEL_P16X2 = 5  /* the same with P as fp16 hi + fp16 lo (lo = fp16(p - hi), exact difference; twice the P.V and row-sum MFMAs):
+                            ~1e-4 at scale 1 on any data, at ~1.4x the time of the bf16-P kernels.  The FA_KERNEL_AUTO choice for
+                            FA_DTYPE_BF16_OUT_F32 (see there).  Same V copy, same device-side fallback. */
 } fa_kernel;
 /* `kernel` arguments: bits 0..7 = fa_kernel; bits 8..15 = 0, or the number of one of the co-compiled tilings of that family
  * (every one of them computes the same function; csrc/fa_fwd_bf16.hip and csrc/fa_split_kernel.h list them, tests/ run them
@@ -117,13 +127,32 @@ int fa_forward_ex(const void* q, const void* k, const void* v, void* o, float* l
                   int32_t dtype, int32_t kernel, void* stream);
 
 /*
+ * fa_workspace_bytes -- bytes of caller-owned scratch THIS call needs (0 = none; also 0 for arguments fa_forward_ws would reject).
+ *                       Same (bh, n, d, causal, dtype, kernel) as the forward it sizes; the figure covers every kernel the call's
+ *                       launch chain may run, so it is an upper bound of what is touched.
+ * fa_forward_ws      -- fa_forward_ex that never allocates: the non-allocating form of the boundary
+ *                       (ownership as in /root/reference/src/flashattention.cu:608-609 inverted: caller owns all buffers).
+ *   workspace        device pointer, 256-byte aligned, at least fa_workspace_bytes() bytes, not overlapping q, k, v, o; NULL is fine
+ *                    when the call needs none.  In use until the forward has completed on `stream`; one forward at a time per
+ *                    workspace (its first bytes hold the launch chain's verdict word).  Contents need no initialisation.
+ *   capture          legal while `stream` is capturing, with every kernel family (the chain clears its verdict word with a memset
+ *                    node, so replays of the graph are independent of each other).
+ */
+size_t fa_workspace_bytes(int64_t bh, int64_t n, int32_t d, int32_t causal, int32_t dtype, int32_t kernel);
+int fa_forward_ws(const void* q, const void* k, const void* v, void* o, float* lse,
+                  int64_t bh, int64_t n, int32_t d, float scale, int32_t causal,
+                  int32_t dtype, int32_t kernel, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * fa_forward_sharded -- the batch*head axis split across several devices of one node, no collective
  *                       (every blockIdx.x of the reference grid is independent: flashattention.cu:144).
  *   n_shards        number of shards
- *   device_ids[i]   HIP device ordinal of shard i (buffers of shard i live there)
+ *   device_ids[i]   HIP device ordinal of shard i (buffers of shard i live there); the devices of non-empty shards must be distinct
+ *                   (FA_ALLOW_SAME_DEVICE=1 in the environment lifts the check: single-GPU test boxes)
  *   q/k/v/o[i]      device pointers of shard i, (bh[i], n, d)
  *   streams[i]      hipStream_t on device_ids[i] (NULL entries / NULL array = null stream)
- * Launches are enqueued shard by shard without synchronising; the caller's current device is restored.
+ * Each shard is enqueued by its own host thread (a forward can be a chain of launches: one thread would start the last device a
+ * whole table's worth of host time behind the first) without synchronising; the caller's current device is untouched.
  */
 int fa_forward_sharded(int32_t n_shards, const int32_t* device_ids,
                        const void* const* q, const void* const* k, const void* const* v, void* const* o,
@@ -143,9 +172,9 @@ int fa_forward_packed_qkv(const float* inp, float* out, int32_t B, int32_t T, in
 /*
  * fa_time_forward -- enqueue `warmup` + `iters` forwards on `stream`, bracket the `iters` timed ones with
  *                    HIP events recorded on that same stream, and return the mean milliseconds per forward.
- *                    Synchronises the stream (this is the one blocking entry point; used by the C driver
- *                    and bench.py's roofline leg, the counterpart of benchmark_kernel,
- *                    /root/reference/src/llm.c/common.h:108-124).
+ *                    Blocking (the counterpart of benchmark_kernel, /root/reference/src/llm.c/common.h:108-124; used by the C
+ *                    driver and bench.py's roofline leg).  The launches go through the fa_forward_ws path with a workspace the
+ *                    measurement owns (hipMalloc / hipFree outside the timed region).
  */
 int fa_time_forward(const void* q, const void* k, const void* v, void* o,
                     int64_t bh, int64_t n, int32_t d, float scale, int32_t causal,
@@ -154,9 +183,9 @@ int fa_time_forward(const void* q, const void* k, const void* v, void* o,
 
 /*
  * fa_time_forward_graph -- the same measurement with the `iters` launches captured into one hipGraph on a private
- *                          stream and ONE replay of that graph timed (after a warm replay).  Back-to-back stream
- *                          launches of a ~0.3 ms forward leave ~25 us between kernels on MI355X; a graph-captured
- *                          pipeline does not.  Reported beside the stream-launch figure, never instead of it.
+ *                          stream; after a warm replay three replays are timed one by one and the median is reported.
+ *                          Reported beside the stream-launch figure, never instead of it.  (On ROCm 7.2 a graph replay of
+ *                          back-to-back forwards is NOT faster than the same launches on a stream: see DESIGN.md section 7.)
  */
 int fa_time_forward_graph(const void* q, const void* k, const void* v, void* o,
                           int64_t bh, int64_t n, int32_t d, float scale, int32_t causal, int32_t dtype,
@@ -165,7 +194,7 @@ int fa_time_forward_graph(const void* q, const void* k, const void* v, void* o,
 /*
  * fa_last_forward_route -- which kernel of a conditional launch chain produced the output of this thread's most recent
  *                          forward.  Blocking (waits for `stream`, reads one word back): diagnostics and benchmarks only.
- *   *route  0 = the call was a single unconditional launch;  1 = the primary kernel (fp32: split products; bf16: fp16 P);
+ *   *route  0 = the call was a single unconditional launch;  1 = the primary kernel (fp32: split products; bf16: fp16 P, one or two terms);
  *           2 = the fallback (fp32: exact fp32 arithmetic -- the logit-width guard fired; bf16: the split kernel -- a V value
  *           did not fit fp16)
  */

@@ -8,16 +8,14 @@ Tolerances (max-abs, stated once here; BASELINE.md section 4 gives the arithmeti
   bf16 kernel, fp32 out, scale 1.0              1.2e-2 unscaled scores: P is near one-hot, so the error tends to 2^-9 * max|v| (one bf16
                                                       rounding of the dominant P); max|v| ~ 5.4 over 8M randn -> 1.05e-2; observed <= 9.0e-3
   bf16 kernel, bf16 out                         2.5e-2 adds half a bf16 ulp of |O| (|O| < 4 -> 7.8e-3); observed <= 1.5e-2
-  bf16 tensors, fp32 out, ACCURATE P            1e-3  north_star bar at scale 1: FA_KERNEL_AUTO with an fp32 output = fp16 P (head dim 64) or hi + lo
-                                                      bf16 terms (head dims 32, 128: ~1e-4).  fp16 P has 11 significant bits; the worst rows have
-                                                      two comparable dominant keys with distant V rows: |err| <= 0.25 * 2^-10 * |v1 - v2|, and the
-                                                      maximum over the launch grows with the number of outputs: observed 6.7e-4 .. 8.4e-4 on one
-                                                      N = 8192 slab, 8.4e-4 / 1.0e-3 over 16 slabs (c4; two data sets), 1.17e-3 over 128 slabs
-                                                      (1.13e-3 on a 26 x 2670 fuzz case, 1.09e-3 on 17 x 4096) -> P16_TOL_BIG = 1.5e-3 for launches
-                                                      of more than ~4 M outputs and for the fuzz through the dispatch (stated where used).
-                                                      Long flat rows (N = 16 384, scale 0.5) were at 1.9e-3 while the row maximum sat at 2^-5 of
-                                                      the fp16 range (subnormal tail); at 2^0 they are at 6e-4 (tests/soak_fuzz.py found it).
-                                                      Hostile data (planted dominant keys, x3 logits): first-order bound 2^-10 * max|v|.
+  bf16 tensors, fp32 out, ACCURATE P            1e-3  north_star bar at scale 1, held with a wide margin: FA_KERNEL_AUTO with an fp32 output = P as fp16
+                                                      hi + fp16 lo (kernel="p16x2": ~22 significant bits; observed <= 3e-5) or, for small launches, hi +
+                                                      lo bf16 terms (kernel="split": ~1e-4).  TOL_ACC = 2e-4 is asserted where only these can be running.
+  bf16 tensors, kernel="p16" (ONE fp16 term)    1e-3 / 1.5e-3  explicit choice only, never AUTO.  11 significant bits; the worst rows have two comparable
+                                                      dominant keys with distant V rows: |err| <= 0.25 * 2^-10 * |v1 - v2|, and the maximum over the
+                                                      launch grows with the number of outputs: observed 6.7e-4 .. 8.4e-4 on one N = 8192 slab, 8.4e-4 /
+                                                      1.0e-3 over 16 slabs, 1.17e-3 over 128 slabs -> P16_TOL_BIG = 1.5e-3 for launches of more than
+                                                      ~4 M outputs, used ONLY in tests of kernel="p16".
 "bf16 kernel" above = the bf16-P kernels (kernel="mfma"; FA_KERNEL_AUTO for a bf16 output).
 The bf16 kernels are always compared with the oracle evaluated on the SAME bf16-valued inputs.
 """
@@ -37,7 +35,8 @@ from tests.conftest import GOLDEN_DIR, golden_cases
 pytestmark = pytest.mark.gpu
 
 TOL_F32 = 1e-3
-P16_TOL_BIG = 1.5e-3   # fp16 P, unscaled logits, more than 16 slabs of N = 8192 (see the header)
+TOL_ACC = 2e-4         # the accurate P of FA_KERNEL_AUTO for bf16 tensors with an fp32 output (two fp16 terms / hi + lo bf16 terms)
+P16_TOL_BIG = 1.5e-3   # kernel="p16" ONLY (one fp16 term): unscaled logits, more than 16 slabs of N = 8192 (see the header)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -352,11 +351,10 @@ def test_fuzz_shapes_through_the_dispatch_against_rung0():
         acc = fa.forward(q, k, v, causal, scale=scale, out_dtype=torch.float32)                    # auto: the accurate P
         err_a = float((acc - ref).abs().max())
         worst_acc = max(worst_acc, err_a)
-        # fp16 P at unscaled logits: 2^-12-relative P, the maximum over millions of outputs reaches 1.0 .. 1.2e-3 (header of this file)
-        tol_a = P16_TOL_BIG if scale >= 0.5 else TOL_F32
-        assert err_a < tol_a, f"accurate P: case {case} bh={bh} n={n} d={d} causal={causal} scale={scale}: {err_a:.3e}"
+        # two fp16 terms of P (large launches) or hi + lo bf16 terms (small ones): the fp32 bar with margin at every scale
+        assert err_a < TOL_ACC, f"accurate P: case {case} bh={bh} n={n} d={d} causal={causal} scale={scale}: {err_a:.3e}"
     OBSERVED.append(("fuzz through dispatch, worst of 48", worst, bf16_tol(1.0, True)))
-    OBSERVED.append(("fuzz through dispatch, accurate P, worst of 48", worst_acc, P16_TOL_BIG))
+    OBSERVED.append(("fuzz through dispatch, accurate P, worst of 48", worst_acc, TOL_ACC))
 
 
 # bf16 tensors through the split machinery (kernel="split"): K and V are exact in one bf16 term, Q*scale*log2e and P are carried
@@ -425,7 +423,8 @@ def test_causal_paired_tile_order_covers_every_tile_once(bh, n):
     be a bijection for every tile count per slab and every bh -- slabs aligned with the 32-position rounds, not aligned, and cut
     by the boundary between two XCDs -- or some rows are computed twice and others never (the output is poisoned with NaN first)."""
     g = torch.Generator(device="cpu").manual_seed(n + bh)
-    for d, kernel, out_dtype, tol in ((32, "auto", torch.bfloat16, 2.5e-2), (64, "p16", torch.float32, P16_TOL_BIG), (32, "p16", torch.float32, P16_TOL_BIG)):
+    for d, kernel, out_dtype, tol in ((32, "auto", torch.bfloat16, 2.5e-2), (64, "p16", torch.float32, P16_TOL_BIG), (32, "p16", torch.float32, P16_TOL_BIG),
+                                      (64, "p16x2", torch.float32, TOL_ACC), (32, "p16x2", torch.float32, TOL_ACC)):
         q, k, v = (torch.randn(bh, n, d, generator=g).to(torch.bfloat16).to(dev()) for _ in range(3))
         ref = fa.forward(q.float(), k.float(), v.float(), True, kernel="naive")
         out = torch.full((bh, n, d), float("nan"), dtype=out_dtype, device=dev())
@@ -507,13 +506,15 @@ def test_key_split_launch_for_grids_that_leave_the_chip_idle(bh, n, d):
         OBSERVED.append((f"key split bh={bh} n={n} d={d} {out_dtype}", err, tol))
         assert err < tol, f"{out_dtype}: {err:.3e}"
         assert float((lse - lse_ref).abs().max()) < 2e-2
-    # FA_KERNEL_AUTO with an fp32 output: the fp16-P chain, key-split (V copy -> S partial launches -> combine -> empty fallback)
-    oa, lsea = fa.forward(qd, kd, vd, False, out_dtype=torch.float32, return_lse=True)
-    assert fa.last_forward_route() == 1
-    erra = float((oa - ref_dev).abs().max())
-    OBSERVED.append((f"key split, fp16 P, bh={bh} n={n} d={d}", erra, P16_TOL_BIG))
-    assert erra < P16_TOL_BIG, f"fp16 P: {erra:.3e}"
-    assert float((lsea - lse_ref).abs().max()) < 2e-3
+    # FA_KERNEL_AUTO with an fp32 output: the fp16-P chain (two terms), key-split (V copy -> S partial launches -> combine -> empty
+    # fallback); kernel="p16": the same chain with one term
+    for kern, tol_k, tol_lse in (("auto", TOL_ACC, 1e-4), ("p16", P16_TOL_BIG, 2e-3)):
+        oa, lsea = fa.forward(qd, kd, vd, False, out_dtype=torch.float32, return_lse=True, kernel=kern)
+        assert fa.last_forward_route() == 1
+        erra = float((oa - ref_dev).abs().max())
+        OBSERVED.append((f"key split, fp16 P ({kern}), bh={bh} n={n} d={d}", erra, tol_k))
+        assert erra < tol_k, f"fp16 P ({kern}): {erra:.3e}"
+        assert float((lsea - lse_ref).abs().max()) < tol_lse
     if bh <= 2 and d == 64:      # ... and its fallback when V does not fit fp16: the split kernel's output must win over the combine's
         vbig = vd.clone()
         vbig[0, 5, 3] = 7.0e4
@@ -576,12 +577,17 @@ def test_noncontiguous_and_out_argument():
     check(out, ref, TOL_F32)
 
 
-def test_sharded_entry_point_on_one_device():
-    """fa_forward_sharded with two shards that both live on device 0 (a 1-GPU box can still exercise the entry point)."""
+def test_sharded_entry_point_on_one_device(monkeypatch):
+    """fa_forward_sharded with two shards that both live on device 0 (a 1-GPU box can still exercise the entry point -- with the
+    duplicate-device check lifted: a shard table that names a device twice is otherwise refused)."""
     q, k, v = (randn(s, 5, 200, 64) for s in (19, 20, 21))
-    ref = orc.attention_f64(q, k, v, causal=True)
     qd, kd, vd = to_dev(q, k, v)
     (b0, e0), (b1, e1) = fa.shard_range(5, 2, 0), fa.shard_range(5, 2, 1)
+    monkeypatch.delenv("FA_ALLOW_SAME_DEVICE", raising=False)
+    with pytest.raises(_cabi.FlashAttnError, match="both name device"):
+        fa.forward_sharded([qd[b0:e0], qd[b1:e1]], [kd[b0:e0], kd[b1:e1]], [vd[b0:e0], vd[b1:e1]], True)
+    monkeypatch.setenv("FA_ALLOW_SAME_DEVICE", "1")
+    ref = orc.attention_f64(q, k, v, causal=True)
     outs = fa.forward_sharded([qd[b0:e0], qd[b1:e1]], [kd[b0:e0], kd[b1:e1]], [vd[b0:e0], vd[b1:e1]], True)
     torch.cuda.synchronize()
     check(torch.cat(outs), ref, TOL_F32)
@@ -606,9 +612,9 @@ FULL = [
     ("c2", 128, 1024, 64, torch.float32, "auto", TOL_F32),
     ("c3", 16, 8192, 64, torch.float32, "auto", TOL_F32),
     ("c4", 16, 8192, 64, torch.bfloat16, "mfma", 1.2e-2),              # the bf16-P kernels (FA_KERNEL_AUTO for a bf16 output)
-    ("c4-accurate", 16, 8192, 64, torch.bfloat16, "auto", TOL_F32),    # fp32 output -> fp16 P: the north star's 1e-3 at scale 1
+    ("c4-accurate", 16, 8192, 64, torch.bfloat16, "auto", TOL_ACC),    # fp32 output -> two fp16 terms of P: the north star's 1e-3 at scale 1, with margin
     ("c5-shard", 128, 8192, 64, torch.bfloat16, "mfma", 1.2e-2),       # one GPU's share of B=64 H=16 split over 8 (src/flashattention.cu:144)
-    ("c5-shard-accurate", 128, 8192, 64, torch.bfloat16, "auto", P16_TOL_BIG),
+    ("c5-shard-accurate", 128, 8192, 64, torch.bfloat16, "auto", TOL_ACC),
     ("c5-full", 1024, 8192, 64, torch.bfloat16, "mfma", 1.2e-2),       # all 1024 slabs on one GPU (4 x 1 GiB tensors)
 ]
 
@@ -620,7 +626,7 @@ def test_full_size_configs(name, bh, n, d, dtype, kernel, tol):
     qd, kd, vd = (torch.randn(bh, n, d, generator=g, device=dev()).to(dtype) for _ in range(3))   # generated on the device: c5 is 3 GiB
     kw = dict(out_dtype=torch.float32, kernel=kernel) if bf else dict(kernel=kernel)
     o = fa.forward(qd, kd, vd, False, **kw)
-    if kernel == "auto":   # which arithmetic ran: the primary kernel of the chain (split products / fp16 P), not its fallback
+    if kernel == "auto":   # which arithmetic ran: the primary kernel of the chain (split products / two fp16 terms of P), not its fallback
         assert fa.last_forward_route() == 1
     host = lambda t, s: t[s:s + 1].float().cpu().numpy()
     # (a) exact oracle on two slabs (first and last)
@@ -689,6 +695,13 @@ def test_p16_kernel_vs_oracle(bh, n, d, causal):
         check(lse, lse_ref, 1e-3, f"p16 lse scale {scale}")       # row sums of fp16-rounded P: 2^-12 relative per term
         ob = fa.forward(qd, kd, vd, causal, scale=scale, kernel="p16")   # bf16 output: its own rounding on top
         check(ob, ref, bf16_tol(scale, False), f"p16 bf16 out scale {scale}")
+        # two fp16 terms of P: the same shapes at the accurate path's tolerance
+        o, lse = fa.forward(qd, kd, vd, causal, scale=scale, kernel="p16x2", out_dtype=torch.float32, return_lse=True)
+        assert fa.last_forward_route() == 1
+        check(o, ref, TOL_ACC, f"p16x2 scale {scale}")
+        check(lse, lse_ref, 1e-4, f"p16x2 lse scale {scale}")
+        ob = fa.forward(qd, kd, vd, causal, scale=scale, kernel="p16x2")
+        check(ob, ref, bf16_tol(scale, False), f"p16x2 bf16 out scale {scale}")
 
 
 @pytest.mark.parametrize("d,bh", [(64, 2), (64, 17), (32, 2), (128, 2)])   # bh = 17 at n = 4096: the NB = 4 tiling
@@ -710,6 +723,9 @@ def test_p16_reference_moves_inside_the_pipelined_loop(causal, d, bh):
     o, lse = fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, kernel="p16", out_dtype=torch.float32, return_lse=True)
     check(o, ref, TOL_F32, "p16")
     check(lse, lse_ref, 2e-3, "p16 lse")
+    o, lse = fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, kernel="p16x2", out_dtype=torch.float32, return_lse=True)
+    check(o, ref, TOL_ACC, "p16x2")
+    check(lse, lse_ref, 1e-4, "p16x2 lse")
 
 
 def test_p16_falls_back_when_v_does_not_fit_fp16():
@@ -722,60 +738,175 @@ def test_p16_falls_back_when_v_does_not_fit_fp16():
     v = orc.round_to_bf16(v)
     ref = orc.attention_f64(q, k, v, scale=0.125)
     qd, kd, vd = to_dev(q, k, v, dtype=torch.bfloat16)
-    o = fa.forward(qd, kd, vd, False, scale=0.125, out_dtype=torch.float32, kernel="p16")
-    assert fa.last_forward_route() == 2
-    got = o.cpu().numpy().astype(np.float64)
-    assert np.isfinite(got).all()
-    rel = np.abs(got - ref).max() / np.abs(ref).max()
-    assert rel < 1e-4, f"relative error {rel:.3e} with huge V entries"
+    for kern in ("p16", "p16x2", "auto"):
+        o = fa.forward(qd, kd, vd, False, scale=0.125, out_dtype=torch.float32, kernel=kern)
+        if kern != "auto":       # (auto takes the split kernel directly at this size: route 0)
+            assert fa.last_forward_route() == 2
+        got = o.cpu().numpy().astype(np.float64)
+        assert np.isfinite(got).all()
+        rel = np.abs(got - ref).max() / np.abs(ref).max()
+        assert rel < 1e-4, f"{kern}: relative error {rel:.3e} with huge V entries"
     # ... and the same tensors without the outliers take the fp16 path again
     v[1, 333, 7] = 1.0
     v[0, 5, 60] = -1.0
-    o = fa.forward(qd, kd, to_dev(v, dtype=torch.bfloat16)[0], False, scale=0.125, out_dtype=torch.float32, kernel="p16")
-    assert fa.last_forward_route() == 1
-    check(o, orc.attention_f64(q, k, v, scale=0.125), TOL_F32)
+    for kern in ("p16", "p16x2"):
+        o = fa.forward(qd, kd, to_dev(v, dtype=torch.bfloat16)[0], False, scale=0.125, out_dtype=torch.float32, kernel=kern)
+        assert fa.last_forward_route() == 1
+        check(o, orc.attention_f64(q, k, v, scale=0.125), TOL_F32 if kern == "p16" else TOL_ACC)
 
 
-def test_scratch_paths_are_not_taken_under_stream_capture():
-    """The fp16-P chain and the key-split launch take scratch from the stream-ordered pool.  Inside a captured graph that is not
-    reliable on this runtime (ROCm 7.2: the first kernels that touch a graph allocation of more than a few MB lose their data --
-    fp16-P chain at 16 x 8192 unwritten on every replay of a one-launch graph), so while the stream is capturing FA_KERNEL_AUTO
-    takes kernels without scratch (hi + lo bf16 P: more accurate, slower) and an explicit FA_KERNEL_P16 is refused."""
-    q, k, v = (torch.randn(16, 4096, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
-    ref = fa.forward(q.float(), k.float(), v.float(), False, kernel="naive")
+def test_scratch_paths_under_graph_capture_through_the_workspace_entry():
+    """fa_forward_ws never allocates: the fp16-P chains (V copy in the caller's workspace, verdict word cleared by a memset node) and the
+    key-split launch are legal inside a captured graph.  16 x 8192 is the size at which stream-ordered GRAPH allocations lost their
+    data on ROCm 7.2 (round 2); one-launch and four-launch graphs, output zeroed first.  (fa_time_forward_graph captures on a
+    private stream with a workspace the measurement owns.)"""
+    q, k, v = (torch.randn(16, 8192, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
+    ref = torch.cat([fa.forward(q[i:i + 4].float(), k[i:i + 4].float(), v[i:i + 4].float(), False, kernel="naive") for i in range(0, 16, 4)])
     o = torch.zeros(q.shape, dtype=torch.float32, device=dev())
     torch.cuda.synchronize()
-    ms_stream = fa.time_forward(q, k, v, False, warmup=1, iters=3, out=o)                  # fp16-P chain on the stream
-    assert fa.last_forward_route() == 1 and float((o - ref).abs().max()) < P16_TOL_BIG
-    for iters in (1, 3):
-        o.zero_()
-        torch.cuda.synchronize()
-        ms_graph = fa.time_forward(q, k, v, False, warmup=0, iters=iters, out=o, graph=True)   # captured: the split kernel
-        torch.cuda.synchronize()
-        assert 0.0 < ms_graph < 50.0 and 0.0 < ms_stream < 50.0
-        assert float((o - ref).abs().max()) < TOL_F32
-    with pytest.raises(Exception):
-        fa.time_forward(q, k, v, False, warmup=0, iters=1, out=o, graph=True, kernel="p16")
-
-
-def test_small_grids_under_stream_capture_take_the_plain_launch():
-    """A grid that would be launched key-split (scratch) is launched plainly while the stream is capturing -- one-launch and
-    four-launch graphs, output zeroed first, bf16 and fp32 outputs."""
-    q, k, v = (torch.randn(2, 8192, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
-    ref = fa.forward(q.float(), k.float(), v.float(), False, kernel="naive")
-    for odt, tol in ((torch.bfloat16, bf16_tol(1.0, False)), (torch.float32, TOL_F32)):
+    ms_stream = fa.time_forward(q, k, v, False, warmup=1, iters=3, out=o)                  # two-term fp16-P chain on the stream
+    assert fa.last_forward_route() == 1 and float((o - ref).abs().max()) < TOL_ACC
+    for kern, tol in (("auto", TOL_ACC), ("p16x2", TOL_ACC), ("p16", P16_TOL_BIG)):
         for iters in (1, 4):
-            o = torch.zeros(q.shape, dtype=odt, device=dev())
+            o.zero_()
             torch.cuda.synchronize()
-            ms = fa.time_forward(q, k, v, False, warmup=0, iters=iters, out=o, graph=True)
+            ms_graph = fa.time_forward(q, k, v, False, warmup=0, iters=iters, out=o, graph=True, kernel=kern)
             torch.cuda.synchronize()
-            assert 0.0 < ms < 50.0 and float((o.float() - ref).abs().max()) < tol, (odt, iters)
+            assert fa.last_forward_route() == 1, (kern, iters)
+            assert 0.0 < ms_graph < 50.0 and 0.0 < ms_stream < 50.0
+            err = float((o - ref).abs().max())
+            assert err < tol, (kern, iters, err)
+    # BH = 1: the key-split launch (8 key shares + combine), bf16-P and inside the fp16-P chain
+    q1, k1, v1 = q[:1], k[:1], v[:1]
+    for odt, kern, tol in ((torch.bfloat16, "auto", bf16_tol(1.0, False)), (torch.float32, "auto", TOL_ACC), (torch.float32, "mfma", bf16_tol(1.0, True))):
+        for iters in (1, 4):
+            o1 = torch.zeros(q1.shape, dtype=odt, device=dev())
+            torch.cuda.synchronize()
+            assert 0.0 < fa.time_forward(q1, k1, v1, False, warmup=0, iters=iters, out=o1, graph=True, kernel=kern) < 50.0
+            torch.cuda.synchronize()
+            assert float((o1.float() - ref[:1]).abs().max()) < tol, (odt, kern, iters)
 
+
+def test_workspace_sizes_and_validation_of_the_non_allocating_entry():
+    """fa_workspace_bytes is what fa_forward_ws uses: a buffer one byte short, a misaligned one and one overlapping a tensor are refused;
+    shapes that need no scratch take workspace = NULL."""
+    L = _cabi.lib()
+    q, k, v = (torch.randn(16, 4096, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
+    o = torch.empty(q.shape, dtype=torch.float32, device=dev())
+    need = fa.workspace_bytes(16, 4096, 64, dtype=torch.bfloat16, out_dtype=torch.float32)
+    assert need == 256 + 16 * 4096 * 64 * 2
+    assert fa.workspace_bytes(16, 4096, 64, dtype=torch.bfloat16) == 0 and fa.workspace_bytes(16, 4096, 64) == 0
+    assert fa.workspace_bytes(1, 8192, 64, dtype=torch.bfloat16) == 256 + 8 * 8192 * 64 * 4 + 8 * 8192 * 4      # key-split partials + LSEs
+    ws = torch.empty(need + 256, dtype=torch.uint8, device=dev())
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    args = (q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), None, 16, 4096, 64, 1.0, 0, _cabi.FA_DTYPE_BF16_OUT_F32, _cabi.FA_KERNEL_AUTO)
+    assert L.fa_forward_ws(*args, ws.data_ptr(), need, s) == 0
+    assert L.fa_forward_ws(*args, ws.data_ptr(), need - 1, s) == 1 and b"too small" in L.fa_last_error()
+    assert L.fa_forward_ws(*args, None, 0, s) == 1
+    assert L.fa_forward_ws(*args, ws.data_ptr() + 16, need, s) == 1 and b"aligned" in L.fa_last_error()
+    assert L.fa_forward_ws(*args, q.data_ptr(), need, s) == 1 and b"overlaps" in L.fa_last_error()
+    # bf16 output at this size needs none: NULL is fine
+    ob = torch.empty_like(q)
+    assert L.fa_forward_ws(q.data_ptr(), k.data_ptr(), v.data_ptr(), ob.data_ptr(), None, 16, 4096, 64, 1.0, 0, _cabi.FA_DTYPE_BF16, _cabi.FA_KERNEL_AUTO, None, 0, s) == 0
+    torch.cuda.synchronize()
+    ref = fa.forward(q.float(), k.float(), v.float(), False, kernel="naive")
+    assert float((o - ref).abs().max()) < TOL_ACC and float((ob.float() - ref).abs().max()) < bf16_tol(1.0, False)
+    # the python wrapper with a caller-owned workspace tensor
+    o2 = fa.forward(q, k, v, False, out_dtype=torch.float32, workspace=ws)
+    assert torch.equal(o2, o)
+    with pytest.raises(ValueError):
+        fa.forward(q, k, v, False, out_dtype=torch.float32, workspace=ws[:1000])
+
+
+def test_torch_graph_capture_of_the_accurate_path_and_independent_replays():
+    """torch.cuda.graph around fa.forward (workspace = a torch tensor of the graph's pool): the captured two-term fp16-P chain clears its
+    verdict word at the start of every replay.  Replay 1 sees a V with entries fp16 cannot hold (fallback: route 2), replay 2 the same
+    buffer with ordinary values (primary: route 1 -- a verdict left standing would keep the slower kernel forever)."""
+    q, k, v = (torch.randn(16, 4096, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
+    vbig = v.clone()
+    vbig[3, 100, 5] = 1.0e5
+    vbuf = vbig.clone()
+    out = torch.zeros(q.shape, dtype=torch.float32, device=dev())
+    fa.forward(q, k, vbuf, False, out=out)          # warm-up outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fa.forward(q, k, vbuf, False, out=out)
+    out.zero_()
+    g.replay()
+    assert fa.last_forward_route() == 2
+    refb = fa.forward(q.float(), k.float(), vbig.float(), False, kernel="naive")
+    assert float((out - refb).abs().max() / refb.abs().max()) < 1e-4
+    vbuf.copy_(v)
+    out.zero_()
+    g.replay()
+    assert fa.last_forward_route() == 1
+    ref = fa.forward(q.float(), k.float(), v.float(), False, kernel="naive")
+    assert float((out - ref).abs().max()) < TOL_ACC
+
+
+def test_convenience_entry_points_take_no_scratch_under_stream_capture():
+    """fa_forward / fa_forward_ex allocate from a private stream-ordered pool -- never while the stream is capturing (graph allocations
+    proved unreliable on ROCm 7.2): FA_KERNEL_AUTO then takes kernels without scratch (hi + lo bf16 P: as accurate, slower; the plain
+    launch instead of key-split), explicit FA_KERNEL_P16 / P16X2 are refused and point at fa_forward_ws."""
+    L = _cabi.lib()
+    q, k, v = (torch.randn(16, 4096, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
+    q1, k1, v1 = (torch.randn(2, 8192, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
+    o = torch.zeros(q.shape, dtype=torch.float32, device=dev())
+    o1 = torch.zeros(q1.shape, dtype=torch.bfloat16, device=dev())
+    rcs = []
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rcs.append(L.fa_forward_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), None, 16, 4096, 64, 1.0, 0, _cabi.FA_DTYPE_BF16_OUT_F32, _cabi.FA_KERNEL_AUTO, s))
+        rcs.append(L.fa_forward_ex(q1.data_ptr(), k1.data_ptr(), v1.data_ptr(), o1.data_ptr(), None, 2, 8192, 64, 1.0, 0, _cabi.FA_DTYPE_BF16, _cabi.FA_KERNEL_AUTO, s))
+        rcs.append(L.fa_forward_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), None, 16, 4096, 64, 1.0, 0, _cabi.FA_DTYPE_BF16_OUT_F32, _cabi.FA_KERNEL_P16X2, s))
+        msg = L.fa_last_error()
+    assert rcs == [0, 0, 2] and b"fa_forward_ws" in msg
+    for _ in range(2):
+        o.zero_(), o1.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert float((o - fa.forward(q.float(), k.float(), v.float(), False, kernel="naive")).abs().max()) < TOL_ACC
+        assert float((o1.float() - fa.forward(q1.float(), k1.float(), v1.float(), False, kernel="naive")).abs().max()) < bf16_tol(1.0, False)
+
+
+def test_a_replayed_graph_keeps_its_verdict_while_thousands_of_chains_run_on_another_stream():
+    """Round 2 kept verdict words in a 4096-slot ring indexed by serial % 4096: a replayed graph (its serial is fixed at capture) could
+    have a raised word overwritten by an eager chain 4096 calls later, between its primary and its fallback kernel.  Now a captured
+    chain owns a slot nobody else is given and eager chains take the slot of their (device, stream).  A captured fp32 chain whose
+    guard FIRES (wide logits: the exact kernel must produce the output) is replayed while another stream enqueues 4300 quiet chains."""
+    q, k, v = (torch.randn(8, 1024, 64, device=dev()) for _ in range(3))
+    kw = k.clone()
+    kw[3, 77] *= 40.0
+    exact = fa.forward(q, kw, v, False, kernel="exact")
+    split = fa.forward(q, kw, v, False, kernel="split")
+    assert float((split - exact).abs().max()) > 2e-4          # the two arithmetic paths are distinguishable on this input
+    out = torch.zeros_like(q)
+    fa.forward(q, kw, v, False, out=out)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fa.forward(q, kw, v, False, out=out)
+    qq, kq, vq = (torch.randn(2, 256, 64, device=dev()) for _ in range(3))
+    side = torch.cuda.Stream()
+    worst = 0.0
+    for rnd in range(43):
+        with torch.cuda.stream(side):
+            for _ in range(100):
+                fa.forward(qq, kq, vq, False)                    # quiet chains: 4300 serials, one slot (their stream's)
+        out.zero_()
+        g.replay()
+        torch.cuda.current_stream().synchronize()
+        worst = max(worst, float((out - exact).abs().max()))
+    torch.cuda.synchronize()
+    assert worst < 1e-4, f"a replay kept the split kernel's output: {worst:.3e}"
 
 
 def test_scratch_paths_on_concurrent_streams():
-    """Two streams, each issuing key-split launches and fp16-P chains back to back (stream-ordered scratch: hipMallocAsync /
-    hipFreeAsync per call): neither may see the other's partial outputs or V copy."""
+    """Two streams, each issuing key-split launches and fp16-P chains back to back (every call with its own workspace tensor from
+    torch's caching allocator): neither may see the other's partial outputs, V copy or verdict word."""
     qa, ka, va = (torch.randn(2, 8192, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
     qb, kb, vb = (torch.randn(16, 4096, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
     refa = fa.forward(qa.float(), ka.float(), va.float(), False, kernel="naive")
@@ -795,8 +926,8 @@ def test_scratch_paths_on_concurrent_streams():
     for o1, o2, o3, o4 in outs:
         assert float((o1.float() - refa).abs().max()) < bf16_tol(1.0, False)
         assert float((o4.float() - refa).abs().max()) < bf16_tol(1.0, False)
-        assert float((o3 - refa).abs().max()) < P16_TOL_BIG
-        assert float((o2 - refb).abs().max()) < P16_TOL_BIG
+        assert float((o3 - refa).abs().max()) < TOL_ACC
+        assert float((o2 - refb).abs().max()) < TOL_ACC
 
 
 def test_guarded_fp32_chain_survives_graph_capture_and_other_streams():
@@ -833,14 +964,34 @@ def test_guarded_fp32_chain_survives_graph_capture_and_other_streams():
 
 
 def test_auto_picks_fp16_p_or_hi_lo_terms_by_launch_size():
-    """FA_KERNEL_AUTO for bf16 tensors with an fp32 output: P in fp16 from 6e9 multiply-adds per contraction on (a launch chain:
-    route 1), hi + lo bf16 terms below (a single launch: route 0) -- both inside the fp32 bar."""
+    """FA_KERNEL_AUTO for bf16 tensors with an fp32 output: P as two fp16 terms from 6e9 multiply-adds per contraction on (a launch
+    chain: route 1), hi + lo bf16 terms below (a single launch: route 0) -- both inside the fp32 bar with margin."""
     for bh, n, want in ((16, 1024, 0), (32, 2048, 1)):
         q, k, v = (torch.randn(bh, n, 64, generator=torch.Generator().manual_seed(5)).bfloat16().to(dev()) for _ in range(3))
         o = fa.forward(q, k, v, False, out_dtype=torch.float32)
         assert fa.last_forward_route() == want, (bh, n)
         ref = fa.forward(q.float(), k.float(), v.float(), False, kernel="naive")
-        assert float((o - ref).abs().max()) < TOL_F32
+        assert float((o - ref).abs().max()) < TOL_ACC
+
+
+@pytest.mark.parametrize("name,bh,n,d", [("c4", 16, 8192, 64), ("c5-shard", 128, 8192, 64), ("d128", 16, 8192, 128), ("d32", 16, 8192, 32)])
+def test_accurate_mode_holds_the_fp32_bar_on_several_seeds(name, bh, n, d):
+    """BASELINE configs 4 and 5 (per-GPU shard) and the d = 128 / d = 32 shapes through FA_KERNEL_AUTO with an fp32 output, three seeds
+    each, unscaled logits (the reference's scale), every slab against the rung-0 kernel and one slab against the fp64 oracle: the
+    north star's 1e-3 without a loosened tolerance (round 2's one-term fp16 P sat AT 1e-3: 8.4e-4 .. 1.17e-3 on these shapes)."""
+    worst = 0.0
+    for seed in (0, 1, 2):
+        g = torch.Generator(device=dev()).manual_seed(seed)
+        q, k, v = (torch.randn(bh, n, d, generator=g, device=dev()).to(torch.bfloat16) for _ in range(3))
+        o = fa.forward(q, k, v, False, out_dtype=torch.float32)
+        assert fa.last_forward_route() == 1
+        for s0 in range(0, bh, 16):
+            sl = slice(s0, s0 + 16)
+            worst = max(worst, float((o[sl] - fa.forward(q[sl].float(), k[sl].float(), v[sl].float(), False, kernel="naive")).abs().max()))
+        host = lambda t: t[bh - 1:].float().cpu().numpy()
+        check(o[bh - 1:], orc.attention_f64(host(q), host(k), host(v)), TOL_ACC, f"{name} seed {seed} last slab vs fp64")
+    OBSERVED.append((f"accurate mode {name}, worst of 3 seeds, every slab vs rung 0", worst, TOL_ACC))
+    assert worst < TOL_ACC, f"{name}: {worst:.3e}"
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -930,7 +1081,8 @@ def test_ablation_tilings_are_not_in_the_product_library():
         fa.forward(*to_dev(*(orc.round_to_bf16(randn(s, 2, 512, 128)) for s in (84, 85, 86)), dtype=torch.bfloat16), False, kernel="mfma:53")
 
 
-def test_sharded_entry_point_noncontiguous_shards_and_every_visible_device():
+def test_sharded_entry_point_noncontiguous_shards_and_every_visible_device(monkeypatch):
+    monkeypatch.setenv("FA_ALLOW_SAME_DEVICE", "1")     # on a 1-GPU box both shards live on device 0
     q, k, v = (randn(s, 6, 200, 64) for s in (19, 20, 21))
     ref = orc.attention_f64(q, k, v, causal=True)
     ndev = torch.cuda.device_count()
@@ -948,6 +1100,27 @@ def test_sharded_entry_point_noncontiguous_shards_and_every_visible_device():
         torch.cuda.synchronize(i)
     assert all(o.is_contiguous() for o in outs)
     check(torch.cat([o.to(dev()) for o in outs]), ref, TOL_F32)
+
+
+def test_sharded_driver_mode_with_config_5_arithmetic():
+    """fa_driver --mode sharded: BASELINE config 5's split (1024 slabs over N shards, contiguous, the first bh % N one longer) on the
+    devices that are visible -- N = device count, and N = 3 shards sharing the device(s) round-robin (FA_ALLOW_SAME_DEVICE) so that the
+    per-shard host threads, streams and private pools run side by side even on a 1-GPU box.  Sizes reduced to keep the test short."""
+    import json
+    drv = os.path.join(ROOT, "flashattention.c_amd", "fa_driver")
+    ndev = torch.cuda.device_count()
+    for shards, env_extra in ((ndev, {}), (3, {"FA_ALLOW_SAME_DEVICE": "1"})):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([drv, "--mode", "sharded", "--devices", str(shards), "--bh", "100", "--n", "2048", "--d", "64", "--iters", "3"],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["shards"] == shards and len(line["per_shard_ms"]) == shards
+        assert abs(line["ms"] - max(line["per_shard_ms"])) < 1e-3 and line["tflops"] > 50.0
+    if ndev == 1:   # without the switch a table that names device 0 twice is refused
+        r = subprocess.run([drv, "--mode", "sharded", "--devices", "2", "--bh", "8", "--n", "512"], capture_output=True, text=True, timeout=600,
+                           env={k_: v_ for k_, v_ in os.environ.items() if k_ != "FA_ALLOW_SAME_DEVICE"})
+        assert r.returncode != 0 and "both name device" in r.stderr
 
 
 def test_compiled_pybind_module_is_a_drop_in_for_the_reference_extension():

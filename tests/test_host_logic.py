@@ -33,34 +33,63 @@ def test_library_exports_every_declared_symbol():
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 128, 0, 2, 300) == b"fa_fwd_bf16_w4_kernel"      # too few workgroups
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 128, 1, 2, 300) == b"fa_fwd_bf16_kernel"
     assert L.fa_kernel_name(_cabi.FA_DTYPE_F32, 48, 0) is None
-    # bf16 tensors with fp32 output: P in fp16 -- NB = 4 tiling where the bf16-P dispatch takes it too, NB = 2 elsewhere
-    assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0) == b"fa_fwd_bf16_x4_p16_kernel"
-    assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 1) == b"fa_fwd_bf16_x2_p16_kernel"
-    assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 128, 0) == b"fa_fwd_bf16_x2_p16_kernel"
-    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 32, 0, 16, 8192) == b"fa_fwd_bf16_x2_p16_kernel"
+    # bf16 tensors with fp32 output: P as two fp16 terms -- NB = 4 tiling where the bf16-P dispatch takes it too, NB = 2 elsewhere
+    assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0) == b"fa_fwd_bf16_x4_p16x2_kernel"
+    assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 1) == b"fa_fwd_bf16_x2_p16x2_kernel"
+    assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 128, 0) == b"fa_fwd_bf16_x2_p16x2_kernel"
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 32, 0, 16, 8192) == b"fa_fwd_bf16_x2_p16x2_kernel"
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 1, 8192) == b"fa_fwd_bf16_x2_p16x2_kernel"   # idle grid: key-split inside the chain
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, 0, 1, 8192) == b"fa_fwd_bf16_x2_kernel"                 # idle grid: key-split launch
     # ... and hi + lo bf16 terms for launches too small to amortise the fp16 path's V copy and extra launches
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 32, 0, 4, 300) == b"fa_fwd_f32_split_kernel"
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 16, 1024) == b"fa_fwd_f32_split_kernel"
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 1, 128, 1024) == b"fa_fwd_f32_split_kernel"
-    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 128, 2048) == b"fa_fwd_bf16_x2_p16_kernel"   # more than one round of 512-row tiles: NB = 2, two per CU
-    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 16, 8192) == b"fa_fwd_bf16_x4_p16_kernel"    # c4: one full round of NB = 4
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 128, 2048) == b"fa_fwd_bf16_x2_p16x2_kernel"   # more than one round of 512-row tiles: NB = 2, two per CU
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 16, 8192) == b"fa_fwd_bf16_x4_p16x2_kernel"    # c4: one full round of NB = 4
 
 
 def test_kernel_ids_match_the_header_and_the_python_names():
     hdr = open(os.path.join(ROOT, "include", "flashattn_amd.h")).read()
-    for name in ("FA_KERNEL_AUTO", "FA_KERNEL_NAIVE", "FA_KERNEL_MFMA", "FA_KERNEL_SPLIT", "FA_KERNEL_P16", "FA_DTYPE_F32", "FA_DTYPE_BF16",
+    for name in ("FA_KERNEL_AUTO", "FA_KERNEL_NAIVE", "FA_KERNEL_MFMA", "FA_KERNEL_SPLIT", "FA_KERNEL_P16", "FA_KERNEL_P16X2", "FA_DTYPE_F32", "FA_DTYPE_BF16",
                  "FA_DTYPE_BF16_OUT_F32"):
-        m = re.search(name + r"\s*=\s*(\d+)", hdr)
+        m = re.search(name + r"\s*=\s*(\d+)\b", hdr)
         assert m and int(m.group(1)) == getattr(_cabi, name), name
     from flashattention_c_amd import flash
     assert flash._kernel_id("split:4") == _cabi.FA_KERNEL_SPLIT | (4 << 8)
     assert flash._kernel_id("exact") == flash._kernel_id("mfma") == _cabi.FA_KERNEL_MFMA
     assert flash._kernel_id("auto") == _cabi.FA_KERNEL_AUTO
-    assert flash._kernel_id("p16") == _cabi.FA_KERNEL_P16
+    assert flash._kernel_id("p16") == _cabi.FA_KERNEL_P16 and flash._kernel_id("p16x2") == _cabi.FA_KERNEL_P16X2
     with pytest.raises(ValueError):
         flash._kernel_id("fast")
     L = _cabi.lib()
     assert L.fa_kernel_name(_cabi.FA_DTYPE_F32, 64, 0) == b"fa_fwd_f32_split_kernel"   # fp32 tensors: the bf16 matrix pipe
+
+
+def test_workspace_sizes_are_host_arithmetic():
+    """fa_workspace_bytes needs no device: the plan of a forward (which launch chain, how much scratch) is decided on the host from the
+    shape alone, and it is the same plan fa_forward_ws executes."""
+    L = _cabi.lib()
+    B16, B16F, F32 = _cabi.FA_DTYPE_BF16, _cabi.FA_DTYPE_BF16_OUT_F32, _cabi.FA_DTYPE_F32
+    A = _cabi.FA_KERNEL_AUTO
+    assert L.fa_workspace_bytes(16, 8192, 64, 0, F32, A) == 0                       # fp32 tensors: the guarded chain keeps its word in a device slot
+    assert L.fa_workspace_bytes(16, 8192, 64, 0, B16, A) == 0                       # c4, bf16 output: one launch
+    assert L.fa_workspace_bytes(16, 8192, 64, 0, B16F, A) == 256 + 16 * 8192 * 64 * 2   # c4, fp32 output: the fp16 copy of V behind the header
+    assert L.fa_workspace_bytes(16, 8192, 64, 1, B16F, A) == 256 + 16 * 8192 * 64 * 2
+    assert L.fa_workspace_bytes(16, 1024, 64, 0, B16F, A) == 0                      # small launch: hi + lo bf16 terms, no scratch
+    assert L.fa_workspace_bytes(128, 8192, 64, 0, B16F, A) == 256 + 128 * 8192 * 64 * 2   # c5's per-GPU shard
+    part = lambda S, bh, n, d: S * bh * n * d * 4 + S * bh * n * 4
+    assert L.fa_workspace_bytes(1, 8192, 64, 0, B16, A) == 256 + part(8, 1, 8192, 64)         # idle grid: key-split partials
+    assert L.fa_workspace_bytes(2, 8192, 64, 0, B16, A) == 256 + part(4, 2, 8192, 64)
+    assert L.fa_workspace_bytes(1, 8192, 64, 1, B16, A) == 0                                   # causal: no key-split (yet)
+    assert L.fa_workspace_bytes(1, 8192, 64, 0, B16F, A) == 256 + 8192 * 64 * 2 + part(8, 1, 8192, 64)   # both
+    assert L.fa_workspace_bytes(1, 8192, 64, 0, B16, _cabi.FA_KERNEL_SPLIT) == 0
+    assert L.fa_workspace_bytes(4, 300, 32, 0, B16F, _cabi.FA_KERNEL_P16) == 256 + ((4 * 300 * 32 * 2 + 255) // 256) * 256   # explicit: any size
+    assert L.fa_workspace_bytes(4, 300, 32, 0, B16F, _cabi.FA_KERNEL_P16X2) == 256 + ((4 * 300 * 32 * 2 + 255) // 256) * 256
+    # arguments fa_forward_ws would reject size to 0 and leave fa_last_error alone
+    assert L.fa_workspace_bytes(0, 8192, 64, 0, B16F, A) == 0 and L.fa_workspace_bytes(16, 8192, 48, 0, B16F, A) == 0
+    assert L.fa_workspace_bytes(16, 8192, 64, 0, 7, A) == 0 and L.fa_workspace_bytes(16, 8192, 64, 0, F32, _cabi.FA_KERNEL_P16) == 0
+    import torch
+    assert fa.workspace_bytes(16, 8192, 64, dtype=torch.bfloat16, out_dtype=torch.float32) == 256 + 16 * 8192 * 64 * 2
 
 
 def test_fp32_auto_choice_follows_the_environment_switch():
