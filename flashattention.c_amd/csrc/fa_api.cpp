@@ -127,6 +127,7 @@ struct FlagRef {
 };
 thread_local FlagRef t_last_flag;   // chain state of this thread's most recent forward (fa_last_forward_route)
 thread_local int t_last_chain = 0;  // 0 = no chain, 1 = fp32 guard, 2 = fp16-P
+thread_local int t_last_route = -1; // >= 0: the route of the last chain, read before its workspace went away (fa_time_forward*)
 
 int current_device()
 {
@@ -298,16 +299,18 @@ int keysplit_factor(const fa::FwdParams& p, int32_t d, int32_t causal)
 
 bool p16_available(const fa::FwdParams& p, int32_t d) { return dense_layout(p, d) && fa::bf16_p16_supported(p, d); }
 
-// FA_KERNEL_AUTO, bf16 tensors, fp32 output: fp16 P or hi + lo bf16 terms?  The fp16 chain has a fixed cost the split kernel does
-// not have -- the V copy (2 x sizeof(V) of HBM traffic) and two extra launches, ~15 us together -- and a faster kernel.  Measured
-// on MI355X (ms, fp16 P / split): BH x N x d = 128 x 2048 x 64: 0.187 / 0.244, 32 x 4096 x 64: 0.169 / 0.234, 128 x 1024 x 128: 0.118 /
-// 0.129, 128 x 1024 x 64: 0.074 / 0.077, the same causal: 0.075 / 0.064, 16 x 1024 x 64: 0.036 / 0.019, 128 x 1024 x 32: 0.046 / 0.056.
-// Rule: fp16 P from 6e9 multiply-adds per contraction on (a causal launch counts half), from 2e9 at d = 32 (where the split kernel is
-// slowest); the split kernel below that.
+// FA_KERNEL_AUTO, bf16 tensors, fp32 output: two fp16 terms of P (a chain) or hi + lo bf16 terms (one launch)?  The fp16 chain has a
+// fixed cost the split kernel does not have -- the V copy (2 x sizeof(V) of HBM traffic) and two extra launches, ~15 us together --
+// and a faster kernel.  Measured on MI355X (ms, p16x2 chain / split kernel), BH x N x d: 16 x 8192 x 64 0.368 / 0.446, 128 x 2048 x 64
+// 0.225 / 0.255, 32 x 4096 x 64 0.226 / 0.245, 64 x 2048 x 128 0.220 / 0.236, 64 x 2048 x 64 0.134 / 0.140, 16 x 4096 x 64 0.135 / 0.132,
+// 128 x 1024 x 64 0.082 / 0.085, 128 x 1024 x 128 0.138 / 0.140, 16 x 2048 x 64 0.066 / 0.044, 128 x 1024 x 32 0.060 / 0.060, 32 x 2048 x 32
+// 0.057 / 0.057; causal 32 x 4096 x 64 0.147 / 0.160, 64 x 2048 x 64 0.094 / 0.096, 128 x 1024 x 64 0.065 / 0.066.
+// Rule: the chain from 1.2e10 multiply-adds per contraction on (a causal launch counts half), from 4e9 at d = 32 (where the split
+// kernel is slowest); the split kernel below that.  Either choice is accurate to ~1e-4 or better.
 bool p16_worthwhile(const fa::FwdParams& p, int32_t d, int32_t causal)
 {
     const double macs = (double)p.bh * (double)p.n * (double)p.n * (double)d * (causal ? 0.5 : 1.0);
-    return macs >= (d == 32 ? 2e9 : 6e9);
+    return macs >= (d == 32 ? 4e9 : 1.2e10);
 }
 
 // ---- the plan of one forward: which launches, how much scratch ---------------------------------------------------------------------
@@ -508,6 +511,7 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
 {
     const KernelSel sel = decode_kernel(kernel);
     t_last_chain = 0;
+    t_last_route = -1;
     const bool capturing = stream_is_capturing(stream);
     Plan pl = make_plan(p, d, causal, dtype, kernel, ws_mode ? true : !capturing);
     if (pl.status != FA_OK) return pl.status;
@@ -825,6 +829,11 @@ static int time_forward_impl(const void* q, const void* k, const void* v, void* 
     (void)hipEventDestroy(e1);
     if (ws) {
         (void)hipStreamSynchronize(s);
+        // the chain's verdict word lives in the workspace: read it for fa_last_forward_route before the buffer goes away
+        if (rc == FA_OK && t_last_chain != 0 && t_last_flag.word != nullptr) {
+            uint32_t word = 0;
+            if (hipMemcpy(&word, t_last_flag.word, sizeof(word), hipMemcpyDeviceToHost) == hipSuccess) t_last_route = word == t_last_flag.serial ? 2 : 1;
+        }
         (void)hipFree(ws);
     }
     return rc;
@@ -850,6 +859,10 @@ int fa_last_forward_route(void* stream, int32_t* route)
     if (!route) return fail(FA_ERR_INVALID_ARGUMENT, "null route pointer");
     *route = 0;
     if (t_last_chain == 0) return FA_OK;
+    if (t_last_route >= 0) {
+        *route = t_last_route;
+        return FA_OK;
+    }
     uint32_t word = 0;
     hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
     if (e == hipSuccess) e = hipMemcpy(&word, t_last_flag.word, sizeof(word), hipMemcpyDeviceToHost);

@@ -18,6 +18,7 @@ are accepted (bf16 MFMA path).
 from __future__ import annotations
 
 import ctypes
+import threading
 from types import SimpleNamespace
 from typing import Optional, Tuple, Union
 
@@ -28,6 +29,7 @@ from . import _cabi
 __all__ = ["forward", "forward_packed_qkv", "load", "time_forward", "last_forward_route", "workspace_bytes", "SUPPORTED_HEAD_DIMS"]
 
 SUPPORTED_HEAD_DIMS = (32, 64, 128)
+_tls = threading.local()
 _DTYPES = {torch.float32: _cabi.FA_DTYPE_F32, torch.bfloat16: _cabi.FA_DTYPE_BF16}
 _KERNELS = {"auto": _cabi.FA_KERNEL_AUTO, "naive": _cabi.FA_KERNEL_NAIVE, "mfma": _cabi.FA_KERNEL_MFMA,
             "exact": _cabi.FA_KERNEL_MFMA, "split": _cabi.FA_KERNEL_SPLIT, "p16": _cabi.FA_KERNEL_P16, "p16x2": _cabi.FA_KERNEL_P16X2}
@@ -120,6 +122,9 @@ def forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = Fa
                              workspace.data_ptr() if workspace is not None else None,
                              workspace.numel() if workspace is not None else 0, ctypes.c_void_p(stream))
     _cabi.check(rc)
+    # the launch chain's verdict word lives in the workspace: keep the buffer referenced until this thread's next forward, so that
+    # last_forward_route() reads the word and not whatever the caching allocator put there since
+    _tls.last_workspace = workspace
     return (out, lse) if return_lse else out
 
 

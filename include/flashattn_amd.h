@@ -73,7 +73,7 @@ typedef enum fa_dtype {
     FA_DTYPE_BF16_OUT_F32 = 2 /* bf16 in, O written as fp32 (the accumulator precision).  Under FA_KERNEL_AUTO this also selects
                                  the ACCURATE P: a caller who wants the fp32 accumulator gets P as two fp16 terms, hi + lo
                                  (FA_KERNEL_P16X2: ~22 significant bits, <= 1e-4 of the fp32 reference at scale 1 on unit-variance
-                                 data where bf16 P shows ~5e-3) -- or, for launches below 6e9 multiply-adds per contraction (2e9 at
+                                 data where bf16 P shows ~5e-3) -- or, for launches below 1.2e10 multiply-adds per contraction (4e9 at
                                  head dim 32; the fp16 path costs a copy of V and two extra launches, ~15 us), for slabs beyond
                                  4 GiB and whenever scratch is not available, P and the scaled Q as hi + lo bf16 terms
                                  (FA_KERNEL_SPLIT, ~1e-4).  A bf16 output rounds at 2^-9 |O| by itself and keeps the fastest

@@ -10,7 +10,7 @@ Tolerances (max-abs, stated once here; BASELINE.md section 4 gives the arithmeti
   bf16 kernel, bf16 out                         2.5e-2 adds half a bf16 ulp of |O| (|O| < 4 -> 7.8e-3); observed <= 1.5e-2
   bf16 tensors, fp32 out, ACCURATE P            1e-3  north_star bar at scale 1, held with a wide margin: FA_KERNEL_AUTO with an fp32 output = P as fp16
                                                       hi + fp16 lo (kernel="p16x2": ~22 significant bits; observed <= 3e-5) or, for small launches, hi +
-                                                      lo bf16 terms (kernel="split": ~1e-4).  TOL_ACC = 2e-4 is asserted where only these can be running.
+                                                      lo bf16 terms (kernel="split": 1 .. 2e-4).  TOL_ACC = 5e-4 is asserted where either can be running, TOL_P16X2 = 1e-4 for the first.
   bf16 tensors, kernel="p16" (ONE fp16 term)    1e-3 / 1.5e-3  explicit choice only, never AUTO.  11 significant bits; the worst rows have two comparable
                                                       dominant keys with distant V rows: |err| <= 0.25 * 2^-10 * |v1 - v2|, and the maximum over the
                                                       launch grows with the number of outputs: observed 6.7e-4 .. 8.4e-4 on one N = 8192 slab, 8.4e-4 /
@@ -35,7 +35,9 @@ from tests.conftest import GOLDEN_DIR, golden_cases
 pytestmark = pytest.mark.gpu
 
 TOL_F32 = 1e-3
-TOL_ACC = 2e-4         # the accurate P of FA_KERNEL_AUTO for bf16 tensors with an fp32 output (two fp16 terms / hi + lo bf16 terms)
+TOL_ACC = 5e-4         # the accurate P of FA_KERNEL_AUTO for bf16 tensors with an fp32 output, whichever kernel the launch size picks: two
+                       # fp16 terms (observed <= 6e-5) or hi + lo bf16 terms of P and Q' (the split kernel: observed <= 2.1e-4 at d = 128)
+TOL_P16X2 = 1e-4       # kernel="p16x2" (and FA_KERNEL_AUTO at sizes that take it): two fp16 terms of P
 P16_TOL_BIG = 1.5e-3   # kernel="p16" ONLY (one fp16 term): unscaled logits, more than 16 slabs of N = 8192 (see the header)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -424,7 +426,7 @@ def test_causal_paired_tile_order_covers_every_tile_once(bh, n):
     by the boundary between two XCDs -- or some rows are computed twice and others never (the output is poisoned with NaN first)."""
     g = torch.Generator(device="cpu").manual_seed(n + bh)
     for d, kernel, out_dtype, tol in ((32, "auto", torch.bfloat16, 2.5e-2), (64, "p16", torch.float32, P16_TOL_BIG), (32, "p16", torch.float32, P16_TOL_BIG),
-                                      (64, "p16x2", torch.float32, TOL_ACC), (32, "p16x2", torch.float32, TOL_ACC)):
+                                      (64, "p16x2", torch.float32, TOL_P16X2), (32, "p16x2", torch.float32, TOL_P16X2)):
         q, k, v = (torch.randn(bh, n, d, generator=g).to(torch.bfloat16).to(dev()) for _ in range(3))
         ref = fa.forward(q.float(), k.float(), v.float(), True, kernel="naive")
         out = torch.full((bh, n, d), float("nan"), dtype=out_dtype, device=dev())
@@ -612,9 +614,9 @@ FULL = [
     ("c2", 128, 1024, 64, torch.float32, "auto", TOL_F32),
     ("c3", 16, 8192, 64, torch.float32, "auto", TOL_F32),
     ("c4", 16, 8192, 64, torch.bfloat16, "mfma", 1.2e-2),              # the bf16-P kernels (FA_KERNEL_AUTO for a bf16 output)
-    ("c4-accurate", 16, 8192, 64, torch.bfloat16, "auto", TOL_ACC),    # fp32 output -> two fp16 terms of P: the north star's 1e-3 at scale 1, with margin
+    ("c4-accurate", 16, 8192, 64, torch.bfloat16, "auto", TOL_P16X2),    # fp32 output -> two fp16 terms of P: the north star's 1e-3 at scale 1, with margin
     ("c5-shard", 128, 8192, 64, torch.bfloat16, "mfma", 1.2e-2),       # one GPU's share of B=64 H=16 split over 8 (src/flashattention.cu:144)
-    ("c5-shard-accurate", 128, 8192, 64, torch.bfloat16, "auto", TOL_ACC),
+    ("c5-shard-accurate", 128, 8192, 64, torch.bfloat16, "auto", TOL_P16X2),
     ("c5-full", 1024, 8192, 64, torch.bfloat16, "mfma", 1.2e-2),       # all 1024 slabs on one GPU (4 x 1 GiB tensors)
 ]
 
@@ -698,7 +700,7 @@ def test_p16_kernel_vs_oracle(bh, n, d, causal):
         # two fp16 terms of P: the same shapes at the accurate path's tolerance
         o, lse = fa.forward(qd, kd, vd, causal, scale=scale, kernel="p16x2", out_dtype=torch.float32, return_lse=True)
         assert fa.last_forward_route() == 1
-        check(o, ref, TOL_ACC, f"p16x2 scale {scale}")
+        check(o, ref, TOL_P16X2, f"p16x2 scale {scale}")
         check(lse, lse_ref, 1e-4, f"p16x2 lse scale {scale}")
         ob = fa.forward(qd, kd, vd, causal, scale=scale, kernel="p16x2")
         check(ob, ref, bf16_tol(scale, False), f"p16x2 bf16 out scale {scale}")
@@ -724,7 +726,7 @@ def test_p16_reference_moves_inside_the_pipelined_loop(causal, d, bh):
     check(o, ref, TOL_F32, "p16")
     check(lse, lse_ref, 2e-3, "p16 lse")
     o, lse = fa.forward(*to_dev(qb, kb, vb, dtype=torch.bfloat16), causal, kernel="p16x2", out_dtype=torch.float32, return_lse=True)
-    check(o, ref, TOL_ACC, "p16x2")
+    check(o, ref, TOL_P16X2, "p16x2")
     check(lse, lse_ref, 1e-4, "p16x2 lse")
 
 
@@ -827,22 +829,25 @@ def test_torch_graph_capture_of_the_accurate_path_and_independent_replays():
     vbig[3, 100, 5] = 1.0e5
     vbuf = vbig.clone()
     out = torch.zeros(q.shape, dtype=torch.float32, device=dev())
+    refb = fa.forward(q.float(), k.float(), vbig.float(), False, kernel="naive")
+    ref = fa.forward(q.float(), k.float(), v.float(), False, kernel="naive")
     fa.forward(q, k, vbuf, False, out=out)          # warm-up outside the capture
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        fa.forward(q, k, vbuf, False, out=out)
+        fa.forward(q, k, vbuf, False, out=out)      # this thread's last forward from here on: last_forward_route() reads ITS verdict word
     out.zero_()
     g.replay()
     assert fa.last_forward_route() == 2
-    refb = fa.forward(q.float(), k.float(), vbig.float(), False, kernel="naive")
     assert float((out - refb).abs().max() / refb.abs().max()) < 1e-4
     vbuf.copy_(v)
     out.zero_()
     g.replay()
     assert fa.last_forward_route() == 1
-    ref = fa.forward(q.float(), k.float(), v.float(), False, kernel="naive")
     assert float((out - ref).abs().max()) < TOL_ACC
+    vbuf.copy_(vbig)
+    g.replay()
+    assert fa.last_forward_route() == 2
 
 
 def test_convenience_entry_points_take_no_scratch_under_stream_capture():
@@ -964,9 +969,9 @@ def test_guarded_fp32_chain_survives_graph_capture_and_other_streams():
 
 
 def test_auto_picks_fp16_p_or_hi_lo_terms_by_launch_size():
-    """FA_KERNEL_AUTO for bf16 tensors with an fp32 output: P as two fp16 terms from 6e9 multiply-adds per contraction on (a launch
+    """FA_KERNEL_AUTO for bf16 tensors with an fp32 output: P as two fp16 terms from 1.2e10 multiply-adds per contraction on (a launch
     chain: route 1), hi + lo bf16 terms below (a single launch: route 0) -- both inside the fp32 bar with margin."""
-    for bh, n, want in ((16, 1024, 0), (32, 2048, 1)):
+    for bh, n, want in ((16, 1024, 0), (32, 2048, 0), (64, 2048, 1)):
         q, k, v = (torch.randn(bh, n, 64, generator=torch.Generator().manual_seed(5)).bfloat16().to(dev()) for _ in range(3))
         o = fa.forward(q, k, v, False, out_dtype=torch.float32)
         assert fa.last_forward_route() == want, (bh, n)
@@ -989,9 +994,9 @@ def test_accurate_mode_holds_the_fp32_bar_on_several_seeds(name, bh, n, d):
             sl = slice(s0, s0 + 16)
             worst = max(worst, float((o[sl] - fa.forward(q[sl].float(), k[sl].float(), v[sl].float(), False, kernel="naive")).abs().max()))
         host = lambda t: t[bh - 1:].float().cpu().numpy()
-        check(o[bh - 1:], orc.attention_f64(host(q), host(k), host(v)), TOL_ACC, f"{name} seed {seed} last slab vs fp64")
-    OBSERVED.append((f"accurate mode {name}, worst of 3 seeds, every slab vs rung 0", worst, TOL_ACC))
-    assert worst < TOL_ACC, f"{name}: {worst:.3e}"
+        check(o[bh - 1:], orc.attention_f64(host(q), host(k), host(v)), TOL_P16X2, f"{name} seed {seed} last slab vs fp64")
+    OBSERVED.append((f"accurate mode {name}, worst of 3 seeds, every slab vs rung 0", worst, TOL_P16X2))
+    assert worst < TOL_P16X2, f"{name}: {worst:.3e}"
 
 
 # ---------------------------------------------------------------------------------------------------------------
