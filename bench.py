@@ -116,9 +116,17 @@ def timed_region(step_fn, steps: int, warmup: int, sync_fn, world: int, dist=Non
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device if device is not None else "cpu")
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)                       # each rank's own time: a straggler GPU is visible in extra.per_rank_ms
+        PER_RANK_S[:] = [float(x.item()) for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    else:
+        PER_RANK_S[:] = [dt]
     return dt
+
+
+PER_RANK_S = []   # seconds of the last timed_region on every rank (filled on all ranks)
 
 
 def make_inputs(bh: int, n: int, d: int, dtype: str, device, seed: int):
@@ -181,6 +189,30 @@ def cpu_sdpa_baseline(total_heads: int, n: int, d: int, causal: bool, scale: flo
             "host_cpus": os.cpu_count(), "ms_per_full_workload_est": round(med / heads * total_heads * 1e3, 1)}
 
 
+def lib_sha256() -> str:
+    """sha256 of the library this process loads: ties a committed PMC traffic figure to the binary it was measured on."""
+    import hashlib
+    from flashattention_c_amd import _cabi
+    h = hashlib.sha256()
+    with open(_cabi.LIB_PATH, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def time_stats(fa, tensors, reps: int = 5, **kw):
+    """`reps` repetitions of fa.time_forward's iters loop (HIP events on the launch stream inside the C ABI): min / median / p90 of
+    the per-repetition means, so that a slow outlier repetition is visible instead of averaged in (the reference's
+    benchmark_kernel, src/llm.c/common.h:108-124, reports one mean)."""
+    warm = kw.pop("warmup", 3)
+    ms = []
+    for r in range(reps):
+        ms.append(fa.time_forward(*tensors, warmup=warm if r == 0 else 1, **kw))
+    ms.sort()
+    p90 = ms[min(len(ms) - 1, int(round(0.9 * (len(ms) - 1))))]
+    return {"min": round(ms[0], 4), "median": round(ms[len(ms) // 2], 4), "p90": round(p90, 4), "reps": reps, "iters_per_rep": kw.get("iters", 20)}
+
+
 def load_pmc_traffic():
     """HBM bytes per launch from the committed PMC profile of this same command (profiles/), if present."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -216,7 +248,7 @@ def main():
                     help="untimed device warm-up before the W warm-up steps: an idle MI355X needs ~100 ms of load before its "
                          "clocks settle (the first ~100 launches of a 0.3 ms kernel run ~10 %% slow)")
     ap.add_argument("--accurate", action="store_true",
-                    help="bf16 workloads: ask for the fp32 accumulator as output -- FA_KERNEL_AUTO then carries P in fp16 (the accurate path); "
+                    help="bf16 workloads: ask for the fp32 accumulator as output -- FA_KERNEL_AUTO then carries P as two fp16 terms (the accurate path); "
                          "used by profiles/collect.sh to profile that kernel chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
@@ -271,10 +303,11 @@ def main():
     prewarm(step)
     dt = timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, world, dist, device)
     ms_per_step = dt / args.steps * 1e3
+    per_rank_ms = [round(x / args.steps * 1e3, 4) for x in PER_RANK_S]
     value = fwd_flop(global_bh, n, d, causal) * args.steps / dt / 1e12
     route = fa.last_forward_route()   # 0: single launch; 1 / 2: primary / fallback kernel of a conditional chain (fp32 guard)
 
-    extras = {}
+    extras = {"per_rank_ms": per_rank_ms} if world > 1 else {}
     # ---- BASELINE config 5 (B=64 H=16, 1024 slabs) sharded over the ranks, same timing protocol: at N = 1 the whole of it on one GPU
     if not args.no_extras and args.workload == "c4":
         B5, H5, d5, n5, dt5, _ = WORKLOADS["c5"]
@@ -287,7 +320,8 @@ def main():
         tf5 = fwd_flop(B5 * H5, n5, d5, causal) * k5_steps / dt5s / 1e12
         extras["c5"] = {"workload": f"B={B5} H={H5} d={d5} N={n5} {dt5}: 1024 slabs, contiguous split over {world} GPU(s), no collective",
                         "scaling": "strong", "n_gpus": world, "bh_per_gpu": s1 - s0, "steps": k5_steps,
-                        "ms_per_step": round(dt5s / k5_steps * 1e3, 4), "tflops": round(tf5, 2), "tflops_per_gpu": round(tf5 / world, 2),
+                        "ms_per_step": round(dt5s / k5_steps * 1e3, 4), "per_rank_ms": [round(x / k5_steps * 1e3, 4) for x in PER_RANK_S],
+                        "tflops": round(tf5, 2), "tflops_per_gpu": round(tf5 / world, 2),
                         "frac_bf16_mfma_peak_per_gpu": round(tf5 / world / PEAK_TFLOPS["bf16"], 4)}
         del q5, k5, v5, o5
         torch.cuda.empty_cache()
@@ -300,33 +334,48 @@ def main():
         kname = L.fa_kernel_name_for(dt_id, d, int(causal), bh, n).decode()
         if dtype == "f32" and route == 2:
             kname = "fa_fwd_f32_kernel"   # the logit-width guard sent this workload to the exact kernel
-        kms = fa.time_forward(q, k, v, causal, scale=args.scale, warmup=3, iters=max(10, min(args.steps, 50)), out=out)
+        kstats = time_stats(fa, (q, k, v), reps=5, causal=causal, scale=args.scale, warmup=3, iters=max(10, min(args.steps, 50)), out=out)
+        kms = kstats["median"]
         achieved = fwd_flop(bh, n, d, causal) / (kms * 1e-3) / 1e12
         elem = 2 if dtype == "bf16" else 4
         pmc = load_pmc_traffic() or {}
         peak, peak_note = kernel_peak(kname, dtype)
         # traffic: HBM bytes of one launch from the committed rocprofv3 PMC passes of this command -- a STATIC figure, quoted only
         # while the kernel it was measured on is still the kernel this run launches
-        traffic = pmc.get(f"{args.workload}_hbm_bytes_per_launch") if pmc.get(f"{args.workload}_kernel") == kname and not causal else None
+        # ... AND while the library loaded here is the very binary the passes ran on (sha256 recorded by profiles/collect.sh)
+        sha = lib_sha256()
+        traffic = (pmc.get(f"{args.workload}_hbm_bytes_per_launch")
+                   if pmc.get(f"{args.workload}_kernel") == kname and pmc.get("lib_sha256") == sha and not causal else None)
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_source": (f"profiles/pmc_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                                    f"{pmc.get('_tag', '?')}; 2*FETCH_SIZE + WRITE_SIZE)") if traffic is not None else None,
-                "kernel": kname, "kernel_ms": round(kms, 4), "peak_note": peak_note,
+                "kernel": kname, "kernel_ms": round(kms, 4), "kernel_ms_stats": kstats, "lib_sha256": sha[:16], "peak_note": peak_note,
                 "algorithmic_flop_per_launch": fwd_flop(bh, n, d, causal),
                 "algorithmic_hbm_bytes_per_launch": algorithmic_bytes(bh, n, d, elem),
                 "hbm_gbps_at_algorithmic_bytes": round(algorithmic_bytes(bh, n, d, elem) / (kms * 1e-3) / 1e9, 1)}
+        # the two clocks of this line: K back-to-back forwards from Python (ms_per_step) and the C ABI's event-timed loop (kernel_ms)
+        ratio = kms / ms_per_step if ms_per_step > 0 else 0.0
+        roof["kernel_ms_over_ms_per_step"] = round(ratio, 4)
+        if abs(ratio - 1.0) > 0.03:
+            roof["timing_warning"] = (f"kernel_ms (median of {kstats['reps']} event-timed loops) and ms_per_step differ by {abs(ratio - 1.0) * 100:.1f} %: "
+                                      f"min / median / p90 of the loops = {kstats['min']} / {kstats['median']} / {kstats['p90']} ms; "
+                                      "expect ms_per_step above kernel_ms when a forward is a launch chain (host enqueue per launch) and "
+                                      "either one high right after an idle period (clock ramp)")
         if dtype == "f32":
             roof["arithmetic"] = {0: "single launch", 1: "split products on the bf16 pipe (guard quiet)",
                                   2: "exact fp32 (logit-width guard fired)"}[route]
         if not args.no_extras:
-            # the same launches captured into one hipGraph and replayed (no stream-launch gap between kernels); reported
-            # beside the stream-launch figures above, never instead of them
+            # the same launches captured into one hipGraph and replayed (median of three timed replays); reported beside the
+            # stream-launch figures above, never instead of them.  per_launch_delta_us = what a graph node costs more (+) or less (-)
+            # than the same launch enqueued on a stream
             try:
-                gms = fa.time_forward(q, k, v, causal, scale=args.scale, warmup=3, iters=max(10, min(args.steps, 50)), out=out, graph=True)
+                gi = max(10, min(args.steps, 50))
+                gms = fa.time_forward(q, k, v, causal, scale=args.scale, warmup=3, iters=gi, out=out, graph=True)
                 gtf = fwd_flop(bh, n, d, causal) / (gms * 1e-3) / 1e12
                 extras["graph_replay"] = {"kernel_ms": round(gms, 4), "tflops": round(gtf, 2),
-                                          "frac_mfma_peak": round(gtf / peak, 4)}
+                                          "frac_mfma_peak": round(gtf / peak, 4), "nodes_per_replay": gi, "replays_timed": 3,
+                                          "per_launch_delta_us_vs_stream": round((gms - kms) * 1e3, 2)}
             except Exception as e:  # pragma: no cover - informational only
                 extras["graph_replay"] = {"error": repr(e)}
         if not args.no_extras and world == 1 and args.workload == "c4":
@@ -371,23 +420,31 @@ def c4_side_measurements(fa, _cabi, q, k, v, causal, args, device):
 
     def timed(what, fn_kwargs, flop_, tensors=(q, k, v), peak=PEAK_TFLOPS["bf16"], note=None, warm=30, iters=20):
         try:
-            ms = fa.time_forward(*tensors, warmup=warm, iters=iters, **fn_kwargs)
+            st = time_stats(fa, tensors, reps=5, warmup=warm, iters=max(2, iters // 2), **fn_kwargs)
+            ms = st["median"]
             tf = flop_ / (ms * 1e-3) / 1e12
-            ent = {"kernel_ms": round(ms, 4), "tflops": round(tf, 2), "frac_mfma_peak": round(tf / peak, 4)}
+            ent = {"kernel_ms": round(ms, 4), "ms_min_median_p90": [st["min"], st["median"], st["p90"]], "tflops": round(tf, 2),
+                   "frac_mfma_peak": round(tf / peak, 4)}
             if note:
                 ent["what"] = note
             ex[what] = ent
         except Exception as e:  # pragma: no cover - informational only
             ex[what] = {"error": repr(e)}
 
-    # the accurate bf16 path on the same tensors: what fa_forward picks for an fp32 output (fp16 P, FA_KERNEL_P16)
+    # the accurate bf16 path on the same tensors: what fa_forward picks for an fp32 output (two fp16 terms of P, FA_KERNEL_P16X2)
     o32 = torch.empty(q.shape, dtype=torch.float32, device=device)
     timed("c4_accurate_mode", dict(causal=causal, scale=args.scale, out=o32), flop,
-          note="bf16 Q, K; P and V in fp16 (v_mfma_f32_32x32x16_f16), fp32 out -- FA_KERNEL_AUTO for an fp32 output; includes the bf16->fp16 "
-               "copy of V; max-abs error < 1e-3 vs the fp32 reference at scale 1 (bf16-P kernels ~5e-3); 1x the algorithmic FLOP")
+          note="FA_KERNEL_AUTO for an fp32 output: bf16 Q, K; P as fp16 hi + fp16 lo and V in fp16 (v_mfma_f32_32x32x16_f16, twice the P.V "
+               "and row-sum MFMAs), fp32 out; the whole launch chain is timed (bf16->fp16 copy of V, kernel, skipped fallback launch); "
+               "max-abs error <= 1e-4 vs the fp32 reference at scale 1 (asserted in tests/ on three seeds; bf16-P kernels ~5e-3); "
+               "frac = algorithmic FLOP over the dense bf16/fp16 peak")
     if "kernel_ms" in ex.get("c4_accurate_mode", {}):
         ex["c4_accurate_mode"]["frac"] = ex["c4_accurate_mode"]["frac_mfma_peak"]
         ex["c4_accurate_mode"]["route"] = fa.last_forward_route()
+        ex["c4_accurate_mode"]["kernel"] = _cabi.lib().fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, d, int(causal), bh, n).decode()
+    timed("c4_p16_one_term", dict(causal=causal, scale=args.scale, out=o32, kernel="p16"), flop,
+          note="kernel=\"p16\" (explicit only): ONE fp16 term of P -- 8e-4 .. 1.2e-3 at scale 1, at the 1e-3 bar but not safely inside it "
+               "(round 2's AUTO choice)")
     timed("c4_accurate_mode_split", dict(causal=causal, scale=args.scale, out=o32, kernel="split"), flop, peak=PEAK_TFLOPS["bf16"] / 2.0,
           note="the round-1 accurate mode (hi + lo bf16 terms of P and Q'; two products per contraction), frac of bf16 peak / 2", iters=10)
     del o32
@@ -419,10 +476,11 @@ def c4_side_measurements(fa, _cabi, q, k, v, causal, args, device):
         fl2 = fwd_flop(B2 * H2, n2, d2, causal)
         ent = {"workload": f"B={B2} H={H2} d={d2} N={n2} {dt2}"}
         for label, kern in (("auto", "auto"), ("exact", "exact")):
-            ms2 = fa.time_forward(q2, k2, v2, causal, scale=args.scale, kernel=kern, warmup=30 if name == "c3" else 100,
-                                  iters=10 if name == "c3" else 50)
+            st2 = time_stats(fa, (q2, k2, v2), reps=5, causal=causal, scale=args.scale, kernel=kern, warmup=30 if name == "c3" else 100,
+                             iters=4 if name == "c3" else 20)
+            ms2 = st2["median"]
             tf2 = fl2 / (ms2 * 1e-3) / 1e12
-            ent[label] = {"ms": round(ms2, 4), "tflops": round(tf2, 2)}
+            ent[label] = {"ms": round(ms2, 4), "ms_min_median_p90": [st2["min"], st2["median"], st2["p90"]], "tflops": round(tf2, 2)}
             if label == "auto":
                 r = fa.last_forward_route()
                 ent[label].update(arithmetic="3 bf16 MFMA products of hi/lo splits, fp32 accumulate, logit-width guard + conditional exact launch "
@@ -432,6 +490,9 @@ def c4_side_measurements(fa, _cabi, q, k, v, causal, args, device):
                 ent[label].update(arithmetic="v_mfma_f32_32x32x2_f32 (FA_KERNEL_MFMA)",
                                   frac_f32_mfma_peak=round(tf2 / PEAK_TFLOPS["f32"], 4))
         ent["ms"], ent["tflops"] = ent["auto"]["ms"], ent["auto"]["tflops"]
+        # the figure to quote for "fp32" in the reference's sense: fp32 ARITHMETIC (v_mfma_f32_32x32x2_f32), against the fp32 MFMA peak
+        ent["reference_arithmetic"] = {"ms": ent["exact"]["ms"], "tflops": ent["exact"]["tflops"],
+                                       "frac_f32_mfma_peak": ent["exact"]["frac_f32_mfma_peak"], "kernel": "fa_fwd_f32_kernel (kernel=\"exact\")"}
         ex[name] = ent
         del q2, k2, v2
     # llm.c harness size (attention_forward.cu:1217-1220): B=6 T=4096 C=768 NH=12, packed (B, T, 3C) fp32, causal, 1/sqrt(hs); mean of

@@ -280,20 +280,28 @@ bool dense_layout(const fa::FwdParams& p, int32_t d)
            p.kv_batch_stride == (int64_t)p.n * d && p.o_batch_stride == (int64_t)p.n * d;
 }
 
-// Key-split launch for grids that leave most of the chip idle (FlashDecoding-style): bf16 tensors, non-causal, dense
-// (bh, n, d) layout, at most 128 tiles of 256 rows.  A lone 256-row tile over 8192 keys takes 0.108 ms whatever bh is (1, 2 or 4
-// slabs: the launch is one tile long), so S = 2 .. 8 workgroups per q-tile each take n / S keys (>= 1024) through the NB = 2
-// kernel -- the split index rides on the "head" index of FwdParams, kv_head_stride carries the key offset, the partial outputs
-// (fp32, normalised) and their log-sum-exps go to scratch -- and fa_combine_splits_kernel merges them.
+// Key-split launch for grids that leave most of the chip idle (FlashDecoding-style): bf16 tensors, dense (bh, n, d) layout.  A lone
+// 256-row tile over 8192 keys takes 0.108 ms whatever bh is (1, 2 or 4 slabs: the launch is one tile long), so S = 2 .. 8 workgroups per
+// q-tile each take n / S keys (>= 1024) through the NB = 2 kernel -- the split index rides on the "head" index of FwdParams,
+// kv_head_stride carries the key offset, the partial outputs (fp32, normalised) and their log-sum-exps go to scratch -- and
+// fa_combine_splits_kernel merges them.  Non-causal: at most 128 tiles of 256 rows.  Causal (round 3): a launch lasts as long as its
+// heaviest tile (all n keys) while the average tile has half of them, so up to 256 tiles are split; the shares are multiples of the
+// tile height (a share then starts at or below a tile's first row, or lies entirely above the tile: an empty share that stores lse = -inf
+// and costs a few microseconds of an otherwise idle CU).
+int keysplit_rows(const fa::FwdParams& p, int S, int32_t causal)   // keys per share
+{
+    const int unit = causal ? 256 : 64;
+    return ((p.n + S - 1) / S + unit - 1) / unit * unit;
+}
 int keysplit_factor(const fa::FwdParams& p, int32_t d, int32_t causal)
 {
-    if (causal || !dense_layout(p, d) || p.n < 4096) return 1;
+    if (!dense_layout(p, d) || p.n < 4096) return 1;
     if (((int64_t)(p.n - 1) * p.kv_row_stride + d) * 2 >= (int64_t)0xffffffffLL) return 1;   // the NB = 2 kernels' 32-bit slab offsets
     const int64_t tiles = (int64_t)p.bh * ((p.n + 255) / 256);
-    if (tiles > 128) return 1;
+    if (tiles > (causal ? 256 : 128)) return 1;
     int S = 1;
-    while (S < 8 && tiles * (2 * S) <= 256 && p.n / (2 * S) >= 1024) S *= 2;
-    while (S > 1 && (int64_t)(S - 1) * (((p.n + S - 1) / S + 63) / 64 * 64) >= p.n) --S;   // every split owns at least one key
+    while (S < 8 && tiles * (2 * S) <= (causal ? 512 : 256) && p.n / (2 * S) >= 1024) S *= 2;
+    while (S > 1 && (int64_t)(S - 1) * keysplit_rows(p, S, causal) >= p.n) --S;   // every split owns at least one key
     return S;
 }
 
@@ -355,7 +363,18 @@ Plan make_plan(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype,
     if (dtype == FA_DTYPE_F32) {
         if (sel.kind == FA_KERNEL_P16 || sel.kind == FA_KERNEL_P16X2) pl.status = fail(FA_ERR_UNSUPPORTED, "FA_KERNEL_P16 / FA_KERNEL_P16X2 are bf16-tensor kernels");
         else if (sel.kind == FA_KERNEL_MFMA || (sel.kind == FA_KERNEL_AUTO && f32_auto_is_exact())) pl.route = kRouteF32Exact;
-        else if (sel.kind == FA_KERNEL_AUTO && sel.variant == 0) pl.route = kRouteF32Guarded;
+        else if (sel.kind == FA_KERNEL_AUTO && sel.variant == 0) {
+            pl.route = kRouteF32Guarded;
+            // grids that leave the chip idle: the split kernel over key shares + combine (non-causal; the guard's verdict is per share,
+            // and any share raising it sends the whole launch to the exact kernel, which runs unsplit)
+            const int S = scratch_ok ? keysplit_factor(p, d, causal) : 1;
+            if (S > 1 && !causal) {
+                pl.S = S;
+                pl.part_off = kWsHeader;
+                pl.part_bytes = (size_t)S * p.bh * p.n * d * 4u + (size_t)S * p.bh * p.n * 4u;
+                pl.total = pl.part_off + align256(pl.part_bytes);
+            }
+        }
 #if FA_ABLATION
         else if (sel.kind == FA_KERNEL_SPLIT && sel.variant >= 8 && sel.variant < 32) {
             pl.route = kRouteF32T3;
@@ -416,9 +435,10 @@ Plan make_plan(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype,
 
 // key-split launch; p16: p0.v is the fp16 copy of V and p0 carries the chain's flag fields (the fp16-P kernel skips itself when the
 // copy overflowed; the combine then merges garbage, which the chain's fallback launch overwrites -- it runs after this function)
-hipError_t launch_bf16_keysplit(const fa::FwdParams& p0, int32_t d, int32_t out_f32, int S, char* part, hipStream_t stream, int p16 = 0)
+hipError_t launch_bf16_keysplit(const fa::FwdParams& p0, int32_t d, int32_t causal, int32_t out_f32, int S, char* part, hipStream_t stream, int p16 = 0)
 {
-    const int n_kv = ((p0.n + S - 1) / S + 63) / 64 * 64;
+    const int n_kv = keysplit_rows(p0, S, causal);
+    const int c = causal ? 1 : 0;
     const size_t o_bytes = (size_t)S * p0.bh * p0.n * d * 4u;
     float* o_part = (float*)part;
     float* lse_part = (float*)(part + o_bytes);
@@ -435,12 +455,39 @@ hipError_t launch_bf16_keysplit(const fa::FwdParams& p0, int32_t d, int32_t out_
     p.n_kv = n_kv;
     p.n_kv_total = p0.n;
     hipError_t e;
-    if (p16 == 0) e = fa::launch_bf16_x2(p, d, 0, 1, 0, stream);
-    else if (p16 == 1) e = d == 32 ? fa::launch_bf16_x2_p16_d32(p, 0, 1, stream) : d == 64 ? fa::launch_bf16_x2_p16_d64(p, 0, 1, stream) : fa::launch_bf16_x2_p16_d128(p, 0, 1, stream);
-    else e = d == 32 ? fa::launch_bf16_x2_p16x2_d32(p, 0, 1, stream) : d == 64 ? fa::launch_bf16_x2_p16x2_d64(p, 0, 1, stream) : fa::launch_bf16_x2_p16x2_d128(p, 0, 1, stream);
+    if (p16 == 0) e = fa::launch_bf16_x2(p, d, c, 1, 0, stream);
+    else if (p16 == 1) e = d == 32 ? fa::launch_bf16_x2_p16_d32(p, c, 1, stream) : d == 64 ? fa::launch_bf16_x2_p16_d64(p, c, 1, stream) : fa::launch_bf16_x2_p16_d128(p, c, 1, stream);
+    else e = d == 32 ? fa::launch_bf16_x2_p16x2_d32(p, c, 1, stream) : d == 64 ? fa::launch_bf16_x2_p16x2_d64(p, c, 1, stream) : fa::launch_bf16_x2_p16x2_d128(p, c, 1, stream);
     fa::FwdParams pc = p0;
     pc.flag_mode = 0;
     if (e == hipSuccess) e = fa::launch_combine_splits(pc, o_part, lse_part, S, d, out_f32, stream);
+    return e;
+}
+
+// fp32 tensors, key-split launch of the split kernel (non-causal): p0 carries the chain's flag fields (flag_mode 3: every share bounds the
+// logit width of its own keys)
+hipError_t launch_f32_keysplit(const fa::FwdParams& p0, int32_t d, int S, char* part, hipStream_t stream)
+{
+    const int n_kv = keysplit_rows(p0, S, 0);
+    const size_t o_bytes = (size_t)S * p0.bh * p0.n * d * 4u;
+    float* o_part = (float*)part;
+    float* lse_part = (float*)(part + o_bytes);
+    fa::FwdParams p = p0;
+    p.bh = p0.bh * S;
+    p.heads = S;
+    p.q_head_stride = 0;
+    p.kv_head_stride = (int64_t)n_kv * p0.kv_row_stride;
+    p.o = o_part;
+    p.o_batch_stride = (int64_t)p0.n * d;
+    p.o_head_stride = (int64_t)p0.bh * p0.n * d;
+    p.o_row_stride = d;
+    p.lse = lse_part;
+    p.n_kv = n_kv;
+    p.n_kv_total = p0.n;
+    hipError_t e = fa::launch_f32_split(p, d, 0, 0, stream);
+    fa::FwdParams pc = p0;
+    pc.flag_mode = 0;
+    if (e == hipSuccess) e = fa::launch_combine_splits(pc, o_part, lse_part, S, d, 1, stream);
     return e;
 }
 
@@ -456,7 +503,7 @@ hipError_t launch_p16_chain(const fa::FwdParams& p0, int32_t d, int32_t causal, 
         p.flag = f.word;
         p.flag_serial = f.serial;
         p.flag_mode = 1;   // skip if the copy found a value fp16 cannot hold
-        if (pl.S > 1) e = launch_bf16_keysplit(p, d, out_f32, pl.S, ws + pl.part_off, stream, pl.terms);
+        if (pl.S > 1) e = launch_bf16_keysplit(p, d, causal, out_f32, pl.S, ws + pl.part_off, stream, pl.terms);
         else if (pl.terms == 1) e = fa::launch_bf16_p16(p, d, causal ? 1 : 0, out_f32, stream);
         else e = fa::launch_bf16_p16x2(p, d, causal ? 1 : 0, out_f32, stream);
     }
@@ -560,7 +607,7 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
         case kRouteF32Split: e = fa::launch_f32_split(p, d, c, sel.variant, stream); break;
         case kRouteF32Guarded: {   // split products behind the logit-width guard, exact kernel as the conditional fallback
             FlagRef f;
-            if (!next_flag(f, stream, capturing, hold)) {   // no slot left for this (device, stream): the always-correct kernel alone
+            if (!chain_flag(f)) {   // no slot left for this (device, stream): the always-correct kernel alone
                 e = fa::launch_fwd_f32(p, d, c, 0, stream);
                 break;
             }
@@ -568,7 +615,8 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
             pg.flag = f.word;
             pg.flag_serial = f.serial;
             pg.flag_mode = 3;
-            e = fa::launch_f32_split(pg, d, c, 0, stream);
+            if (pl.S > 1) e = launch_f32_keysplit(pg, d, pl.S, scratch + pl.part_off, stream);
+            else e = fa::launch_f32_split(pg, d, c, 0, stream);
             if (e == hipSuccess) {
                 pg.flag_mode = 2;
                 e = fa::launch_fwd_f32(pg, d, c, 0, stream);
@@ -593,7 +641,7 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
 #endif
         case kRouteBf16Plain: e = fa::launch_fwd_bf16(p, d, c, out_f32, sel.variant, stream); break;
         case kRouteBf16Split: e = fa::launch_bf16_split(p, d, c, out_f32, sel.variant, stream); break;
-        case kRouteBf16KeySplit: e = launch_bf16_keysplit(p, d, out_f32, pl.S, scratch + pl.part_off, stream); break;
+        case kRouteBf16KeySplit: e = launch_bf16_keysplit(p, d, causal, out_f32, pl.S, scratch + pl.part_off, stream); break;
         case kRouteP16Chain: {
             FlagRef f;
             if (!chain_flag(f)) {

@@ -589,12 +589,12 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
     static_assert(G == 1 || G == 2, "ring index arithmetic written for G = 1, 2");
     constexpr int T = C::kTileBytes;
 
-    char* const k_ring = smem;  // K ring, then V ring
-    char* const v_ring = smem + KR * T;
-
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lq = lane & 31, hi = lane >> 5;
+
+    char* const k_ring = smem;  // K ring, then V ring
+    char* const v_ring = k_ring + KR * T;
 
     const int total = p.bh * p.q_tiles;
     const int w = xcd_remap(blockIdx.x, total);
@@ -610,20 +610,30 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
     const __bf16* vg = (const __bf16*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
     const int64_t o_slab_off = b * p.o_batch_stride + h * p.o_head_stride;
 
-    // keys of this workgroup: all n, or its share of a key-split launch (FwdParams::n_kv; non-causal only)
-    int nk = n;
-    if (!CAUSAL && p.n_kv > 0) nk = min(p.n_kv, p.n_kv_total - h * p.n_kv);
+    // Keys of this workgroup: all n, or its share of a key-split launch (FwdParams::n_kv): the workgroup whose "head" index is h reads the
+    // keys [h * n_kv, min((h + 1) * n_kv, n_kv_total)) -- kv_head_stride carries the offset -- and works in LOCAL key indices (local key i
+    // is key kbeg + i of the slab).  Causal shares: n_kv is a multiple of the tile height, so a share starts at or below the tile's first
+    // row (every row then sees the share's first key and has an exponent reference) or past its last row (an empty share: lse = -inf is
+    // stored, the combine gives it weight 0 and never reads its O).
+    int nk = n, kbeg = 0;
+    if (p.n_kv > 0) {
+        kbeg = h * p.n_kv;
+        nk = min(p.n_kv, p.n_kv_total - kbeg);
+    }
     int kv_end = nk;
-    if (CAUSAL) kv_end = min(n, qt * BM + BM);
+    if (CAUSAL) kv_end = min(nk, qt * BM + BM - kbeg);
+    const bool idle = CAUSAL && kv_end <= 0;         // causal key share entirely above this tile's rows
+    if (idle) kv_end = 0;
     const int nst = (kv_end + kKvBlk - 1) / kKvBlk;  // 64-key stages
     const int nsub = (kv_end + 31) / 32;             // 32-key sub-tiles
+    const int q0r = q0 - kbeg;                       // first row of block 0 in local key coordinates (causal: local key <= local row)
 
     auto k_slot = [&](int j) { return k_ring + (j & (KR - 1)) * T; };
     auto v_slot = [&](int j) { return v_ring + (j & (VR - 1)) * T; };
 
     TileDma<D, NWAVES> dma;
-    dma.init(kg, vg, nk, p.kv_row_stride, wave, lane);
-    dma.issue_k(0u, k_slot(0), wave);
+    dma.init(kg, vg, max(nk, 1), p.kv_row_stride, wave, lane);
+    if (!idle) dma.issue_k(0u, k_slot(0), wave);
     // every tile the first barrier group needs is requested before anything is waited for: one memory round trip, not two
 #pragma unroll
     for (int g = 1; g <= G; ++g)
@@ -700,7 +710,7 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
         float mx[NB];
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk) {
-            if (needs_mask(t, q0 + 32 * blk)) mask16(s[blk], t * 32, q0 + 32 * blk + lq, nk, hi, CAUSAL);
+            if (needs_mask(t, q0r + 32 * blk)) mask16(s[blk], t * 32, q0r + 32 * blk + lq, nk, hi, CAUSAL);
             mx[blk] = rowmax16(s[blk]);
         }
         if (first) {  // nothing accumulated yet: set the references, leave the (zero) accumulators alone
@@ -758,20 +768,22 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0][0]), "+v"(qf[NB - 1][KS - 1]));   // Q fragments have arrived as well
         prof_landed = stamp();
     }
-    load_kf(0);
-    qk_regs(0, s0, true);
-    load_kf(1);
+    if (!idle) {
+        load_kf(0);
+        qk_regs(0, s0, true);
+        load_kf(1);
+    }
 
     // ---------------- fast loop: groups of G whole stages whose sub-tiles 2j .. 2j+2 are in range and mask-free ----------------
     // (closed form of: jf = 0; while ((2 jf + 3) 32 <= kv_end && !needs_mask(2 jf + 2, q0) && !needs_mask(0, q0)) ++jf; -- the loop was
     // O(N / 64) scalar iterations per wave, ~2.5k cycles at N = 8192)
     int jf = kv_end >= 96 ? (kv_end / 32 - 3) / 2 + 1 : 0;                    // (2 jf + 3) * 32 <= kv_end; kv_end <= n covers the ragged tail
-    if (CAUSAL) jf = q0 >= 95 ? min(jf, (q0 - 95) / 64 + 1) : 0;             // 64 j + 95 <= q0: sub-tile 2 j + 2 lies below the first row's diagonal
+    if (CAUSAL) jf = q0r >= 95 ? min(jf, (q0r - 95) / 64 + 1) : 0;           // 64 j + 95 <= q0: sub-tile 2 j + 2 lies below the first row's diagonal
     if (nk < 32) jf = 0;
     // The last stage may run in the fast loop too when its own two sub-tiles are whole and mask-free: its second step then
     // computes scores of a sub-tile that does not exist (from whatever the ring slot holds) and nobody consumes them --
     // the rescale test of that step is ignored.  Without this the final 128 keys of every slab took the slow tail path.
-    if (jf == nst - 1 && (2 * jf + 2) * 32 <= kv_end && !needs_mask(2 * jf + 1, q0) && !needs_mask(0, q0)) jf = nst;
+    if (jf == nst - 1 && (2 * jf + 2) * 32 <= kv_end && !needs_mask(2 * jf + 1, q0r) && !needs_mask(0, q0r)) jf = nst;
     jf -= jf % G;
     unsigned long long prof_t0 = 0, prof_r0 = 0;
     if constexpr ((ABL & 1024) != 0) {   // ablation library only: cycle stamps around the fast loop (shader clock and the 100 MHz real-time counter)
@@ -809,7 +821,7 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
 
     // ---------------- tail: remaining stages, phase-structured, masks applied where needed ----------------
     // Invariant at the top of stage j: scores of sub-tile 2j in s0 with the rescale decision taken, kf = fragments of sub-tile 2j+1.
-    const int nsub_w = CAUSAL ? min(nsub, (q0 + 32 * (NB - 1) + 31) / 32 + 1) : nsub;
+    const int nsub_w = CAUSAL ? min(nsub, (q0r + 32 * (NB - 1) + 31) / 32 + 1) : nsub;
     for (int j = jf; j < nst; ++j) {
         if (j % G == 0) sync_top(j);
         const int t0 = 2 * j, t1 = 2 * j + 1;
@@ -827,6 +839,8 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
         }
     }
 
+    bool bad = false;
+
     unsigned long long prof_tail = 0;
     if constexpr ((ABL & 1024) != 0) prof_tail = stamp();
     // ---------------- store; verify (optimistic mix) ----------------
@@ -834,7 +848,6 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
     // and nothing of the first attempt is live across the vote (with the store behind the vote hipcc carried the
     // accumulators of the common path through copies and 12 MB of scratch per launch).
     drain_accumulators<NB, DB>(o, st);  // tied to the accumulators: a bare drain has no data dependence and may be scheduled past
-    bool bad = false;
     if (OPT) {
         // every P was exponentiated against the first sub-tile's maximum: the tile stands iff no term left the safe range,
         // which the row sums prove (a term > 2^100, +inf or NaN makes its row sum fail this test)
@@ -850,7 +863,9 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
         const float lt = st[blk].lacc[0];
         const float inv = 1.0f / lt;
         const int qi = q0 + 32 * blk + lq;
-        if (qi < n) {
+        if (qi < n && idle) {   // empty causal key share: only its log-sum-exp (-inf) is stored; the combine never reads its O
+            if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = -INFINITY;
+        } else if (qi < n) {
             if constexpr (OPT) asm volatile("; rows, optimistic mix");
             else asm volatile("; rows, rescaled mix");
             const int64_t o_off = o_slab_off + (int64_t)qi * p.o_row_stride + 4 * hi;

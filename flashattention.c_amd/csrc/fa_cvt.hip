@@ -138,7 +138,7 @@ hipError_t launch_t3_prepass(const void* q, const void* k, const void* v, void* 
 
 // ---- combine of a key-split launch (fa_api.cpp: launch_bf16_keysplit) -------------------------------------------------------
 // S workgroups per q-tile each saw a share of the keys and left a normalised partial output O_s (fp32, [S][bh][n][d]) and the
-// log-sum-exp of its share (natural log, [bh][S][n]).  O = sum_s w_s O_s / sum_s w_s with w_s = exp(lse_s - max_s lse_s);
+// log-sum-exp of its share (natural log, [bh][S][n]; -inf for a causal share that lies entirely above the row).  O = sum_s w_s O_s / sum_s w_s with w_s = exp(lse_s - max_s lse_s);
 // lse = max + log(sum w_s).  One thread per four output columns; HBM-bound and small (S * 4 bytes per output element).
 template <bool OUT_F32>
 __global__ __launch_bounds__(256) void fa_combine_splits_kernel(FwdParams p, const float* __restrict__ o_part, const float* __restrict__ lse_part,
@@ -157,6 +157,7 @@ __global__ __launch_bounds__(256) void fa_combine_splits_kernel(FwdParams p, con
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int s = 0; s < S; ++s) {
         const float w = __expf(lse_part[((int64_t)slab * S + s) * p.n + row] - m);
+        if (w == 0.0f) continue;   // an empty share (causal launches: its keys lie above this row's tile; lse = -inf) or a negligible one
         const f32x4 x = *(const f32x4*)(o_part + (((int64_t)s * p.bh + slab) * p.n + row) * d + c);
         acc += w * x;
         wsum += w;

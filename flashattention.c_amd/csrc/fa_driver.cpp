@@ -511,8 +511,10 @@ int main(int argc, char** argv)
             const size_t qt = (a.n + rows_per_wg - 1) / rows_per_wg;
             printf("# slab 0, per launch position: steps, loop cycles, inputs_landed, first_scores, tail, epilogue_issue, whole tile\n");
             for (size_t t = 0; t < qt; t += (qt > 16 ? qt / 16 : 1)) {
-                const float* r = &h[(t * 4 + 0) * 8];   // wave 0 of workgroup t (xcd_remap keeps slab 0's tiles in the first positions of XCD 0)
-                printf("#  pos %3zu: %5.0f %8.0f %7.0f %7.0f %7.0f %7.0f %8.0f\n", t, r[2], r[0], r[4], r[5], r[6], r[7], r[3]);
+                for (int wv = 0; wv < 4; wv += 3) {     // wave 0 (lowest rows: fewest diagonal sub-tiles) and wave 3 (highest rows: most)
+                    const float* r = &h[(t * 4 + wv) * 8];   // workgroup t (xcd_remap keeps slab 0's tiles in the first positions of XCD 0)
+                    printf("#  pos %3zu wave %d: %5.0f %8.0f %7.0f %7.0f %7.0f %7.0f %8.0f\n", t, wv, r[2], r[0], r[4], r[5], r[6], r[7], r[3]);
+                }
             }
         }
         return 0;

@@ -203,7 +203,10 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     const T* vg = (const T*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
     const int64_t o_slab = b * p.o_batch_stride + h * p.o_head_stride;   // elements (fp32 or bf16 output, p.o_is_bf16)
 
-    int kv_end = n;
+    // keys of this workgroup: all n, or (non-causal key-split launches, fa_api.cpp) its share [h * n_kv, min((h + 1) * n_kv, n_kv_total)) --
+    // kv_head_stride carries the offset, nk bounds the local key indices
+    const int nk = (!CAUSAL && p.n_kv > 0) ? min(p.n_kv, p.n_kv_total - h * p.n_kv) : n;
+    int kv_end = nk;
     if (CAUSAL) kv_end = min(n, qt * BM + BM);
     const int nt = (kv_end + kKvSplit - 1) / kKvSplit;
 
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     auto load_tile = [&](int kv0) {
 #pragma unroll
         for (int i = 0; i < GPT; ++i) {
-            const bool kok = g_on[i] && (kv0 + g_krow[i] < n), vok = g_on[i] && (kv0 + g_vrow[i] < n);
+            const bool kok = g_on[i] && (kv0 + g_krow[i] < nk), vok = g_on[i] && (kv0 + g_vrow[i] < nk);
             const int64_t koff = (int64_t)kv0 * p.kv_row_stride + g_ksrc[i], voff = (int64_t)kv0 * p.kv_row_stride + g_vsrc[i];
             const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
             if constexpr (IN_BF16) {   // eight bf16 values = one 16-byte register group, passed through unchanged
@@ -308,6 +311,9 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
 
     // The whole tile, OPT = optimistic pass (fixed reference m0) or the textbook redo.  Returns whether this lane's rows
     // came out inside the range the optimistic pass can prove.
+    // guard: a NaN in a row sum or an output of the first attempt (the running maxima above drop NaNs: v_max3_f32 and fmaxf return the
+    // other operand) -- a NaN in Q, K or V reaches one of them -- raises the word like a wide logit does
+    bool saw_nan = false;
     auto run_tile = [&](auto opt_c) -> bool {
         constexpr bool OPT = decltype(opt_c)::value;
         // MREG: -m_ref of a row lives in a 16-register tuple, the accumulator the first product of every tile starts from (the
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kv0 + 4 * hi + (r & 3) + 8 * (r >> 2);
-                if ((key >= n) || (CAUSAL && key > qi)) sq[r] = -INFINITY;
+                if ((key >= nk) || (CAUSAL && key > qi)) sq[r] = -INFINITY;
             }
         };
         auto row_max = [&](const f32x16& sq) {
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
             // reference of each row: the maximum over the first tile (every row sees key 0, so it is finite for finite inputs)
             f32x16 s[QB];
             scores(smem, s);
-            const bool need_mask = (kKvSplit > n) || (CAUSAL && (kKvSplit - 1 > q0));
+            const bool need_mask = (kKvSplit > nk) || (CAUSAL && (kKvSplit - 1 > q0));
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 if (need_mask) mask(s[qb], 0, q0 + qb * 32 + lq);
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                 scores(kh_lds, s);   // S'^T = K Q'^T - m_ref
 
                 // ================= softmax (registers only) =================
-                const bool need_mask = (kv0 + kKvSplit > n) || (CAUSAL && (kv0 + kKvSplit - 1 > q0));
+                const bool need_mask = (kv0 + kKvSplit > nk) || (CAUSAL && (kv0 + kKvSplit - 1 > q0));
                 bf16x8 ph[QB][2], pl[QB][2];
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
@@ -524,6 +530,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                     }
                 if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (m[qb] + __builtin_amdgcn_logf(lt)) * kLn2;
                 if (OPT) ok = ok && (lt < kSplitLimit) && (mag < INFINITY);   // false for NaN as well
+                if (GUARD) saw_nan = saw_nan || (lt != lt) || (mag != mag);
             }
         }
         return ok;
@@ -556,7 +563,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
         // loads of tile t through buffer descriptors: rows past the end of the slab come back as zeros from the bounds check,
         // so there is no branch (a branch inside the loop body lets LLVM sink vector work out of its slot)
         constexpr unsigned ES = sizeof(T);
-        const unsigned slab_bytes = ((unsigned)(n - 1) * (unsigned)p.kv_row_stride + D) * ES;
+        const unsigned slab_bytes = ((unsigned)(nk - 1) * (unsigned)p.kv_row_stride + D) * ES;
         const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kg, 0, slab_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vg, 0, slab_bytes, 0x00020000);
         const unsigned tile_step = (unsigned)kKvSplit * (unsigned)p.kv_row_stride * ES;
@@ -642,7 +649,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = kv0 + 4 * hi + (r & 3) + 8 * (r >> 2);
-                        if ((key >= n) || (CAUSAL && key > qi)) s[qb][r] = -INFINITY;
+                        if ((key >= nk) || (CAUSAL && key > qi)) s[qb][r] = -INFINITY;
                     }
                 }
 #pragma unroll
@@ -682,7 +689,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                     }
                 }
         };
-        auto needs_mask = [&](int kv0) { return (kv0 + kKvSplit > n) || (CAUSAL && (kv0 + kKvSplit - 1 > q0)); };
+        auto needs_mask = [&](int kv0) { return (kv0 + kKvSplit > nk) || (CAUSAL && (kv0 + kKvSplit - 1 > q0)); };
 
         // ---- prologue: K(0) and K(1) staged, scores of tile 0 under way
         load_k(0);
@@ -870,6 +877,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                     }
                 if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = __builtin_amdgcn_logf(lt) * kLn2;
                 ok = ok && (lt > 1.0f / kSplitLimit) && (lt < kSplitLimit) && (mag < INFINITY);   // false for NaN as well
+                if (GUARD) saw_nan = saw_nan || (lt != lt) || (mag != mag);
             }
         }
         return ok;
@@ -884,8 +892,9 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     }
     const bool redo = __syncthreads_or(!ok);
     if constexpr (GUARD) {
-        // |q'|_2 carries scale * log2(e); a NaN on either side raises the word as well (the exact kernel propagates it faithfully)
-        if (p.flag_mode == 3 && !(sqrtf(qn2) * __uint_as_float(s_kmax) <= kGuardLimit * kLog2e))
+        // |q'|_2 carries scale * log2(e); +-inf on either side fails the comparison, a NaN is caught through the first attempt's
+        // results (saw_nan): either way the exact kernel then produces the output in fp32 arithmetic
+        if (p.flag_mode == 3 && (saw_nan || !(sqrtf(qn2) * __uint_as_float(s_kmax) <= kGuardLimit * kLog2e)))
             __hip_atomic_store(p.flag, p.flag_serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (redo) run_tile(std::false_type{});

@@ -27,6 +27,20 @@ BENCHA="$R/bench.py --accurate --steps 20 --warmup 3 --no-cpu-baseline --no-extr
 rocprofv3 --kernel-trace --stats -d $OUT/stats_acc -- python3 $BENCHA > $OUT/stats_acc.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES \
     --kernel-trace -d $OUT/pmc_acc_sq -- python3 $BENCHA > $OUT/pmc_acc_sq.log 2>&1
+# shapes that had no profile before round 3: BASELINE config 2 (fp32 tensors, N = 1024; AUTO and exact arithmetic) and the README's d = 32 rows,
+# through the C driver (one kernel family per pass; 200 launches each)
+DRV=$R/flashattention.c_amd/fa_driver
+SQ="GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
+shape_pass() {   # name, driver args...
+    local name=$1; shift
+    rocprofv3 --kernel-trace --stats -d $OUT/stats_$name -- $DRV --mode rand --check 0 --warmup 50 --iters 200 "$@" > $OUT/stats_$name.log 2>&1
+    rocprofv3 --pmc $SQ --kernel-trace -d $OUT/pmc_${name}_sq -- $DRV --mode rand --check 0 --warmup 50 --iters 200 "$@" > $OUT/pmc_${name}_sq.log 2>&1
+}
+shape_pass c2_auto  --bh 128 --n 1024 --d 64 --dtype f32s --kernel auto
+shape_pass c2_exact --bh 128 --n 1024 --d 64 --dtype f32
+shape_pass d32_n1024_bf16 --bh 128 --n 1024 --d 32 --dtype bf16
+shape_pass d32_n8192_bf16 --bh 16 --n 8192 --d 32 --dtype bf16
+shape_pass c4_causal --bh 16 --n 8192 --d 64 --dtype bf16 --causal 1
 cd $R
 python3 bench.py --accurate --no-cpu-baseline --no-extras > $OUT/bench_line_accurate.json 2> $OUT/bench_acc.err
 python3 bench.py --workload c3 --no-cpu-baseline > $OUT/bench_line_c3.json 2> $OUT/bench_c3.err

@@ -46,7 +46,11 @@ def main(src: str, tag: str, out: str = None):
     # HBM traffic of the dominant kernel per workload (what bench.py's roofline.traffic quotes), with the kernel it was measured on:
     # bench.py prints the figure only while that is still the kernel it launches.  gfx950: FETCH_SIZE counts 64 B per 128-B
     # request on wide coalesced reads -> doubled (MI355X_MICROARCH.md, HBM section); both counters are in KiB.
+    import hashlib
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flashattention.c_amd", "libflashattn_amd.so")
+    sha = hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None
     traffic = {"_tag": tag,
+               "lib_sha256": sha,   # the binary these passes ran on: bench.py prints `traffic` only while it loads this very library
                "_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py [--workload c3] --steps 20 --warmup 3 "
                           "--no-cpu-baseline --no-extras` (profiles/collect.sh)",
                "_method": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per dispatch of the dominant kernel"}

@@ -535,6 +535,54 @@ def test_key_split_launch_for_grids_that_leave_the_chip_idle(bh, n, d):
     check(out[sl], ref, bf16_tol(1.0, False), "vs fp64 oracle")
 
 
+@pytest.mark.parametrize("bh,n,d", [(1, 8192, 64), (2, 8192, 64), (4, 8192, 64), (8, 8192, 64), (3, 5000, 64), (1, 16384, 64), (2, 7777, 32),
+                                    (1, 8192, 128), (5, 4200, 128), (7, 4097, 64), (1, 4096, 32)])
+def test_causal_key_split_launch(bh, n, d):
+    """Causal launches of up to 256 tiles (round 3): shares of the keys that are multiples of the tile height, so every share either
+    starts at or below a tile's first row or lies entirely above the tile (an empty share: lse = -inf, skipped by the combine).  The
+    causal mask works in the share's local key coordinates.  Output poisoned with NaN first; bf16 P, both accurate kernels, LSE."""
+    q, k, v = (orc.round_to_bf16(randn(s, bh, n, d)) for s in (94, 95, 96))
+    k[0, n // 3] = 6.0 * q[0, n - 9] / np.linalg.norm(q[0, n - 9])     # a dominant key in one share for a late row
+    k = orc.round_to_bf16(k)
+    qd, kd, vd = to_dev(q, k, v, dtype=torch.bfloat16)
+    assert fa.workspace_bytes(bh, n, d, True, dtype=torch.bfloat16) > 0
+    ref_dev, lse_ref = fa.forward(qd.float(), kd.float(), vd.float(), True, kernel="naive", return_lse=True)
+    for kern, odt, tol, tol_lse in (("auto", torch.bfloat16, bf16_tol(1.0, False), 2e-2), ("mfma", torch.float32, bf16_tol(1.0, True), 2e-2),
+                                    ("p16x2", torch.float32, TOL_P16X2, 1e-4), ("p16", torch.float32, P16_TOL_BIG, 2e-3)):
+        out = torch.full((bh, n, d), float("nan"), dtype=odt, device=dev())
+        _, lse = fa.forward(qd, kd, vd, True, kernel=kern, out=out, return_lse=True)
+        assert not torch.isnan(out.float()).any(), f"{kern}: unwritten rows"
+        err = float((out.float() - ref_dev).abs().max())
+        OBSERVED.append((f"causal key split bh={bh} n={n} d={d} {kern}", err, tol))
+        assert err < tol, f"{kern}: {err:.3e}"
+        assert float((lse - lse_ref).abs().max()) < tol_lse, kern
+    check(out[:1], orc.attention_f64(q[:1], k[:1], v[:1], causal=True), P16_TOL_BIG, "vs fp64 oracle")
+
+
+@pytest.mark.parametrize("bh,n,d", [(1, 8192, 64), (2, 8192, 64), (3, 5000, 64), (1, 16384, 64), (2, 7777, 32), (1, 8192, 128), (4, 4100, 64)])
+def test_fp32_key_split_launch(bh, n, d):
+    """fp32 tensors, non-causal, grids that leave the chip idle: the split kernel over key shares + combine inside the guarded AUTO chain
+    (every share bounds the logit width of its own keys; any share raising the verdict hands the launch to the exact kernel)."""
+    q, k, v = (randn(s, bh, n, d) for s in (97, 98, 99))
+    qd, kd, vd = to_dev(q, k, v)
+    assert fa.workspace_bytes(bh, n, d, False) > 0
+    ref, lse_ref = fa.forward(qd, kd, vd, False, kernel="naive", return_lse=True)
+    out = torch.full((bh, n, d), float("nan"), device=dev())
+    _, lse = fa.forward(qd, kd, vd, False, out=out, return_lse=True)
+    assert fa.last_forward_route() == 1
+    assert not torch.isnan(out).any()
+    err = float((out - ref).abs().max())
+    OBSERVED.append((f"fp32 key split bh={bh} n={n} d={d}", err, TOL_F32))
+    assert err < TOL_F32 and float((lse - lse_ref).abs().max()) < 1e-3
+    check(out[:1], orc.attention_f64(q[:1], k[:1], v[:1]), TOL_F32, "vs fp64 oracle")
+    # a wide key in the LAST share: that share's guard fires, the exact kernel (unsplit) produces the output
+    k[0, n - 7] *= 40.0
+    (kw,) = to_dev(k)
+    o2 = fa.forward(qd, kw, vd, False)
+    assert fa.last_forward_route() == 2
+    assert float((o2 - fa.forward(qd, kw, vd, False, kernel="exact")).abs().max()) < 1e-5
+
+
 def test_graph_replay_timing_entry():
     q, k, v = (torch.randn(4, 512, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
     ms_stream = fa.time_forward(q, k, v, False, warmup=1, iters=5)
@@ -1041,10 +1089,13 @@ def test_fp32_auto_guard_stays_quiet_on_the_reference_workloads():
     o = fa.forward(*to_dev(q, k, v), True)
     assert fa.last_forward_route() == 2
     check(o, orc.attention_f64(q, k, v, causal=True), TOL_F32)
-    # inf / NaN in K: whatever comes out, it comes out of fp32 arithmetic
-    k[0, 3, 3] = np.inf
-    fa.forward(*to_dev(q, k, v), False)
-    assert fa.last_forward_route() == 2
+    # inf / NaN in K, NaN in Q or V: whatever comes out, it comes out of fp32 arithmetic (the running maxima drop NaNs -- v_max3_f32 returns
+    # the other operand -- so a NaN is caught through the first attempt's row sums and outputs)
+    for t_idx, val in ((1, np.inf), (1, np.nan), (0, np.nan), (2, np.nan)):
+        q, k, v = (randn(s, 2, 1024, 64) for s in (74, 75, 76))
+        (q, k, v)[t_idx][0, 3, 3] = val
+        fa.forward(*to_dev(q, k, v), False)
+        assert fa.last_forward_route() == 2, (t_idx, val)
 
 
 def test_packed_qkv_guard_and_llmc_harness_size():
