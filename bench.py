@@ -456,7 +456,25 @@ def c4_side_measurements(fa, _cabi, q, k, v, causal, args, device):
     q1, k1, v1 = make_inputs(1, n, d, "bf16", device, seed=3)
     timed("bh1_n8192_bf16_keysplit", dict(causal=False, scale=args.scale), fwd_flop(1, n, d, False), tensors=(q1, k1, v1),
           note="B*H = 1 at the c4 length, bf16 tensors: 32 q-tiles x 8 key shares + combine instead of 32 workgroups", warm=100, iters=50)
+    timed("bh1_n8192_bf16_unsplit", dict(causal=False, scale=args.scale, kernel="mfma:50"), fwd_flop(1, n, d, False), tensors=(q1, k1, v1),
+          note="the same launch without the key split (kernel=\"mfma:50\": 32 workgroups of 256 rows over all 8192 keys)", warm=100, iters=50)
+    timed("bh1_n8192_bf16_causal_keysplit", dict(causal=True, scale=args.scale), fwd_flop(1, n, d, True), tensors=(q1, k1, v1),
+          note="B*H = 1, causal: key shares of 1024 keys (multiples of the tile height; shares above a tile's rows are empty and skipped) + combine", warm=100, iters=50)
     del q1, k1, v1
+    # causal launches of up to 256 tiles are key-split as well (a causal launch lasts as long as its heaviest tile): B*H = 8
+    q8, k8, v8 = make_inputs(8, n, d, "bf16", device, seed=4)
+    timed("bh8_n8192_bf16_causal_keysplit", dict(causal=True, scale=args.scale), fwd_flop(8, n, d, True), tensors=(q8, k8, v8),
+          note="B*H = 8, causal, bf16 tensors: 256 tiles x 2 key shares + combine (FA_KERNEL_AUTO)", warm=100, iters=50)
+    timed("bh8_n8192_bf16_causal_unsplit", dict(causal=True, scale=args.scale, kernel="mfma:50"), fwd_flop(8, n, d, True), tensors=(q8, k8, v8),
+          note="the same launch without the key split (kernel=\"mfma:50\"): round 2's path", warm=100, iters=50)
+    del q8, k8, v8
+    # fp32 tensors, one slab: the split kernel over key shares inside the guarded chain
+    qf, kf, vf = make_inputs(1, n, d, "f32", device, seed=5)
+    timed("bh1_n8192_f32_keysplit", dict(causal=False, scale=args.scale), fwd_flop(1, n, d, False), tensors=(qf, kf, vf), peak=PEAK_TFLOPS["bf16"] / 3.0,
+          note="B*H = 1, fp32 tensors (FA_KERNEL_AUTO): split kernel over 8 key shares + combine + the guard's conditional exact launch; frac of bf16 peak / 3", warm=100, iters=50)
+    timed("bh1_n8192_f32_unsplit", dict(causal=False, scale=args.scale, kernel="split"), fwd_flop(1, n, d, False), tensors=(qf, kf, vf), peak=PEAK_TFLOPS["bf16"] / 3.0,
+          note="the same tensors through kernel=\"split\" (one launch, no key split, no guard): round 2's path", warm=100, iters=50)
+    del qf, kf, vf
     # README rows 2 and 4 (d = 32), bf16 and fp32 tensors
     for name, (B2, H2, n2) in (("d32_n8192", (2, 8, 8192)), ("d32_n1024", (8, 16, 1024))):
         q2, k2, v2 = make_inputs(B2 * H2, n2, 32, "bf16", device, seed=2)

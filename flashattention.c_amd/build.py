@@ -32,16 +32,17 @@ DRIVER_PATH = os.path.join(PKG_DIR, "fa_driver")
 ARCH = "gfx950"
 
 # longest translation units first: the thread pool starts them in this order
-LIB_SOURCES = ["fa_fwd_bf16_x4_p16x2.hip", "fa_fwd_bf16_x4.hip", "fa_fwd_bf16_x4_causal.hip", "fa_fwd_bf16_x2.hip",
+LIB_SOURCES = ["fa_fwd_bf16_x4_p16x2.hip", "fa_fwd_bf16_x4.hip", "fa_fwd_bf16_x2.hip",
                "fa_fwd_bf16_pipelined.hip", "fa_split_f32_d64.hip", "fa_split_f32_d128.hip", "fa_split_f32_d32.hip",
                "fa_split_bf16_d64.hip", "fa_split_bf16_d128.hip", "fa_split_bf16_d32.hip", "fa_fwd_bf16.hip",
-               "fa_fwd_bf16_x4_p16.hip", "fa_fwd_bf16_x4_p16_causal.hip", "fa_fwd_bf16_x2_p16_d128.hip", "fa_fwd_bf16_x2_p16_d64.hip",
+               "fa_fwd_bf16_x4_p16.hip", "fa_fwd_bf16_x2_p16_d128.hip", "fa_fwd_bf16_x2_p16_d64.hip",
                "fa_fwd_bf16_x2_p16_d32.hip", "fa_fwd_bf16_x2_p16x2_d128.hip", "fa_fwd_bf16_x2_p16x2_d64.hip", "fa_fwd_bf16_x2_p16x2_d32.hip", "fa_cvt.hip",
                "fa_fwd_f32.hip", "fa_fwd_f32_split.hip", "fa_fwd_bf16_split.hip", "fa_naive.hip", "fa_api.cpp"]
 # timing-only instantiations (garbage results): only in libflashattn_amd_ablation.so
-ABLATION_SOURCES = ["fa_fwd_bf16_x4_ablation.hip", "fa_fwd_bf16_pp2.hip", "fa_fwd_f32_t3.hip"]
+ABLATION_SOURCES = ["fa_fwd_bf16_x4_ablation.hip", "fa_fwd_bf16_x4_causal.hip", "fa_fwd_bf16_pp2.hip", "fa_fwd_f32_t3.hip"]
 # product sources whose text depends on FA_ABLATION (the variant dispatch): recompiled for the ablation library, the rest is shared
-ABLATION_DEPENDENT = ["fa_fwd_bf16.hip", "fa_fwd_bf16_x4.hip", "fa_fwd_bf16_pipelined.hip", "fa_fwd_bf16_x2.hip", "fa_cvt.hip", "fa_api.cpp"]
+ABLATION_DEPENDENT = ["fa_fwd_bf16.hip", "fa_fwd_bf16_x4.hip", "fa_fwd_bf16_pipelined.hip", "fa_fwd_bf16_x2.hip", "fa_cvt.hip", "fa_api.cpp",
+                      "fa_split_f32_d32.hip", "fa_split_f32_d64.hip"]
 ABL_LIB_PATH = os.path.join(PKG_DIR, "libflashattn_amd_ablation.so")
 ABL_DRIVER_PATH = os.path.join(PKG_DIR, "fa_driver_ablation")
 HEADERS = ["fa_common.h", "fa_kernels.h", "fa_bf16_common.h", "fa_split_kernel.h", "fa_bf16_xn_kernel.h", "fa_f32_t3_kernel.h", "fa_bf16_step.h", os.path.join(ROOT, "include", "flashattn_amd.h")]

@@ -307,19 +307,15 @@ int keysplit_factor(const fa::FwdParams& p, int32_t d, int32_t causal)
 
 bool p16_available(const fa::FwdParams& p, int32_t d) { return dense_layout(p, d) && fa::bf16_p16_supported(p, d); }
 
-// FA_KERNEL_AUTO, bf16 tensors, fp32 output: two fp16 terms of P (a chain) or hi + lo bf16 terms (one launch)?  The fp16 chain has a
-// fixed cost the split kernel does not have -- the V copy (2 x sizeof(V) of HBM traffic) and two extra launches, ~15 us together --
-// and a faster kernel.  Measured on MI355X (ms, p16x2 chain / split kernel), BH x N x d: 16 x 8192 x 64 0.368 / 0.446, 128 x 2048 x 64
-// 0.225 / 0.255, 32 x 4096 x 64 0.226 / 0.245, 64 x 2048 x 128 0.220 / 0.236, 64 x 2048 x 64 0.134 / 0.140, 16 x 4096 x 64 0.135 / 0.132,
-// 128 x 1024 x 64 0.082 / 0.085, 128 x 1024 x 128 0.138 / 0.140, 16 x 2048 x 64 0.066 / 0.044, 128 x 1024 x 32 0.060 / 0.060, 32 x 2048 x 32
-// 0.057 / 0.057; causal 32 x 4096 x 64 0.147 / 0.160, 64 x 2048 x 64 0.094 / 0.096, 128 x 1024 x 64 0.065 / 0.066.
-// Rule: the chain from 1.2e10 multiply-adds per contraction on (a causal launch counts half), from 4e9 at d = 32 (where the split
-// kernel is slowest); the split kernel below that.  Either choice is accurate to ~1e-4 or better.
-bool p16_worthwhile(const fa::FwdParams& p, int32_t d, int32_t causal)
-{
-    const double macs = (double)p.bh * (double)p.n * (double)p.n * (double)d * (causal ? 0.5 : 1.0);
-    return macs >= (d == 32 ? 4e9 : 1.2e10);
-}
+// FA_KERNEL_AUTO, bf16 tensors, fp32 output: two fp16 terms of P (a chain of three launches) whenever scratch is available, whatever the
+// launch size.  The alternative without scratch -- hi + lo bf16 terms of P AND of Q' = Q * scale * log2(e) in one launch (the split
+// kernel) -- is faster below ~1.2e10 multiply-adds per contraction (ms chain / split kernel, BH x N x d: 16 x 8192 x 64 0.368 / 0.446,
+// 128 x 2048 x 64 0.225 / 0.255, 64 x 2048 x 64 0.134 / 0.140, 16 x 4096 x 64 0.135 / 0.132, 128 x 1024 x 64 0.082 / 0.085, 16 x 2048 x 64
+// 0.066 / 0.044, 16 x 1024 x 64 0.036 / 0.019), but its 16-bit Q' makes the error of a score grow with the logit width (the fp32-tensor
+// path has a device-side guard for exactly that; bf16 tensors have no exact kernel to fall back to): the round-3 soak (tests/soak_fuzz.py,
+// x3 logits at d = 128) read 6.5e-4 from it where the two-term fp16 kernel -- whose Q.K^T is exact in the fp32 accumulator -- stayed
+// below 1e-4 on every data family.  A caller who asks for the fp32 accumulator gets the kernel whose error does not depend on the data;
+// the split kernel remains the choice when there is no scratch (a capturing stream without a workspace) and for slabs beyond 4 GiB.
 
 // ---- the plan of one forward: which launches, how much scratch ---------------------------------------------------------------------
 // One function decides for fa_workspace_bytes, fa_forward_ws and the convenience entries alike, so the size a caller is told is the
@@ -405,7 +401,7 @@ Plan make_plan(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype,
     }
     const int S = (scratch_ok && sel.variant == 0) ? keysplit_factor(p, d, causal) : 1;
     const bool p16 = p16_kind ||
-                     (scratch_ok && sel.kind == FA_KERNEL_AUTO && out_f32 && sel.variant == 0 && p16_available(p, d) && (p16_worthwhile(p, d, causal) || S > 1));
+                     (scratch_ok && sel.kind == FA_KERNEL_AUTO && out_f32 && sel.variant == 0 && p16_available(p, d));
     const size_t part = (size_t)S * p.bh * p.n * d * 4u + (size_t)S * p.bh * p.n * 4u;
     if (p16) {
         pl.route = kRouteP16Chain;
@@ -953,7 +949,6 @@ const char* fa_kernel_name_for(int32_t dtype, int32_t d, int32_t causal, int64_t
         if (((n - 1) * d + d) * 2 >= 0xffffffffLL) return "fa_fwd_f32_split_kernel";
         const fa::FwdParams pk = make_params(nullptr, nullptr, nullptr, nullptr, nullptr, bh, n, d, 1.0f);
         if (keysplit_factor(pk, d, causal) > 1) return "fa_fwd_bf16_x2_p16x2_kernel";   // small grids: key-split launch of the NB = 2 kernel
-        if (!p16_worthwhile(pk, d, causal)) return "fa_fwd_f32_split_kernel";
         return (d == 64 && fa::bf16_p16_uses_x4(bh, n, causal)) ? "fa_fwd_bf16_x4_p16x2_kernel" : "fa_fwd_bf16_x2_p16x2_kernel";
     }
     return nullptr;

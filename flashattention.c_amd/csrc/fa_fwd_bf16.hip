@@ -563,7 +563,9 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
         case 64:
             switch (variant) {
                 case 1: return launch_cfg<64, 4, 1, 4, 3>(p, causal, out_f32, stream);   // phase-structured, 4 waves/SIMD
+#if FA_ABLATION
                 case 2: return launch_cfg<64, 4, 2, 2>(p, causal, out_f32, stream);   // phase-structured, 64 rows/wave
+#endif
                 case 7: return launch_bf16_pipelined(p, 64, 4, causal, out_f32, 0, stream);
                 case 24: return launch_bf16_pipelined(p, 64, 2, causal, out_f32, 0, stream);
 #if FA_ABLATION
@@ -615,7 +617,9 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
             if (variant == 53) return launch_bf16_x2(p, 128, causal, out_f32, 12, stream);
 #endif
             if (variant == 10) return launch_w4<128, 4, 2>(p, causal, out_f32, stream);
+#if FA_ABLATION
             if (variant == 23) return launch_w4<128, 4, 3>(p, causal, out_f32, stream);
+#endif
             if (variant == 1) return launch_cfg<128, 4, 1, 2>(p, causal, out_f32, stream);  // phase-structured (the pipelined kernel needs > 256 VGPRs at D = 128)
             return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;

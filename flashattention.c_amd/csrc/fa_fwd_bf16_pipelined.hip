@@ -523,12 +523,16 @@ hipError_t launch_bf16_pipelined(const FwdParams& p, int d, int nwaves, int caus
 #else
     if (mode == 1) return hipErrorInvalidValue;
 #endif
-    if (d == 64) {
-        if (nwaves == 2) return mode == 3 ? launch_pp3<64, 2, 1, false>(p, causal, out_f32, stream) : launch_pp3<64, 2, 1>(p, causal, out_f32, stream);
-        return mode == 3 ? launch_pp3<64, 4, 2, false>(p, causal, out_f32, stream) : launch_pp3<64, 4, 2>(p, causal, out_f32, stream);
-    }
-    if (nwaves == 2) return launch_pp3<32, 2, 1>(p, causal, out_f32, stream);
-    return mode == 3 ? launch_pp3<32, 4, 2, false>(p, causal, out_f32, stream) : launch_pp3<32, 4, 2>(p, causal, out_f32, stream);
+#if FA_ABLATION
+    // previous-generation and comparison tilings: two-wave workgroups, the lazily rescaled mix alone, head dim 32 (the NB = 2 kernel took it over)
+    if (d == 64 && nwaves == 2) return mode == 3 ? launch_pp3<64, 2, 1, false>(p, causal, out_f32, stream) : launch_pp3<64, 2, 1>(p, causal, out_f32, stream);
+    if (d == 64 && mode == 3) return launch_pp3<64, 4, 2, false>(p, causal, out_f32, stream);
+    if (d == 32 && nwaves == 2) return launch_pp3<32, 2, 1>(p, causal, out_f32, stream);
+    if (d == 32) return mode == 3 ? launch_pp3<32, 4, 2, false>(p, causal, out_f32, stream) : launch_pp3<32, 4, 2>(p, causal, out_f32, stream);
+#endif
+    // the product tiling: head dim 64, four-wave workgroups, optimistic mix first (the only one the dispatch reaches)
+    if (d != 64 || nwaves != 4 || mode != 0) return hipErrorInvalidValue;
+    return launch_pp3<64, 4, 2>(p, causal, out_f32, stream);
 }
 
 }  // namespace fa

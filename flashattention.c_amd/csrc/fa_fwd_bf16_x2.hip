@@ -5,8 +5,9 @@
 
 namespace fa {
 
-// d in {32, 64, 128}.  mode: 0 = product configuration (optimistic mix first, barrier every 2 stages), 1 = barrier every stage,
-// 3 = lazily rescaled mix only, 12 = timing-only ablation without the VALU units (D = 128; ablation library only)
+// d in {32, 64, 128}.  mode 0 = the product configuration (optimistic mix first with the lazily rescaled redo behind it, barrier every 2
+// stages) -- the only one in the product library.  Ablation library: 1 = barrier every stage, 3 = lazily rescaled mix only (the same code
+// the redo runs), 12 = timing-only ablation without the VALU units (D = 128), 40 = cycle stamps.
 hipError_t launch_bf16_x2(const FwdParams& p, int d, int causal, int out_f32, int mode, hipStream_t stream)
 {
     if (d != 32 && d != 64 && d != 128) return hipErrorInvalidValue;
@@ -21,18 +22,17 @@ hipError_t launch_bf16_x2(const FwdParams& p, int d, int causal, int out_f32, in
         return hipGetLastError();
     }
 #endif
-    if (d == 32) {
-        if (mode == 1) return launch_x2<32, 1>(p, causal, out_f32, stream);
-        if (mode == 3) return launch_x2<32, 2, false>(p, causal, out_f32, stream);
-        return launch_x2<32, 2>(p, causal, out_f32, stream);
-    }
-    if (d == 64) {
-        if (mode == 1) return launch_x2<64, 1>(p, causal, out_f32, stream);
-        if (mode == 3) return launch_x2<64, 2, false>(p, causal, out_f32, stream);
-        return launch_x2<64, 2>(p, causal, out_f32, stream);
-    }
-    if (mode == 1) return launch_x2<128, 1>(p, causal, out_f32, stream);
-    if (mode == 3) return launch_x2<128, 2, false>(p, causal, out_f32, stream);
+#if FA_ABLATION
+    if (d == 32 && mode == 1) return launch_x2<32, 1>(p, causal, out_f32, stream);
+    if (d == 32 && mode == 3) return launch_x2<32, 2, false>(p, causal, out_f32, stream);
+    if (d == 64 && mode == 1) return launch_x2<64, 1>(p, causal, out_f32, stream);
+    if (d == 64 && mode == 3) return launch_x2<64, 2, false>(p, causal, out_f32, stream);
+    if (d == 128 && mode == 1) return launch_x2<128, 1>(p, causal, out_f32, stream);
+    if (d == 128 && mode == 3) return launch_x2<128, 2, false>(p, causal, out_f32, stream);
+#endif
+    if (mode != 0 && mode != 12) return hipErrorInvalidValue;   // not a tiling of this library
+    if (d == 32) return launch_x2<32, 2>(p, causal, out_f32, stream);
+    if (d == 64) return launch_x2<64, 2>(p, causal, out_f32, stream);
 #if FA_ABLATION
     if (mode == 12) {
         FwdParams q;
@@ -41,6 +41,8 @@ hipError_t launch_bf16_x2(const FwdParams& p, int d, int causal, int out_f32, in
         hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<128, 4, false, false, 2, 2>), grid, block, 0, stream, q);
         return hipGetLastError();
     }
+#else
+    if (mode == 12) return hipErrorInvalidValue;
 #endif
     return launch_x2<128, 2>(p, causal, out_f32, stream);
 }

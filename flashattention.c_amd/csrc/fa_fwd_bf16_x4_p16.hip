@@ -1,17 +1,15 @@
 // fa_fwd_bf16_x4_p16.hip -- the fp16-P ("accurate") instantiations of the x4 kernel (fa_bf16_xn_kernel.h), D = 64: bf16 Q, K; P and V
 // in fp16 (v_mfma_f32_32x32x16_f16 for the second contraction), 11 significant bits of P instead of 8 -- the bf16 path that
-// meets the 1e-3 bar of the reference comparison (bench_flashattention.py:36-40,74) at scale 1.  Non-causal here, causal in
-// fa_fwd_bf16_x4_p16_causal.hip (parallel compilation).
+// meets the 1e-3 bar of the reference comparison (bench_flashattention.py:36-40,74) at scale 1.  Non-causal only: the dispatch
+// gives 512-row workgroups to non-causal grids only.
 #include "fa_bf16_xn_kernel.h"
 
 namespace fa {
 
-hipError_t launch_bf16_x4_p16_causal(const FwdParams& p, int out_f32, hipStream_t stream);
-
 hipError_t launch_bf16_x4_p16(const FwdParams& p, int causal, int out_f32, hipStream_t stream)
 {
     if (!bf16_pipelined_supported(p, 64)) return hipErrorInvalidValue;
-    if (causal) return launch_bf16_x4_p16_causal(p, out_f32, stream);
+    if (causal) return hipErrorInvalidValue;   // the dispatch gives 512-row workgroups to non-causal grids only (bf16_p16_uses_x4)
     return launch_x4_p16<false>(p, out_f32, stream);
 }
 

@@ -968,8 +968,10 @@ static hipError_t launch_split_modes(const FwdParams& p, int causal, int mode, h
         if (mode == 5) return launch_split<128, 8, 1, 1, false, IN_BF16>(p, causal, stream);   // 8 waves: 256-row workgroups
     } else {
         if (mode == 1) return launch_split<D, 4, 1, 2, false, IN_BF16>(p, causal, stream);
+#if FA_ABLATION
         if constexpr (!IN_BF16)
-            if (mode == 2) return launch_split<D, 4, 2, 1, false, false>(p, causal, stream);
+            if (mode == 2) return launch_split<D, 4, 2, 1, false, false>(p, causal, stream);   // two blocks per wave, not pipelined: superseded by mode 4
+#endif
         if (mode == 3) return launch_split<D, 4, 1, 2, true, IN_BF16>(p, causal, stream);
         if (mode == 4) return launch_split<D, 4, 2, 1, true, IN_BF16>(p, causal, stream);
     }

@@ -72,12 +72,12 @@ typedef enum fa_dtype {
     FA_DTYPE_BF16 = 1,        /* bf16 in, bf16 MFMA with fp32 accumulate and fp32 softmax, bf16 out     */
     FA_DTYPE_BF16_OUT_F32 = 2 /* bf16 in, O written as fp32 (the accumulator precision).  Under FA_KERNEL_AUTO this also selects
                                  the ACCURATE P: a caller who wants the fp32 accumulator gets P as two fp16 terms, hi + lo
-                                 (FA_KERNEL_P16X2: ~22 significant bits, <= 1e-4 of the fp32 reference at scale 1 on unit-variance
-                                 data where bf16 P shows ~5e-3) -- or, for launches below 1.2e10 multiply-adds per contraction (4e9 at
-                                 head dim 32; the fp16 path costs a copy of V and two extra launches, ~15 us), for slabs beyond
-                                 4 GiB and whenever scratch is not available, P and the scaled Q as hi + lo bf16 terms
-                                 (FA_KERNEL_SPLIT, ~1e-4).  A bf16 output rounds at 2^-9 |O| by itself and keeps the fastest
-                                 kernels (bf16 P). */
+                                 (FA_KERNEL_P16X2: ~22 significant bits, Q.K^T exact in the fp32 accumulator: <= 1e-4 of the fp32
+                                 reference at scale 1 on every data family tried, where bf16 P shows ~5e-3) at every launch size.
+                                 Only when there is no scratch (fa_forward / fa_forward_ex on a capturing stream) and for slabs
+                                 beyond 4 GiB it is P and the scaled Q as hi + lo bf16 terms instead (FA_KERNEL_SPLIT: 1 .. 2e-4
+                                 on unit-variance data, growing with the logit width).  A bf16 output rounds at 2^-9 |O| by itself
+                                 and keeps the fastest kernels (bf16 P). */
 } fa_dtype;
 
 typedef enum fa_kernel {

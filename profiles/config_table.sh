@@ -2,9 +2,11 @@
 # profiles/config_table.sh -- the per-config timing table of DESIGN.md §3 (C driver, steady clocks) and the README-shape
 # harness table.  Run on the GPU box: gpurun -- 'bash profiles/config_table.sh > gpurun_out/config_table.txt 2> gpurun_out/harness.txt'
 D=./flashattention.c_amd/fa_driver
+DA=./flashattention.c_amd/fa_driver_ablation    # tilings that are not in the product library (round 3: only what the dispatch reaches ships)
 W="--warmup 150 --iters 50 --check 0"
-echo "== c4 non-causal: dispatch(0)=x4 opt, 42=x4 rescaling, 7=pp3 opt, 25=pp3 rescaling"
-for v in 0 42 7 25; do $D --mode rand --bh 16 --n 8192 --d 64 --dtype bf16 $W --variant $v; done
+echo "== c4 non-causal: dispatch(0)=x4 opt, 7=pp3 opt; ablation library: 42=x4 rescaling mix only, 25=pp3 rescaling mix only"
+for v in 0 7; do $D --mode rand --bh 16 --n 8192 --d 64 --dtype bf16 $W --variant $v; done
+for v in 42 25; do $DA --mode rand --bh 16 --n 8192 --d 64 --dtype bf16 $W --variant $v; done
 echo "== bh=128"
 for v in 0 7; do $D --mode rand --bh 128 --n 8192 --d 64 --dtype bf16 --warmup 20 --iters 10 --check 0 --variant $v; done
 echo "== causal c4 / bh=128"
@@ -23,7 +25,23 @@ $D --mode rand --bh 16 --n 8192 --d 32 --dtype f32s --warmup 60 --iters 20 --che
 echo "== fp32 tensors, exact fp32 arithmetic: c3, c2"
 $D --mode rand --bh 16 --n 8192 --d 64 --dtype f32 --warmup 20 --iters 10 --check 0
 $D --mode rand --bh 128 --n 1024 --d 64 --dtype f32 --warmup 100 --iters 30 --check 0
-echo "== fp16-P (accurate) kernels: --kernel p16 --out_f32 1  (c4 at scale 1, 0.5, 1/sqrt(d); causal; bh=128; d=128; d=32; c2 shape)"
+echo "== two-term fp16-P kernels (FA_KERNEL_AUTO for an fp32 output): --kernel p16x2 --out_f32 1  (c4 at scale 1, 0.5, 1/sqrt(d); causal; bh=128; d=128; d=32; c2 shape)"
+P="--dtype bf16 --kernel p16x2 --out_f32 1 --warmup 100 --iters 30 --check 0"
+for sc in 1 0.5 0.125; do $D --mode rand --bh 16 --n 8192 --d 64 $P --scale $sc; done
+$D --mode rand --bh 16 --n 8192 --d 64 $P --causal 1
+$D --mode rand --bh 128 --n 8192 --d 64 $P --iters 10
+$D --mode rand --bh 16 --n 8192 --d 128 $P
+$D --mode rand --bh 16 --n 8192 --d 128 $P --causal 1
+$D --mode rand --bh 16 --n 8192 --d 32 $P
+$D --mode rand --bh 128 --n 1024 --d 64 $P
+echo "== hi + lo bf16 terms (--kernel split --out_f32 1): c4"
+$D --mode rand --bh 16 --n 8192 --d 64 --dtype bf16 --kernel split --out_f32 1 --warmup 100 --iters 30 --check 0
+echo "== key-split launches (grids that leave the chip idle): bf16 non-causal / causal BH = 1, 2, 4, 8; fp32 BH = 1, 2"
+K="--dtype bf16 --kernel auto --warmup 100 --iters 50 --check 0"
+for b in 1 2 4; do $D --mode rand --bh $b --n 8192 --d 64 $K; done
+for b in 1 2 4 8; do $D --mode rand --bh $b --n 8192 --d 64 $K --causal 1; done
+for b in 1 2; do $D --mode rand --bh $b --n 8192 --d 64 --dtype f32s --kernel auto --warmup 100 --iters 50 --check 0; done
+echo "== one-term fp16-P kernels (explicit only): --kernel p16 --out_f32 1  (c4 at scale 1, 0.5, 1/sqrt(d); causal; bh=128; d=128; d=32; c2 shape)"
 P="--dtype bf16 --kernel p16 --out_f32 1 --warmup 100 --iters 30 --check 0"
 for sc in 1 0.5 0.125; do $D --mode rand --bh 16 --n 8192 --d 64 $P --scale $sc; done
 $D --mode rand --bh 16 --n 8192 --d 64 $P --causal 1

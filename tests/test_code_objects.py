@@ -24,16 +24,66 @@ def kernels(tmp_path_factory):
 def test_no_kernel_of_the_product_library_uses_scratch(kernels):
     """private_segment_fixed_size == 0 for every kernel (FA_KERNEL_AUTO can pick any family): a spill inside an attention loop is
     an HBM round trip per step, and register pressure regressions show up here before they show up in a benchmark."""
-    assert len(kernels) > 100
+    assert len(kernels) > 60
     spilling = [f"{k.scratch} B: {k.name}" for k in kernels.values() if k.scratch != 0]
     assert not spilling, "\n".join(spilling)
 
 
 def test_every_kernel_family_the_dispatch_names_is_present(kernels):
     names = "\n".join(k.name for k in kernels.values())
-    for fam in ("fa_fwd_bf16_x4_kernel", "fa_fwd_bf16_x4_p16_kernel", "fa_fwd_bf16_x2_kernel", "fa_fwd_bf16_pp3_kernel", "fa_fwd_bf16_w4_kernel",
-                "fa_fwd_bf16_kernel", "fa_fwd_f32_split_kernel", "fa_fwd_f32_kernel", "fa_naive_f32_kernel", "fa_cvt_bf16_to_f16_kernel"):
+    for fam in ("fa_fwd_bf16_x4_kernel", "fa_fwd_bf16_x4_p16_kernel", "fa_fwd_bf16_x4_p16x2_kernel", "fa_fwd_bf16_x2_kernel", "fa_fwd_bf16_x2_p16_kernel",
+                "fa_fwd_bf16_x2_p16x2_kernel", "fa_fwd_bf16_pp3_kernel", "fa_fwd_bf16_w4_kernel", "fa_fwd_bf16_kernel", "fa_fwd_f32_split_kernel",
+                "fa_fwd_f32_kernel", "fa_naive_f32_kernel", "fa_cvt_bf16_to_f16_kernel", "fa_combine_splits_kernel"):
         assert fam + "<" in names or fam + "(" in names, fam
+
+
+def _family(name: str) -> str:
+    return re.sub(r"^void ", "", name).split("<")[0].split("(")[0].split("::")[-1]
+
+
+def test_every_kernel_of_the_product_library_is_reachable_or_documented(kernels):
+    """Round 2 shipped five bf16 families x 11 selectable tilings, several of them unreachable from FA_KERNEL_AUTO.  Now: every kernel
+    FAMILY in the product library is named by fa_kernel_name_for() for some (dtype, d, causal, bh, n) of a shape grid -- i.e. the
+    dispatch reaches it -- or is one of the few documented helpers / explicit choices of include/flashattn_amd.h; and within the
+    one-wave-per-SIMD families only the instantiations the dispatch launches are present (barrier every two stages, optimistic mix with
+    its redo; 512-row workgroups non-causal only)."""
+    from flashattention_c_amd import _cabi
+    L = _cabi.lib()
+    reachable = set()
+    for dtype in (_cabi.FA_DTYPE_F32, _cabi.FA_DTYPE_BF16, _cabi.FA_DTYPE_BF16_OUT_F32):
+        for d in (32, 64, 128):
+            for causal in (0, 1):
+                for bh in (1, 2, 3, 8, 12, 16, 24, 33, 64, 128, 130, 256, 1024, 70000):
+                    for n in (1, 31, 300, 700, 1024, 2048, 3000, 4096, 8192, 16384, 40000):
+                        nm = L.fa_kernel_name_for(dtype, d, causal, bh, n)
+                        assert nm is not None
+                        reachable.add(nm.decode())
+    documented = {
+        "fa_naive_f32_kernel",            # FA_KERNEL_NAIVE: rung 0, the on-device cross-check
+        "fa_fwd_f32_kernel",              # FA_KERNEL_MFMA for fp32 tensors and the guarded chain's fallback
+        "fa_cvt_bf16_to_f16_kernel",      # V -> fp16 copy of the fp16-P chains
+        "fa_combine_splits_kernel",       # combine of a key-split launch
+        "fa_fwd_bf16_x4_p16_kernel", "fa_fwd_bf16_x2_p16_kernel",   # FA_KERNEL_P16 (explicit only): one fp16 term of P
+        "fa_fwd_bf16_kernel", "fa_fwd_bf16_w4_kernel",              # slabs beyond 32-bit byte offsets / small d = 128 grids (phase-structured)
+    }
+    present = {_family(k.name) for k in kernels.values()}
+    stray = present - reachable - documented
+    assert not stray, f"kernel families neither reachable from FA_KERNEL_AUTO nor documented: {sorted(stray)}"
+    assert reachable <= present | {"fa_fwd_f32_kernel"}, sorted(reachable - present)
+    for k in kernels.values():
+        m = re.search(r"fa_fwd_bf16_x4(?:_p16|_p16x2)?_kernel<(.*?)>\(", k.name)
+        if m:   # <NWAVES, CAUSAL, OUT_F32, G, ...>: non-causal, barrier every two stages
+            a = m.group(1).split(", ")
+            assert a[1] == "false" and a[3] == "2", k.name
+        m = re.search(r"fa_fwd_bf16_x2_kernel<(.*?)>\(", k.name)
+        if m:   # <D, NWAVES, CAUSAL, OUT_F32, G, ABL, OPTIMISTIC>
+            a = m.group(1).split(", ")
+            assert a[4] == "2" and a[6] == "true", k.name
+        m = re.search(r"fa_fwd_bf16_pp3_kernel<(.*?)>\(", k.name)
+        if m:   # <D, NWAVES, CAUSAL, OUT_F32, PROF, G, OPTIMISTIC>
+            a = m.group(1).split(", ")
+            assert a[0] == "64" and a[1] == "4" and a[6] == "true", k.name
+    assert os.path.getsize(LIB) < 4 * 1024 * 1024, "the product library grew past 4 MB (it was 5.7 MB with every round-2 tiling in it)"
 
 
 def test_timing_only_ablations_are_not_in_the_product_library(kernels):
@@ -61,7 +111,7 @@ def test_asm_mfma_kernels_drain_the_matrix_pipe_before_reading_accumulators(kern
     dis_cache = {}
     checked = 0
     for k in kernels.values():
-        if not re.search(r"fa_fwd_bf16_x[24](_p16)?_kernel<", k.name):
+        if not re.search(r"fa_fwd_bf16_x[24](_p16|_p16x2)?_kernel<", k.name):
             continue
         dis = dis_cache.setdefault(k.code_object, codeobj.disassemble(k.code_object))
         i = dis.index("<" + k.mangled + ">:")
@@ -81,4 +131,4 @@ def test_asm_mfma_kernels_drain_the_matrix_pipe_before_reading_accumulators(kern
             wait += int(ins[1]) + 1 if op == "s_nop" else 1
         assert reads > 0 and worst is not None and worst >= 18, f"{k.name}: {worst} wait states between an MFMA and an accumulator read"
         checked += 1
-    assert checked >= 40
+    assert checked >= 36

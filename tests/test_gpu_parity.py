@@ -9,8 +9,8 @@ Tolerances (max-abs, stated once here; BASELINE.md section 4 gives the arithmeti
                                                       rounding of the dominant P); max|v| ~ 5.4 over 8M randn -> 1.05e-2; observed <= 9.0e-3
   bf16 kernel, bf16 out                         2.5e-2 adds half a bf16 ulp of |O| (|O| < 4 -> 7.8e-3); observed <= 1.5e-2
   bf16 tensors, fp32 out, ACCURATE P            1e-3  north_star bar at scale 1, held with a wide margin: FA_KERNEL_AUTO with an fp32 output = P as fp16
-                                                      hi + fp16 lo (kernel="p16x2": ~22 significant bits; observed <= 3e-5) or, for small launches, hi +
-                                                      lo bf16 terms (kernel="split": 1 .. 2e-4).  TOL_ACC = 5e-4 is asserted where either can be running, TOL_P16X2 = 1e-4 for the first.
+                                                      hi + fp16 lo (kernel="p16x2": ~22 significant bits; observed <= 4e-5 on the BASELINE configs) at every launch size; hi + lo
+                                                      bf16 terms (kernel="split": 1 .. 2e-4) only without scratch.  TOL_P16X2 = 2e-4 for the first, TOL_ACC = 5e-4 where the second may run.
   bf16 tensors, kernel="p16" (ONE fp16 term)    1e-3 / 1.5e-3  explicit choice only, never AUTO.  11 significant bits; the worst rows have two comparable
                                                       dominant keys with distant V rows: |err| <= 0.25 * 2^-10 * |v1 - v2|, and the maximum over the
                                                       launch grows with the number of outputs: observed 6.7e-4 .. 8.4e-4 on one N = 8192 slab, 8.4e-4 /
@@ -35,9 +35,13 @@ from tests.conftest import GOLDEN_DIR, golden_cases
 pytestmark = pytest.mark.gpu
 
 TOL_F32 = 1e-3
-TOL_ACC = 5e-4         # the accurate P of FA_KERNEL_AUTO for bf16 tensors with an fp32 output, whichever kernel the launch size picks: two
-                       # fp16 terms (observed <= 6e-5) or hi + lo bf16 terms of P and Q' (the split kernel: observed <= 2.1e-4 at d = 128)
-TOL_P16X2 = 1e-4       # kernel="p16x2" (and FA_KERNEL_AUTO at sizes that take it): two fp16 terms of P
+TOL_ACC = 5e-4         # bf16 tensors, fp32 output, when hi + lo bf16 terms of P and Q' (the split kernel: observed <= 2.1e-4 at d = 128 on
+                       # unit-variance data) may have produced it: no scratch (capturing stream without a workspace), the chain's fallback
+TOL_P16X2 = 2e-4       # kernel="p16x2" = FA_KERNEL_AUTO with an fp32 output whenever scratch is available: two fp16 terms of P.  Observed: <= 4e-5
+                       # on every BASELINE config (scale 1, N <= 8192), <= 1e-4 over 2 000 soak launches of hostile data -- except long flat rows
+                       # (N = 16 384 at scale 0.5: 1.3e-4 against the fp64 oracle, where hi + lo bf16 terms read 5e-5 and fp32 arithmetic 1.4e-5):
+                       # most of such a row's weight sits 2^-10 .. 2^-20 below its maximum, and below 2^-14 of the exponent reference fp16 is
+                       # subnormal in BOTH terms (absolute precision 2^-25).  Five times inside the 1e-3 bar.
 P16_TOL_BIG = 1.5e-3   # kernel="p16" ONLY (one fp16 term): unscaled logits, more than 16 slabs of N = 8192 (see the header)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -152,9 +156,10 @@ def test_fp32_vs_oracle(bh, n, d, causal, kernel):
     check(o, ref, TOL_F32)
 
 
-# every tiling of the split kernel: 1 / 2 = one / two 32-row blocks per wave (first-tile reference), 3 / 4 = the software-
-# pipelined reference-free pass; ragged length (700 = 21 tiles + 28 keys), both scales, LSE as well
-@pytest.mark.parametrize("d,mode", [(64, 1), (64, 2), (64, 3), (64, 4), (128, 1), (128, 3), (128, 5), (32, 1), (32, 2), (32, 3), (32, 4)])
+# every shipped tiling of the split kernel (the ones choose_split() reaches): 1 = one 32-row block per wave (first-tile reference), 3 / 4 =
+# the software-pipelined reference-free pass with one / two blocks per wave, 5 = eight waves at d = 128; ragged length (700 = 21 tiles
+# + 28 keys), both scales, LSE as well
+@pytest.mark.parametrize("d,mode", [(64, 1), (64, 3), (64, 4), (128, 1), (128, 3), (128, 5), (32, 1), (32, 3), (32, 4)])
 @pytest.mark.parametrize("causal", [False, True])
 def test_split_kernel_tilings(d, mode, causal):
     q, k, v = (randn(s, 2, 700, d) for s in (1, 2, 3))
@@ -169,7 +174,7 @@ def test_split_kernel_tilings(d, mode, causal):
     check(fa.forward(*to_dev(qb, kb, vb), causal, scale=0.125, kernel=f"split:{mode}"), ref, 2e-5, "bf16-valued inputs")
 
 
-@pytest.mark.parametrize("d,mode", [(64, 0), (64, 2), (64, 3), (64, 4), (128, 0), (128, 1), (128, 3), (128, 5), (32, 0), (32, 1), (32, 3), (32, 4), (64, 1)])
+@pytest.mark.parametrize("d,mode", [(64, 0), (64, 3), (64, 4), (128, 0), (128, 1), (128, 3), (128, 5), (32, 0), (32, 1), (32, 3), (32, 4), (64, 1)])
 @pytest.mark.parametrize("causal", [False, True])
 def test_split_kernel_redo_outside_the_optimistic_range(d, mode, causal):
     """Rows whose scores leave the range the optimistic pass can prove (exp2-domain row sums outside 2^-100 .. 2^100, or a
@@ -198,17 +203,21 @@ def test_bf16_vs_oracle(bh, n, d, causal, scale):
     qd, kd, vd = to_dev(q, k, v, dtype=torch.bfloat16)
     check(fa.forward(qd, kd, vd, causal, scale=scale, out_dtype=torch.float32, kernel="mfma"), ref, bf16_tol(scale, True, causal, n), "f32-out, bf16 P")
     check(fa.forward(qd, kd, vd, causal, scale=scale), ref, bf16_tol(scale, False), "bf16-out")
-    # FA_KERNEL_AUTO with an fp32 output: the accurate P (fp16 at d = 64, hi + lo bf16 terms at d = 32 / 128) -- the fp32 bar
-    check(fa.forward(qd, kd, vd, causal, scale=scale, out_dtype=torch.float32), ref, TOL_F32, "f32-out, auto (accurate P)")
+    # FA_KERNEL_AUTO with an fp32 output: the accurate P (two fp16 terms) -- the fp32 bar with a decade to spare
+    check(fa.forward(qd, kd, vd, causal, scale=scale, out_dtype=torch.float32), ref, TOL_P16X2, "f32-out, auto (accurate P)")
 
 
-# 0 = product dispatch, 1 = phase-structured kernel, 7 / 24 = pipelined kernel with 4- / 2-wave workgroups (optimistic mix with
-# verified redo), 25 / 26 = the same with the lazily rescaled mix only, 30 / 31 = one-wave-per-SIMD 128-rows-per-wave kernel
-# (barrier every 2 / every stage), 42 = that kernel with the lazily rescaled mix only, 50 / 51 / 52 = one-wave-per-SIMD kernel
-# with 64 rows per wave (optimistic, barrier every 2 / every stage; rescaled mix only)
-@pytest.mark.parametrize("variant", [0, 1, 7, 24, 25, 26, 30, 31, 42, 50, 51, 52])
+# The tilings of the product library = the ones FA_KERNEL_AUTO reaches for some shape: 0 = product dispatch, 1 = phase-structured kernel,
+# 7 = two-wave pipelined kernel (4-wave workgroups), 30 = one-wave-per-SIMD kernel with 128 rows per wave (non-causal grids only), 50 =
+# the same with 64 rows per wave.  Everything else round 2 shipped (2-wave workgroups 24, rescaled-mix-only forms 25 / 26 / 42 / 52,
+# barrier-every-stage forms 31 / 51, the causal NB = 4 instantiations) lives in the ablation library: test_ablation_library_tilings.
+@pytest.mark.parametrize("variant", [0, 1, 7, 30, 50])
 @pytest.mark.parametrize("causal", [False, True])
 def test_bf16_tiling_variants_agree(variant, causal):
+    if variant == 30 and causal:
+        with pytest.raises(_cabi.FlashAttnError):   # 512-row workgroups are a non-causal tiling
+            fa.forward(*to_dev(*(orc.round_to_bf16(randn(s, 3, 700, 64)) for s in (7, 8, 9)), dtype=torch.bfloat16), True, kernel="mfma:30")
+        return
     q, k, v = (orc.round_to_bf16(randn(s, 3, 700, 64)) for s in (7, 8, 9))
     ref = orc.attention_f64(q, k, v, causal=causal, scale=0.125)
     qd, kd, vd = to_dev(q, k, v, dtype=torch.bfloat16)
@@ -282,7 +291,7 @@ def test_dominant_key_in_the_last_keys(n, out_f32):
 
 # d = 128: 0 = product dispatch (too few workgroups here: phase-structured kernels), 10 = 4-waves/SIMD diet kernel, 50 / 51 =
 # one-wave-per-SIMD kernel (optimistic mix with verified redo; barrier every 2 / every stage), 52 = its lazily rescaled mix only
-@pytest.mark.parametrize("variant", [0, 10, 50, 51, 52])
+@pytest.mark.parametrize("variant", [0, 1, 10, 50])
 @pytest.mark.parametrize("causal", [False, True])
 def test_bf16_d128_tiling_variants_agree(variant, causal):
     _tiling_variant_case(128, variant, causal)
@@ -290,7 +299,7 @@ def test_bf16_d128_tiling_variants_agree(variant, causal):
 
 # d = 32: 0 = product dispatch (one-wave-per-SIMD kernel), 1 = phase-structured, 7 / 24 = pipelined two-wave kernel, 50 / 52 =
 # one-wave-per-SIMD kernel (optimistic / lazily rescaled mix)
-@pytest.mark.parametrize("variant", [0, 1, 7, 24, 50, 52])
+@pytest.mark.parametrize("variant", [0, 1, 50])
 @pytest.mark.parametrize("causal", [False, True])
 def test_bf16_d32_tiling_variants_agree(variant, causal):
     _tiling_variant_case(32, variant, causal)
@@ -305,16 +314,17 @@ def _tiling_variant_case(d, variant, causal):
     check(fa.forward(qd, kd, vd, causal, scale=0.125, kernel=f"mfma:{variant}"), ref, bf16_tol(0.125, False))
 
 
-@pytest.mark.parametrize("d,variant", [(64, 0), (64, 7), (64, 24), (64, 25), (64, 26), (64, 30), (64, 42), (64, 50), (64, 52), (128, 50), (128, 52),
-                                       (32, 50), (32, 52), (32, 7)])
+@pytest.mark.parametrize("d,variant", [(64, 0), (64, 1), (64, 7), (64, 30), (64, 50), (128, 50), (128, 10), (32, 50), (32, 1)])
 @pytest.mark.parametrize("causal", [False, True])
 def test_rescale_inside_the_pipelined_loop(d, variant, causal):
     """Keys that outgrow a row's first-sub-tile maximum by 2^140 .. 2^230, placed in the middle of the sequence.  Lazily
-    rescaled mix (variants 25, 26, 42 and every redo): the rare rescale branch of the software-pipelined main loop has
+    rescaled mix (every redo of a tile whose optimistic attempt failed its verification): the rare rescale branch of the software-pipelined main loop has
     to fire, for single rows, for a whole 32-row block and for neighbouring blocks of one wave, and everything already
     accumulated at the old reference has to be scaled exactly once.  Optimistic mix: growth below 2^200 must come out
     right without any rescale (the LSE exposes a clamped or saturated P that O / l would hide), growth above it must
     fail the end-of-tile verification and be redone."""
+    if variant == 30 and causal:
+        pytest.skip("512-row workgroups are a non-causal tiling")
     bh, n = 2, 1536
     q, k, v = (randn(s, bh, n, d) for s in (41, 42, 43))
     q *= np.sqrt(64.0 / d)                         # |q| ~ 8 at either head dim (the gains below are tuned to that)
@@ -353,10 +363,10 @@ def test_fuzz_shapes_through_the_dispatch_against_rung0():
         acc = fa.forward(q, k, v, causal, scale=scale, out_dtype=torch.float32)                    # auto: the accurate P
         err_a = float((acc - ref).abs().max())
         worst_acc = max(worst_acc, err_a)
-        # two fp16 terms of P (large launches) or hi + lo bf16 terms (small ones): the fp32 bar with margin at every scale
-        assert err_a < TOL_ACC, f"accurate P: case {case} bh={bh} n={n} d={d} causal={causal} scale={scale}: {err_a:.3e}"
+        # two fp16 terms of P at every launch size: the fp32 bar with a decade to spare at every scale
+        assert err_a < TOL_P16X2, f"accurate P: case {case} bh={bh} n={n} d={d} causal={causal} scale={scale}: {err_a:.3e}"
     OBSERVED.append(("fuzz through dispatch, worst of 48", worst, bf16_tol(1.0, True)))
-    OBSERVED.append(("fuzz through dispatch, accurate P, worst of 48", worst_acc, TOL_ACC))
+    OBSERVED.append(("fuzz through dispatch, accurate P, worst of 48", worst_acc, TOL_P16X2))
 
 
 # bf16 tensors through the split machinery (kernel="split"): K and V are exact in one bf16 term, Q*scale*log2e and P are carried
@@ -510,7 +520,7 @@ def test_key_split_launch_for_grids_that_leave_the_chip_idle(bh, n, d):
         assert float((lse - lse_ref).abs().max()) < 2e-2
     # FA_KERNEL_AUTO with an fp32 output: the fp16-P chain (two terms), key-split (V copy -> S partial launches -> combine -> empty
     # fallback); kernel="p16": the same chain with one term
-    for kern, tol_k, tol_lse in (("auto", TOL_ACC, 1e-4), ("p16", P16_TOL_BIG, 2e-3)):
+    for kern, tol_k, tol_lse in (("auto", TOL_P16X2, 1e-4), ("p16", P16_TOL_BIG, 2e-3)):
         oa, lsea = fa.forward(qd, kd, vd, False, out_dtype=torch.float32, return_lse=True, kernel=kern)
         assert fa.last_forward_route() == 1
         erra = float((oa - ref_dev).abs().max())
@@ -790,8 +800,7 @@ def test_p16_falls_back_when_v_does_not_fit_fp16():
     qd, kd, vd = to_dev(q, k, v, dtype=torch.bfloat16)
     for kern in ("p16", "p16x2", "auto"):
         o = fa.forward(qd, kd, vd, False, scale=0.125, out_dtype=torch.float32, kernel=kern)
-        if kern != "auto":       # (auto takes the split kernel directly at this size: route 0)
-            assert fa.last_forward_route() == 2
+        assert fa.last_forward_route() == 2
         got = o.cpu().numpy().astype(np.float64)
         assert np.isfinite(got).all()
         rel = np.abs(got - ref).max() / np.abs(ref).max()
@@ -802,7 +811,7 @@ def test_p16_falls_back_when_v_does_not_fit_fp16():
     for kern in ("p16", "p16x2"):
         o = fa.forward(qd, kd, to_dev(v, dtype=torch.bfloat16)[0], False, scale=0.125, out_dtype=torch.float32, kernel=kern)
         assert fa.last_forward_route() == 1
-        check(o, orc.attention_f64(q, k, v, scale=0.125), TOL_F32 if kern == "p16" else TOL_ACC)
+        check(o, orc.attention_f64(q, k, v, scale=0.125), TOL_F32 if kern == "p16" else TOL_P16X2)
 
 
 def test_scratch_paths_under_graph_capture_through_the_workspace_entry():
@@ -815,8 +824,8 @@ def test_scratch_paths_under_graph_capture_through_the_workspace_entry():
     o = torch.zeros(q.shape, dtype=torch.float32, device=dev())
     torch.cuda.synchronize()
     ms_stream = fa.time_forward(q, k, v, False, warmup=1, iters=3, out=o)                  # two-term fp16-P chain on the stream
-    assert fa.last_forward_route() == 1 and float((o - ref).abs().max()) < TOL_ACC
-    for kern, tol in (("auto", TOL_ACC), ("p16x2", TOL_ACC), ("p16", P16_TOL_BIG)):
+    assert fa.last_forward_route() == 1 and float((o - ref).abs().max()) < TOL_P16X2
+    for kern, tol in (("auto", TOL_P16X2), ("p16x2", TOL_P16X2), ("p16", P16_TOL_BIG)):
         for iters in (1, 4):
             o.zero_()
             torch.cuda.synchronize()
@@ -828,7 +837,7 @@ def test_scratch_paths_under_graph_capture_through_the_workspace_entry():
             assert err < tol, (kern, iters, err)
     # BH = 1: the key-split launch (8 key shares + combine), bf16-P and inside the fp16-P chain
     q1, k1, v1 = q[:1], k[:1], v[:1]
-    for odt, kern, tol in ((torch.bfloat16, "auto", bf16_tol(1.0, False)), (torch.float32, "auto", TOL_ACC), (torch.float32, "mfma", bf16_tol(1.0, True))):
+    for odt, kern, tol in ((torch.bfloat16, "auto", bf16_tol(1.0, False)), (torch.float32, "auto", TOL_P16X2), (torch.float32, "mfma", bf16_tol(1.0, True))):
         for iters in (1, 4):
             o1 = torch.zeros(q1.shape, dtype=odt, device=dev())
             torch.cuda.synchronize()
@@ -860,7 +869,7 @@ def test_workspace_sizes_and_validation_of_the_non_allocating_entry():
     assert L.fa_forward_ws(q.data_ptr(), k.data_ptr(), v.data_ptr(), ob.data_ptr(), None, 16, 4096, 64, 1.0, 0, _cabi.FA_DTYPE_BF16, _cabi.FA_KERNEL_AUTO, None, 0, s) == 0
     torch.cuda.synchronize()
     ref = fa.forward(q.float(), k.float(), v.float(), False, kernel="naive")
-    assert float((o - ref).abs().max()) < TOL_ACC and float((ob.float() - ref).abs().max()) < bf16_tol(1.0, False)
+    assert float((o - ref).abs().max()) < TOL_P16X2 and float((ob.float() - ref).abs().max()) < bf16_tol(1.0, False)
     # the python wrapper with a caller-owned workspace tensor
     o2 = fa.forward(q, k, v, False, out_dtype=torch.float32, workspace=ws)
     assert torch.equal(o2, o)
@@ -892,7 +901,7 @@ def test_torch_graph_capture_of_the_accurate_path_and_independent_replays():
     out.zero_()
     g.replay()
     assert fa.last_forward_route() == 1
-    assert float((out - ref).abs().max()) < TOL_ACC
+    assert float((out - ref).abs().max()) < TOL_P16X2
     vbuf.copy_(vbig)
     g.replay()
     assert fa.last_forward_route() == 2
@@ -979,8 +988,8 @@ def test_scratch_paths_on_concurrent_streams():
     for o1, o2, o3, o4 in outs:
         assert float((o1.float() - refa).abs().max()) < bf16_tol(1.0, False)
         assert float((o4.float() - refa).abs().max()) < bf16_tol(1.0, False)
-        assert float((o3 - refa).abs().max()) < TOL_ACC
-        assert float((o2 - refb).abs().max()) < TOL_ACC
+        assert float((o3 - refa).abs().max()) < TOL_P16X2
+        assert float((o2 - refb).abs().max()) < TOL_P16X2
 
 
 def test_guarded_fp32_chain_survives_graph_capture_and_other_streams():
@@ -1016,15 +1025,20 @@ def test_guarded_fp32_chain_survives_graph_capture_and_other_streams():
     assert float((o2 - fa.forward(q, kw, v, False, kernel="exact")).abs().max()) < 1e-4
 
 
-def test_auto_picks_fp16_p_or_hi_lo_terms_by_launch_size():
-    """FA_KERNEL_AUTO for bf16 tensors with an fp32 output: P as two fp16 terms from 1.2e10 multiply-adds per contraction on (a launch
-    chain: route 1), hi + lo bf16 terms below (a single launch: route 0) -- both inside the fp32 bar with margin."""
-    for bh, n, want in ((16, 1024, 0), (32, 2048, 0), (64, 2048, 1)):
-        q, k, v = (torch.randn(bh, n, 64, generator=torch.Generator().manual_seed(5)).bfloat16().to(dev()) for _ in range(3))
-        o = fa.forward(q, k, v, False, out_dtype=torch.float32)
-        assert fa.last_forward_route() == want, (bh, n)
-        ref = fa.forward(q.float(), k.float(), v.float(), False, kernel="naive")
-        assert float((o - ref).abs().max()) < TOL_ACC
+def test_auto_takes_the_two_term_fp16_chain_at_every_launch_size():
+    """FA_KERNEL_AUTO for bf16 tensors with an fp32 output: P as two fp16 terms (a launch chain: route 1) whatever the size -- the kernel
+    whose error does not depend on the logit width (Q.K^T of bf16 operands is exact in the fp32 accumulator).  x3 logits, the family on
+    which the hi + lo bf16 split kernel (16-bit Q') read 6.5e-4 in the round-3 soak, stay below 1e-4."""
+    for bh, n, d in ((16, 1024, 64), (32, 2048, 64), (64, 2048, 64), (4, 300, 32), (6, 3691, 128)):
+        q, k, v = (torch.randn(bh, n, d, generator=torch.Generator().manual_seed(5)) for _ in range(3))
+        q = q * 3.0
+        q, k, v = (t.bfloat16().to(dev()) for t in (q, k, v))
+        o = fa.forward(q, k, v, True, out_dtype=torch.float32)
+        assert fa.last_forward_route() == 1, (bh, n, d)
+        ref = fa.forward(q.float(), k.float(), v.float(), True, kernel="naive")
+        err = float((o - ref).abs().max())
+        OBSERVED.append((f"auto, fp32 out, x3 logits bh={bh} n={n} d={d}", err, TOL_P16X2))
+        assert err < TOL_P16X2, (bh, n, d, err)
 
 
 @pytest.mark.parametrize("name,bh,n,d", [("c4", 16, 8192, 64), ("c5-shard", 128, 8192, 64), ("d128", 16, 8192, 128), ("d32", 16, 8192, 32)])
@@ -1129,12 +1143,27 @@ def test_output_aliasing_an_input_is_rejected():
 def test_ablation_tilings_are_not_in_the_product_library():
     """Timing-only instantiations (garbage results by design) live in libflashattn_amd_ablation.so; the product ABI rejects them."""
     q, k, v = to_dev(*(orc.round_to_bf16(randn(s, 2, 1024, 64)) for s in (84, 85, 86)), dtype=torch.bfloat16)
-    for variant in (33, 34, 35, 39, 45, 22, 9, 6, 11, 99):
+    for variant in (33, 34, 35, 39, 45, 22, 9, 6, 11, 99, 24, 25, 26, 31, 42, 51, 52, 2):
         with pytest.raises(_cabi.FlashAttnError) as ei:
             fa.forward(q, k, v, False, kernel=f"mfma:{variant}")
         assert ei.value.code == 2, variant
     with pytest.raises(_cabi.FlashAttnError):
+        fa.forward(q.float(), k.float(), v.float(), False, kernel="split:2")
+    with pytest.raises(_cabi.FlashAttnError):
         fa.forward(*to_dev(*(orc.round_to_bf16(randn(s, 2, 512, 128)) for s in (84, 85, 86)), dtype=torch.bfloat16), False, kernel="mfma:53")
+
+
+@pytest.mark.parametrize("variant,causal", [(24, 0), (24, 1), (25, 0), (26, 1), (30, 1), (31, 0), (42, 0), (42, 1), (51, 1), (52, 0), (52, 1)])
+def test_ablation_library_tilings(variant, causal):
+    """The tilings round 3 moved out of the product library (unreachable from FA_KERNEL_AUTO) still compute the same function: the
+    ablation driver runs them against the rung-0 kernel on the device."""
+    import json
+    drv = os.path.join(ROOT, "flashattention.c_amd", "fa_driver_ablation")
+    r = subprocess.run([drv, "--mode", "rand", "--bh", "3", "--n", "1300", "--d", "64", "--dtype", "bf16", "--variant", str(variant), "--causal", str(causal),
+                        "--scale", "0.125", "--out_f32", "1", "--iters", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["nan"] == 0 and 0.0 <= line["max_abs_err_vs_naive"] < 4e-3, line
 
 
 def test_sharded_entry_point_noncontiguous_shards_and_every_visible_device(monkeypatch):

@@ -40,10 +40,11 @@ def test_library_exports_every_declared_symbol():
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 32, 0, 16, 8192) == b"fa_fwd_bf16_x2_p16x2_kernel"
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 1, 8192) == b"fa_fwd_bf16_x2_p16x2_kernel"   # idle grid: key-split inside the chain
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, 0, 1, 8192) == b"fa_fwd_bf16_x2_kernel"                 # idle grid: key-split launch
-    # ... and hi + lo bf16 terms for launches too small to amortise the fp16 path's V copy and extra launches
-    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 32, 0, 4, 300) == b"fa_fwd_f32_split_kernel"
-    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 16, 1024) == b"fa_fwd_f32_split_kernel"
-    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 1, 128, 1024) == b"fa_fwd_f32_split_kernel"
+    # ... at every launch size (round 2 sent small launches to the hi + lo bf16 split kernel, whose 16-bit Q' is not data-independent)
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 32, 0, 4, 300) == b"fa_fwd_bf16_x2_p16x2_kernel"
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 16, 1024) == b"fa_fwd_bf16_x2_p16x2_kernel"
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 1, 128, 1024) == b"fa_fwd_bf16_x2_p16x2_kernel"
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 128, 0, 2, 1 << 24) == b"fa_fwd_f32_split_kernel"    # a 4 GiB slab: beyond 32-bit byte offsets
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 128, 2048) == b"fa_fwd_bf16_x2_p16x2_kernel"   # more than one round of 512-row tiles: NB = 2, two per CU
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 16, 8192) == b"fa_fwd_bf16_x4_p16x2_kernel"    # c4: one full round of NB = 4
 
@@ -75,7 +76,7 @@ def test_workspace_sizes_are_host_arithmetic():
     assert L.fa_workspace_bytes(16, 8192, 64, 0, B16, A) == 0                       # c4, bf16 output: one launch
     assert L.fa_workspace_bytes(16, 8192, 64, 0, B16F, A) == 256 + 16 * 8192 * 64 * 2   # c4, fp32 output: the fp16 copy of V behind the header
     assert L.fa_workspace_bytes(16, 8192, 64, 1, B16F, A) == 256 + 16 * 8192 * 64 * 2
-    assert L.fa_workspace_bytes(16, 1024, 64, 0, B16F, A) == 0                      # small launch: hi + lo bf16 terms, no scratch
+    assert L.fa_workspace_bytes(16, 1024, 64, 0, B16F, A) == 256 + 16 * 1024 * 64 * 2   # small launches too: the data-independent kernel
     assert L.fa_workspace_bytes(128, 8192, 64, 0, B16F, A) == 256 + 128 * 8192 * 64 * 2   # c5's per-GPU shard
     part = lambda S, bh, n, d: S * bh * n * d * 4 + S * bh * n * 4
     assert L.fa_workspace_bytes(1, 8192, 64, 0, B16, A) == 256 + part(8, 1, 8192, 64)         # idle grid: key-split partials
