@@ -32,7 +32,7 @@ DRIVER_PATH = os.path.join(PKG_DIR, "fa_driver")
 ARCH = "gfx950"
 
 # longest translation units first: the thread pool starts them in this order
-LIB_SOURCES = ["fa_fwd_bf16_x4_p16x2.hip", "fa_fwd_bf16_x4.hip", "fa_fwd_bf16_x2.hip",
+LIB_SOURCES = ["fa_fwd_bf16_x4.hip", "fa_fwd_bf16_x2.hip",
                "fa_fwd_bf16_pipelined.hip", "fa_split_f32_d64.hip", "fa_split_f32_d128.hip", "fa_split_f32_d32.hip",
                "fa_split_bf16_d64.hip", "fa_split_bf16_d128.hip", "fa_split_bf16_d32.hip", "fa_fwd_bf16.hip",
                "fa_fwd_bf16_x4_p16.hip", "fa_fwd_bf16_x2_p16_d128.hip", "fa_fwd_bf16_x2_p16_d64.hip",

@@ -949,7 +949,7 @@ const char* fa_kernel_name_for(int32_t dtype, int32_t d, int32_t causal, int64_t
         if (((n - 1) * d + d) * 2 >= 0xffffffffLL) return "fa_fwd_f32_split_kernel";
         const fa::FwdParams pk = make_params(nullptr, nullptr, nullptr, nullptr, nullptr, bh, n, d, 1.0f);
         if (keysplit_factor(pk, d, causal) > 1) return "fa_fwd_bf16_x2_p16x2_kernel";   // small grids: key-split launch of the NB = 2 kernel
-        return (d == 64 && fa::bf16_p16_uses_x4(bh, n, causal)) ? "fa_fwd_bf16_x4_p16x2_kernel" : "fa_fwd_bf16_x2_p16x2_kernel";
+        return "fa_fwd_bf16_x2_p16x2_kernel";
     }
     return nullptr;
 }

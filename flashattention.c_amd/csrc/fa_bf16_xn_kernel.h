@@ -958,7 +958,8 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x2_kernel(FwdPar
 
 // The accurate modes: P and V in fp16, lazily rescaled mix only (XSoft<false, PF>).  PF = 1: one fp16 term of P, 11 significant bits
 // instead of bf16's 8 ("p16": ~1e-3 of the fp32 reference at scale 1, not guaranteed inside it for large launches).  PF = 2: hi + lo
-// fp16 terms ("p16x2": ~22 bits, the kernel FA_KERNEL_AUTO gives a caller who asks for the fp32 accumulator).  p.v points at the fp16
+// fp16 terms ("p16x2": ~22 bits, the kernel FA_KERNEL_AUTO gives a caller who asks for the fp32 accumulator; NB = 2 only, see
+// launch_bf16_p16x2 -- the NB = 4 form was built, measured 6 % behind and dropped).  p.v points at the fp16
 // copy of V made by launch_cvt_v_f16 (fa_cvt.hip), whose overflow flag these kernels honour (FwdParams::flag_mode = 1).
 template <int NWAVES, bool CAUSAL, bool OUT_F32, int G>
 __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_p16_kernel(FwdParams p)
@@ -966,13 +967,6 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_p16_kernel(Fw
     __shared__ __attribute__((aligned(1024))) char smem[4 * G * Bf16Cfg<64, NWAVES>::kTileBytes];
     if (flag_says_skip(p)) return;
     (void)xn_tile<64, 4, NWAVES, CAUSAL, OUT_F32, G, 0, false, 1>(p, smem);
-}
-template <int NWAVES, bool CAUSAL, bool OUT_F32, int G>
-__global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_p16x2_kernel(FwdParams p)
-{
-    __shared__ __attribute__((aligned(1024))) char smem[4 * G * Bf16Cfg<64, NWAVES>::kTileBytes];
-    if (flag_says_skip(p)) return;
-    (void)xn_tile<64, 4, NWAVES, CAUSAL, OUT_F32, G, 0, false, 2>(p, smem);
 }
 // Causal launches rely on one workgroup per CU (heavy tiles first, light ones behind them on the same CU): when the allocation
 // happens to leave room for a second wave per SIMD the hardware co-schedules two heavy tiles and the launch gets 20-30 % slower
@@ -1032,23 +1026,16 @@ static hipError_t launch_x4_modes(const FwdParams& p, int out_f32, int mode, hip
     return launch_x4<2, true, CAUSAL>(p, out_f32, stream);
 }
 
-template <bool CAUSAL, int PF = 1>
+template <bool CAUSAL>
 static hipError_t launch_x4_p16(const FwdParams& p0, int out_f32, hipStream_t stream)
 {
     FwdParams p;
     dim3 grid, block;
     if (!xn_grid<4>(p0, p, grid, block)) return hipErrorInvalidValue;
-    if constexpr (PF == 2) {
-        if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_x4_p16x2_kernel<4, CAUSAL, true, 2>), grid, block, 0, stream, p);
-        else
-            hipLaunchKernelGGL((fa_fwd_bf16_x4_p16x2_kernel<4, CAUSAL, false, 2>), grid, block, 0, stream, p);
-    } else {
-        if (out_f32)
-            hipLaunchKernelGGL((fa_fwd_bf16_x4_p16_kernel<4, CAUSAL, true, 2>), grid, block, 0, stream, p);
-        else
-            hipLaunchKernelGGL((fa_fwd_bf16_x4_p16_kernel<4, CAUSAL, false, 2>), grid, block, 0, stream, p);
-    }
+    if (out_f32)
+        hipLaunchKernelGGL((fa_fwd_bf16_x4_p16_kernel<4, CAUSAL, true, 2>), grid, block, 0, stream, p);
+    else
+        hipLaunchKernelGGL((fa_fwd_bf16_x4_p16_kernel<4, CAUSAL, false, 2>), grid, block, 0, stream, p);
     return hipGetLastError();
 }
 

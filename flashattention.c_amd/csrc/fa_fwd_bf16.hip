@@ -522,12 +522,15 @@ hipError_t launch_bf16_p16(const FwdParams& p, int d, int causal, int out_f32, h
     return launch_bf16_x2_p16_d64(p, causal, out_f32, stream);
 }
 
+// Two fp16 terms of P: the NB = 2 kernel at every grid size.  With twice the P.V and row-sum MFMAs the loop is bound by instruction issue
+// at a clock near the chip's maximum (2.3 GHz, matrix pipe 54 % busy: profiles/r03a_rocprof_summary.txt, pass pmc_acc_sq), and two
+// resident workgroups per CU beat one NB = 4 workgroup wherever both were measured (ms NB = 4 / NB = 2, BH x 8192 x 64: 16: 0.374 / 0.352,
+// 12: 0.37 / 0.337; 22.0 us per slab in full rounds against 23.4).
 hipError_t launch_bf16_p16x2(const FwdParams& p, int d, int causal, int out_f32, hipStream_t stream)
 {
     if (!bf16_p16_supported(p, d)) return hipErrorInvalidValue;
     if (d == 32) return launch_bf16_x2_p16x2_d32(p, causal, out_f32, stream);
     if (d == 128) return launch_bf16_x2_p16x2_d128(p, causal, out_f32, stream);
-    if (bf16_p16_uses_x4(p.bh, p.n, causal)) return launch_bf16_x4_p16x2(p, out_f32, stream);
     return launch_bf16_x2_p16x2_d64(p, causal, out_f32, stream);
 }
 

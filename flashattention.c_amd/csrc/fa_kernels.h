@@ -29,9 +29,8 @@ bool bf16_p16_uses_x4(int64_t bh, int64_t n, int causal);
 hipError_t launch_bf16_x2_p16_d32(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
 hipError_t launch_bf16_x2_p16_d64(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
 hipError_t launch_bf16_x2_p16_d128(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
-// two-term fp16 P (hi + lo): the same chain, kernels fa_fwd_bf16_x{2,4}_p16x2_kernel
+// two-term fp16 P (hi + lo): the same chain, kernel fa_fwd_bf16_x2_p16x2_kernel (NB = 2 at every grid size)
 hipError_t launch_bf16_p16x2(const FwdParams& p, int d, int causal, int out_f32, hipStream_t stream);
-hipError_t launch_bf16_x4_p16x2(const FwdParams& p, int out_f32, hipStream_t stream);   // non-causal only
 hipError_t launch_bf16_x2_p16x2_d32(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
 hipError_t launch_bf16_x2_p16x2_d64(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
 hipError_t launch_bf16_x2_p16x2_d128(const FwdParams& p, int causal, int out_f32, hipStream_t stream);

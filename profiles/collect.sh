@@ -46,5 +46,7 @@ python3 bench.py --accurate --no-cpu-baseline --no-extras > $OUT/bench_line_accu
 python3 bench.py --workload c3 --no-cpu-baseline > $OUT/bench_line_c3.json 2> $OUT/bench_c3.err
 python3 bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 python3 profiles/summarize_rocpd.py $OUT $TAG --out $OUT || echo "summarize_rocpd.py FAILED (kernel name mismatch?)"
+# the raw rocpd databases are tens of MB per pass (gpurun merges at most 64 MiB back): keep the summaries and the logs only
+find $OUT -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
 grep -h '"metric"' $OUT/*.log | head -3
 cat $OUT/bench_line.json

@@ -31,7 +31,7 @@ def test_no_kernel_of_the_product_library_uses_scratch(kernels):
 
 def test_every_kernel_family_the_dispatch_names_is_present(kernels):
     names = "\n".join(k.name for k in kernels.values())
-    for fam in ("fa_fwd_bf16_x4_kernel", "fa_fwd_bf16_x4_p16_kernel", "fa_fwd_bf16_x4_p16x2_kernel", "fa_fwd_bf16_x2_kernel", "fa_fwd_bf16_x2_p16_kernel",
+    for fam in ("fa_fwd_bf16_x4_kernel", "fa_fwd_bf16_x4_p16_kernel", "fa_fwd_bf16_x2_kernel", "fa_fwd_bf16_x2_p16_kernel",
                 "fa_fwd_bf16_x2_p16x2_kernel", "fa_fwd_bf16_pp3_kernel", "fa_fwd_bf16_w4_kernel", "fa_fwd_bf16_kernel", "fa_fwd_f32_split_kernel",
                 "fa_fwd_f32_kernel", "fa_naive_f32_kernel", "fa_cvt_bf16_to_f16_kernel", "fa_combine_splits_kernel"):
         assert fam + "<" in names or fam + "(" in names, fam

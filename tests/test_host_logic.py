@@ -33,8 +33,8 @@ def test_library_exports_every_declared_symbol():
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 128, 0, 2, 300) == b"fa_fwd_bf16_w4_kernel"      # too few workgroups
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 128, 1, 2, 300) == b"fa_fwd_bf16_kernel"
     assert L.fa_kernel_name(_cabi.FA_DTYPE_F32, 48, 0) is None
-    # bf16 tensors with fp32 output: P as two fp16 terms -- NB = 4 tiling where the bf16-P dispatch takes it too, NB = 2 elsewhere
-    assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0) == b"fa_fwd_bf16_x4_p16x2_kernel"
+    # bf16 tensors with fp32 output: P as two fp16 terms -- the NB = 2 tiling at every grid size (two resident workgroups per CU)
+    assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0) == b"fa_fwd_bf16_x2_p16x2_kernel"
     assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 1) == b"fa_fwd_bf16_x2_p16x2_kernel"
     assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 128, 0) == b"fa_fwd_bf16_x2_p16x2_kernel"
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 32, 0, 16, 8192) == b"fa_fwd_bf16_x2_p16x2_kernel"
@@ -46,7 +46,7 @@ def test_library_exports_every_declared_symbol():
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 1, 128, 1024) == b"fa_fwd_bf16_x2_p16x2_kernel"
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 128, 0, 2, 1 << 24) == b"fa_fwd_f32_split_kernel"    # a 4 GiB slab: beyond 32-bit byte offsets
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 128, 2048) == b"fa_fwd_bf16_x2_p16x2_kernel"   # more than one round of 512-row tiles: NB = 2, two per CU
-    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 16, 8192) == b"fa_fwd_bf16_x4_p16x2_kernel"    # c4: one full round of NB = 4
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 16, 8192) == b"fa_fwd_bf16_x2_p16x2_kernel"    # c4: one full round of two NB = 2 workgroups per CU
 
 
 def test_kernel_ids_match_the_header_and_the_python_names():
