@@ -75,7 +75,9 @@ def _compile(src: str, force: bool, ablation: bool = False) -> str:
     srcp = os.path.join(CSRC, src)
     if not force and _mtime(obj) > max(_mtime(srcp), _newest_dep()):
         return obj
-    cmd = [hipcc(), *COMMON_FLAGS, f"-DFA_ABLATION={1 if ablation else 0}", *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", srcp, "-o", obj]
+    # FA_EXTRA_ABL_FLAGS: experiment switch -- extra -D flags for the ablation library only (A/B of a kernel change in one process)
+    extra_abl = os.environ.get("FA_EXTRA_ABL_FLAGS", "").split() if ablation else []
+    cmd = [hipcc(), *COMMON_FLAGS, f"-DFA_ABLATION={1 if ablation else 0}", *extra_abl, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", srcp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")

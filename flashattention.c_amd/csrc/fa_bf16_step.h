@@ -47,7 +47,14 @@ __device__ __forceinline__ float rowmax16(const f32x16& s)
     p1 = max3_safe(p1, s[14], s[15]);
     return xhalf_max(fmaxf(max3_safe(p0, p1, p2), p3));
 }
-
+// row minimum over a lane pair's 32 keys (prologue only: decides whether the optimistic mix samples more keys for its reference)
+__device__ __forceinline__ float rowmin16(const f32x16& s)
+{
+    float m = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m = fminf(m, s[r]);
+    return -xhalf_max(-m);
+}
 
 __device__ __forceinline__ void mask16(f32x16& s, int key0, int qi, int n, int hi, bool causal)
 {

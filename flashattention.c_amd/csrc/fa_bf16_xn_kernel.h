@@ -29,6 +29,10 @@
 #include "fa_bf16_step.h"
 #include "fa_kernels.h"
 
+#ifndef FA_OPT_SAMPLE
+#define FA_OPT_SAMPLE 1   // 0: experiment switch -- the optimistic mix takes its exponent reference from the first sub-tile only (round 2)
+#endif
+
 namespace fa {
 
 // PF: the format of P (and of the V image) in the second contraction -- 0 = bf16, 1 = fp16 (11 significant bits), 2 = fp16 hi + fp16 lo
@@ -107,6 +111,10 @@ __device__ __forceinline__ void mfma_l(f32x4_t& l, const bf16x8& ones, const bf1
 //   rescaled,   fp16 hi + lo   the same window; lo = fp16(p - hi) carries the next 11 bits of p (exact difference, one
 //                        v_fma_mixlo/hi_f16 per score) while hi >= 2^-3 or so and fades out below (its own subnormals): P is good to
 //                        ~2^-22 relative at the row maximum and never worse than one-term fp16 P.  Twice the P.V and row-sum MFMAs.
+// optimistic mix, sampled exponent reference (xn_tile prologue): tiles of at least this many 64-key stages, first sub-tile spread (binades)
+constexpr int kSampleMinStages = 64;
+constexpr float kSampleSpread = 28.0f;
+
 template <bool OPT, int PF>
 struct XSoft {
     static_assert(!(OPT && PF != 0), "fp16 P has no room for a fixed exponent reference");
@@ -698,7 +706,11 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
         for (int ks = 0; ks < KS; ++ks) kf[ks] = load_k_frag<D>(k_lds, k_row_off, k_g, t & 1, ks);
     };
     // scores of sub-tile t for all blocks from the fragments in kf, phase-structured (prologue and tail)
-    auto qk_regs = [&](int t, f32x16 (&s)[NB], bool first = false) {
+    float mx_sample[NB];   // optimistic mix: row maxima over the sub-tiles the prologue samples (see the prologue)
+    bool wide = false;     // ... and whether the first sub-tile's scores spread over enough binades for that to pay
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) mx_sample[blk] = -INFINITY;
+    auto qk_regs = [&](int t, f32x16 (&s)[NB], bool first = false, bool sample = false) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -713,12 +725,19 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
             if (needs_mask(t, q0r + 32 * blk)) mask16(s[blk], t * 32, q0r + 32 * blk + lq, nk, hi, CAUSAL);
             mx[blk] = rowmax16(s[blk]);
         }
+        if (sample) {   // only the maxima are kept
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) mx_sample[blk] = fmaxf(mx_sample[blk], mx[blk]);
+            return;
+        }
         if (first) {  // nothing accumulated yet: set the references, leave the (zero) accumulators alone
 #pragma unroll
             for (int blk = 0; blk < NB; ++blk) {
+                mx_sample[blk] = mx[blk];
                 const float mc = mx[blk] * c;
                 st[blk].m = fmaf(-fabsf(mc), 0x1p-23f, mc);
                 off[blk] = st[blk].m + kBias;
+                if constexpr (OPT && FA_OPT_SAMPLE) wide = wide || (mx[blk] - rowmin16(s[blk])) * c > kSampleSpread;
             }
         } else if (!OPT) {
             xn_rescale<NB, DB, PF>(mx, c, st, o, off);
@@ -771,7 +790,33 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
     if (!idle) {
         load_kf(0);
         qk_regs(0, s0, true);
-        load_kf(1);
+        // Optimistic mix: the exponent reference of a row is fixed for the whole tile, and every P more than 26 binades below it underflows
+        // bf16 to an exact zero.  Zero operands cost the matrix core less power, and the chip runs to its power budget (DESIGN.md 4.6:
+        // c4 at scale 2, 80 % zeros, runs 5.5 % faster than at scale 1, 40 % zeros, through the same instruction stream).  ANY score of
+        // the row is a valid reference (a lower bound of the row maximum), so the maximum over all sub-tiles the prologue has in LDS
+        // anyway (K stages 0 .. G: 64 (G + 1) keys) is taken instead of the first sub-tile's: 2.7 sigma instead of 2.0 sigma expected on
+        // random data.  Costs 2 G + 1 phase-structured K.Q^T passes, so only long tiles take it (measured on one box, sampled / not:
+        // c4 0.2319 / 0.2363 ms, c5's shard 1.806 / 1.845, d = 128 0.4136 / 0.4203, but 16 x 2048 0.0364 / 0.0347), and only waves whose
+        // first sub-tile spreads over enough binades for anything to underflow (at 1/sqrt(d) scaling nothing does: 0.2400 / 0.2380).
+        bool sampled = false;
+        if constexpr (OPT && FA_OPT_SAMPLE) {
+            if (nst >= kSampleMinStages && __any(wide)) {
+                const int ts = min(nsub, 2 * min(G + 1, nst));   // sub-tiles of the K stages the prologue requested
+#pragma unroll 1
+                for (int t = ts - 1; t >= 1; --t) {              // ends with sub-tile 1: its fragments stay in kf for the first step
+                    load_kf(t);
+                    qk_regs(t, s1, false, true);
+                }
+                sampled = ts > 1;
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk) {
+                    const float mc = mx_sample[blk] * c;
+                    st[blk].m = fmaf(-fabsf(mc), 0x1p-23f, mc);
+                    off[blk] = st[blk].m + kBias;
+                }
+            }
+        }
+        if (!sampled) load_kf(1);
     }
 
     // ---------------- fast loop: groups of G whole stages whose sub-tiles 2j .. 2j+2 are in range and mask-free ----------------
