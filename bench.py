@@ -566,7 +566,9 @@ def stub_main(args, rank: int, world: int):
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
                           "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": dtype, "data": "none (cpu stub)",
                           "config": {"workload": f"{args.workload} (cpu stub)", "global_bh": global_bh, "bh_per_gpu": bh},
-                          "roofline": None, "cpu_baseline": None, "extra": {"c5": {"slabs_covered": sizes[0], "n_gpus": world}}}), flush=True)
+                          "roofline": None, "cpu_baseline": None,
+                          "extra": {"c5": {"slabs_covered": sizes[0], "n_gpus": world},
+                                    "per_rank_ms": [round(x / args.steps * 1e3, 4) for x in PER_RANK_S]}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -2,13 +2,14 @@
 // the number NB of 32-row blocks a wave owns.  ONE source for what used to be two near-copies:
 //     NB = 4, D = 64          "x4": 128 query rows per wave, 512-row workgroups   (fa_fwd_bf16_x4*.hip: large non-causal grids, c4 / c5)
 //     NB = 2, D = 32/64/128   "x2":  64 query rows per wave, 256-row workgroups   (fa_fwd_bf16_x2.hip: d = 128, d = 32, causal and small grids)
-// and, through the PF switch, the fp16-P ("accurate") forms of both (fa_fwd_bf16_x4_p16*.hip, fa_fwd_bf16_x2_p16.hip).
+// and, through the PF switch, the fp16-P forms: one fp16 term of P (PF = 1: fa_fwd_bf16_x4_p16.hip, fa_fwd_bf16_x2_p16_d*.hip; explicit
+// choice only) and two (PF = 2: fa_fwd_bf16_x2_p16x2_d*.hip -- the accurate path FA_KERNEL_AUTO gives an fp32 output).
 // Replaces the hot loop of flash_tiled_coarse{,_causal} (/root/reference/src/flashattention.cu:214-354, :434,480-484).
 //
-// Why one wave per SIMD: on gfx950 two waves of a SIMD do not issue VALU work side by side once matrix instructions are in their
-// streams (a wave parked on the busy matrix pipe holds the vector issue port; measured in profiles/ubench), so the loop is bound
-// by the number of instructions issued per MFMA, and both the chip's power budget and that issue budget are spent best by the
-// stream with the fewest instructions per FLOP.  More blocks per wave share every K / V^T fragment read, barrier, DMA and piece of
+// Why one wave per SIMD: the loop is bound by the number of instructions issued per MFMA AND by the chip's power budget (a second
+// resident wave does add issue capacity -- 1330 cycles per step for each of two NB = 2 workgroups against 1057 for one alone -- but on
+// a fully loaded chip the clock gives most of it back: DESIGN.md 4.6), and both budgets are spent best by the stream with the
+// fewest instructions per FLOP.  More blocks per wave share every K / V^T fragment read, barrier, DMA and piece of
 // per-step bookkeeping among more FLOP; the single resident wave needs every latency hidden by the software pipeline itself:
 //
 //   step t (32 keys), NB = 4:   K.Q^T of sub-tile t+1 for blocks A,B | P.V + row sums of A | K.Q^T (t+1) for C,D, first half
@@ -16,8 +17,8 @@
 //   step t (32 keys), NB = 2:   K.Q^T of sub-tile t+1 for A and B (2 KS slots) | P.V + row sums of A (NV + 2) | P.V + row sums of B
 //   VALU work (exp + pack of every block for sub-tile t; rescaled mixes: the lane maxima of sub-tile t+1 and the rescale test) is
 //   cut into ~4-instruction units and dealt out over the MFMA slots by measured issue cost, which by construction finishes exp(X)
-//   before P.V(X) and starts max(X) only after K.Q^T(X) has retired (profiles/r01_x4_schedule_check.py re-derives the tables and
-//   checks every dependency offline).  V^T fragments of the step are read in its first NV slots, the K fragments of the next step
+//   before P.V(X) and starts max(X) only after K.Q^T(X) has retired (xn_schedule_ok checks every dependency of every instantiated
+//   schedule at compile time; profiles/r03_xn_schedule_check.py is the offline model used to search the dealing limits).  V^T fragments of the step are read in its first NV slots, the K fragments of the next step
 //   right after the step's last K.Q^T slot.
 //
 // D = 128 (NB = 2): a 32x32-key block has 18 MFMAs for the same 40 (48) VALU instructions as at D = 64 -- the step is bound by the

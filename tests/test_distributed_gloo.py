@@ -92,6 +92,8 @@ def test_bench_self_launches_its_ranks_when_typed_directly():
         assert line["config"]["bh_per_gpu"] == bh_per_gpu and line["config"]["global_bh"] == global_bh
         assert line["extra"]["c5"]["slabs_covered"] == 1024       # the two ranks' c5 shards cover B*H = 64*16 exactly once
         assert line["scaling"] == ("weak" if workload == "c4" else "strong")
+        assert len(line["extra"]["per_rank_ms"]) == 2 and all(t > 0 for t in line["extra"]["per_rank_ms"])   # every rank's own time (all-gather)
+        assert abs(max(line["extra"]["per_rank_ms"]) - line["ms_per_step"]) < 1e-3                          # the reported time is the slowest rank's
 
 
 def test_bench_under_torchrun_is_one_rank_not_a_launcher():

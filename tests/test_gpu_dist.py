@@ -47,3 +47,17 @@ def test_bench_under_the_drivers_launch_line_with_one_gpu():
         assert key in line, key
     assert line["n_gpus"] == 1 and line["steps"] == 5 and line["warmup"] == 2 and line["value"] > 100.0
     assert 0.2 < line["roofline"]["frac"] < 1.0 and line["roofline"]["bound"] == "mfma"
+
+
+def test_bench_config_5_under_the_drivers_launch_line_with_one_gpu():
+    """`--workload c5` (BASELINE config 5 as the headline: 1024 slabs split over the ranks, strong scaling) under the driver's launcher with
+    one rank over RCCL: all 1024 slabs on the one GPU."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "c5", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extras", "--backend", "nccl"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["config"]["global_bh"] == 1024 and line["config"]["bh_per_gpu"] == 1024
+    assert line["value"] > 500.0 and line["roofline"]["kernel"] == "fa_fwd_bf16_x4_kernel"
