@@ -42,6 +42,10 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef FA_SPLIT_REF
+#define FA_SPLIT_REF 1   // 0: experiment switch -- the fast pass runs reference-free (p = exp2(s), round 2)
+#endif
+
 namespace fa {
 
 constexpr int kKvSplit = 32;         // keys per tile
@@ -552,6 +556,20 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     auto run_fast = [&]() -> bool {
         f32x16 o[QB][DB];
         float la[QB], lb[QB];   // two partial row sums per block (even / odd score registers)
+        // Exponent reference of the fast pass (round 3).  It is still "nothing between the matrix core and v_exp_f32": -(m0 + B) of a
+        // row sits in the accumulator every K.Q'^T product STARTS from, m0 = the row maximum over the first one or two tiles, and
+        // p = 2^(s - m0 - B) with B = 109 - ceil(log2 n): every term more than 2^-(17 + log2 n) below the m0 level underflows the bf16 hi
+        // AND lo terms to exact zeros (together they drop at most 2^-17 of a row's mass: two orders below this path's own error).
+        // Zero operands cost the matrix core less power, and this kernel runs at the chip's power limit (c3: all-zero V -14 % time;
+        // DESIGN.md 4.6).  Rows may still outgrow m0 by 2^(100 + B) before the verification below fails them.
+        f32x16 minit[QB];
+        float mref[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            mref[qb] = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) minit[qb][r] = 0.0f;
+        }
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             la[qb] = lb[qb] = 0.0f;
@@ -618,24 +636,56 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
             }
         };
         auto qk = [&](const char* kh_lds, f32x16 (&s)[QB]) {
-            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 kfh = *(const bf16x8*)(kh_lds + k_off[ks]);
                 if constexpr (IN_BF16) {
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) {
-                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, ql[qb][ks], ks == 0 ? zero : s[qb], 0, 0, 0);
+                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, ql[qb][ks], ks == 0 ? minit[qb] : s[qb], 0, 0, 0);
                         s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, qh[qb][ks], s[qb], 0, 0, 0);
                     }
                 } else {
                     const bf16x8 kfl = *(const bf16x8*)(kh_lds + C::kImageBytes + k_off[ks]);
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) {
-                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl, qh[qb][ks], ks == 0 ? zero : s[qb], 0, 0, 0);
+                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl, qh[qb][ks], ks == 0 ? minit[qb] : s[qb], 0, 0, 0);
                         s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, ql[qb][ks], s[qb], 0, 0, 0);
                         s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, qh[qb][ks], s[qb], 0, 0, 0);
                     }
+                }
+            }
+        };
+        // the reference of every row from the scores of tile 0 (in `c0`) and, when it needs no mask, tile 1 (`c1`): both were computed
+        // from a zero accumulator and are shifted here, once; every later product starts from minit
+        auto set_reference = [&](f32x16 (&c0)[QB], f32x16 (&c1)[QB], bool mask0, bool have1, bool use1) {
+            const float bias = 109.0f - (float)(32 - __builtin_clz((unsigned)max(n - 1, 1)));   // B = 109 - ceil(log2 n)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                if (mask0) {
+                    asm volatile("; mask" ::: "memory");
+                    const int qi = q0 + qb * 32 + lq;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = 4 * hi + (r & 3) + 8 * (r >> 2);
+                        if ((key >= nk) || (CAUSAL && key > qi)) c0[qb][r] = -INFINITY;
+                    }
+                }
+                auto lane_max = [](const f32x16& sq) {   // (compiler-visible: hipcc pads the MFMA -> VALU hazard itself)
+                    float m = fmaxf(sq[0], sq[1]);
+#pragma unroll
+                    for (int r = 2; r < 16; r += 2) m = max3_safe(m, sq[r], sq[r + 1]);
+                    return m;
+                };
+                float mx = lane_max(c0[qb]);
+                if (use1) mx = fmaxf(mx, lane_max(c1[qb]));
+                mx = xhalf_max(mx);
+                mref[qb] = mx + bias;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    minit[qb][r] = -mref[qb];
+                    c0[qb][r] -= mref[qb];
+                    if (have1) c1[qb][r] -= mref[qb];
                 }
             }
         };
@@ -715,6 +765,11 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
             const int kv0 = j * kKvSplit;
             if constexpr (FIRST || LAST) {   // executed once each: plain phases
                 if (!LAST) qk(st_oth, next);                                   // K(j+1)
+                if constexpr (FIRST && FA_SPLIT_REF) {
+                    mfma_drain();   // the reference reads scores the matrix core may still be writing (hipcc pads its own MFMA -> VALU
+                                    // hazards, but `next` is only read here when tile 1 is sampled -- keep the drain unconditional)
+                    set_reference(cur, next, needs_mask(0), !LAST, !LAST && !needs_mask(kKvSplit));
+                }
                 softmax(cur, phc, plc, (LAST || CAUSAL) && needs_mask(kv0), kv0);
                 if (!FIRST) pv(php, plp, st_oth + 2 * C::kImageBytes);          // V(j-1)
                 if (!LAST) store_k(st_cur);                                     // K(j+2) over K(j)
@@ -800,7 +855,6 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                         }
                     }
                 };
-                const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 load_frags(std::integral_constant<int, 0>{});
                 auto slot = [&](auto ic) {
                     constexpr int I = decltype(ic)::value;
@@ -811,7 +865,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                     const bf16x8& a = a_lo ? fl[G & 1] : fh[G & 1];
                     if constexpr (G < KS) {
                         const bf16x8& bq = b_lo ? ql[qb][G] : qh[qb][G];
-                        if constexpr (G == 0 && term == 0) next[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, zero, 0, 0, 0);
+                        if constexpr (G == 0 && term == 0) next[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, minit[qb], 0, 0, 0);
                         else next[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, next[qb], 0, 0, 0);
                     } else {
                         constexpr int t = (G - KS) / DB, db = (G - KS) % DB;
@@ -875,7 +929,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                         }
                         store4(p, o_off + db * 32 + 8 * g, pk);
                     }
-                if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = __builtin_amdgcn_logf(lt) * kLn2;
+                if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (mref[qb] + __builtin_amdgcn_logf(lt)) * kLn2;
                 ok = ok && (lt > 1.0f / kSplitLimit) && (lt < kSplitLimit) && (mag < INFINITY);   // false for NaN as well
                 if (GUARD) saw_nan = saw_nan || (lt != lt) || (mag != mag);
             }
