@@ -474,6 +474,10 @@ def c4_side_measurements(fa, _cabi, q, k, v, causal, args, device):
           note="B*H = 1, fp32 tensors (FA_KERNEL_AUTO): split kernel over 8 key shares + combine + the guard's conditional exact launch; frac of bf16 peak / 3", warm=100, iters=50)
     timed("bh1_n8192_f32_unsplit", dict(causal=False, scale=args.scale, kernel="split"), fwd_flop(1, n, d, False), tensors=(qf, kf, vf), peak=PEAK_TFLOPS["bf16"] / 3.0,
           note="the same tensors through kernel=\"split\" (one launch, no key split, no guard): round 2's path", warm=100, iters=50)
+    timed("bh1_n8192_f32_causal_keysplit", dict(causal=True, scale=args.scale), fwd_flop(1, n, d, True), tensors=(qf, kf, vf), peak=PEAK_TFLOPS["bf16"] / 3.0,
+          note="B*H = 1, fp32 tensors, causal (FA_KERNEL_AUTO): key shares of 1024 keys in the share's local coordinates, empty shares skipped", warm=100, iters=50)
+    timed("bh1_n8192_f32_causal_unsplit", dict(causal=True, scale=args.scale, kernel="split"), fwd_flop(1, n, d, True), tensors=(qf, kf, vf), peak=PEAK_TFLOPS["bf16"] / 3.0,
+          note="the same tensors through kernel=\"split\" (no key split, no guard)", warm=100, iters=50)
     del qf, kf, vf
     # README rows 2 and 4 (d = 32), bf16 and fp32 tensors
     for name, (B2, H2, n2) in (("d32_n8192", (2, 8, 8192)), ("d32_n1024", (8, 16, 1024))):

@@ -293,12 +293,16 @@ int keysplit_rows(const fa::FwdParams& p, int S, int32_t causal)   // keys per s
     const int unit = causal ? 256 : 64;
     return ((p.n + S - 1) / S + unit - 1) / unit * unit;
 }
-int keysplit_factor(const fa::FwdParams& p, int32_t d, int32_t causal)
+int keysplit_factor(const fa::FwdParams& p, int32_t d, int32_t causal, bool f32 = false)
 {
     if (!dense_layout(p, d) || p.n < 4096) return 1;
     if (((int64_t)(p.n - 1) * p.kv_row_stride + d) * 2 >= (int64_t)0xffffffffLL) return 1;   // the NB = 2 kernels' 32-bit slab offsets
     const int64_t tiles = (int64_t)p.bh * ((p.n + 255) / 256);
     if (tiles > (causal ? 256 : 128)) return 1;
+    // fp32 tensors, causal (split kernel, ms unsplit / key-split at d = 64: BH x N 1 x 8192 0.183 / 0.066, 2 x 8192 0.172 / 0.111, 4 x 8192
+    // 0.185 / 0.178, 8 x 8192 0.299 / 0.230, 1 x 16384 0.346 / 0.187, 2 x 16384 0.361 / 0.333, 4 x 16384 0.586 / 0.611): a full round of
+    // 256-row tiles is split only while a row is 8192 keys or shorter
+    if (f32 && causal && tiles > 128 && p.n > 8192) return 1;
     int S = 1;
     while (S < 8 && tiles * (2 * S) <= (causal ? 512 : 256) && p.n / (2 * S) >= 1024) S *= 2;
     while (S > 1 && (int64_t)(S - 1) * keysplit_rows(p, S, causal) >= p.n) --S;   // every split owns at least one key
@@ -361,10 +365,10 @@ Plan make_plan(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype,
         else if (sel.kind == FA_KERNEL_MFMA || (sel.kind == FA_KERNEL_AUTO && f32_auto_is_exact())) pl.route = kRouteF32Exact;
         else if (sel.kind == FA_KERNEL_AUTO && sel.variant == 0) {
             pl.route = kRouteF32Guarded;
-            // grids that leave the chip idle: the split kernel over key shares + combine (non-causal; the guard's verdict is per share,
-            // and any share raising it sends the whole launch to the exact kernel, which runs unsplit)
-            const int S = scratch_ok ? keysplit_factor(p, d, causal) : 1;
-            if (S > 1 && !causal) {
+            // grids that leave the chip idle: the split kernel over key shares + combine (the guard's verdict is per share, and any share
+            // raising it sends the whole launch to the exact kernel, which runs unsplit)
+            const int S = scratch_ok ? keysplit_factor(p, d, causal, true) : 1;
+            if (S > 1) {
                 pl.S = S;
                 pl.part_off = kWsHeader;
                 pl.part_bytes = (size_t)S * p.bh * p.n * d * 4u + (size_t)S * p.bh * p.n * 4u;
@@ -460,11 +464,11 @@ hipError_t launch_bf16_keysplit(const fa::FwdParams& p0, int32_t d, int32_t caus
     return e;
 }
 
-// fp32 tensors, key-split launch of the split kernel (non-causal): p0 carries the chain's flag fields (flag_mode 3: every share bounds the
-// logit width of its own keys)
-hipError_t launch_f32_keysplit(const fa::FwdParams& p0, int32_t d, int S, char* part, hipStream_t stream)
+// fp32 tensors, key-split launch of the split kernel: p0 carries the chain's flag fields (flag_mode 3: every share bounds the logit
+// width of its own keys)
+hipError_t launch_f32_keysplit(const fa::FwdParams& p0, int32_t d, int32_t causal, int S, char* part, hipStream_t stream)
 {
-    const int n_kv = keysplit_rows(p0, S, 0);
+    const int n_kv = keysplit_rows(p0, S, causal);
     const size_t o_bytes = (size_t)S * p0.bh * p0.n * d * 4u;
     float* o_part = (float*)part;
     float* lse_part = (float*)(part + o_bytes);
@@ -480,7 +484,7 @@ hipError_t launch_f32_keysplit(const fa::FwdParams& p0, int32_t d, int S, char* 
     p.lse = lse_part;
     p.n_kv = n_kv;
     p.n_kv_total = p0.n;
-    hipError_t e = fa::launch_f32_split(p, d, 0, 0, stream);
+    hipError_t e = fa::launch_f32_split(p, d, causal ? 1 : 0, 0, stream);
     fa::FwdParams pc = p0;
     pc.flag_mode = 0;
     if (e == hipSuccess) e = fa::launch_combine_splits(pc, o_part, lse_part, S, d, 1, stream);
@@ -611,7 +615,7 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
             pg.flag = f.word;
             pg.flag_serial = f.serial;
             pg.flag_mode = 3;
-            if (pl.S > 1) e = launch_f32_keysplit(pg, d, pl.S, scratch + pl.part_off, stream);
+            if (pl.S > 1) e = launch_f32_keysplit(pg, d, causal, pl.S, scratch + pl.part_off, stream);
             else e = fa::launch_f32_split(pg, d, c, 0, stream);
             if (e == hipSuccess) {
                 pg.flag_mode = 2;

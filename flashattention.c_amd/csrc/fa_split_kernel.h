@@ -207,11 +207,24 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     const T* vg = (const T*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
     const int64_t o_slab = b * p.o_batch_stride + h * p.o_head_stride;   // elements (fp32 or bf16 output, p.o_is_bf16)
 
-    // keys of this workgroup: all n, or (non-causal key-split launches, fa_api.cpp) its share [h * n_kv, min((h + 1) * n_kv, n_kv_total)) --
-    // kv_head_stride carries the offset, nk bounds the local key indices
-    const int nk = (!CAUSAL && p.n_kv > 0) ? min(p.n_kv, p.n_kv_total - h * p.n_kv) : n;
+    // keys of this workgroup: all n, or (key-split launches, fa_api.cpp) its share [h * n_kv, min((h + 1) * n_kv, n_kv_total)) --
+    // kv_head_stride carries the offset, nk bounds the LOCAL key indices (local key i is key kbeg + i of the slab; causal: local key <=
+    // local row q - kbeg).  Causal shares are multiples of the tile height: a share starts at or below the tile's first row (every row sees
+    // its first key) or lies entirely above the tile -- an empty share, which stores lse = -inf for its rows (the combine gives it weight
+    // 0 and never reads its O) and is done.
+    const int kbeg = p.n_kv > 0 ? h * p.n_kv : 0;
+    const int nk = p.n_kv > 0 ? min(p.n_kv, p.n_kv_total - kbeg) : n;
     int kv_end = nk;
-    if (CAUSAL) kv_end = min(n, qt * BM + BM);
+    if (CAUSAL) kv_end = min(nk, qt * BM + BM - kbeg);
+    if (CAUSAL && kv_end <= 0) {   // workgroup-uniform
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const int qi = q0 + qb * 32 + lq;
+            if (qi < n && p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = -INFINITY;
+        }
+        return;
+    }
+    const int q0l = q0 - kbeg;   // first row of this wave in local key coordinates
     const int nt = (kv_end + kKvSplit - 1) / kKvSplit;
 
     // ---- this thread's pieces of a tile: group g = tid + i * NT -> (row, 8-column slot) of K and of V
@@ -406,10 +419,10 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
             // reference of each row: the maximum over the first tile (every row sees key 0, so it is finite for finite inputs)
             f32x16 s[QB];
             scores(smem, s);
-            const bool need_mask = (kKvSplit > nk) || (CAUSAL && (kKvSplit - 1 > q0));
+            const bool need_mask = (kKvSplit > nk) || (CAUSAL && (kKvSplit - 1 > q0l));
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
-                if (need_mask) mask(s[qb], 0, q0 + qb * 32 + lq);
+                if (need_mask) mask(s[qb], 0, q0l + qb * 32 + lq);
                 m[qb] = row_max(s[qb]);
                 if constexpr (MREG) {
 #pragma unroll
@@ -427,16 +440,16 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
             const char* kh_lds = smem + STG * C::kStageBytes;
             const char* vh_lds = kh_lds + 2 * C::kImageBytes;
 
-            if (!(CAUSAL && kv0 > q0 + QB * 32 - 1)) {   // else: tile entirely above this wave's diagonal
+            if (!(CAUSAL && kv0 > q0l + QB * 32 - 1)) {   // else: tile entirely above this wave's diagonal
                 f32x16 s[QB];
                 scores(kh_lds, s);   // S'^T = K Q'^T - m_ref
 
                 // ================= softmax (registers only) =================
-                const bool need_mask = (kv0 + kKvSplit > nk) || (CAUSAL && (kv0 + kKvSplit - 1 > q0));
+                const bool need_mask = (kv0 + kKvSplit > nk) || (CAUSAL && (kv0 + kKvSplit - 1 > q0l));
                 bf16x8 ph[QB][2], pl[QB][2];
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
-                    if (need_mask) mask(s[qb], kv0, q0 + qb * 32 + lq);
+                    if (need_mask) mask(s[qb], kv0, q0l + qb * 32 + lq);
                     if constexpr (!OPT) {
                         const float mx = row_max(s[qb]);                  // row maximum relative to m_ref
                         const bool grow = (j == 0) || (mx > 0.0f);        // tile 0 sets the reference (m_ref starts at 0)
@@ -664,7 +677,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
             for (int qb = 0; qb < QB; ++qb) {
                 if (mask0) {
                     asm volatile("; mask" ::: "memory");
-                    const int qi = q0 + qb * 32 + lq;
+                    const int qi = q0l + qb * 32 + lq;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = 4 * hi + (r & 3) + 8 * (r >> 2);
@@ -695,7 +708,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
             for (int qb = 0; qb < QB; ++qb) {
                 if (need_mask) {
                     asm volatile("; mask" ::: "memory");  // not speculatable: keeps the wave-uniform `if` a real branch
-                    const int qi = q0 + qb * 32 + lq;
+                    const int qi = q0l + qb * 32 + lq;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = kv0 + 4 * hi + (r & 3) + 8 * (r >> 2);
@@ -739,7 +752,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                     }
                 }
         };
-        auto needs_mask = [&](int kv0) { return (kv0 + kKvSplit > nk) || (CAUSAL && (kv0 + kKvSplit - 1 > q0)); };
+        auto needs_mask = [&](int kv0) { return (kv0 + kKvSplit > nk) || (CAUSAL && (kv0 + kKvSplit - 1 > q0l)); };
 
         // ---- prologue: K(0) and K(1) staged, scores of tile 0 under way
         load_k(0);
@@ -785,7 +798,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) {
                         asm volatile("; mask" ::: "memory");
-                        const int qi = q0 + qb * 32 + lq;
+                        const int qi = q0l + qb * 32 + lq;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int key = kv0 + 4 * hi + (r & 3) + 8 * (r >> 2);

@@ -569,28 +569,30 @@ def test_causal_key_split_launch(bh, n, d):
     check(out[:1], orc.attention_f64(q[:1], k[:1], v[:1], causal=True), P16_TOL_BIG, "vs fp64 oracle")
 
 
+@pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("bh,n,d", [(1, 8192, 64), (2, 8192, 64), (3, 5000, 64), (1, 16384, 64), (2, 7777, 32), (1, 8192, 128), (4, 4100, 64)])
-def test_fp32_key_split_launch(bh, n, d):
-    """fp32 tensors, non-causal, grids that leave the chip idle: the split kernel over key shares + combine inside the guarded AUTO chain
-    (every share bounds the logit width of its own keys; any share raising the verdict hands the launch to the exact kernel)."""
+def test_fp32_key_split_launch(bh, n, d, causal):
+    """fp32 tensors, grids that leave the chip idle: the split kernel over key shares + combine inside the guarded AUTO chain (every
+    share bounds the logit width of its own keys; any share raising the verdict hands the launch to the exact kernel).  Causal: shares
+    are multiples of the tile height, shares above a tile's diagonal are empty (lse = -inf, weight 0 in the combine)."""
     q, k, v = (randn(s, bh, n, d) for s in (97, 98, 99))
     qd, kd, vd = to_dev(q, k, v)
-    assert fa.workspace_bytes(bh, n, d, False) > 0
-    ref, lse_ref = fa.forward(qd, kd, vd, False, kernel="naive", return_lse=True)
+    assert fa.workspace_bytes(bh, n, d, causal) > 0
+    ref, lse_ref = fa.forward(qd, kd, vd, causal, kernel="naive", return_lse=True)
     out = torch.full((bh, n, d), float("nan"), device=dev())
-    _, lse = fa.forward(qd, kd, vd, False, out=out, return_lse=True)
+    _, lse = fa.forward(qd, kd, vd, causal, out=out, return_lse=True)
     assert fa.last_forward_route() == 1
     assert not torch.isnan(out).any()
     err = float((out - ref).abs().max())
-    OBSERVED.append((f"fp32 key split bh={bh} n={n} d={d}", err, TOL_F32))
+    OBSERVED.append((f"fp32 key split bh={bh} n={n} d={d} causal={causal}", err, TOL_F32))
     assert err < TOL_F32 and float((lse - lse_ref).abs().max()) < 1e-3
-    check(out[:1], orc.attention_f64(q[:1], k[:1], v[:1]), TOL_F32, "vs fp64 oracle")
+    check(out[:1], orc.attention_f64(q[:1], k[:1], v[:1], causal=causal), TOL_F32, "vs fp64 oracle")
     # a wide key in the LAST share: that share's guard fires, the exact kernel (unsplit) produces the output
     k[0, n - 7] *= 40.0
     (kw,) = to_dev(k)
-    o2 = fa.forward(qd, kw, vd, False)
+    o2 = fa.forward(qd, kw, vd, causal)
     assert fa.last_forward_route() == 2
-    assert float((o2 - fa.forward(qd, kw, vd, False, kernel="exact")).abs().max()) < 1e-5
+    assert float((o2 - fa.forward(qd, kw, vd, causal, kernel="exact")).abs().max()) < 1e-5
 
 
 def test_graph_replay_timing_entry():

@@ -85,7 +85,8 @@ def test_workspace_sizes_are_host_arithmetic():
     assert L.fa_workspace_bytes(8, 8192, 64, 1, B16, A) == 256 + part(2, 8, 8192, 64)         # causal: up to 256 tiles are split
     assert L.fa_workspace_bytes(8, 8192, 64, 0, B16, A) == 0 and L.fa_workspace_bytes(16, 8192, 64, 1, B16, A) == 0
     assert L.fa_workspace_bytes(1, 8192, 64, 0, F32, A) == 256 + part(8, 1, 8192, 64)         # fp32 tensors: the split kernel over key shares
-    assert L.fa_workspace_bytes(1, 8192, 64, 1, F32, A) == 0 and L.fa_workspace_bytes(1, 8192, 64, 0, F32, _cabi.FA_KERNEL_MFMA) == 0
+    assert L.fa_workspace_bytes(1, 8192, 64, 1, F32, A) == 256 + part(8, 1, 8192, 64)         # ... causal too
+    assert L.fa_workspace_bytes(16, 8192, 64, 1, F32, A) == 0 and L.fa_workspace_bytes(1, 8192, 64, 0, F32, _cabi.FA_KERNEL_MFMA) == 0
     assert L.fa_workspace_bytes(1, 8192, 64, 0, B16F, A) == 256 + 8192 * 64 * 2 + part(8, 1, 8192, 64)   # both
     assert L.fa_workspace_bytes(1, 8192, 64, 0, B16, _cabi.FA_KERNEL_SPLIT) == 0
     assert L.fa_workspace_bytes(4, 300, 32, 0, B16F, _cabi.FA_KERNEL_P16) == 256 + ((4 * 300 * 32 * 2 + 255) // 256) * 256   # explicit: any size
