@@ -31,7 +31,10 @@ class Kernel(NamedTuple):
 
 def extract(lib_path: str, outdir: str) -> List[str]:
     fat = os.path.join(outdir, "fatbin")
-    subprocess.run([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", lib_path], check=True)
+    # with one positional argument llvm-objcopy rewrites its INPUT in place (a normalised copy: other bytes, another sha256 -- the
+    # library bench.py ties the PMC traffic to): the copy goes to a throwaway file, the library under test is only read
+    subprocess.run([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", lib_path, os.path.join(outdir, "objcopy_out")],
+                   check=True)
     data = open(fat, "rb").read()
     paths, pos = [], 0
     while True:

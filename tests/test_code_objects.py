@@ -132,3 +132,12 @@ def test_asm_mfma_kernels_drain_the_matrix_pipe_before_reading_accumulators(kern
         assert reads > 0 and worst is not None and worst >= 18, f"{k.name}: {worst} wait states between an MFMA and an accumulator read"
         checked += 1
     assert checked >= 36
+
+
+def test_inspecting_the_library_does_not_modify_it(tmp_path):
+    """The code-object extraction only READS the library: bench.py ties the committed PMC traffic to the library's sha256, and an
+    llvm-objcopy call with one positional argument used to rewrite the file in place (same code, other bytes)."""
+    import hashlib
+    before = hashlib.sha256(open(LIB, "rb").read()).hexdigest()
+    assert len(codeobj.kernels_of(LIB, str(tmp_path))) > 60
+    assert hashlib.sha256(open(LIB, "rb").read()).hexdigest() == before
