@@ -446,6 +446,11 @@ enum Bf16Choice { kChoosePhase, kChoosePipelined4, kChoosePipelined2, kChooseX4,
 
 static Bf16Choice choose_bf16(int64_t bh, int64_t n, int d, int causal, bool addressable)
 {
+    // Rows of two stages: the phase-structured kernel (128-row workgroups, nothing to fill or drain).  ms at BH x N = 131072 rows,
+    // phase-structured / one-wave-per-SIMD (profiles/r03_short_rows.txt): N = 128 d=64 0.017 / 0.021 (causal 0.017 / 0.024), d=32 0.008 /
+    // 0.013 (0.009 / 0.016), d=128 0.033 / 0.044 (0.032 / 0.052); d=128 causal N = 256 0.037 / 0.044, N = 512 0.050 / 0.055; at N = 256
+    // the other head dims tie, from N = 512 on the pipelined kernels lead.
+    if (n <= 128 || (d == 128 && causal && n <= 512)) return kChoosePhase;
     if (d == 128) {
         // one wave per SIMD, 256-row workgroups, one workgroup per CU: needs enough workgroups to occupy the CUs
         if (addressable && bh * ((n + 255) / 256) >= 128) return kChooseX2D128;

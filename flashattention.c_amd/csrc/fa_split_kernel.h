@@ -1006,22 +1006,37 @@ static bool split_addressable(const FwdParams& p, int d, unsigned elem_size)
     return ((uint64_t)(p.n - 1) * (uint64_t)p.kv_row_stride + (uint64_t)d) * elem_size < (1ull << 32);
 }
 
+// Short rows (round 3, profiles/r03_short_rows.txt; ms at BH x N = 131072 rows, m1 / m3 / m4-or-m5): the pipelined pass fills and
+// drains over four tiles and wants whole 256-row workgroups --
+//   d=64  non-causal  N=128 0.034 / 0.052 / 0.092   256 0.047 / 0.076 / 0.088   512 0.070 / 0.075 / 0.094   640 0.081 / 0.071 / 0.095
+//                     896 0.104 / 0.094 / 0.121     1024 0.115 / 0.102 / 0.104  (16 x 256: 0.013 / 0.021 / 0.036, 16 x 512: 0.022 / 0.016 / 0.025)
+//         causal      N=512 0.059 / 0.064 / 0.114   768 0.075 / 0.067 / 0.084   1024 0.095 / 0.086 / 0.100
+//   d=32  non-causal  N=128 0.022 / 0.035 / 0.065   256 0.031 / 0.053 / 0.059   384 0.042 / 0.039 / 0.049   512 0.050 / 0.047 / 0.046
+//         causal      N=256 0.028 / 0.052 / 0.070   512 0.044 / 0.042 / 0.070   768 0.058 / 0.052 / 0.062
+//   d=128 non-causal  N=128 0.072 / 0.117 / 0.081   640 0.176 / 0.146 / 0.171   896 0.223 / 0.184 / 0.227 (m5's 256-row tiles: 1024 rows of work)
 static int choose_split(const FwdParams& p, int d, int causal, unsigned elem_size)
 {
     // the pipelined pass addresses K/V through 32-bit buffer offsets
     const bool addressable = split_addressable(p, d, elem_size);
     if (!addressable) return 1;
     const int64_t tiles256 = (int64_t)p.bh * ((p.n + 255) / 256);
+    const int64_t tiles128 = (int64_t)p.bh * ((p.n + 127) / 128);
+    // 256-row workgroups compute whole tiles: rows past N are wasted, and with N mod 256 in (0, 128] the 128-row tiling wastes a tile less
+    const bool fits256 = p.n % 256 == 0 || p.n % 256 > 128 || p.n >= 4096;
     if (d == 128) {
+        if (p.n <= 128) return 1;
         // two blocks per wave do not fit the register file; EIGHT waves of one block each (256-row workgroups, two waves per
         // SIMD, phases in sequence) halve the K/V conversion work and the L2 traffic per row
-        return tiles256 >= 256 ? 5 : 3;   // small grids (BH=4 N=4096: m1 0.231, m3 0.158, m5 0.274 ms): 128-row workgroups, pipelined
+        return (tiles256 >= 256 && (fits256 || p.n <= 512)) ? 5 : 3;   // (N = 384: 0.124 m5 against 0.161 m3) small grids (BH=4 N=4096: m1 0.231, m3 0.158, m5 0.274 ms): 128-row workgroups, pipelined
     }
+    // rows of a few tiles: the first-tile-reference pass (no pipeline to fill); at d = 64 up to 512 keys once the grid is two rounds deep
+    if (p.n <= 256 || (d == 64 && p.n <= 512 && tiles128 >= 1024)) return 1;
     if (causal) {
-        if (p.n <= 1024) return 1;                                         // short rows: skipping tiles beats masking them
+        if (p.n <= (d == 64 ? 512 : 384)) return 1;                        // short rows: skipping tiles beats masking them
         return (p.n >= 8192 && tiles256 >= 256) ? 4 : 3;                 // 256-row tiles only pay on long rows
     }
-    return tiles256 >= 256 ? 4 : 3;                                        // small grids: 128-row workgroups fill more CUs
+    if (d == 64 && p.n <= 1024) return 3;
+    return (tiles256 >= 256 && fits256) ? 4 : 3;                           // small grids: 128-row workgroups fill more CUs
 }
 
 // every tiling instantiated for head dim D (one translation unit per (dtype, D): fa_split_{f32,bf16}_d{32,64,128}.hip, so the

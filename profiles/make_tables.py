@@ -45,10 +45,10 @@ def fr(j, peak=2500.0):
     return f"{j['tflops'] / peak:.3f}"
 
 
-def replace_block(path, body):
+def replace_block(path, body, name="results"):
     text = open(path).read()
-    pat = re.compile(r"(<!-- results:begin -->\n).*?(<!-- results:end -->)", re.S)
-    assert pat.search(text), f"{path}: no results markers"
+    pat = re.compile(r"(<!-- %s:begin -->\n).*?(<!-- %s:end -->)" % (name, name), re.S)
+    assert pat.search(text), f"{path}: no {name} markers"
     open(path, "w").write(pat.sub(lambda m: m.group(1) + body + m.group(2), text))
 
 
@@ -87,6 +87,20 @@ def main():
     design = (f"Generated by `python profiles/make_tables.py {tag}` from `profiles/{tag}_config_table.txt` and `profiles/{tag}_bench_line*.json` "
               f"(library sha256 {b4['roofline']['lib_sha256']}…):\n\n" + "\n".join(rows) + "\n")
     replace_block(os.path.join(ROOT, "DESIGN.md"), design)
+
+    # the c4 sentence of DESIGN.md section 7: profiler passes of the same collection
+    pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json")))
+    k4 = next(v for k, v in pmc.items() if "fa_fwd_bf16_x4_kernel" in k)
+    traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert traffic["_tag"] == tag and b4["roofline"]["lib_sha256"] and traffic["lib_sha256"].startswith(b4["roofline"]["lib_sha256"][:16]), "pmc_traffic.json is from another collection"
+    summ = open(os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.txt")).read()
+    m = re.search(r"== pass stats: kernel durations.*?\n.*?\n\s*(\d+)\s+(\d+)\s+\d+\s+\d+\s+\d+\s+void fa::fa_fwd_bf16_x4_kernel", summ, re.S)
+    calls, avg_ns = int(m.group(1)), int(m.group(2))
+    gui = k4["GRBM_GUI_ACTIVE"] / 8.0   # summed over the 8 XCDs
+    sec7 = (f"c4 from the final passes (`{tag}`): {avg_ns / 1e3:.1f} µs average of {calls} dispatches under the profiler, `SQ_VALU_MFMA_BUSY_CYCLES` ÷ (1024 SIMDs ×\n"
+            f"{gui / 1e3:.1f} k cycles) = {k4['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * gui):.2f} of the matrix pipe, {gui / avg_ns:.2f} GHz, HBM traffic {traffic['c4_hbm_bytes_per_launch'] / 1e6:.2f} MB against 67.11 MB\n"
+            f"algorithmic, `SQ_LDS_BANK_CONFLICT` {k4['SQ_LDS_BANK_CONFLICT']:.0f}; the bench line of that call: {b4['roofline']['kernel_ms']:.4f} ms = **{b4['roofline']['frac']:.3f}**.\n")
+    replace_block(os.path.join(ROOT, "DESIGN.md"), sec7, "profile7")
 
     readme = (
         f"Measured on MI355X (steady clocks, ONE run of the final binary on one box — `profiles/{tag}_config_table.txt`, generated by\n"

@@ -1290,3 +1290,32 @@ def test_bench_harness_reports_pass(extra):
                         "--batch_size", "2", "--seq_len", "1024", "--iters", "3"] + extra, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "[Correctness] attn values sanity check: PASSED" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("d", [32, 64, 128])
+@pytest.mark.parametrize("n", [96, 128, 200, 256, 384, 512, 640, 896])
+def test_short_rows_through_the_round3_dispatch(n, d, causal):
+    """Rows of a few tiles take other tilings since round 3 (choose_split: the first-tile-reference pass up to 256 / 512 keys, 128-row
+    workgroups where 256-row tiles would compute rows past N; choose_bf16: the phase-structured kernel up to 128 keys) -- every rule
+    on a grid two rounds deep and on a small one, fp32 and bf16 tensors, against rung 0 on the same inputs."""
+    for bh in (1100 * 128 // n // 4, 5):
+        q, k, v = (randn(s, bh, n, d) for s in (211, 212, 213))
+        qd, kd, vd = to_dev(q, k, v)
+        ref, lse_ref = fa.forward(qd, kd, vd, causal, kernel="naive", return_lse=True)
+        out = torch.full((bh, n, d), float("nan"), device=dev())
+        _, lse = fa.forward(qd, kd, vd, causal, out=out, return_lse=True)
+        assert not torch.isnan(out).any()
+        err = float((out - ref).abs().max())
+        OBSERVED.append((f"short rows fp32 bh={bh} n={n} d={d} causal={causal}", err, TOL_F32))
+        assert err < TOL_F32 and float((lse - lse_ref).abs().max()) < 1e-3
+        qb, kb, vb = (t.to(torch.bfloat16) for t in (qd, kd, vd))
+        refb = fa.forward(qb.float(), kb.float(), vb.float(), causal, kernel="naive")
+        for odt, tol in ((torch.bfloat16, bf16_tol(1.0, False)), (torch.float32, TOL_ACC)):
+            ob = torch.full((bh, n, d), float("nan"), dtype=odt, device=dev())
+            fa.forward(qb, kb, vb, causal, out=ob)
+            assert not torch.isnan(ob.float()).any()
+            errb = float((ob.float() - refb).abs().max())
+            OBSERVED.append((f"short rows bf16->{odt} bh={bh} n={n} d={d} causal={causal}", errb, tol))
+            assert errb < tol

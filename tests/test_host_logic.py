@@ -47,6 +47,12 @@ def test_library_exports_every_declared_symbol():
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 128, 0, 2, 1 << 24) == b"fa_fwd_f32_split_kernel"    # a 4 GiB slab: beyond 32-bit byte offsets
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 128, 2048) == b"fa_fwd_bf16_x2_p16x2_kernel"   # more than one round of 512-row tiles: NB = 2, two per CU
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 16, 8192) == b"fa_fwd_bf16_x2_p16x2_kernel"    # c4: one full round of two NB = 2 workgroups per CU
+    # rows of two stages: the phase-structured kernel (round 3); longer rows keep the one-wave-per-SIMD kernels
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, 0, 1024, 128) == b"fa_fwd_bf16_kernel"
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 32, 1, 1024, 100) == b"fa_fwd_bf16_kernel"
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 128, 1, 256, 512) == b"fa_fwd_bf16_kernel"
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 128, 0, 256, 512) == b"fa_fwd_bf16_x2_kernel"
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, 0, 512, 256) == b"fa_fwd_bf16_pp3_kernel"
 
 
 def test_kernel_ids_match_the_header_and_the_python_names():
