@@ -457,11 +457,18 @@ static Bf16Choice choose_bf16(int64_t bh, int64_t n, int d, int causal, bool add
         return causal ? kChoosePhase : kChooseW4;
     }
     if (!addressable) return kChoosePhase;
+    const int64_t items256 = bh * ((n + 255) / 256), items512 = bh * ((n + 511) / 512);
+    // Grids of at most 128 tiles of 256 rows leave half the CUs idle under the one-wave-per-SIMD kernels: the phase-structured kernel's
+    // 128-row workgroups are twice as many.  ms phase-structured / NB = 2 (profiles/r03_short_rows.txt, second part), d = 64, BH x N:
+    // 8 x 1024 0.0166 / 0.0188 (causal 0.0182 / 0.0236), 32 x 1024 0.0194 / 0.0207 (0.0198 / 0.0246), 8 x 2048 0.0302 / 0.0320
+    // (0.0326 / 0.0367), 4 x 3072 0.0423 / 0.0442, 16 x 512 causal 0.0111 / 0.0171; 16 x 2048 (128 tiles) 0.0342 / 0.0345, 32 x 1536 (192)
+    // 0.0389 / 0.0306; d = 32: 8 x 1024 0.0123 / 0.0146 (0.0143 / 0.0193), 16 x 1536 0.0187 / 0.0207.  Rows of 4096 keys and more on such
+    // grids are key-split launches of the NB = 2 kernel (fa_api.cpp).
+    if (n < 4096 && items256 <= 128) return kChoosePhase;
     // d = 32 (TFLOP/s, x2 / pipelined / phase-structured): 16 x 8192 non-causal 780 / 767 / -, causal 428 / 415 / 416; 128 x 8192
     // causal 709 / - / 560
     if (d == 32) return kChooseX2D32;
     // d == 64
-    const int64_t items256 = bh * ((n + 255) / 256), items512 = bh * ((n + 511) / 512);
     if (causal) {
         // With every workgroup resident at once (two-wave kernel) a causal launch lasts as long as its heaviest pair of tiles.  The
         // one-wave-per-SIMD kernel with 256-row tiles runs one or two workgroups per CU in an order chosen for the grid (heavy tiles

@@ -26,7 +26,8 @@ def test_library_exports_every_declared_symbol():
     assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16, 64, 1) == b"fa_fwd_bf16_x2_kernel"        # causal, few items: 256-row tiles, one per CU
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, 1, 128, 8192) == b"fa_fwd_bf16_x2_kernel"         # long causal rows: NB = 2 tiles whatever the grid
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, 1, 128, 2048) == b"fa_fwd_bf16_pp3_kernel"        # short causal rows, many tiles: the two-wave kernel
-    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, 0, 3, 700) == b"fa_fwd_bf16_x2_kernel"   # at most one round of 256-row tiles
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, 0, 3, 700) == b"fa_fwd_bf16_kernel"      # at most 128 tiles of 256 rows: 128-row workgroups (round 3)
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, 0, 48, 1024) == b"fa_fwd_bf16_x2_kernel"  # at most one round of 256-row tiles
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, 0, 24, 8192) == b"fa_fwd_bf16_pp3_kernel"  # 1.5 rounds: two-wave kernel
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, 0, 12, 8192) == b"fa_fwd_bf16_x4_kernel"
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 128, 0, 16, 8192) == b"fa_fwd_bf16_x2_kernel"
