@@ -298,13 +298,15 @@ int keysplit_factor(const fa::FwdParams& p, int32_t d, int32_t causal, bool f32 
     if (!dense_layout(p, d) || p.n < 4096) return 1;
     if (((int64_t)(p.n - 1) * p.kv_row_stride + d) * 2 >= (int64_t)0xffffffffLL) return 1;   // the NB = 2 kernels' 32-bit slab offsets
     const int64_t tiles = (int64_t)p.bh * ((p.n + 255) / 256);
-    if (tiles > (causal ? 256 : 128)) return 1;
-    // fp32 tensors, causal (split kernel, ms unsplit / key-split at d = 64: BH x N 1 x 8192 0.183 / 0.066, 2 x 8192 0.172 / 0.111, 4 x 8192
-    // 0.185 / 0.178, 8 x 8192 0.299 / 0.230, 1 x 16384 0.346 / 0.187, 2 x 16384 0.361 / 0.333, 4 x 16384 0.586 / 0.611): a full round of
-    // 256-row tiles is split only while a row is 8192 keys or shorter
-    if (f32 && causal && tiles > 128 && p.n > 8192) return 1;
+    // bf16 tensors: causal launches of up to a full round of 256-row tiles are split (a causal launch lasts as long as its heaviest tile).
+    // fp32 tensors (split kernel): its 128-row tiling, two workgroups per CU in the paired order, balances a causal round by itself --
+    // ms unsplit / key-split at d = 64, BH x N: 16 x 4096 causal 0.126 / 0.151, 8 x 8192 causal 0.222 / 0.247; 8 x 4096 0.097 / 0.090,
+    // 4 x 8192 0.197 / 0.191, 2 x 16384 0.369 / 0.342; 1 x 8192 0.179 / 0.059 -- and at d = 128 the split stops paying at 128 tiles
+    // (8 x 4096 0.196 / 0.206, 4 x 8192 0.361 / 0.361; 4 x 4096 0.163 / 0.122): profiles/r03_short_rows.txt, third part.
+    const int64_t cap = f32 ? (d == 128 ? 64 : 128) : (causal ? 256 : 128);
+    if (tiles > cap) return 1;
     int S = 1;
-    while (S < 8 && tiles * (2 * S) <= (causal ? 512 : 256) && p.n / (2 * S) >= 1024) S *= 2;
+    while (S < 8 && tiles * (2 * S) <= 2 * cap && p.n / (2 * S) >= 1024) S *= 2;
     while (S > 1 && (int64_t)(S - 1) * keysplit_rows(p, S, causal) >= p.n) --S;   // every split owns at least one key
     return S;
 }

@@ -1023,20 +1023,28 @@ static int choose_split(const FwdParams& p, int d, int causal, unsigned elem_siz
     const int64_t tiles128 = (int64_t)p.bh * ((p.n + 127) / 128);
     // 256-row workgroups compute whole tiles: rows past N are wasted, and with N mod 256 in (0, 128] the 128-row tiling wastes a tile less
     const bool fits256 = p.n % 256 == 0 || p.n % 256 > 128 || p.n >= 4096;
+    // 256-row workgroups run one per CU: a round that is filled to between a quarter and three quarters costs a whole one (32 x 3072,
+    // 384 tiles: m3 0.213 / m4 0.239 at d = 64, 0.161 / 0.180 at d = 32)
+    const int64_t part = tiles256 % 256;
+    const bool rounds256 = tiles256 >= 1024 || part == 0 || part >= 192;
     if (d == 128) {
         if (p.n <= 128) return 1;
         // two blocks per wave do not fit the register file; EIGHT waves of one block each (256-row workgroups, two waves per
         // SIMD, phases in sequence) halve the K/V conversion work and the L2 traffic per row
+        // causal, ms m3 / m5: 64 x 2048 0.257 / 0.291, 32 x 4096 0.412 / 0.511, 8 x 8192 0.387 / 0.560; 16 x 8192 0.796 / 0.702, 128 x 1024 0.168 / 0.157
+        if (causal && p.n > 1536 && (p.n < 8192 || tiles256 < 512)) return 3;
         return (tiles256 >= 256 && (fits256 || p.n <= 512)) ? 5 : 3;   // (N = 384: 0.124 m5 against 0.161 m3) small grids (BH=4 N=4096: m1 0.231, m3 0.158, m5 0.274 ms): 128-row workgroups, pipelined
     }
     // rows of a few tiles: the first-tile-reference pass (no pipeline to fill); at d = 64 up to 512 keys once the grid is two rounds deep
     if (p.n <= 256 || (d == 64 && p.n <= 512 && tiles128 >= 1024)) return 1;
     if (causal) {
         if (p.n <= (d == 64 ? 512 : 384)) return 1;                        // short rows: skipping tiles beats masking them
-        return (p.n >= 8192 && tiles256 >= 256) ? 4 : 3;                 // 256-row tiles only pay on long rows
+        // 256-row tiles only pay on long rows, and from two rounds on: one round of them lasts as long as its heaviest tile, alone on its
+        // CU (8 x 8192: m3 0.220 / m4 0.309 at d = 64, 0.173 / 0.238 at d = 32; 16 x 8192: 0.410 / 0.376)
+        return (p.n >= 8192 && tiles256 >= 512) ? 4 : 3;
     }
     if (d == 64 && p.n <= 1024) return 3;
-    return (tiles256 >= 256 && fits256) ? 4 : 3;                           // small grids: 128-row workgroups fill more CUs
+    return (tiles256 >= 256 && fits256 && rounds256) ? 4 : 3;              // small grids: 128-row workgroups fill more CUs
 }
 
 // every tiling instantiated for head dim D (one translation unit per (dtype, D): fa_split_{f32,bf16}_d{32,64,128}.hip, so the

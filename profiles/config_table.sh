@@ -36,18 +36,18 @@ $D --mode rand --bh 16 --n 8192 --d 32 $P
 $D --mode rand --bh 128 --n 1024 --d 64 $P
 echo "== hi + lo bf16 terms (--kernel split --out_f32 1): c4"
 $D --mode rand --bh 16 --n 8192 --d 64 --dtype bf16 --kernel split --out_f32 1 --warmup 100 --iters 30 --check 0
-echo "== key-split launches (grids that leave the chip idle): bf16 non-causal / causal BH = 1, 2, 4, 8; fp32 BH = 1, 2; fp32 causal BH = 1, 2, 8"
+echo "== key-split launches (grids that leave the chip idle): bf16 non-causal / causal BH = 1, 2, 4, 8; fp32 BH = 1, 2; fp32 causal BH = 1, 2, 4"
 K="--dtype bf16 --kernel auto --warmup 100 --iters 50 --check 0"
 for b in 1 2 4; do $D --mode rand --bh $b --n 8192 --d 64 $K; done
 for b in 1 2 4 8; do $D --mode rand --bh $b --n 8192 --d 64 $K --causal 1; done
 for b in 1 2; do $D --mode rand --bh $b --n 8192 --d 64 --dtype f32s --kernel auto --warmup 100 --iters 50 --check 0; done
-for b in 1 2 8; do $D --mode rand --bh $b --n 8192 --d 64 --dtype f32s --kernel auto --warmup 100 --iters 50 --check 0 --causal 1; done
-echo "== the same launches without the key split (bf16: --kernel mfma --variant 50; fp32 tensors: --kernel split): bf16 non-causal BH = 1, 2, 4; causal 1, 2, 4, 8; fp32 1, 2; fp32 causal 1, 2, 8"
+for b in 1 2 4; do $D --mode rand --bh $b --n 8192 --d 64 --dtype f32s --kernel auto --warmup 100 --iters 50 --check 0 --causal 1; done
+echo "== the same launches without the key split (bf16: --kernel mfma --variant 50; fp32 tensors: --kernel split): bf16 non-causal BH = 1, 2, 4; causal 1, 2, 4, 8; fp32 1, 2; fp32 causal 1, 2, 4"
 U="--dtype bf16 --kernel mfma --variant 50 --warmup 100 --iters 50 --check 0"
 for b in 1 2 4; do $D --mode rand --bh $b --n 8192 --d 64 $U; done
 for b in 1 2 4 8; do $D --mode rand --bh $b --n 8192 --d 64 $U --causal 1; done
 for b in 1 2; do $D --mode rand --bh $b --n 8192 --d 64 --dtype f32s --kernel split --warmup 100 --iters 50 --check 0; done
-for b in 1 2 8; do $D --mode rand --bh $b --n 8192 --d 64 --dtype f32s --kernel split --warmup 100 --iters 50 --check 0 --causal 1; done
+for b in 1 2 4; do $D --mode rand --bh $b --n 8192 --d 64 --dtype f32s --kernel split --warmup 100 --iters 50 --check 0 --causal 1; done
 echo "== one-term fp16-P kernels (explicit only): --kernel p16 --out_f32 1  (c4 at scale 1, 0.5, 1/sqrt(d); causal; bh=128; d=128; d=32; c2 shape)"
 P="--dtype bf16 --kernel p16 --out_f32 1 --warmup 100 --iters 30 --check 0"
 for sc in 1 0.5 0.125; do $D --mode rand --bh 16 --n 8192 --d 64 $P --scale $sc; done
