@@ -303,7 +303,10 @@ int keysplit_factor(const fa::FwdParams& p, int32_t d, int32_t causal, bool f32 
     // ms unsplit / key-split at d = 64, BH x N: 16 x 4096 causal 0.126 / 0.151, 8 x 8192 causal 0.222 / 0.247; 8 x 4096 0.097 / 0.090,
     // 4 x 8192 0.197 / 0.191, 2 x 16384 0.369 / 0.342; 1 x 8192 0.179 / 0.059 -- and at d = 128 the split stops paying at 128 tiles
     // (8 x 4096 0.196 / 0.206, 4 x 8192 0.361 / 0.361; 4 x 4096 0.163 / 0.122): profiles/r03_short_rows.txt, third part.
-    const int64_t cap = f32 ? (d == 128 ? 64 : 128) : (causal ? 256 : 128);
+    // bf16, causal, more than 128 tiles (ms unsplit / key-split): 8 x 8192 0.128 / 0.098 (d = 32 0.099 / 0.072, d = 128 0.191 / 0.170), 4 x 16384
+    // 0.235 / 0.219; but 16 x 4096 0.071 / 0.077 (d = 128 0.108 / 0.131), 12 x 4096 0.070 / 0.074, d = 128 4 x 16384 0.358 / 0.384
+    const bool long_causal = causal && p.n >= 8192 && (d < 128 || p.n < 16384);
+    const int64_t cap = f32 ? (d == 128 ? 64 : 128) : (long_causal ? 256 : 128);
     if (tiles > cap) return 1;
     int S = 1;
     while (S < 8 && tiles * (2 * S) <= 2 * cap && p.n / (2 * S) >= 1024) S *= 2;
