@@ -22,7 +22,8 @@
  *   ownership   the caller owns every buffer; nothing is allocated, freed or zero-filled by fa_forward_ws, the entry point of this
  *               boundary proper (the reference allocates O and a dead O_l inside forward(), :608-609).  Two paths need scratch --
  *               the fp16 copy of V of the fp16-P kernels (FA_KERNEL_P16X2 / FA_KERNEL_P16, and FA_KERNEL_AUTO with an fp32 output),
- *               and the partial outputs of a key-split launch (bf16 tensors, non-causal, grids of at most 128 256-row tiles: several
+ *               and the partial outputs of a key-split launch (rows of 4096 keys and more on grids that leave the chip idle -- at most
+ *               128 tiles of 256 rows, 256 for long causal bf16 launches --, bf16 and fp32 tensors, causal or not: several
  *               workgroups per q-tile share the keys and a combine kernel merges them): fa_workspace_bytes() reports the size for a
  *               call, fa_forward_ws() takes the caller's buffer, and every path is then legal inside a captured hipGraph.
  *               fa_forward / fa_forward_ex / fa_forward_sharded are CONVENIENCE WRAPPERS: they take the same bytes from a private
