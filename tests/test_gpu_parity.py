@@ -1300,7 +1300,7 @@ def test_short_rows_through_the_round3_dispatch(n, d, causal):
     """Rows of a few tiles take other tilings since round 3 (choose_split: the first-tile-reference pass up to 256 / 512 keys, 128-row
     workgroups where 256-row tiles would compute rows past N; choose_bf16: the phase-structured kernel up to 128 keys) -- every rule
     on a grid two rounds deep and on a small one, fp32 and bf16 tensors, against rung 0 on the same inputs."""
-    for bh in (1100 * 128 // n // 4, 5):
+    for bh in (1100 * 128 // n, 5):   # tiles of 128 rows: >= 1024 (the grid depth some rules ask for), and a handful
         q, k, v = (randn(s, bh, n, d) for s in (211, 212, 213))
         qd, kd, vd = to_dev(q, k, v)
         ref, lse_ref = fa.forward(qd, kd, vd, causal, kernel="naive", return_lse=True)
