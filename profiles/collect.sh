@@ -42,6 +42,9 @@ shape_pass d32_n1024_bf16 --bh 128 --n 1024 --d 32 --dtype bf16
 shape_pass d32_n8192_bf16 --bh 16 --n 8192 --d 32 --dtype bf16
 shape_pass c4_causal --bh 16 --n 8192 --d 64 --dtype bf16 --causal 1
 cd $R
+# first summary: writes profiles/pmc_traffic.json (with this library's sha256) from the PMC passes above, so that the bench lines below --
+# which print `traffic` only for the library the counters were collected on -- carry it; the second one at the end checks the kernel names
+python3 profiles/summarize_rocpd.py $OUT $TAG --out $OUT > /dev/null 2>&1 || true
 python3 bench.py --accurate --no-cpu-baseline --no-extras > $OUT/bench_line_accurate.json 2> $OUT/bench_acc.err
 python3 bench.py --workload c3 --no-cpu-baseline > $OUT/bench_line_c3.json 2> $OUT/bench_c3.err
 python3 bench.py > $OUT/bench_line.json 2> $OUT/bench.err
