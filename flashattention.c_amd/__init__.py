@@ -6,8 +6,8 @@ Import name: ``flashattention_c_amd`` (the directory name contains a dot; ``flas
 aliases it).
 """
 from . import _cabi  # noqa: F401
-from .flash import SUPPORTED_HEAD_DIMS, forward, forward_packed_qkv, last_forward_route, load, time_forward, workspace_bytes  # noqa: F401
+from .flash import SUPPORTED_HEAD_DIMS, forward, forward_packed_qkv, last_forward_route, load, stats, time_forward, workspace_bytes  # noqa: F401
 from .sharding import forward_sharded, shard_range, shard_sizes  # noqa: F401
 
 __all__ = ["forward", "forward_packed_qkv", "load", "time_forward", "last_forward_route", "forward_sharded", "shard_range", "shard_sizes", "workspace_bytes",
-           "SUPPORTED_HEAD_DIMS"]
+           "stats", "SUPPORTED_HEAD_DIMS"]

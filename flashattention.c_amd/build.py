@@ -34,24 +34,28 @@ ARCH = "gfx950"
 # longest translation units first: the thread pool starts them in this order
 LIB_SOURCES = ["fa_fwd_bf16_x4.hip", "fa_fwd_bf16_x2.hip",
                "fa_fwd_bf16_pipelined.hip", "fa_split_f32_d64.hip", "fa_split_f32_d128.hip", "fa_split_f32_d32.hip",
-               "fa_split_bf16_d64.hip", "fa_split_bf16_d128.hip", "fa_split_bf16_d32.hip", "fa_fwd_bf16.hip",
-               "fa_fwd_bf16_x4_p16.hip", "fa_fwd_bf16_x2_p16_d128.hip", "fa_fwd_bf16_x2_p16_d64.hip",
-               "fa_fwd_bf16_x2_p16_d32.hip", "fa_fwd_bf16_x2_p16x2_d128.hip", "fa_fwd_bf16_x2_p16x2_d64.hip", "fa_fwd_bf16_x2_p16x2_d32.hip", "fa_cvt.hip",
+               "fa_split_bf16_d64.hip", "fa_split_bf16_d128.hip", "fa_split_bf16_d32.hip", "fa_fwd_bf16.hip", "fa_combine.hip",
+               "fa_fwd_bf16_x4_pb2.hip", "fa_fwd_bf16_x2_pb2_d128.hip", "fa_fwd_bf16_x2_pb2_d64.hip", "fa_fwd_bf16_x2_pb2_d32.hip",
                "fa_fwd_f32.hip", "fa_fwd_f32_split.hip", "fa_fwd_bf16_split.hip", "fa_naive.hip", "fa_api.cpp"]
-# timing-only instantiations (garbage results): only in libflashattn_amd_ablation.so
-ABLATION_SOURCES = ["fa_fwd_bf16_x4_ablation.hip", "fa_fwd_bf16_x4_causal.hip", "fa_fwd_bf16_pp2.hip", "fa_fwd_f32_t3.hip"]
+# csrc/experiments/: only in libflashattn_amd_ablation.so -- timing-only instantiations (garbage results), superseded kernel generations
+# and the fp16-P families the round-4 accurate path (P as two bf16 terms) replaced (correct, tested through fa_driver_ablation)
+ABLATION_SOURCES = ["experiments/" + f for f in (
+    "fa_fwd_bf16_x4_ablation.hip", "fa_fwd_bf16_x4_causal.hip", "fa_fwd_bf16_pp2.hip", "fa_fwd_f32_t3.hip", "fa_cvt.hip", "fa_fwd_bf16_x4_p16.hip",
+    "fa_fwd_bf16_x2_p16_d128.hip", "fa_fwd_bf16_x2_p16_d64.hip", "fa_fwd_bf16_x2_p16_d32.hip", "fa_fwd_bf16_x2_p16x2_d128.hip",
+    "fa_fwd_bf16_x2_p16x2_d64.hip", "fa_fwd_bf16_x2_p16x2_d32.hip")]
 # product sources whose text depends on FA_ABLATION (the variant dispatch): recompiled for the ablation library, the rest is shared
-ABLATION_DEPENDENT = ["fa_fwd_bf16.hip", "fa_fwd_bf16_x4.hip", "fa_fwd_bf16_pipelined.hip", "fa_fwd_bf16_x2.hip", "fa_cvt.hip", "fa_api.cpp",
+ABLATION_DEPENDENT = ["fa_fwd_bf16.hip", "fa_fwd_bf16_x4.hip", "fa_fwd_bf16_pipelined.hip", "fa_fwd_bf16_x2.hip", "fa_api.cpp",
                       "fa_split_f32_d32.hip", "fa_split_f32_d64.hip"]
 ABL_LIB_PATH = os.path.join(PKG_DIR, "libflashattn_amd_ablation.so")
 ABL_DRIVER_PATH = os.path.join(PKG_DIR, "fa_driver_ablation")
-HEADERS = ["fa_common.h", "fa_kernels.h", "fa_bf16_common.h", "fa_split_kernel.h", "fa_bf16_xn_kernel.h", "fa_f32_t3_kernel.h", "fa_bf16_step.h", os.path.join(ROOT, "include", "flashattn_amd.h")]
+HEADERS = ["fa_common.h", "fa_kernels.h", "fa_bf16_common.h", "fa_split_kernel.h", "fa_bf16_xn_kernel.h", "experiments/fa_f32_t3_kernel.h", "fa_bf16_step.h",
+           os.path.join(ROOT, "include", "flashattn_amd.h")]
 COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-                "-I", os.path.join(ROOT, "include")]
+                "-I", os.path.join(ROOT, "include"), "-I", CSRC]
 # per-source extras.  The split kernel keeps its fp32 arithmetic scalar: the SLP vectoriser would pair it into
 # v_pk_add_f32 / v_pk_mul_f32, which block the matrix pipe's issue for a full MFMA slot each on gfx950.
 EXTRA_FLAGS = {f"fa_split_{dt}_d{d}.hip": ["-fno-slp-vectorize"] for dt in ("f32", "bf16") for d in (32, 64, 128)}
-EXTRA_FLAGS["fa_fwd_f32_t3.hip"] = ["-fno-slp-vectorize"]
+EXTRA_FLAGS["experiments/fa_fwd_f32_t3.hip"] = ["-fno-slp-vectorize"]
 
 
 def hipcc() -> str:
@@ -71,7 +75,7 @@ def _newest_dep() -> float:
 
 
 def _compile(src: str, force: bool, ablation: bool = False) -> str:
-    obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + (".abl.o" if ablation else ".o"))
+    obj = os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + (".abl.o" if ablation else ".o"))
     srcp = os.path.join(CSRC, src)
     if not force and _mtime(obj) > max(_mtime(srcp), _newest_dep()):
         return obj

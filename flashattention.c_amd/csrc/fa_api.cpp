@@ -17,6 +17,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "fa_kernels.h"
@@ -91,42 +92,53 @@ fa::FwdParams make_params(const void* q, const void* k, const void* v, void* o, 
 }
 
 // ---- conditional launch chains ------------------------------------------------------------------------------------------------
-// Two FA_KERNEL_AUTO paths are chains of launches on the caller's stream in which a later kernel runs or skips itself depending on
-// what an earlier one found on the device (nothing is read back, nothing synchronises):
+// The FA_KERNEL_AUTO path of fp32 tensors is a chain of launches on the caller's stream in which a later kernel runs or skips itself
+// depending on what an earlier one found on the device (nothing is read back, nothing synchronises):
 //   fp32 tensors   split kernel (bf16 pipe, 16-bit operand terms; raises the word when the logits are too wide for that)
-//                  -> exact fp32 kernel, only if the word is raised;
-//   bf16 tensors with fp32 output   V -> fp16 copy (raises the word when some |v| >= 2^16) -> fp16-P kernel unless raised
-//                  -> split kernel (hi + lo bf16 terms of P) only if raised.
+//                  -> exact fp32 kernel, only if the word is raised.
+// (bf16 tensors with an fp32 output were a chain too until round 4 -- V -> fp16 copy, fp16-P kernel, split kernel as the fallback; P as
+// two bf16 terms made that one unconditional launch.  The fp16 chain lives on in the ablation library.)
 // "Raised" means "the word equals this call's serial number" (serials are unique per call), so a word never needs clearing between
 // eager calls.  WHERE the word lives is what keeps two chains from ever sharing one:
-//   * a chain that runs with a caller-owned workspace (fa_forward_ws) keeps its word in the first bytes of that workspace -- the
-//     caller's buffer, in use by one forward at a time like every other buffer of the call;
-//   * every other eager chain takes the slot of its (device, stream) pair from a per-device pool, and the pool's mutex is held while
+//   * a chain that runs with a caller-owned workspace (fa_forward_ws; fa_workspace_bytes() reports at least the 256-byte header for
+//     every chained call) keeps its word in the first bytes of that workspace -- the caller's buffer, in use by one forward at a time
+//     like every other buffer of the call;
+//   * every other eager chain takes the slot of its (device, stream) pair from a per-device table, and the table's mutex is held while
 //     the chain is enqueued: chains that share a slot are on one stream, one after the other, so the second chain's first kernel
-//     runs after the first chain's last;
-//   * a chain enqueued while its stream is CAPTURING takes a slot of its own that is never handed out again (the graph keeps slot and
-//     serial for every replay; a verdict left by an earlier replay can only send a later one down the slower, always-correct
-//     kernel); with a workspace the captured chain clears its word first (a memset node), so replays are independent.
+//     runs after the first chain's last.  An event recorded behind each chain tells when its slot may change hands: when the table is
+//     full the least recently used slot whose last chain has COMPLETED is given to the new stream (a long-running host that creates and
+//     destroys streams never runs out; round 3 handed slots out once and degraded to the slow kernel after 8192 streams);
+//   * a chain enqueued while its stream is CAPTURING takes a slot of its own and starts with a memset node that clears the word, so
+//     replays of the graph are independent of each other (round 3 left the verdict of an earlier replay standing).  The slot goes back
+//     to the table when the graph -- and every executable instantiated from it -- has been destroyed (a hipUserObject retained by
+//     the capturing graph; where the runtime refuses that, the slot is simply never reused).
+// When no slot can be had the always-correct kernel of the chain is launched alone; fa_get_stats() counts those calls.
 // (Round 2 indexed a 4096-slot ring with serial % 4096: a chain whose serial was congruent -- every 4096th eager call, or a replayed
 // graph -- could overwrite a raised word between the other chain's primary and its fallback kernel.)
 constexpr int kFlagSlots = 16384;          // eager slots [0, kEagerSlots), capture slots behind them
 constexpr int kEagerSlots = 8192;
 __device__ uint32_t g_flag_ring[kFlagSlots];
-__device__ unsigned long long g_stat_ring[kFlagSlots][2];   // pre-pass maxima of the t3 chain, tagged with the call's serial (fa_cvt.hip)
+__device__ unsigned long long g_stat_ring[kFlagSlots][2];   // pre-pass maxima of the t3 chain, tagged with the call's serial (experiments/fa_cvt.hip)
 constexpr int kMaxDevices = 64;
 std::atomic<uint32_t*> g_ring_base[kMaxDevices];
 std::atomic<unsigned long long*> g_stat_base[kMaxDevices];
-std::atomic<int> g_next_eager[kMaxDevices];
-std::atomic<int> g_next_capture[kMaxDevices];
 std::atomic<uint32_t> g_serial{1};
+
+// process-wide counters behind fa_get_stats()
+struct Stats {
+    std::atomic<uint64_t> forwards{0}, chains{0}, chains_degraded{0}, scratch_replans{0}, slot_evictions{0}, capture_slots_recycled{0};
+};
+Stats g_stats;
 
 struct FlagRef {
     uint32_t* word = nullptr;
     uint32_t serial = 0;
     unsigned long long* stats = nullptr;   // two 64-bit words of the same slot (nullptr for a workspace word)
+    hipEvent_t done = nullptr;             // eager slot: recorded behind the chain's last launch (see SlotTable)
+    int dev = -1, eager_slot = -1;         // ... of this device's table
 };
 thread_local FlagRef t_last_flag;   // chain state of this thread's most recent forward (fa_last_forward_route)
-thread_local int t_last_chain = 0;  // 0 = no chain, 1 = fp32 guard, 2 = fp16-P
+thread_local int t_last_chain = 0;  // 0 = no chain, 1 = fp32 guard, 2 = fp16-P (ablation library)
 thread_local int t_last_route = -1; // >= 0: the route of the last chain, read before its workspace went away (fa_time_forward*)
 
 int current_device()
@@ -149,22 +161,70 @@ uint32_t next_serial()
     return serial;
 }
 
-// eager slots by (device, stream).  Chains that share a slot are on one stream; the per-device mutex is held while a chain is being
-// enqueued, so two host threads feeding one stream cannot interleave their chains' kernels either.  hipStreamPerThread is one handle
-// for a different stream in every thread: those chains take a slot per thread.
-struct SlotKey {
-    hipStream_t stream;
-    int slot;
+// The slots of one device.  Eager slots are keyed by stream (hipStreamPerThread is one handle for a different stream in every thread:
+// those chains are keyed by a per-thread number instead).  The mutex is held from taking a slot to the chain's last launch, so two host
+// threads feeding one stream cannot interleave their chains' kernels either.
+struct EagerSlot {
+    uint64_t key = 0;            // stream handle, or (1 << 63) | thread number for hipStreamPerThread
+    hipEvent_t done = nullptr;   // created on first use; recorded behind every chain of this slot
+    bool recorded = false;
+    uint64_t tick = 0;           // last use (LRU)
 };
-struct SlotMap {
+struct SlotTable {
     std::mutex mu;
-    std::vector<SlotKey> slots;
+    std::vector<EagerSlot> eager;                  // index = slot number, grows to kEagerSlots
+    std::unordered_map<uint64_t, int> by_key;
+    uint64_t tick = 0;
+    std::vector<int> free_capture;                 // capture slots given back by destroyed graphs
+    int next_capture = 0;
 };
-SlotMap g_slot_map[kMaxDevices];
-thread_local int t_own_slot = -1, t_own_slot_dev = -1;   // hipStreamPerThread chains of this thread
+SlotTable g_slots[kMaxDevices];
+std::atomic<uint64_t> g_thread_numbers{1};
+thread_local uint64_t t_thread_number = 0;
 
-// The flag word of a chain that has no workspace (see above).  false = no slot left (or no device symbol): the caller then launches
-// the always-correct kernel of the chain alone.  `hold` keeps the device's slot map locked until the chain is enqueued.
+// capture slots come back through a hipUserObject the capturing graph retains: its destructor runs when the graph and every executable
+// instantiated from it are gone.  (No HIP call is allowed in there: it only pushes a number onto a list.)
+struct CaptureSlotToken {
+    int dev, slot;
+};
+void release_capture_slot(void* ptr)
+{
+    CaptureSlotToken* t = static_cast<CaptureSlotToken*>(ptr);
+    if (t->dev >= 0 && t->dev < kMaxDevices) {
+        std::lock_guard<std::mutex> g(g_slots[t->dev].mu);
+        g_slots[t->dev].free_capture.push_back(t->slot);
+        g_stats.capture_slots_recycled.fetch_add(1, std::memory_order_relaxed);
+    }
+    delete t;
+}
+// true: the graph being captured on `stream` now owns `slot` (it returns it when it dies)
+bool tie_capture_slot_to_graph(hipStream_t stream, int dev, int slot)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    hipGraph_t graph = nullptr;
+    if (hipStreamGetCaptureInfo_v2(stream, &st, &id, &graph, nullptr, nullptr) != hipSuccess || graph == nullptr) {
+        (void)hipGetLastError();
+        return false;
+    }
+    CaptureSlotToken* tok = new CaptureSlotToken{dev, slot};
+    hipUserObject_t uo = nullptr;
+    if (hipUserObjectCreate(&uo, tok, release_capture_slot, 1, hipUserObjectNoDestructorSync) != hipSuccess || uo == nullptr) {
+        (void)hipGetLastError();
+        delete tok;
+        return false;
+    }
+    if (hipGraphRetainUserObject(graph, uo, 1, hipGraphUserObjectMove) != hipSuccess) {
+        (void)hipGetLastError();
+        tok->dev = -1;                       // the destructor then only frees the token
+        (void)hipUserObjectRelease(uo, 1);
+        return false;
+    }
+    return true;
+}
+
+// The flag word of a chain that has no workspace (see above).  false = no slot to be had (or no device symbol): the caller then launches
+// the always-correct kernel of the chain alone.  `hold` keeps the device's slot table locked until the chain is enqueued.
 bool next_flag(FlagRef& f, hipStream_t stream, bool capturing, std::unique_lock<std::mutex>& hold)
 {
     const int dev = current_device();
@@ -179,38 +239,86 @@ bool next_flag(FlagRef& f, hipStream_t stream, bool capturing, std::unique_lock<
         g_stat_base[dev].store(static_cast<unsigned long long*>(sym2), std::memory_order_release);
         g_ring_base[dev].store(base, std::memory_order_release);
     }
+    SlotTable& tb = g_slots[dev];
+    hold = std::unique_lock<std::mutex>(tb.mu);
     int slot = -1;
+    f.done = nullptr;
     if (capturing) {
-        const int k = g_next_capture[dev].fetch_add(1, std::memory_order_relaxed);
-        if (k >= kFlagSlots - kEagerSlots) return false;
-        slot = kEagerSlots + k;
-    } else if (stream == hipStreamPerThread) {
-        if (t_own_slot < 0 || t_own_slot_dev != dev) {   // (a thread that hops devices takes a new one; slots are plentiful)
-            const int k = g_next_eager[dev].fetch_add(1, std::memory_order_relaxed);
-            if (k >= kEagerSlots) return false;
-            t_own_slot = k;
-            t_own_slot_dev = dev;
+        int k = -1;
+        if (!tb.free_capture.empty()) {
+            k = tb.free_capture.back();
+            tb.free_capture.pop_back();
+        } else if (tb.next_capture < kFlagSlots - kEagerSlots) {
+            k = tb.next_capture++;
         }
-        slot = t_own_slot;
+        if (k < 0) {
+            hold.unlock();
+            return false;
+        }
+        slot = kEagerSlots + k;
+        hold.unlock();                                   // (the runtime may run a user-object destructor -- which takes this mutex -- inside its calls)
+        (void)tie_capture_slot_to_graph(stream, dev, k);   // not tied: the slot is never handed out again, as in round 3
+        hold.lock();
     } else {
-        SlotMap& m = g_slot_map[dev];
-        hold = std::unique_lock<std::mutex>(m.mu);
-        for (const SlotKey& s : m.slots)
-            if (s.stream == stream) slot = s.slot;
-        if (slot < 0) {
-            const int k = g_next_eager[dev].fetch_add(1, std::memory_order_relaxed);
-            if (k >= kEagerSlots) {
+        uint64_t key = reinterpret_cast<uint64_t>(stream);
+        if (stream == hipStreamPerThread) {
+            if (t_thread_number == 0) t_thread_number = g_thread_numbers.fetch_add(1, std::memory_order_relaxed);
+            key = (1ull << 63) | t_thread_number;
+        }
+        auto it = tb.by_key.find(key);
+        if (it != tb.by_key.end()) {
+            slot = it->second;
+        } else if ((int)tb.eager.size() < kEagerSlots) {
+            slot = (int)tb.eager.size();
+            tb.eager.emplace_back();
+        } else {
+            // table full: the least recently used slot whose last chain has completed changes hands (a few candidates at most: a slot
+            // found busy is moved to the young end)
+            for (int attempt = 0; attempt < 16 && slot < 0; ++attempt) {
+                int lru = 0;
+                for (int i = 1; i < (int)tb.eager.size(); ++i)
+                    if (tb.eager[i].tick < tb.eager[lru].tick) lru = i;
+                EagerSlot& c = tb.eager[lru];
+                if (!c.recorded || hipEventQuery(c.done) == hipSuccess) {
+                    tb.by_key.erase(c.key);
+                    slot = lru;
+                    g_stats.slot_evictions.fetch_add(1, std::memory_order_relaxed);
+                } else {
+                    (void)hipGetLastError();
+                    c.tick = ++tb.tick;
+                }
+            }
+            if (slot < 0) {
                 hold.unlock();
                 return false;
             }
-            slot = k;
-            m.slots.push_back(SlotKey{stream, slot});
         }
+        EagerSlot& e = tb.eager[slot];
+        if (e.key != key) {
+            e.key = key;
+            e.recorded = false;
+            tb.by_key[key] = slot;
+        }
+        if (e.done == nullptr && hipEventCreateWithFlags(&e.done, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            e.done = nullptr;   // without an event the slot could never change hands safely: it simply stays with its stream
+        }
+        e.tick = ++tb.tick;
+        f.done = e.done;
+        f.dev = dev;
+        f.eager_slot = slot;
     }
     f.word = base + slot;
     f.serial = next_serial();
     f.stats = g_stat_base[dev].load(std::memory_order_acquire) + 2 * (size_t)slot;
     return true;
+}
+// behind the chain's last launch, table still locked (`hold`): the event that tells when this slot may change hands
+void chain_enqueued(const FlagRef& f, hipStream_t stream)
+{
+    if (f.done == nullptr || f.dev < 0 || f.eager_slot < 0) return;
+    if (hipEventRecord(f.done, stream) == hipSuccess) g_slots[f.dev].eager[f.eager_slot].recorded = true;
+    else (void)hipGetLastError();
 }
 
 // ---- scratch ------------------------------------------------------------------------------------------------------------------
@@ -314,17 +422,16 @@ int keysplit_factor(const fa::FwdParams& p, int32_t d, int32_t causal, bool f32 
     return S;
 }
 
+// FA_KERNEL_AUTO, bf16 tensors, fp32 output (round 4): P as bf16 hi + bf16 lo in the one-wave-per-SIMD kernel (FA_KERNEL_PB2) -- one launch,
+// V as it is, no scratch, at every launch size: ms at BH x N x d against round 3's chain (V -> fp16 copy, two fp16 terms of P, empty
+// fallback launch), same box: 16 x 8192 x 64 0.352 / 0.367, 128 x 8192 x 64 2.78 / 2.79, causal 16 x 8192 x 64 0.205 / 0.227, 16 x 8192 x 128
+// 0.589 / 0.631, 16 x 8192 x 32 0.260 / 0.272, 128 x 1024 x 64 0.060 / 0.072, 16 x 1024 x 64 0.028 / 0.037, 1 x 8192 x 64 (key-split) 0.043 / 0.051
+// (profiles/r04_pb2_ab.txt), at 2.4e-5 against 3.1e-5 of the fp32 reference on c4.  Q.K^T is one bf16 product, exact in the fp32
+// accumulator, so the error does not grow with the logit width (the split kernel's 16-bit Q' does: round 3's soak read 6.5e-4 from it
+// at x3 logits); the split kernel remains the choice for slabs beyond 32-bit byte offsets.
+#if FA_ABLATION
 bool p16_available(const fa::FwdParams& p, int32_t d) { return dense_layout(p, d) && fa::bf16_p16_supported(p, d); }
-
-// FA_KERNEL_AUTO, bf16 tensors, fp32 output: two fp16 terms of P (a chain of three launches) whenever scratch is available, whatever the
-// launch size.  The alternative without scratch -- hi + lo bf16 terms of P AND of Q' = Q * scale * log2(e) in one launch (the split
-// kernel) -- is faster below ~1.2e10 multiply-adds per contraction (ms chain / split kernel, BH x N x d: 16 x 8192 x 64 0.368 / 0.446,
-// 128 x 2048 x 64 0.225 / 0.255, 64 x 2048 x 64 0.134 / 0.140, 16 x 4096 x 64 0.135 / 0.132, 128 x 1024 x 64 0.082 / 0.085, 16 x 2048 x 64
-// 0.066 / 0.044, 16 x 1024 x 64 0.036 / 0.019), but its 16-bit Q' makes the error of a score grow with the logit width (the fp32-tensor
-// path has a device-side guard for exactly that; bf16 tensors have no exact kernel to fall back to): the round-3 soak (tests/soak_fuzz.py,
-// x3 logits at d = 128) read 6.5e-4 from it where the two-term fp16 kernel -- whose Q.K^T is exact in the fp32 accumulator -- stayed
-// below 1e-4 on every data family.  A caller who asks for the fp32 accumulator gets the kernel whose error does not depend on the data;
-// the split kernel remains the choice when there is no scratch (a capturing stream without a workspace) and for slabs beyond 4 GiB.
+#endif
 
 // ---- the plan of one forward: which launches, how much scratch ---------------------------------------------------------------------
 // One function decides for fa_workspace_bytes, fa_forward_ws and the convenience entries alike, so the size a caller is told is the
@@ -334,9 +441,11 @@ enum Route {
     kRouteBf16Plain,      // one launch of the bf16-P dispatch (launch_fwd_bf16)
     kRouteBf16KeySplit,   // bf16-P NB = 2 kernel over key shares + combine
     kRouteBf16Split,      // hi + lo bf16 terms of P and Q' (no scratch)
-    kRouteP16Chain        // V -> fp16 copy, fp16-P kernel (key-split for idle grids), split kernel as the conditional fallback
+    kRouteBf16Pb2,        // hi + lo bf16 terms of P in the one-wave-per-SIMD kernel (one launch, no scratch; key-split for idle grids)
+    kRouteP16Chain        // (ablation library) V -> fp16 copy, fp16-P kernel (key-split for idle grids), split kernel as the conditional fallback
 };
-constexpr size_t kWsHeader = 256;   // first bytes of a workspace: the chain's flag word (and alignment of what follows)
+constexpr size_t kWsHeader = 256;   // first bytes of a workspace: the chain's flag word (and alignment of what follows); a chained call
+                                    // without other scratch asks for just these bytes
 struct Plan {
     int status = FA_OK;   // FA_OK, or the error fail() recorded
     Route route = kRouteNaive;
@@ -357,7 +466,8 @@ Plan make_plan(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype,
         pl.route = kRouteNaive;
         return pl;
     }
-    if (sel.kind != FA_KERNEL_AUTO && sel.kind != FA_KERNEL_MFMA && sel.kind != FA_KERNEL_SPLIT && sel.kind != FA_KERNEL_P16 && sel.kind != FA_KERNEL_P16X2) {
+    if (sel.kind != FA_KERNEL_AUTO && sel.kind != FA_KERNEL_MFMA && sel.kind != FA_KERNEL_SPLIT && sel.kind != FA_KERNEL_P16 && sel.kind != FA_KERNEL_P16X2 &&
+        sel.kind != FA_KERNEL_PB2) {
         pl.status = fail(FA_ERR_UNSUPPORTED, "unknown kernel id %d", sel.kind);
         return pl;
     }
@@ -366,10 +476,12 @@ Plan make_plan(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype,
         return pl;
     }
     if (dtype == FA_DTYPE_F32) {
-        if (sel.kind == FA_KERNEL_P16 || sel.kind == FA_KERNEL_P16X2) pl.status = fail(FA_ERR_UNSUPPORTED, "FA_KERNEL_P16 / FA_KERNEL_P16X2 are bf16-tensor kernels");
+        if (sel.kind == FA_KERNEL_P16 || sel.kind == FA_KERNEL_P16X2 || sel.kind == FA_KERNEL_PB2)
+            pl.status = fail(FA_ERR_UNSUPPORTED, "FA_KERNEL_P16 / FA_KERNEL_P16X2 / FA_KERNEL_PB2 are bf16-tensor kernels");
         else if (sel.kind == FA_KERNEL_MFMA || (sel.kind == FA_KERNEL_AUTO && f32_auto_is_exact())) pl.route = kRouteF32Exact;
         else if (sel.kind == FA_KERNEL_AUTO && sel.variant == 0) {
             pl.route = kRouteF32Guarded;
+            if (scratch_ok) pl.total = kWsHeader;   // the chain's verdict word (a caller-owned workspace keeps it off the slot table)
             // grids that leave the chip idle: the split kernel over key shares + combine (the guard's verdict is per share, and any share
             // raising it sends the whole launch to the exact kernel, which runs unsplit)
             const int S = scratch_ok ? keysplit_factor(p, d, causal, true) : 1;
@@ -393,11 +505,17 @@ Plan make_plan(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype,
         else pl.route = kRouteF32Split;
         return pl;
     }
-    // bf16 tensors.  AUTO: a caller who asks for the fp32 accumulator gets the accurate P (two fp16 terms where instantiated and
-    // worthwhile, hi + lo bf16 terms elsewhere: ~1e-4 either way); a bf16 output rounds at 2^-9 of |O| anyway and takes the fastest
-    // kernels (bf16 P).  MFMA / SPLIT / P16 / P16X2 force one family.
+    // bf16 tensors.  AUTO: a caller who asks for the fp32 accumulator gets the accurate P (two bf16 terms: ~3e-5); a bf16 output rounds
+    // at 2^-9 of |O| anyway and takes the fastest kernels (bf16 P).  MFMA / SPLIT / PB2 force one family.
     const int out_f32 = dtype == FA_DTYPE_BF16_OUT_F32 ? 1 : 0;
     const bool p16_kind = sel.kind == FA_KERNEL_P16 || sel.kind == FA_KERNEL_P16X2;
+#if !FA_ABLATION
+    if (p16_kind) {
+        pl.status = fail(FA_ERR_UNSUPPORTED, "FA_KERNEL_P16 / FA_KERNEL_P16X2 (P and V in fp16) were replaced by FA_KERNEL_PB2 (P as two bf16 terms: faster, one launch, "
+                                             "no scratch) and are built into libflashattn_amd_ablation.so only");
+        return pl;
+    }
+#else
     if (p16_kind && !p16_available(p, d)) {
         pl.status = fail(FA_ERR_UNSUPPORTED, "the fp16-P kernels need dense (bh, n, d) tensors and address a slab with 32-bit byte offsets (slabs below 4 GiB; got n = %d, d = %d)", p.n, d);
         return pl;
@@ -408,11 +526,26 @@ Plan make_plan(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype,
                                              "kernel without scratch while the stream is capturing");
         return pl;
     }
+#endif
+    if (sel.kind == FA_KERNEL_PB2 && !fa::bf16_p16_supported(p, d)) {
+        pl.status = fail(FA_ERR_UNSUPPORTED, "FA_KERNEL_PB2 addresses a slab with 32-bit byte offsets (slabs below 4 GiB; got n = %d, d = %d)", p.n, d);
+        return pl;
+    }
     const int S = (scratch_ok && sel.variant == 0) ? keysplit_factor(p, d, causal) : 1;
-    const bool p16 = p16_kind ||
-                     (scratch_ok && sel.kind == FA_KERNEL_AUTO && out_f32 && sel.variant == 0 && p16_available(p, d));
+    // AUTO for an fp32 output (round 4): hi + lo bf16 terms of P in the one-wave-per-SIMD kernel -- one launch, V as it is, any layout
+    // (slabs beyond 32-bit byte offsets: the split kernel below)
+    if (sel.kind == FA_KERNEL_PB2 || (sel.kind == FA_KERNEL_AUTO && out_f32 && sel.variant == 0 && fa::bf16_p16_supported(p, d))) {
+        pl.route = kRouteBf16Pb2;
+        if (S > 1) {
+            pl.S = S;
+            pl.part_off = kWsHeader;
+            pl.part_bytes = (size_t)S * p.bh * p.n * d * 4u + (size_t)S * p.bh * p.n * 4u;
+            pl.total = pl.part_off + align256(pl.part_bytes);
+        }
+        return pl;
+    }
     const size_t part = (size_t)S * p.bh * p.n * d * 4u + (size_t)S * p.bh * p.n * 4u;
-    if (p16) {
+    if (p16_kind) {
         pl.route = kRouteP16Chain;
         pl.terms = sel.kind == FA_KERNEL_P16 ? 1 : 2;
         pl.S = S;
@@ -461,8 +594,13 @@ hipError_t launch_bf16_keysplit(const fa::FwdParams& p0, int32_t d, int32_t caus
     p.n_kv_total = p0.n;
     hipError_t e;
     if (p16 == 0) e = fa::launch_bf16_x2(p, d, c, 1, 0, stream);
+    else if (p16 == 3) e = fa::launch_bf16_pb2(p, d, c, 1, 1, stream);   // bf16 hi + lo terms of P, NB = 2
+#if FA_ABLATION
     else if (p16 == 1) e = d == 32 ? fa::launch_bf16_x2_p16_d32(p, c, 1, stream) : d == 64 ? fa::launch_bf16_x2_p16_d64(p, c, 1, stream) : fa::launch_bf16_x2_p16_d128(p, c, 1, stream);
     else e = d == 32 ? fa::launch_bf16_x2_p16x2_d32(p, c, 1, stream) : d == 64 ? fa::launch_bf16_x2_p16x2_d64(p, c, 1, stream) : fa::launch_bf16_x2_p16x2_d128(p, c, 1, stream);
+#else
+    else e = hipErrorInvalidValue;
+#endif
     fa::FwdParams pc = p0;
     pc.flag_mode = 0;
     if (e == hipSuccess) e = fa::launch_combine_splits(pc, o_part, lse_part, S, d, out_f32, stream);
@@ -496,7 +634,8 @@ hipError_t launch_f32_keysplit(const fa::FwdParams& p0, int32_t d, int32_t causa
     return e;
 }
 
-// bf16 tensors, fp16 P: V -> fp16 copy in scratch, fp16-P kernel, split kernel as the conditional fallback
+#if FA_ABLATION
+// bf16 tensors, fp16 P (ablation library): V -> fp16 copy in scratch, fp16-P kernel, split kernel as the conditional fallback
 hipError_t launch_p16_chain(const fa::FwdParams& p0, int32_t d, int32_t causal, int32_t out_f32, const Plan& pl, char* ws, const FlagRef& f,
                             hipStream_t stream)
 {
@@ -522,7 +661,6 @@ hipError_t launch_p16_chain(const fa::FwdParams& p0, int32_t d, int32_t causal, 
     return e;
 }
 
-#if FA_ABLATION
 // fp32 tensors, long non-causal rows at head dim 64: K / V split once per launch into scratch (the same pass bounds the logit width),
 // then the static-slot three-product kernel; guard, range or finiteness trouble raises the flag -> exact kernel.
 // The pre-pass moves 2.5 x sizeof(K + V) + sizeof(Q) through HBM (~40 us at c3).
@@ -564,47 +702,64 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
     const KernelSel sel = decode_kernel(kernel);
     t_last_chain = 0;
     t_last_route = -1;
+    g_stats.forwards.fetch_add(1, std::memory_order_relaxed);
     const bool capturing = stream_is_capturing(stream);
     Plan pl = make_plan(p, d, causal, dtype, kernel, ws_mode ? true : !capturing);
     if (pl.status != FA_OK) return pl.status;
     char* scratch = static_cast<char*>(ws);
     bool owned = false;
-    if (pl.total > 0) {
-        if (ws_mode) {
-            if (scratch == nullptr || ws_bytes < pl.total)
-                return fail(FA_ERR_INVALID_ARGUMENT, "workspace of %zu bytes is too small: this call needs fa_workspace_bytes() = %zu", scratch ? ws_bytes : (size_t)0, pl.total);
-            if ((reinterpret_cast<uintptr_t>(scratch) & 255u) != 0) return fail(FA_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
+    if (pl.total > 0 && ws_mode) {
+        if (scratch == nullptr || ws_bytes == 0) {
+            // a binder that skips fa_workspace_bytes(): FA_KERNEL_AUTO runs without scratch (the unsplit launch; the verdict word of a
+            // chain from the slot table) instead of refusing -- an explicit kernel that cannot do without scratch still says so
+            scratch = nullptr;
+            if (sel.kind != FA_KERNEL_AUTO) return fail(FA_ERR_INVALID_ARGUMENT, "this kernel choice needs a workspace of fa_workspace_bytes() = %zu bytes", pl.total);
+            pl = make_plan(p, d, causal, dtype, kernel, false);
+            if (pl.status != FA_OK) return pl.status;
+            g_stats.scratch_replans.fetch_add(1, std::memory_order_relaxed);
         } else {
-            void* ptr = nullptr;
-            const hipError_t ea = scratch_alloc(&ptr, pl.total, stream);
-            if (ea != hipSuccess || ptr == nullptr) {
-                (void)hipGetLastError();
-                // the scratch paths are optimisations (and FA_KERNEL_P16 an explicit request): AUTO falls back to the kernels without scratch
-                if (sel.kind == FA_KERNEL_P16 || sel.kind == FA_KERNEL_P16X2 || pl.route == kRouteF32T3)
-                    return fail(FA_ERR_HIP, "stream-ordered allocation of %zu scratch bytes failed: %s", pl.total, hipGetErrorString(ea));
-                pl = make_plan(p, d, causal, dtype, kernel, false);
-                if (pl.status != FA_OK) return pl.status;
-            } else {
-                scratch = static_cast<char*>(ptr);
-                owned = true;
-            }
+            if (ws_bytes < pl.total) return fail(FA_ERR_INVALID_ARGUMENT, "workspace of %zu bytes is too small: this call needs fa_workspace_bytes() = %zu", ws_bytes, pl.total);
+            if ((reinterpret_cast<uintptr_t>(scratch) & 255u) != 0) return fail(FA_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
+        }
+    } else if (pl.total > kWsHeader) {   // (a header-only plan needs no allocation: the word of an owned chain comes from the slot table)
+        void* ptr = nullptr;
+        const hipError_t ea = scratch_alloc(&ptr, pl.total, stream);
+        if (ea != hipSuccess || ptr == nullptr) {
+            (void)hipGetLastError();
+            // the scratch paths are optimisations (and the fp16-P kernels of the ablation library an explicit request): AUTO falls back to
+            // the kernels without scratch
+            if (sel.kind == FA_KERNEL_P16 || sel.kind == FA_KERNEL_P16X2 || pl.route == kRouteF32T3)
+                return fail(FA_ERR_HIP, "stream-ordered allocation of %zu scratch bytes failed: %s", pl.total, hipGetErrorString(ea));
+            pl = make_plan(p, d, causal, dtype, kernel, false);
+            if (pl.status != FA_OK) return pl.status;
+            g_stats.scratch_replans.fetch_add(1, std::memory_order_relaxed);
+        } else {
+            scratch = static_cast<char*>(ptr);
+            owned = true;
         }
     }
     const int out_f32 = dtype == FA_DTYPE_BF16_OUT_F32 ? 1 : 0;
     const int c = causal ? 1 : 0;
     hipError_t e = hipSuccess;
-    // the chain's flag word: in the workspace when the call has one, else the slot of (device, stream) / a capture slot
-    std::unique_lock<std::mutex> hold;   // slot map of the device, locked from taking a slot to the chain's last launch
+    // The chain's flag word: in the CALLER's workspace when the call has one, else the slot of (device, stream) / a capture slot.  Never
+    // in scratch this call owns: that goes back to the pool behind the last kernel, and fa_last_forward_route() reads the word later
+    // (round 3 put it there and read freed memory).
+    std::unique_lock<std::mutex> hold;   // slot table of the device, locked from taking a slot to the chain's last launch
     auto chain_flag = [&](FlagRef& f) -> bool {
-        if (scratch != nullptr && pl.total > 0) {
+        bool ok;
+        if (ws_mode && scratch != nullptr && ws_bytes >= kWsHeader) {
+            f = FlagRef{};
             f.word = reinterpret_cast<uint32_t*>(scratch);
             f.serial = next_serial();
-            f.stats = nullptr;
-            // a captured chain is replayed with the same serial: clear the word first, or a verdict of an earlier replay would stand
-            if (capturing) return hipMemsetAsync(f.word, 0, sizeof(uint32_t), stream) == hipSuccess;
-            return true;
+            ok = true;
+        } else {
+            ok = next_flag(f, stream, capturing, hold);
         }
-        return next_flag(f, stream, capturing, hold);
+        // a captured chain is replayed with the same serial: clear the word first, or a verdict of an earlier replay would stand
+        if (ok && capturing) ok = hipMemsetAsync(f.word, 0, sizeof(uint32_t), stream) == hipSuccess;
+        g_stats.chains.fetch_add(1, std::memory_order_relaxed);
+        if (!ok) g_stats.chains_degraded.fetch_add(1, std::memory_order_relaxed);
+        return ok;
     };
     switch (pl.route) {
         case kRouteNaive: e = fa::launch_naive_f32(p, d, c, stream); break;
@@ -612,7 +767,7 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
         case kRouteF32Split: e = fa::launch_f32_split(p, d, c, sel.variant, stream); break;
         case kRouteF32Guarded: {   // split products behind the logit-width guard, exact kernel as the conditional fallback
             FlagRef f;
-            if (!chain_flag(f)) {   // no slot left for this (device, stream): the always-correct kernel alone
+            if (!chain_flag(f)) {   // no slot to be had for this (device, stream): the always-correct kernel alone
                 e = fa::launch_fwd_f32(p, d, c, 0, stream);
                 break;
             }
@@ -626,6 +781,7 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
                 pg.flag_mode = 2;
                 e = fa::launch_fwd_f32(pg, d, c, 0, stream);
             }
+            chain_enqueued(f, stream);
             if (e == hipSuccess) {
                 t_last_flag = f;
                 t_last_chain = 1;
@@ -637,9 +793,24 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
             FlagRef f;
             if (!next_flag(f, stream, capturing, hold)) return fail(FA_ERR_HIP, "no device flag slot (hipGetSymbolAddress failed or slots exhausted)");
             e = launch_f32_t3_chain(p, d, scratch + pl.part_off, f, stream, sel.variant == 8, sel.variant >= 16 ? sel.variant - 16 : 0);
+            chain_enqueued(f, stream);
             if (e == hipSuccess) {
                 t_last_flag = f;
                 t_last_chain = 1;
+            }
+            break;
+        }
+        case kRouteP16Chain: {
+            FlagRef f;
+            if (!chain_flag(f)) {
+                e = fa::launch_bf16_split(p, d, c, out_f32, 0, stream);
+                break;
+            }
+            e = launch_p16_chain(p, d, causal, out_f32, pl, scratch, f, stream);
+            chain_enqueued(f, stream);
+            if (e == hipSuccess) {
+                t_last_flag = f;
+                t_last_chain = 2;
             }
             break;
         }
@@ -647,21 +818,13 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
         case kRouteBf16Plain: e = fa::launch_fwd_bf16(p, d, c, out_f32, sel.variant, stream); break;
         case kRouteBf16Split: e = fa::launch_bf16_split(p, d, c, out_f32, sel.variant, stream); break;
         case kRouteBf16KeySplit: e = launch_bf16_keysplit(p, d, causal, out_f32, pl.S, scratch + pl.part_off, stream); break;
-        case kRouteP16Chain: {
-            FlagRef f;
-            if (!chain_flag(f)) {
-                e = fa::launch_bf16_split(p, d, c, out_f32, 0, stream);   // cannot happen with a workspace; kept total
-                break;
-            }
-            e = launch_p16_chain(p, d, causal, out_f32, pl, scratch, f, stream);
-            if (e == hipSuccess) {
-                t_last_flag = f;
-                t_last_chain = 2;
-            }
+        case kRouteBf16Pb2:
+            if (pl.S > 1) e = launch_bf16_keysplit(p, d, causal, out_f32, pl.S, scratch + pl.part_off, stream, 3);
+            else e = fa::launch_bf16_pb2(p, d, c, out_f32, sel.variant, stream);
             break;
-        }
         default: return fail(FA_ERR_UNSUPPORTED, "kernel id %d is not in this build", sel.kind);
     }
+    if (hold.owns_lock()) hold.unlock();
     if (owned) {
         const hipError_t ef = hipFreeAsync(scratch, stream);
         if (e == hipSuccess) e = ef;
@@ -748,6 +911,8 @@ int fa_forward_sharded(int32_t n_shards, const int32_t* device_ids, const void* 
     }
     int prev = 0;
     if (hipGetDevice(&prev) != hipSuccess) return fail(FA_ERR_HIP, "hipGetDevice failed");
+    t_last_chain = 0;   // the shards' chains belong to their worker threads: fa_last_forward_route() of this thread reports "no chain"
+    t_last_route = -1;
     // One host thread per shard: a forward may be a chain of launches plus a stream-ordered allocation, and enqueued from one
     // thread the last device would start a whole chain's worth of host time behind the first.  The current device is per host
     // thread in HIP, so the workers do not disturb the caller's; each worker's scratch comes from its own device's private pool.
@@ -768,11 +933,19 @@ int fa_forward_sharded(int32_t n_shards, const int32_t* device_ids, const void* 
         if (bh[i] > 0) ++active, last = i;   // bh[i] == 0: more devices than slabs, this shard is empty
     if (active == 1) {
         work(last);
+        t_last_chain = 0;
     } else if (active > 1) {
         std::vector<std::thread> th;
-        for (int i = 0; i < n_shards; ++i)
-            if (bh[i] > 0) th.emplace_back(work, i);
+        for (int i = 0; i < n_shards; ++i) {
+            if (bh[i] <= 0) continue;
+            try {
+                th.emplace_back(work, i);
+            } catch (const std::exception&) {   // no thread to be had (nothing may cross the extern "C" boundary): this shard from here
+                work(i);
+            }
+        }
         for (auto& t : th) t.join();
+        t_last_chain = 0;
     }
     (void)hipSetDevice(prev);
     for (int i = 0; i < n_shards; ++i)
@@ -924,6 +1097,26 @@ int fa_last_forward_route(void* stream, int32_t* route)
     return FA_OK;
 }
 
+int fa_get_stats(fa_stats* out)
+{
+    if (!out) return fail(FA_ERR_INVALID_ARGUMENT, "null stats pointer");
+    memset(out, 0, sizeof(*out));
+    out->forwards = g_stats.forwards.load(std::memory_order_relaxed);
+    out->chains = g_stats.chains.load(std::memory_order_relaxed);
+    out->chains_degraded = g_stats.chains_degraded.load(std::memory_order_relaxed);
+    out->scratch_replans = g_stats.scratch_replans.load(std::memory_order_relaxed);
+    out->slot_evictions = g_stats.slot_evictions.load(std::memory_order_relaxed);
+    out->capture_slots_recycled = g_stats.capture_slots_recycled.load(std::memory_order_relaxed);
+    for (int dev = 0; dev < kMaxDevices; ++dev) {
+        std::lock_guard<std::mutex> g(g_slots[dev].mu);
+        out->eager_slots_in_use += (uint64_t)g_slots[dev].eager.size();
+        out->capture_slots_in_use += (uint64_t)(g_slots[dev].next_capture - (int)g_slots[dev].free_capture.size());
+    }
+    out->eager_slots_per_device = kEagerSlots;
+    out->capture_slots_per_device = kFlagSlots - kEagerSlots;
+    return FA_OK;
+}
+
 const char* fa_last_error(void) { return g_err; }
 
 int fa_device_count(void)
@@ -936,9 +1129,9 @@ int fa_device_count(void)
 const char* fa_version(void)
 {
 #if FA_ABLATION
-    return "flashattn_amd abi 3 gfx950 (hip, mfma f32 32x32x2 / bf16, f16 32x32x16, lds-dma) +ablation";
+    return "flashattn_amd abi 4 gfx950 (hip, mfma f32 32x32x2 / bf16 32x32x16, lds-dma) +ablation";
 #else
-    return "flashattn_amd abi 3 gfx950 (hip, mfma f32 32x32x2 / bf16, f16 32x32x16, lds-dma)";
+    return "flashattn_amd abi 4 gfx950 (hip, mfma f32 32x32x2 / bf16 32x32x16, lds-dma)";
 #endif
 }
 
@@ -954,11 +1147,11 @@ const char* fa_kernel_name_for(int32_t dtype, int32_t d, int32_t causal, int64_t
         if (keysplit_factor(pk, d, causal) > 1) return "fa_fwd_bf16_x2_kernel";       // small grids: key-split launch of the NB = 2 kernel
         return fa::bf16_kernel_name(bh, n, d, causal);
     }
-    if (dtype == FA_DTYPE_BF16_OUT_F32) {   // the accurate P (see fa_dtype): fp16 (slabs below 4 GiB, launches large enough), hi + lo bf16 terms otherwise
+    if (dtype == FA_DTYPE_BF16_OUT_F32) {   // the accurate P (see fa_dtype): hi + lo bf16 terms in the one-wave-per-SIMD kernel (slabs below 4 GiB)
         if (((n - 1) * d + d) * 2 >= 0xffffffffLL) return "fa_fwd_f32_split_kernel";
         const fa::FwdParams pk = make_params(nullptr, nullptr, nullptr, nullptr, nullptr, bh, n, d, 1.0f);
-        if (keysplit_factor(pk, d, causal) > 1) return "fa_fwd_bf16_x2_p16x2_kernel";   // small grids: key-split launch of the NB = 2 kernel
-        return "fa_fwd_bf16_x2_p16x2_kernel";
+        if (keysplit_factor(pk, d, causal) > 1) return "fa_fwd_bf16_x2_pb2_kernel";   // small grids: key-split launch of the NB = 2 kernel
+        return d == 64 && fa::bf16_pb2_uses_x4(bh, n, causal) ? "fa_fwd_bf16_x4_pb2_kernel" : "fa_fwd_bf16_x2_pb2_kernel";
     }
     return nullptr;
 }

@@ -148,12 +148,17 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(const f32x16& s, int base)
     return r;
 }
 
+// The format of P (and of the V image) in the second contraction, `PF` throughout the one-wave-per-SIMD kernels:
+//   0 = bf16;  1 = fp16;  2 = fp16 hi + fp16 lo (V copied to fp16);  3 = bf16 hi + bf16 lo (V as it is; round 4)
+constexpr bool pf_f16(int PF) { return PF == 1 || PF == 2; }
+constexpr int pf_terms(int PF) { return PF >= 2 ? 2 : 1; }
+
 // P fragment in the format of the second contraction: bf16 (default) or fp16 (round to nearest even: v_cvt_pk_f16_f32)
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-template <int PF>   // 0 = bf16, 1 / 2 = fp16
+template <int PF>
 __device__ __forceinline__ bf16x8 pack_p16x8(const f32x16& s, int base)
 {
-    if constexpr (PF != 0) {
+    if constexpr (pf_f16(PF)) {
         f16x8 r;
 #pragma unroll
         for (int i = 0; i < 8; ++i) r[i] = (_Float16)s[base + i];
@@ -238,7 +243,7 @@ template <int PF = 0>
 __device__ __forceinline__ bf16x8 rowsum_a_operand(int lane)
 {
     const bool one = (((lane & 15) >> 2) & 1) == ((lane >> 4) & 1);
-    if constexpr (PF != 0) {
+    if constexpr (pf_f16(PF)) {
         f16x8 a;
 #pragma unroll
         for (int i = 0; i < 8; ++i) a[i] = one ? (_Float16)1.0f : (_Float16)0.0f;

@@ -85,6 +85,52 @@ __device__ __forceinline__ void lo_half(const f32x16& s, int f, int h, const bf1
     lo = __builtin_bit_cast(bf16x8, lv);
 }
 
+// PF = 3: the lo term of P in bf16, lo = bf16(p - float(hi)) with hi = bf16(p) (round to nearest even, v_cvt_pk_bf16_f32).  gfx950 has
+// no v_fma_mix with bf16 sources; the exact difference comes from the dot-product unit instead -- one VOP2 instruction per element:
+//     v_dot2c_f32_bf16 p, K, hi_pk      p += K.lo * hi_pk.lo + K.hi * hi_pk.hi      with K = (-1, 0) for the low half, (0, -1) for the high
+// (products of bf16 values and their sum with p are exact here: profiles/ubench/ubench_dot2.hip checks 4 M values bit for bit, including
+// the ends of the optimistic mix's exponent window) -- IN PLACE: the fp32 p is dead once both terms exist, so the residuals need no
+// registers.  One v_cvt_pk_bf16_f32 per register then packs them.  Hazard (ours inside asm; LLVM's DotWriteDifferentVALURead): a VALU
+// instruction other than the same dot opcode may read a dot result three wait states after it at the earliest -- so the dots and the
+// packs of a half fragment are SEPARATE units of the step schedule with at least one other unit between them (xn_schedule_ok), and the
+// phase-structured form below runs a whole fragment's eight dots in front of its four packs.
+constexpr unsigned kDotNegLo = 0x0000bf80u, kDotNegHi = 0xbf800000u;   // bf16 pairs (-1, 0) and (0, -1)
+// dots of half h (0 / 1) of fragment f: elements 8 f + 4 h .. + 3 of s become p - hi
+__device__ __forceinline__ void lo_dots_bf16(f32x16& s, int f, int h, const bf16x8& hi)
+{
+    const u32x4 hv = __builtin_bit_cast(u32x4, hi);
+    const int e = 8 * f + 4 * h;
+    asm volatile("v_dot2c_f32_bf16 %0, %4, %6\n\tv_dot2c_f32_bf16 %1, %5, %6\n\tv_dot2c_f32_bf16 %2, %4, %7\n\tv_dot2c_f32_bf16 %3, %5, %7"
+                 : "+v"(s[e]), "+v"(s[e + 1]), "+v"(s[e + 2]), "+v"(s[e + 3])
+                 : "s"(kDotNegLo), "s"(kDotNegHi), "v"(hv[2 * h]), "v"(hv[2 * h + 1]));
+}
+// packs of the same half: two registers of the lo fragment
+__device__ __forceinline__ void lo_packs_bf16(const f32x16& s, int f, int h, bf16x8& lo)
+{
+    u32x4 lv = __builtin_bit_cast(u32x4, lo);
+    const int e = 8 * f + 4 * h;
+    unsigned d0, d1;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5" : "=&v"(d0), "=&v"(d1) : "v"(s[e]), "v"(s[e + 1]), "v"(s[e + 2]), "v"(s[e + 3]));
+    lv[2 * h] = d0;
+    lv[2 * h + 1] = d1;
+    lo = __builtin_bit_cast(bf16x8, lv);
+}
+// a whole fragment, phase-structured (prologue / tail stages): eight dots, then four packs -- every pack at least three instructions
+// behind the last dot it reads
+__device__ __forceinline__ void lo_frag_bf16(f32x16& s, int f, const bf16x8& hi, bf16x8& lo)
+{
+    const u32x4 hv = __builtin_bit_cast(u32x4, hi);
+    const int e = 8 * f;
+    u32x4 lv;
+    asm volatile("v_dot2c_f32_bf16 %4, %12, %14\n\tv_dot2c_f32_bf16 %5, %13, %14\n\tv_dot2c_f32_bf16 %6, %12, %15\n\tv_dot2c_f32_bf16 %7, %13, %15\n\t"
+                 "v_dot2c_f32_bf16 %8, %12, %16\n\tv_dot2c_f32_bf16 %9, %13, %16\n\tv_dot2c_f32_bf16 %10, %12, %17\n\tv_dot2c_f32_bf16 %11, %13, %17\n\t"
+                 "v_cvt_pk_bf16_f32 %0, %4, %5\n\tv_cvt_pk_bf16_f32 %1, %6, %7\n\tv_cvt_pk_bf16_f32 %2, %8, %9\n\tv_cvt_pk_bf16_f32 %3, %10, %11"
+                 : "=&v"(lv[0]), "=&v"(lv[1]), "=&v"(lv[2]), "=&v"(lv[3]), "+v"(s[e]), "+v"(s[e + 1]), "+v"(s[e + 2]), "+v"(s[e + 3]), "+v"(s[e + 4]),
+                   "+v"(s[e + 5]), "+v"(s[e + 6]), "+v"(s[e + 7])
+                 : "s"(kDotNegLo), "s"(kDotNegHi), "v"(hv[0]), "v"(hv[1]), "v"(hv[2]), "v"(hv[3]));
+    lo = __builtin_bit_cast(bf16x8, lv);
+}
+
 template <int PF = 0>
 __device__ __forceinline__ void exp_range(f32x16& s, bf16x8 (&pf)[2], float c, float off, int e0, int e1, bool clamp = true)
 {

@@ -33,19 +33,59 @@
 #ifndef FA_OPT_SAMPLE
 #define FA_OPT_SAMPLE 1   // 0: experiment switch -- the optimistic mix takes its exponent reference from the first sub-tile only (round 2)
 #endif
+// dealing limits of the PF = 3 step schedules (half-slots; see XShape), overridable for the offline search's A/B builds
+#ifndef FA_WEND_OPT3_X4
+#define FA_WEND_OPT3_X4 102
+#endif
+#ifndef FA_WEND_RSC3_X4
+#define FA_WEND_RSC3_X4 112
+#endif
+#ifndef FA_WEND_OPT3_32
+#define FA_WEND_OPT3_32 26
+#endif
+#ifndef FA_WEND_RSC3_32
+#define FA_WEND_RSC3_32 30
+#endif
+#ifndef FA_WEND_OPT3_64
+#define FA_WEND_OPT3_64 47
+#endif
+#ifndef FA_WEND_RSC3_64
+#define FA_WEND_RSC3_64 52
+#endif
+#ifndef FA_WEND_OPT3_128
+#define FA_WEND_OPT3_128 90
+#endif
+#ifndef FA_WEND_RSC3_128
+#define FA_WEND_RSC3_128 98
+#endif
+#ifndef FA_PB2_DOTS_LAST
+#define FA_PB2_DOTS_LAST 1   // 0: experiment switch -- a slot's VALU units in list order
+#endif
+namespace fa {
+// (D = 32: 52 units in 20 slots -- no dealing keeps every pack out of its dots' slot; list order there)
+constexpr bool pb2_dots_last(int D) { return FA_PB2_DOTS_LAST != 0 && D >= 64; }
+}  // namespace fa
+// workgroups of the NB = 2 pb2 kernel a CU is asked to hold (register budget 512 / this per lane)
+// (asked for two at d = 64, hipcc spills: 17 registers to scratch in the causal instantiation, ~20 VGPRs into AGPRs inside the loop in the
+// non-causal one -- 659 v_accvgpr_read in the binary; asked for one they come out at 252 / 256 registers without either and fit a CU
+// twice anyway -- like the bf16-P NB = 2 kernel, see xn_launch_order; tests/test_code_objects.py pins that on the binary)
+#ifndef FA_PB2_WGS_PER_CU
+#define FA_PB2_WGS_PER_CU(D, CAUSAL) ((D) == 32 ? 2 : 1)
+#endif
 
 namespace fa {
 
 // PF: the format of P (and of the V image) in the second contraction -- 0 = bf16, 1 = fp16 (11 significant bits), 2 = fp16 hi + fp16 lo
-// (two products per P.V and per row sum: P to ~22 bits; see XSoft)
+// (two products per P.V and per row sum: P to ~22 bits; see XSoft), 3 = bf16 hi + bf16 lo (round 4: P to ~17 bits with bf16's exponent
+// range, so V stays as it is -- no copy, no scratch, no launch chain -- and the optimistic mix applies)
 template <int D, int NB, int PF = 0>
 struct XShape {
     static_assert((NB == 4 && D == 64) || (NB == 2 && (D == 32 || D == 64 || D == 128)), "instantiated shapes");
-    static_assert(PF >= 0 && PF <= 2, "P formats");
+    static_assert(PF >= 0 && PF <= 3, "P formats");
     static constexpr int KS = D / 16;          // k-steps of K.Q^T
     static constexpr int DB = D / 32;          // 32-column blocks of O
     static constexpr int NV = 2 * DB;          // V^T fragments per 32-key sub-tile
-    static constexpr int NT = PF == 2 ? 2 : 1; // terms of P
+    static constexpr int NT = pf_terms(PF);    // terms of P
     static constexpr int GRP = NT * (NV + 2);  // slots of one P.V + row-sum group
     static constexpr int kSlots = NB * (KS + GRP);
     static constexpr int kFirstPv = 2 * KS;    // first slot that needs the V^T fragments (both layouts start with K.Q^T of A, B)
@@ -54,11 +94,19 @@ struct XShape {
     static constexpr bool kVWaitPerFrag = NB == 4;
     // K fragments of the next step: KS slots starting here (after the step's last K.Q^T slot)
     static constexpr int kKLoad = NB == 4 ? 16 + 2 * GRP : 2 * KS + 1;
-    static constexpr int kUnitsOpt = NB * 18, kUnitsRsc = NB * (21 + (PF == 2 ? 4 : 0)) + 1;
-    // NB = 2: VALU units are dealt out over the first kWend half-slots of the step (largest values that put every pack in front of
-    // the first MFMA reading it, found offline and re-checked at compile time: xn_schedule_ok); NB = 4: see weight_end()
-    static constexpr int kWendOpt2 = D == 128 ? 58 : D == 64 ? 30 : 16;
-    static constexpr int kWendRsc2 = PF == 2 ? (D == 128 ? 99 : D == 64 ? 52 : 29) : (D == 128 ? 64 : D == 64 ? 34 : 18);
+    // VALU units per block: 16 exponentials + 2 packs; the lo term of P adds 4 half fragments (PF = 2: one v_fma_mix per element packs
+    // as it goes) or 4 + 4 (PF = 3: the dots of a half fragment and its packs are separate units, see lo_dots_bf16); rescaled mixes:
+    // 3 lane-max micro-steps per block and the test
+    static constexpr int kLoUnits = PF == 2 ? 4 : PF == 3 ? 8 : 0;
+    static constexpr int kUnitsOpt = NB * (18 + kLoUnits), kUnitsRsc = NB * (21 + kLoUnits) + 1;
+    // VALU units are dealt out over the first kWend half-slots of the step (largest values that put every pack in front of the first MFMA
+    // reading it, found offline -- profiles/r04_xn_schedule_check.py -- and re-checked at compile time: xn_schedule_ok); NB = 4 with one
+    // term of P: see weight_end()
+    static constexpr int kWendOpt2 = PF == 3 ? (D == 128 ? FA_WEND_OPT3_128 : D == 64 ? FA_WEND_OPT3_64 : FA_WEND_OPT3_32) : (D == 128 ? 58 : D == 64 ? 30 : 16);
+    static constexpr int kWendRsc2 = PF == 3   ? (D == 128 ? FA_WEND_RSC3_128 : D == 64 ? FA_WEND_RSC3_64 : FA_WEND_RSC3_32)
+                                     : PF == 2 ? (D == 128 ? 99 : D == 64 ? 52 : 29)
+                                               : (D == 128 ? 64 : D == 64 ? 34 : 18);
+    static constexpr int kWendOpt4 = FA_WEND_OPT3_X4, kWendRsc4 = FA_WEND_RSC3_X4;   // NB = 4, PF = 3
 };
 // ---- matrix instructions with explicit register files ------------------------------------------------------------------
 // With one wave per SIMD the wave owns 256 architectural VGPRs and 256 accumulation registers (AGPRs).  VALU instructions
@@ -86,13 +134,13 @@ __device__ __forceinline__ void mfma_s(f32x16& s, const bf16x8& kf, const bf16x8
 template <int PF = 0>
 __device__ __forceinline__ void mfma_o(f32x16& o, const bf16x8& vf, const bf16x8& pfrag)
 {
-    if constexpr (PF != 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(o) : "v"(vf), "v"(pfrag));
+    if constexpr (pf_f16(PF)) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(o) : "v"(vf), "v"(pfrag));
     else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(vf), "v"(pfrag));
 }
 template <int PF = 0>
 __device__ __forceinline__ void mfma_l(f32x4_t& l, const bf16x8& ones, const bf16x8& pfrag)
 {
-    if constexpr (PF != 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(pfrag));
+    if constexpr (pf_f16(PF)) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(pfrag));
     else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(l) : "v"(ones), "v"(pfrag));
 }
 
@@ -116,11 +164,15 @@ __device__ __forceinline__ void mfma_l(f32x4_t& l, const bf16x8& ones, const bf1
 constexpr int kSampleMinStages = 64;
 constexpr float kSampleSpread = 28.0f;
 
+//   bf16 hi + lo (PF = 3)      the bf16 mixes as they are (optimistic first, rescaled redo): lo = bf16(p - hi) has bf16's exponent range,
+//                        so nothing about the window changes; P is good to 2^-17 relative wherever lo is a normal number (p > 2^-117:
+//                        17 binades below the optimistic reference; further down the terms fade to one-term accuracy and then to the
+//                        exact zeros the clock likes)
 template <bool OPT, int PF>
 struct XSoft {
-    static_assert(!(OPT && PF != 0), "fp16 P has no room for a fixed exponent reference");
-    static constexpr float kBias = OPT ? kOptBias : PF != 0 ? 0.0f : kLazyThr;
-    static constexpr float kThr = PF != 0 ? 15.9f : 0.0f;   // fp16: p < 2^15.9 = 61 147 (fp16 ends at 65 504)
+    static_assert(!(OPT && pf_f16(PF)), "fp16 P has no room for a fixed exponent reference");
+    static constexpr float kBias = OPT ? kOptBias : pf_f16(PF) ? 0.0f : kLazyThr;
+    static constexpr float kThr = pf_f16(PF) ? 15.9f : 0.0f;   // fp16: p < 2^15.9 = 61 147 (fp16 ends at 65 504)
 };
 
 // mfma_drain() with the registers it protects as operands: the drain is an asm statement without a data dependence of its
@@ -252,7 +304,8 @@ template <int D, int NB, int PF = 0>
 constexpr int xn_weight_end(bool opt)
 {
     using S = XShape<D, NB, PF>;
-    if constexpr (NB == 4) return opt ? xn_weight_before<D, NB, PF>(16 + 3 * S::GRP + S::DB + 1) : xn_weight_before<D, NB, PF>(S::kSlots);
+    if constexpr (NB == 4 && PF == 3) return opt ? S::kWendOpt4 : S::kWendRsc4;
+    else if constexpr (NB == 4) return opt ? xn_weight_before<D, NB, PF>(16 + 3 * S::GRP + S::DB + 1) : xn_weight_before<D, NB, PF>(S::kSlots);
     else return opt ? S::kWendOpt2 : S::kWendRsc2;
 }
 // VALU units are dealt out by ISSUE COST, not by count: measured beside MFMAs (profiles/ubench/ubench_clock.hip) a plain
@@ -266,12 +319,14 @@ struct XTable {
 // instruction that reads the result of a transcendental issued just before it costs a wait state (hipcc pads an s_nop).
 // PF = 2: the two halves of a fragment's lo term follow its pack, one exp unit apart (they read the pack's result and the
 // exponentials the pack read).
+// PF = 3: the four dots of a half fragment (kind 4) and its two packs (kind 5) are separate units, two positions apart at least.
 struct XUnit {
     int kind;  // 0 = exp of one element, 1 = pack of one fragment, 2 = lane-max micro-step, 3 = rescale test, 4 = half a lo fragment
+               // (PF = 2: complete; PF = 3: its dots), 5 = the packs of half a lo fragment (PF = 3)
     int blk, idx, cost;
 };
 struct XUnitList {
-    XUnit u[120];
+    XUnit u[128];
 };
 template <int NB, int PF = 0>
 __device__ __host__ constexpr XUnitList xn_make_units(bool opt)
@@ -279,26 +334,32 @@ __device__ __host__ constexpr XUnitList xn_make_units(bool opt)
     XUnitList l{};
     int n = 0;
     int npend = 0;
-    XUnit pend[3] = {};
+    XUnit pend[5] = {};
     for (int b = 0; b < NB; ++b) {
         for (int e = 0; e < 16; ++e) {
             l.u[n++] = {0, b, e, 12};
-            if (npend > 0 && (e == 1 || e == 2 || e == 3)) {   // the previous block's second fragment: pack, then (PF = 2) its lo halves
+            if (npend > 0 && e >= 1 && e <= 5) {   // the previous block's second fragment: pack, then (two terms) its lo halves
                 l.u[n++] = pend[0];
-                pend[0] = pend[1];
-                pend[1] = pend[2];
+                for (int k = 0; k + 1 < 5; ++k) pend[k] = pend[k + 1];
                 --npend;
             }
             if (e == 9) l.u[n++] = {1, b, 0, 16};
-            if (PF == 2 && e == 10) l.u[n++] = {4, b, 0, 16};
-            if (PF == 2 && e == 11) l.u[n++] = {4, b, 1, 16};
+            if (PF >= 2 && e == 10) l.u[n++] = {4, b, 0, 16};
+            if (PF >= 2 && e == 11) l.u[n++] = {4, b, 1, 16};
+            if (PF == 3 && e == 12) l.u[n++] = {5, b, 0, 8};
+            if (PF == 3 && e == 13) l.u[n++] = {5, b, 1, 8};
         }
         pend[0] = {1, b, 1, 16};
         npend = 1;
-        if (PF == 2) {
+        if (PF >= 2) {
             pend[1] = {4, b, 2, 16};
             pend[2] = {4, b, 3, 16};
             npend = 3;
+        }
+        if (PF == 3) {
+            pend[3] = {5, b, 2, 8};
+            pend[4] = {5, b, 3, 8};
+            npend = 5;
         }
     }
     if (opt) {
@@ -311,7 +372,7 @@ __device__ __host__ constexpr XUnitList xn_make_units(bool opt)
             l.u[n++] = {2, b, m, m == 2 ? 8 : 12};
             if (m >= 1 && used < npend) l.u[n++] = pend[used++];   // one term: after max(0, 1); two terms: the lo halves after max(0, 2), max(1, 1)
         }
-    for (; used < npend; ++used) l.u[n++] = pend[used];   // (not reached for NB >= 2)
+    for (; used < npend; ++used) l.u[n++] = pend[used];   // (NB = 2, PF = 3: the last packs; not reached otherwise)
     l.u[n++] = {3, 0, 0, 20};
     return l;
 }
@@ -339,7 +400,8 @@ __device__ __host__ constexpr XTable xn_make_table(bool opt)
     return t;
 }
 
-// index of the unit that completes the P fragment MFMA slot sl reads: the pack of fragment tt (hi term), the second lo half (lo term)
+// index of the unit that completes the P fragment MFMA slot sl reads: the pack of fragment tt (hi term), the second lo half (lo term;
+// PF = 3: its packs)
 template <int D, int NB, int PF = 0>
 __device__ __host__ constexpr int xn_producer_unit(XSlot sl, bool opt)
 {
@@ -347,7 +409,7 @@ __device__ __host__ constexpr int xn_producer_unit(XSlot sl, bool opt)
     const XUnitList l = xn_make_units<NB, PF>(opt);
     for (int u = 0; u < xn_num_units<D, NB, PF>(opt); ++u) {
         if (sl.term == 0 && l.u[u].kind == 1 && l.u[u].blk == sl.blk && l.u[u].idx == frag) return u;
-        if (sl.term == 1 && l.u[u].kind == 4 && l.u[u].blk == sl.blk && l.u[u].idx == 2 * frag + 1) return u;
+        if (sl.term == 1 && l.u[u].kind == (PF == 3 ? 5 : 4) && l.u[u].blk == sl.blk && l.u[u].idx == 2 * frag + 1) return u;
     }
     return 1 << 20;
 }
@@ -376,7 +438,7 @@ __device__ __host__ constexpr bool xn_schedule_ok(bool opt)
     // unit count: the list is zero-initialised past its end (cost 0) and every real unit has a cost
     for (int u = 0; u < nu; ++u)
         if (l.u[u].cost == 0) return false;
-    if (nu < 120 && l.u[nu].cost != 0) return false;
+    if (nu < 128 && l.u[nu].cost != 0) return false;
     int last_qk[NB] = {};
     for (int i = 0; i < S::kSlots; ++i) {
         const XSlot sl = xn_slot<D, NB, PF>(i);
@@ -387,7 +449,7 @@ __device__ __host__ constexpr bool xn_schedule_ok(bool opt)
         if (sl.term >= S::NT) return false;
         if (xn_producer_unit<D, NB, PF>(sl, opt) >= t.ub[i]) return false;       // fragment not complete before its MFMA
     }
-    int pos[NB][8] = {};   // per block: unit index of exp 7, exp 15, pack 0, pack 1, lo 0.1, lo 1.1 (order checks)
+    int pos[NB][8] = {};   // per block: unit index of exp 7, exp 15, pack 0, pack 1, (PF = 3) dots of lo half 0 .. 3 (order checks)
     for (int u = 0; u < nu; ++u) {
         const XUnit un = l.u[u];
         if (un.kind == 0 && un.idx == 7) pos[un.blk][0] = u;
@@ -395,6 +457,16 @@ __device__ __host__ constexpr bool xn_schedule_ok(bool opt)
         if (un.kind == 1) pos[un.blk][2 + un.idx] = u;
         if (un.kind == 4) {
             if (u <= pos[un.blk][2 + un.idx / 2] || pos[un.blk][2 + un.idx / 2] == 0) return false;   // lo half in front of its pack
+            pos[un.blk][4 + un.idx] = u;
+        }
+        if (un.kind == 5) {   // packs of a lo half: behind its dots, with a whole unit between (a dot result is readable three wait states
+                              // later) and in a later slot (a slot's dots are emitted behind its other units: xn_units)
+            const int ud = pos[un.blk][4 + un.idx];
+            if (PF != 3 || ud == 0 || u < ud + 2) return false;
+            int sd = 0, sp = 0;
+            while (sd < S::kSlots && !(t.ub[sd] <= ud && ud < t.ub[sd + 1])) ++sd;
+            while (sp < S::kSlots && !(t.ub[sp] <= u && u < t.ub[sp + 1])) ++sp;
+            if (pb2_dots_last(D) && sp <= sd) return false;
         }
         if (un.kind == 2 && un.idx == 0) {
             int s0 = 0;
@@ -448,11 +520,15 @@ __device__ __forceinline__ void xn_unit(XCtx<D, NB>& x)
     } else if constexpr (un.kind == 0) {
         // optimistic mix: no clamp -- an overflow has to reach the row sum (as a huge value or +inf): that is what the final
         // check reads.  fp16 P: no clamp either -- p ranges up to 2^kThr by design
-        if constexpr (OPT || PF != 0) x.sc[un.blk][un.idx] = fast_exp2(fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]));
+        if constexpr (OPT || pf_f16(PF)) x.sc[un.blk][un.idx] = fast_exp2(fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]));
         else x.sc[un.blk][un.idx] = exp2_clamp01(fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]));
     } else if constexpr (un.kind == 1) {
         x.pf[un.blk][un.idx] = pack_p16x8<PF>(x.sc[un.blk], 8 * un.idx);
         asm volatile("" : "+v"(x.pf[un.blk][un.idx]));
+    } else if constexpr (un.kind == 4 && PF == 3) {
+        lo_dots_bf16(x.sc[un.blk], un.idx / 2, un.idx % 2, x.pf[un.blk][un.idx / 2]);
+    } else if constexpr (un.kind == 5) {
+        lo_packs_bf16(x.sc[un.blk], un.idx / 2, un.idx % 2, x.pl[un.blk][un.idx / 2]);
     } else if constexpr (un.kind == 4) {
         lo_half(x.sc[un.blk], un.idx / 2, un.idx % 2, x.pf[un.blk][un.idx / 2], x.pl[un.blk][un.idx / 2]);
     } else if constexpr (un.kind == 2) {
@@ -464,10 +540,26 @@ __device__ __forceinline__ void xn_unit(XCtx<D, NB>& x)
         x.need = t > XSoft<false, PF>::kThr;  // off = m + kBias
     }
 }
+// PASS: 0 = every unit of the slot in list order; PF = 3 (FA_PB2_DOTS_LAST): 1 = all but the dot units, 2 = the dot units.  The dot
+// product unit shares the matrix pipe: a v_dot2c issued behind an MFMA waits until that MFMA has left the pipe (four of them beside one
+// 32-cycle MFMA: 63.8 cycles against 33.5 for four v_fma_f32, profiles/r04_ubench_dot2.txt), so a slot's dots go behind its other VALU
+// work, where the pipe has (nearly) drained.  Legal because nothing in a slot depends on its dots: their packs sit in a later slot
+// (xn_schedule_ok), and the dots read a pack of an earlier unit, which the reordering keeps in front of them.
+template <int D, int NB, bool OPT, int U, int ABL, int PF, int PASS>
+__device__ __forceinline__ void xn_unit_pass(XCtx<D, NB>& x)
+{
+    constexpr bool is_dot = PF == 3 && xn_make_units<NB, PF>(OPT).u[U].kind == 4;
+    if constexpr (PASS == 0 || (PASS == 1 && !is_dot) || (PASS == 2 && is_dot)) xn_unit<D, NB, OPT, U, ABL, PF>(x);
+}
 template <int D, int NB, bool OPT, int ABL, int PF, int U0, int... Us>
 __device__ __forceinline__ void xn_units(XCtx<D, NB>& x, std::integer_sequence<int, Us...>)
 {
-    (xn_unit<D, NB, OPT, U0 + Us, ABL, PF>(x), ...);
+    if constexpr (PF == 3 && pb2_dots_last(D)) {
+        (xn_unit_pass<D, NB, OPT, U0 + Us, ABL, PF, 1>(x), ...);
+        (xn_unit_pass<D, NB, OPT, U0 + Us, ABL, PF, 2>(x), ...);
+    } else {
+        (xn_unit_pass<D, NB, OPT, U0 + Us, ABL, PF, 0>(x), ...);
+    }
 }
 
 // wait for the asm-issued V^T reads (two ds_read per fragment, LDS returns in order) and hand the fragments to the MFMA operands
@@ -590,7 +682,7 @@ template <int D, int NB, int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL, 
 __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
 {
     constexpr int KS = XShape<D, NB>::KS, DB = XShape<D, NB>::DB;
-    constexpr float kBias = XSoft<OPT, PF>::kBias;
+    constexpr float kBiasC = XSoft<OPT, PF>::kBias;
     const unsigned long long prof_entry = (ABL & 1024) ? stamp() : 0ull;
     using C = Bf16Cfg<D, NWAVES>;
     constexpr int BM = NWAVES * 32 * NB;
@@ -636,6 +728,10 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
     const int nst = (kv_end + kKvBlk - 1) / kKvBlk;  // 64-key stages
     const int nsub = (kv_end + 31) / 32;             // 32-key sub-tiles
     const int q0r = q0 - kbeg;                       // first row of block 0 in local key coordinates (causal: local key <= local row)
+    // The optimistic mix drops every term more than 126 - bias binades below the row's reference (bf16 underflow: the exact zeros the
+    // clock likes).  For the accurate P (PF = 3) the dropped mass is bounded by the row length: nk * 2^-(126 - bias) <= 2^-13 of the
+    // reference term -- bias = 100 up to 8192 keys, one less per doubling beyond (the range test at the end of the tile is unchanged).
+    const float kBias = (OPT && PF == 3) ? kBiasC - (float)max(0, 32 - __builtin_clz(max(nk, 2) - 1) - 13) : kBiasC;
 
     auto k_slot = [&](int j) { return k_ring + (j & (KR - 1)) * T; };
     auto v_slot = [&](int j) { return v_ring + (j & (VR - 1)) * T; };
@@ -753,9 +849,15 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk) {
             bf16x8 pf[2];
-            exp_range<PF>(s[blk], pf, c, off[blk], 0, 8, !OPT && PF == 0);
-            exp_range<PF>(s[blk], pf, c, off[blk], 8, 16, !OPT && PF == 0);
+            exp_range<PF>(s[blk], pf, c, off[blk], 0, 8, !OPT && !pf_f16(PF));
+            exp_range<PF>(s[blk], pf, c, off[blk], 8, 16, !OPT && !pf_f16(PF));
             bf16x8 pl[2];
+            if constexpr (PF == 3) {
+                asm volatile("s_nop 0" : "+v"(pf[0]), "+v"(pf[1]));   // as below
+                lo_frag_bf16(s[blk], 0, pf[0], pl[0]);
+                lo_frag_bf16(s[blk], 1, pf[1], pl[1]);
+                asm volatile("s_nop 1" : "+v"(pl[0]), "+v"(pl[1]));
+            }
             if constexpr (PF == 2) {
                 asm volatile("s_nop 0" : "+v"(pf[0]), "+v"(pf[1]));   // the lo halves are asm: a transcendental's result needs a wait state
 #pragma unroll
@@ -770,7 +872,7 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
             mfma_l<PF>(st[blk].lacc, ones_a, pf[0]);
             asm volatile("s_nop 7");  // dependent row-sum MFMAs back to back: the hazard is ours
             mfma_l<PF>(st[blk].lacc, ones_a, pf[1]);
-            if constexpr (PF == 2) {
+            if constexpr (PF >= 2) {
 #pragma unroll
                 for (int v = 0; v < 2 * DB; ++v) mfma_o<PF>(o[blk][v % DB], vf[v], pl[v / DB]);
                 mfma_l<PF>(st[blk].lacc, ones_a, pl[0]);
@@ -976,17 +1078,17 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
 // ---- kernels -----------------------------------------------------------------------------------------------------------
 // OPTIMISTIC: try the fixed-reference mix first, redo the tile with the rescaling mix if its verification fails.  ABL != 0: the
 // timing-only ablations of DESIGN.md section 4 (results are garbage; instantiated in the ablation library only).
-template <int D, int NB, int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL, bool OPTIMISTIC>
+template <int D, int NB, int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL, bool OPTIMISTIC, int PF = 0>
 __device__ __forceinline__ void xn_kernel_body(const FwdParams& p, char* smem)
 {
     if (OPTIMISTIC && ABL == 0) {
-        if (xn_tile<D, NB, NWAVES, CAUSAL, OUT_F32, G, 0, true>(p, smem)) return;
+        if (xn_tile<D, NB, NWAVES, CAUSAL, OUT_F32, G, 0, true, PF>(p, smem)) return;
     }
     if (ABL != 0 && OPTIMISTIC) {
-        (void)xn_tile<D, NB, NWAVES, CAUSAL, OUT_F32, G, ABL, true>(p, smem);
+        (void)xn_tile<D, NB, NWAVES, CAUSAL, OUT_F32, G, ABL, true, PF>(p, smem);
         return;
     }
-    (void)xn_tile<D, NB, NWAVES, CAUSAL, OUT_F32, G, ABL, false>(p, smem);
+    (void)xn_tile<D, NB, NWAVES, CAUSAL, OUT_F32, G, ABL, false, PF>(p, smem);
 }
 
 template <int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL = 0, bool OPTIMISTIC = true>
@@ -1033,6 +1135,23 @@ __global__ __launch_bounds__(NWAVES* kWave, D <= 64 ? 2 : 1) void fa_fwd_bf16_x2
     __shared__ __attribute__((aligned(1024))) char smem[4 * G * Bf16Cfg<D, NWAVES>::kTileBytes];
     if (flag_says_skip(p)) return;
     (void)xn_tile<D, 2, NWAVES, CAUSAL, OUT_F32, G, 0, false, 2>(p, smem);
+}
+
+// P as bf16 hi + bf16 lo ("pb2", PF = 3; round 4): the accurate path in ONE launch.  bf16 has fp32's exponent range, so V is used as it
+// is (no fp16 copy, no scratch, no overflow flag, no fallback launch), the optimistic mix applies (no maxima, no test, no branch in the
+// loop, and the exact zeros far below the sampled reference that the power budget likes) with the lazily rescaled redo behind it, and
+// every layout the bf16-P kernels take is legal.  P is good to ~2^-17 (hi: 8 bits to nearest, lo: the next 8 of the exact residual).
+template <int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL = 0, bool OPTIMISTIC = true>
+__global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_pb2_kernel(FwdParams p)
+{
+    __shared__ __attribute__((aligned(1024))) char smem[4 * G * Bf16Cfg<64, NWAVES>::kTileBytes];
+    xn_kernel_body<64, 4, NWAVES, CAUSAL, OUT_F32, G, ABL, OPTIMISTIC, 3>(p, smem);
+}
+template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL = 0, bool OPTIMISTIC = true>
+__global__ __launch_bounds__(NWAVES* kWave, FA_PB2_WGS_PER_CU(D, CAUSAL)) void fa_fwd_bf16_x2_pb2_kernel(FwdParams p)
+{
+    __shared__ __attribute__((aligned(1024))) char smem[4 * G * Bf16Cfg<D, NWAVES>::kTileBytes];
+    xn_kernel_body<D, 2, NWAVES, CAUSAL, OUT_F32, G, ABL, OPTIMISTIC, 3>(p, smem);
 }
 
 // ---- launch helpers ----------------------------------------------------------------------------------------------------
@@ -1173,6 +1292,44 @@ static hipError_t launch_x2_p16(const FwdParams& p0, int causal, int out_f32, hi
                 hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, false, true, 2>), grid, block, 0, stream, p);
             else
                 hipLaunchKernelGGL((fa_fwd_bf16_x2_p16_kernel<D, 4, false, false, 2>), grid, block, 0, stream, p);
+        }
+        return hipGetLastError();
+    };
+    hipError_t e = go(solo);
+    if (e != hipSuccess && solo != 0) e = go(0);   // see launch_x2
+    return e;
+}
+
+template <bool CAUSAL, bool OPTIMISTIC = true>
+static hipError_t launch_x4_pb2(const FwdParams& p0, int out_f32, hipStream_t stream)
+{
+    FwdParams p;
+    dim3 grid, block;
+    if (!xn_grid<4>(p0, p, grid, block)) return hipErrorInvalidValue;
+    if (out_f32)
+        hipLaunchKernelGGL((fa_fwd_bf16_x4_pb2_kernel<4, CAUSAL, true, 2, 0, OPTIMISTIC>), grid, block, 0, stream, p);
+    else
+        hipLaunchKernelGGL((fa_fwd_bf16_x4_pb2_kernel<4, CAUSAL, false, 2, 0, OPTIMISTIC>), grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+template <int D, bool OPTIMISTIC = true>
+static hipError_t launch_x2_pb2(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
+{
+    FwdParams p;
+    dim3 grid, block;
+    if (!xn_grid<2>(p0, p, grid, block)) return hipErrorInvalidValue;
+    const unsigned solo = xn_launch_order<D, 2>(p, grid, causal, D <= 64);
+    auto go = [&](unsigned dyn_lds) {
+        if (causal) {
+            if (out_f32)
+                hipLaunchKernelGGL((fa_fwd_bf16_x2_pb2_kernel<D, 4, true, true, 2, 0, OPTIMISTIC>), grid, block, dyn_lds, stream, p);
+            else
+                hipLaunchKernelGGL((fa_fwd_bf16_x2_pb2_kernel<D, 4, true, false, 2, 0, OPTIMISTIC>), grid, block, dyn_lds, stream, p);
+        } else {
+            if (out_f32)
+                hipLaunchKernelGGL((fa_fwd_bf16_x2_pb2_kernel<D, 4, false, true, 2, 0, OPTIMISTIC>), grid, block, 0, stream, p);
+            else
+                hipLaunchKernelGGL((fa_fwd_bf16_x2_pb2_kernel<D, 4, false, false, 2, 0, OPTIMISTIC>), grid, block, 0, stream, p);
         }
         return hipGetLastError();
     };

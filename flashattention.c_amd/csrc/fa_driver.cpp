@@ -204,6 +204,7 @@ static void run_one(const Args& a, Buffers& b, int variant, const std::vector<fl
     else if (a.kernel == "split") family = FA_KERNEL_SPLIT;
     else if (a.kernel == "p16") family = FA_KERNEL_P16;
     else if (a.kernel == "p16x2") family = FA_KERNEL_P16X2;
+    else if (a.kernel == "pb2") family = FA_KERNEL_PB2;
     else if (!a.kernel.empty()) {
         fprintf(stderr, "unknown --kernel %s\n", a.kernel.c_str());
         exit(2);

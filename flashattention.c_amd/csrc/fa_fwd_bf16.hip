@@ -514,12 +514,14 @@ const char* bf16_kernel_name(int64_t bh, int64_t n, int d, int causal)
     }
 }
 
-// the fp16-P kernels exist in the one-wave-per-SIMD family only: NB = 4 where the bf16-P dispatch would take it too (large non-causal
-// d = 64 grids), NB = 2 everywhere else
+// the two-term-P kernels exist in the one-wave-per-SIMD family only (32-bit byte offsets into a slab): NB = 4 where the bf16-P dispatch
+// would take it too (large non-causal d = 64 grids), NB = 2 everywhere else
 bool bf16_p16_supported(const FwdParams& p, int d)
 {
     return (d == 32 || d == 64 || d == 128) && ((int64_t)(p.n - 1) * p.kv_row_stride + d) * 2 < (int64_t)0xffffffffLL;
 }
+
+#if FA_ABLATION   // the fp16-P families (csrc/experiments/): replaced by P as two bf16 terms in round 4, kept for A/B runs
 
 // d = 64 fp16 P: the NB = 4 kernel (512-row workgroups, one per CU) only where it is not behind -- a single, well filled round of
 // them.  Elsewhere the NB = 2 kernel, which fits a CU twice: ms NB = 4 / NB = 2, BH x 8192: 16: 0.279 / 0.278, 12: 0.260 / 0.251,
@@ -549,6 +551,21 @@ hipError_t launch_bf16_p16x2(const FwdParams& p, int d, int causal, int out_f32,
     if (d == 32) return launch_bf16_x2_p16x2_d32(p, causal, out_f32, stream);
     if (d == 128) return launch_bf16_x2_p16x2_d128(p, causal, out_f32, stream);
     return launch_bf16_x2_p16x2_d64(p, causal, out_f32, stream);
+}
+
+#endif   // FA_ABLATION
+
+// P as bf16 hi + bf16 lo (round 4): NB = 4 on the grids the bf16-P dispatch gives 512-row workgroups, NB = 2 elsewhere.
+// variant 0 = the dispatch, 1 = NB = 2 forced, 2 = NB = 4 forced (d = 64, non-causal)
+bool bf16_pb2_uses_x4(int64_t bh, int64_t n, int causal) { return choose_bf16(bh, n, 64, causal, true) == kChooseX4; }
+
+hipError_t launch_bf16_pb2(const FwdParams& p, int d, int causal, int out_f32, int variant, hipStream_t stream)
+{
+    if (!bf16_p16_supported(p, d) || variant < 0 || variant > 2) return hipErrorInvalidValue;
+    if (d == 32) return launch_bf16_x2_pb2_d32(p, causal, out_f32, stream);
+    if (d == 128) return launch_bf16_x2_pb2_d128(p, causal, out_f32, stream);
+    if (variant == 2 || (variant == 0 && bf16_pb2_uses_x4(p.bh, p.n, causal))) return launch_bf16_x4_pb2(p, causal, out_f32, stream);
+    return launch_bf16_x2_pb2_d64(p, causal, out_f32, stream);
 }
 
 hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, int variant, hipStream_t stream)

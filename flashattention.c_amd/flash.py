@@ -26,13 +26,14 @@ import torch
 
 from . import _cabi
 
-__all__ = ["forward", "forward_packed_qkv", "load", "time_forward", "last_forward_route", "workspace_bytes", "SUPPORTED_HEAD_DIMS"]
+__all__ = ["forward", "forward_packed_qkv", "load", "time_forward", "last_forward_route", "workspace_bytes", "stats", "SUPPORTED_HEAD_DIMS"]
 
 SUPPORTED_HEAD_DIMS = (32, 64, 128)
 _tls = threading.local()
 _DTYPES = {torch.float32: _cabi.FA_DTYPE_F32, torch.bfloat16: _cabi.FA_DTYPE_BF16}
 _KERNELS = {"auto": _cabi.FA_KERNEL_AUTO, "naive": _cabi.FA_KERNEL_NAIVE, "mfma": _cabi.FA_KERNEL_MFMA,
-            "exact": _cabi.FA_KERNEL_MFMA, "split": _cabi.FA_KERNEL_SPLIT, "p16": _cabi.FA_KERNEL_P16, "p16x2": _cabi.FA_KERNEL_P16X2}
+            "exact": _cabi.FA_KERNEL_MFMA, "split": _cabi.FA_KERNEL_SPLIT, "p16": _cabi.FA_KERNEL_P16, "p16x2": _cabi.FA_KERNEL_P16X2,
+            "pb2": _cabi.FA_KERNEL_PB2}
 
 
 def _kernel_id(kernel: Union[str, int]) -> int:
@@ -80,14 +81,14 @@ def forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = Fa
     the bf16 matrix pipe as three products of two-term bf16 splits (within 1e-3 of the fp32 reference) behind a device-side
     guard that hands launches with too wide logits to the exact fp32 kernel; ``"split"`` is the same without the guard,
     ``"exact"`` (= ``"mfma"``) computes in fp32 arithmetic.  bf16 tensors: ``out_dtype=torch.float32`` stores the fp32
-    accumulator (FA_DTYPE_BF16_OUT_F32) and, under ``"auto"``, selects the accurate P -- two fp16 terms (``"p16x2"``) or, for
-    small launches, hi + lo bf16 terms (``"split"``) -- which is within 1e-4 of the fp32 reference at scale 1; ``"p16"`` (one
-    fp16 term, ~1e-3) is an explicit choice only; a bf16 output keeps the fastest kernels (bf16 P, ``"mfma"``; ~5e-3 at scale 1).
-    ``out`` must not overlap q, k or v.
+    accumulator (FA_DTYPE_BF16_OUT_F32) and, under ``"auto"``, selects the accurate P -- bf16 hi + bf16 lo terms in one launch
+    (``"pb2"``), within 1e-4 of the fp32 reference at scale 1 (2.4e-5 on B=2 H=8 d=64 N=8192); a bf16 output keeps the fastest
+    kernels (bf16 P, ``"mfma"``: ~8e-3 in the accumulator at scale 1, ~1.5e-2 after the output's own rounding; 4e-4 at 1/sqrt(d)).
+    ``"p16"`` / ``"p16x2"`` (P in fp16, round 3) exist in the ablation library only.  ``out`` must not overlap q, k or v.
 
-    The call goes through ``fa_forward_ws``: scratch (the fp16 copy of V, key-split partials), when the chosen kernels need any,
-    is a ``torch.empty`` byte tensor from torch's caching allocator on the current stream -- the C ABI itself allocates nothing,
-    which also makes every kernel family legal under ``torch.cuda.graph`` capture.  ``workspace`` may pass a preallocated
+    The call goes through ``fa_forward_ws``: scratch (key-split partials, the verdict word of the fp32 launch chain), when the call
+    needs any, is a ``torch.empty`` byte tensor from torch's caching allocator on the current stream -- the C ABI itself allocates
+    nothing, which also makes every kernel family legal under ``torch.cuda.graph`` capture.  ``workspace`` may pass a preallocated
     ``torch.uint8`` tensor of at least ``workspace_bytes(...)`` bytes instead.
     """
     bh, n, d = _check_qkv(q, k, v)
@@ -192,12 +193,20 @@ def time_forward(q, k, v, causal: bool = False, *, scale: float = 1.0, kernel: U
 
 def last_forward_route(stream: Optional[torch.cuda.Stream] = None) -> int:
     """Which kernel of a conditional launch chain produced this thread's most recent forward (blocking; diagnostics):
-    0 = single unconditional launch, 1 = primary kernel (fp32: split products, bf16: fp16 P in one or two terms), 2 = fallback (fp32: the
-    logit-width guard fired and the exact kernel ran; bf16: a V value did not fit fp16 and the split kernel ran)."""
+    0 = single unconditional launch (every bf16 path), 1 = primary kernel (fp32 tensors: split products), 2 = fallback (fp32 tensors: the
+    logit-width guard fired and the exact kernel ran)."""
     r = ctypes.c_int32(0)
     s = (stream or torch.cuda.current_stream()).cuda_stream
     _cabi.check(_cabi.lib().fa_last_forward_route(ctypes.c_void_p(s), ctypes.byref(r)))
     return int(r.value)
+
+
+def stats() -> dict:
+    """Process-wide counters of the launch machinery (``fa_get_stats``): forwards, launch chains, chains that found no verdict slot and
+    ran their always-correct kernel alone, re-plans without scratch, slot evictions, recycled capture slots."""
+    st = _cabi.FaStats()
+    _cabi.check(_cabi.lib().fa_get_stats(ctypes.byref(st)))
+    return {n: int(getattr(st, n)) for n, _ in _cabi.FaStats._fields_}
 
 
 def load(name: str = "flash", sources=None, extra_cuda_cflags=None, **_ignored):

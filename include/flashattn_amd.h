@@ -20,17 +20,14 @@
  *   ragged N    any N >= 1 is handled exactly (tail keys are masked, not zero-filled as at
  *               flashattention.cu:224-231)
  *   ownership   the caller owns every buffer; nothing is allocated, freed or zero-filled by fa_forward_ws, the entry point of this
- *               boundary proper (the reference allocates O and a dead O_l inside forward(), :608-609).  Two paths need scratch --
- *               the fp16 copy of V of the fp16-P kernels (FA_KERNEL_P16X2 / FA_KERNEL_P16, and FA_KERNEL_AUTO with an fp32 output),
- *               and the partial outputs of a key-split launch (rows of 4096 keys and more on grids that leave the chip idle -- at most
- *               128 tiles of 256 rows, 256 for long causal bf16 launches --, bf16 and fp32 tensors, causal or not: several
- *               workgroups per q-tile share the keys and a combine kernel merges them): fa_workspace_bytes() reports the size for a
- *               call, fa_forward_ws() takes the caller's buffer, and every path is then legal inside a captured hipGraph.
- *               fa_forward / fa_forward_ex / fa_forward_sharded are CONVENIENCE WRAPPERS: they take the same bytes from a private
- *               stream-ordered pool of the device (hipMemPoolCreate; hipMallocFromPoolAsync / hipFreeAsync on `stream`; the device's
- *               default pool is never touched) -- except while `stream` is capturing (graph allocations proved unreliable on ROCm
- *               7.2): FA_KERNEL_AUTO then picks kernels without scratch, an explicit FA_KERNEL_P16 / P16X2 returns
- *               FA_ERR_UNSUPPORTED.  A failed pool allocation makes FA_KERNEL_AUTO fall back to those kernels as well
+ *               boundary proper (the reference allocates O and a dead O_l inside forward(), :608-609).  Scratch is needed only for
+ *               key-split launches (rows of 4096 keys and more on grids that leave the chip idle: the partial outputs of the key
+ *               shares) and, 256 bytes of it, for the verdict word of the fp32 FA_KERNEL_AUTO launch chain: fa_workspace_bytes()
+ *               sizes it, fa_forward_ws() takes it.  The convenience entry points (fa_forward, fa_forward_ex, fa_forward_sharded,
+ *               fa_forward_packed_qkv) draw the key-split scratch from a PRIVATE stream-ordered pool of the device
+ *               (hipMemPoolCreate; hipMallocFromPoolAsync / hipFreeAsync on `stream`; the device's default pool is never touched) --
+ *               except while `stream` is capturing (graph allocations proved unreliable on ROCm 7.2): the launch then runs unsplit.
+ *               A failed pool allocation has the same effect.  Their verdict words live in a per-device slot table (see fa_get_stats)
  *   aliasing    o must not overlap q, k or v (a tile that fails its verification is recomputed from q, k, v after o was
  *               written): overlapping ranges are rejected with FA_ERR_INVALID_ARGUMENT
  *   ordering    the kernel is enqueued on `stream` and the call returns without synchronising
@@ -49,7 +46,7 @@
 extern "C" {
 #endif
 
-#define FLASHATTN_AMD_ABI_VERSION 3
+#define FLASHATTN_AMD_ABI_VERSION 4
 
 typedef enum fa_status {
     FA_OK = 0,
@@ -72,13 +69,13 @@ typedef enum fa_dtype {
                          FA_KERNEL_AUTO choice for the whole process */
     FA_DTYPE_BF16 = 1,        /* bf16 in, bf16 MFMA with fp32 accumulate and fp32 softmax, bf16 out     */
     FA_DTYPE_BF16_OUT_F32 = 2 /* bf16 in, O written as fp32 (the accumulator precision).  Under FA_KERNEL_AUTO this also selects
-                                 the ACCURATE P: a caller who wants the fp32 accumulator gets P as two fp16 terms, hi + lo
-                                 (FA_KERNEL_P16X2: ~22 significant bits, Q.K^T exact in the fp32 accumulator: <= 1e-4 of the fp32
-                                 reference at scale 1 on every data family tried, where bf16 P shows ~5e-3) at every launch size.
-                                 Only when there is no scratch (fa_forward / fa_forward_ex on a capturing stream) and for slabs
-                                 beyond 4 GiB it is P and the scaled Q as hi + lo bf16 terms instead (FA_KERNEL_SPLIT: 1 .. 2e-4
-                                 on unit-variance data, growing with the logit width).  A bf16 output rounds at 2^-9 |O| by itself
-                                 and keeps the fastest kernels (bf16 P). */
+                                 the ACCURATE P: a caller who wants the fp32 accumulator gets P as two bf16 terms, hi + lo
+                                 (FA_KERNEL_PB2: ~17 significant bits, Q.K^T exact in the fp32 accumulator: <= 1e-4 of the fp32
+                                 reference at scale 1 on every data family tried -- 2.4e-5 on B=2 H=8 d=64 N=8192 -- where bf16 P reads
+                                 ~8e-3 in the accumulator and ~1.5e-2 after the bf16 output's own rounding) in ONE launch without
+                                 scratch, at every launch size and layout.  Only slabs beyond 4 GiB take P and the scaled Q as hi + lo
+                                 bf16 terms in the split kernel instead (FA_KERNEL_SPLIT: 1 .. 2e-4 on unit-variance data, growing with
+                                 the logit width).  A bf16 output rounds at 2^-9 |O| by itself and keeps the fastest kernels (bf16 P). */
 } fa_dtype;
 
 typedef enum fa_kernel {
@@ -90,14 +87,15 @@ typedef enum fa_kernel {
                             bf16 tensors: K, V exact in one term, Q*scale*log2e and P carried as hi + lo (two products per
                             contraction): max-abs error ~1e-4 against fp64 at scale 1 with FA_DTYPE_BF16_OUT_F32, at ~2x the
                             time of the bf16-P kernels */
-    FA_KERNEL_P16 = 4,   /* bf16 tensors: P and V in fp16 for the second contraction (v_mfma_f32_32x32x16_f16), ONE fp16 term of P
-                            (11 significant bits), Q.K^T in bf16 (exact in the fp32 accumulator): 8e-4 .. 1.2e-3 at scale 1 -- AT the
-                            1e-3 bar, not safely inside it (the maximum grows with the number of outputs) -- at ~1.15x the time of the
-                            bf16-P kernels.  Never chosen by FA_KERNEL_AUTO.  V is copied to fp16 into scratch first; if some
-                            |v| >= 2^16 the split kernel takes the launch instead (decided on the device). */
-    FA_KERNEL_P16X2 = 5  /* the same with P as fp16 hi + fp16 lo (lo = fp16(p - hi), exact difference; twice the P.V and row-sum MFMAs):
-                            ~1e-4 at scale 1 on any data, at ~1.4x the time of the bf16-P kernels.  The FA_KERNEL_AUTO choice for
-                            FA_DTYPE_BF16_OUT_F32 (see there).  Same V copy, same device-side fallback. */
+    FA_KERNEL_P16 = 4,   /* (libflashattn_amd_ablation.so only since ABI 4; FA_ERR_UNSUPPORTED in the product library)  P and V in fp16,
+                            ONE fp16 term of P (11 significant bits): 8e-4 .. 1.2e-3 at scale 1 -- AT the 1e-3 bar, not inside it. */
+    FA_KERNEL_P16X2 = 5, /* (ablation library only since ABI 4)  P as fp16 hi + fp16 lo, V copied to fp16 in scratch, split kernel as the
+                            device-side fallback when some |v| >= 2^16: round 3's accurate path, a chain of three launches. */
+    FA_KERNEL_PB2 = 6    /* bf16 tensors: P as bf16 hi + bf16 lo (lo = bf16(p - hi), the exact difference from one v_dot2c_f32_bf16 per
+                            element; twice the P.V and row-sum MFMAs; P to ~2^-17), V as it is: ONE launch, no copy of V, no scratch
+                            except for key-split launches of idle grids, any |v|, any layout with slabs below 4 GiB; the optimistic
+                            softmax of the bf16-P kernels with its rescaled redo.  ~1.5x the time of the bf16-P kernels.  The
+                            FA_KERNEL_AUTO choice for FA_DTYPE_BF16_OUT_F32. */
 } fa_kernel;
 /* `kernel` arguments: bits 0..7 = fa_kernel; bits 8..15 = 0, or the number of one of the co-compiled tilings of that family
  * (every one of them computes the same function; csrc/fa_fwd_bf16.hip and csrc/fa_split_kernel.h list them, tests/ run them
@@ -136,8 +134,10 @@ int fa_forward_ex(const void* q, const void* k, const void* v, void* o, float* l
  *   workspace        device pointer, 256-byte aligned, at least fa_workspace_bytes() bytes, not overlapping q, k, v, o; NULL is fine
  *                    when the call needs none.  In use until the forward has completed on `stream`; one forward at a time per
  *                    workspace (its first bytes hold the launch chain's verdict word).  Contents need no initialisation.
- *   capture          legal while `stream` is capturing, with every kernel family (the chain clears its verdict word with a memset
- *                    node, so replays of the graph are independent of each other).
+ *                    NULL with FA_KERNEL_AUTO when the call would use one: the forward runs without scratch (unsplit launch; the
+ *                    chain's verdict word from the slot table) instead of failing -- a binder that skips fa_workspace_bytes() works.
+ *   capture          legal while `stream` is capturing, with every kernel family (a chain clears its verdict word with a memset
+ *                    node, so replays of the graph are independent of each other -- with or without a workspace).
  */
 size_t fa_workspace_bytes(int64_t bh, int64_t n, int32_t d, int32_t causal, int32_t dtype, int32_t kernel);
 int fa_forward_ws(const void* q, const void* k, const void* v, void* o, float* lse,
@@ -195,11 +195,30 @@ int fa_time_forward_graph(const void* q, const void* k, const void* v, void* o,
 /*
  * fa_last_forward_route -- which kernel of a conditional launch chain produced the output of this thread's most recent
  *                          forward.  Blocking (waits for `stream`, reads one word back): diagnostics and benchmarks only.
- *   *route  0 = the call was a single unconditional launch;  1 = the primary kernel (fp32: split products; bf16: fp16 P, one or two terms);
- *           2 = the fallback (fp32: exact fp32 arithmetic -- the logit-width guard fired; bf16: the split kernel -- a V value
- *           did not fit fp16)
+ *   *route  0 = the call was a single unconditional launch (every bf16 path; explicit kernels);  1 = the primary kernel (fp32 tensors:
+ *           split products);  2 = the fallback (fp32 tensors: exact fp32 arithmetic -- the logit-width guard fired)
  */
 int fa_last_forward_route(void* stream, int32_t* route);
+
+/*
+ * fa_get_stats -- process-wide counters of the launch machinery (never fails for a non-NULL pointer; cheap; no device access).
+ * The verdict word of a launch chain that has no caller-owned workspace comes from a per-device table: one slot per (device, stream)
+ * for eager chains -- when all eager_slots_per_device are taken, the least recently used slot whose last chain has completed changes
+ * hands (slot_evictions) --, one slot per captured chain, returned when the graph and its executables are destroyed
+ * (capture_slots_recycled; on a runtime that refuses the user-object hook a capture slot is used once, and capture_slots_per_device
+ * captures without a workspace exhaust them).  chains_degraded counts the forwards that found no slot and ran the chain's
+ * always-correct kernel alone (fp32 FA_KERNEL_AUTO: the exact kernel, ~3x slower): non-zero means "pass a workspace".
+ */
+typedef struct fa_stats {
+    uint64_t forwards;                 /* forwards enqueued through any entry point                          */
+    uint64_t chains;                   /* ... of which conditional launch chains                             */
+    uint64_t chains_degraded;          /* chains that ran their always-correct kernel alone: no verdict slot */
+    uint64_t scratch_replans;          /* forwards re-planned without scratch (NULL workspace / pool failure) */
+    uint64_t slot_evictions;           /* eager slots that changed hands                                     */
+    uint64_t capture_slots_recycled;   /* capture slots returned by destroyed graphs                         */
+    uint64_t eager_slots_in_use, capture_slots_in_use, eager_slots_per_device, capture_slots_per_device;
+} fa_stats;
+int fa_get_stats(fa_stats* out);
 
 /* Thread-local description of the last failure on this thread ("" if none). */
 const char* fa_last_error(void);

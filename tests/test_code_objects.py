@@ -31,9 +31,9 @@ def test_no_kernel_of_the_product_library_uses_scratch(kernels):
 
 def test_every_kernel_family_the_dispatch_names_is_present(kernels):
     names = "\n".join(k.name for k in kernels.values())
-    for fam in ("fa_fwd_bf16_x4_kernel", "fa_fwd_bf16_x4_p16_kernel", "fa_fwd_bf16_x2_kernel", "fa_fwd_bf16_x2_p16_kernel",
-                "fa_fwd_bf16_x2_p16x2_kernel", "fa_fwd_bf16_pp3_kernel", "fa_fwd_bf16_w4_kernel", "fa_fwd_bf16_kernel", "fa_fwd_f32_split_kernel",
-                "fa_fwd_f32_kernel", "fa_naive_f32_kernel", "fa_cvt_bf16_to_f16_kernel", "fa_combine_splits_kernel"):
+    for fam in ("fa_fwd_bf16_x4_kernel", "fa_fwd_bf16_x4_pb2_kernel", "fa_fwd_bf16_x2_kernel", "fa_fwd_bf16_x2_pb2_kernel",
+                "fa_fwd_bf16_pp3_kernel", "fa_fwd_bf16_w4_kernel", "fa_fwd_bf16_kernel", "fa_fwd_f32_split_kernel",
+                "fa_fwd_f32_kernel", "fa_naive_f32_kernel", "fa_combine_splits_kernel"):
         assert fam + "<" in names or fam + "(" in names, fam
 
 
@@ -61,9 +61,7 @@ def test_every_kernel_of_the_product_library_is_reachable_or_documented(kernels)
     documented = {
         "fa_naive_f32_kernel",            # FA_KERNEL_NAIVE: rung 0, the on-device cross-check
         "fa_fwd_f32_kernel",              # FA_KERNEL_MFMA for fp32 tensors and the guarded chain's fallback
-        "fa_cvt_bf16_to_f16_kernel",      # V -> fp16 copy of the fp16-P chains
         "fa_combine_splits_kernel",       # combine of a key-split launch
-        "fa_fwd_bf16_x4_p16_kernel", "fa_fwd_bf16_x2_p16_kernel",   # FA_KERNEL_P16 (explicit only): one fp16 term of P
         "fa_fwd_bf16_kernel", "fa_fwd_bf16_w4_kernel",              # slabs beyond 32-bit byte offsets / small d = 128 grids (phase-structured)
     }
     present = {_family(k.name) for k in kernels.values()}
@@ -71,11 +69,12 @@ def test_every_kernel_of_the_product_library_is_reachable_or_documented(kernels)
     assert not stray, f"kernel families neither reachable from FA_KERNEL_AUTO nor documented: {sorted(stray)}"
     assert reachable <= present | {"fa_fwd_f32_kernel"}, sorted(reachable - present)
     for k in kernels.values():
-        m = re.search(r"fa_fwd_bf16_x4(?:_p16|_p16x2)?_kernel<(.*?)>\(", k.name)
+        assert not re.search(r"_p16(x2)?_kernel|fa_cvt_bf16_to_f16", k.name), f"fp16-P family in the product library (ablation library only since round 4): {k.name}"
+        m = re.search(r"fa_fwd_bf16_x4(?:_pb2)?_kernel<(.*?)>\(", k.name)
         if m:   # <NWAVES, CAUSAL, OUT_F32, G, ...>: non-causal, barrier every two stages
             a = m.group(1).split(", ")
             assert a[1] == "false" and a[3] == "2", k.name
-        m = re.search(r"fa_fwd_bf16_x2_kernel<(.*?)>\(", k.name)
+        m = re.search(r"fa_fwd_bf16_x2(?:_pb2)?_kernel<(.*?)>\(", k.name)
         if m:   # <D, NWAVES, CAUSAL, OUT_F32, G, ABL, OPTIMISTIC>
             a = m.group(1).split(", ")
             assert a[4] == "2" and a[6] == "true", k.name
@@ -83,6 +82,11 @@ def test_every_kernel_of_the_product_library_is_reachable_or_documented(kernels)
         if m:   # <D, NWAVES, CAUSAL, OUT_F32, PROF, G, OPTIMISTIC>
             a = m.group(1).split(", ")
             assert a[0] == "64" and a[1] == "4" and a[6] == "true", k.name
+        # the launchers of the NB = 2 kernels at d <= 64 assume two workgroups fit a CU (xn_launch_order pairs causal tiles on that
+        # premise; a kernel that silently grew past half a SIMD's register file would run one per CU in the paired order)
+        m = re.search(r"fa_fwd_bf16_x2(?:_pb2)?_kernel<(32|64), ", k.name)
+        if m:
+            assert k.vgprs <= 256, f"{k.name}: {k.vgprs} registers -- no longer fits a CU twice"
     assert os.path.getsize(LIB) < 4 * 1024 * 1024, "the product library grew past 4 MB (it was 5.7 MB with every round-2 tiling in it)"
 
 
@@ -111,7 +115,7 @@ def test_asm_mfma_kernels_drain_the_matrix_pipe_before_reading_accumulators(kern
     dis_cache = {}
     checked = 0
     for k in kernels.values():
-        if not re.search(r"fa_fwd_bf16_x[24](_p16|_p16x2)?_kernel<", k.name):
+        if not re.search(r"fa_fwd_bf16_x[24](_pb2)?_kernel<", k.name):
             continue
         dis = dis_cache.setdefault(k.code_object, codeobj.disassemble(k.code_object))
         i = dis.index("<" + k.mangled + ">:")
@@ -131,7 +135,7 @@ def test_asm_mfma_kernels_drain_the_matrix_pipe_before_reading_accumulators(kern
             wait += int(ins[1]) + 1 if op == "s_nop" else 1
         assert reads > 0 and worst is not None and worst >= 18, f"{k.name}: {worst} wait states between an MFMA and an accumulator read"
         checked += 1
-    assert checked >= 36
+    assert checked >= 28   # x4: 2, x2: 12, x4_pb2: 2, x2_pb2: 12
 
 
 def test_inspecting_the_library_does_not_modify_it(tmp_path):

@@ -35,20 +35,19 @@ def test_library_exports_every_declared_symbol():
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 128, 0, 2, 300) == b"fa_fwd_bf16_w4_kernel"      # too few workgroups
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 128, 1, 2, 300) == b"fa_fwd_bf16_kernel"
     assert L.fa_kernel_name(_cabi.FA_DTYPE_F32, 48, 0) is None
-    # bf16 tensors with fp32 output: P as two fp16 terms -- the NB = 2 tiling at every grid size (two resident workgroups per CU)
-    assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0) == b"fa_fwd_bf16_x2_p16x2_kernel"
-    assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 1) == b"fa_fwd_bf16_x2_p16x2_kernel"
-    assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 128, 0) == b"fa_fwd_bf16_x2_p16x2_kernel"
-    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 32, 0, 16, 8192) == b"fa_fwd_bf16_x2_p16x2_kernel"
-    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 1, 8192) == b"fa_fwd_bf16_x2_p16x2_kernel"   # idle grid: key-split inside the chain
+    # bf16 tensors with fp32 output (round 4): P as two bf16 terms in one launch -- the tilings of the bf16-P one-wave-per-SIMD kernels
+    assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0) == b"fa_fwd_bf16_x4_pb2_kernel"     # c4: 512-row workgroups
+    assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 1) == b"fa_fwd_bf16_x2_pb2_kernel"
+    assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 128, 0) == b"fa_fwd_bf16_x2_pb2_kernel"
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 32, 0, 16, 8192) == b"fa_fwd_bf16_x2_pb2_kernel"
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 1, 8192) == b"fa_fwd_bf16_x2_pb2_kernel"   # idle grid: key-split launch of the NB = 2 kernel
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, 0, 1, 8192) == b"fa_fwd_bf16_x2_kernel"                 # idle grid: key-split launch
     # ... at every launch size (round 2 sent small launches to the hi + lo bf16 split kernel, whose 16-bit Q' is not data-independent)
-    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 32, 0, 4, 300) == b"fa_fwd_bf16_x2_p16x2_kernel"
-    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 16, 1024) == b"fa_fwd_bf16_x2_p16x2_kernel"
-    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 1, 128, 1024) == b"fa_fwd_bf16_x2_p16x2_kernel"
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 32, 0, 4, 300) == b"fa_fwd_bf16_x2_pb2_kernel"
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 16, 1024) == b"fa_fwd_bf16_x2_pb2_kernel"
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 1, 128, 1024) == b"fa_fwd_bf16_x2_pb2_kernel"
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 128, 0, 2, 1 << 24) == b"fa_fwd_f32_split_kernel"    # a 4 GiB slab: beyond 32-bit byte offsets
-    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 128, 2048) == b"fa_fwd_bf16_x2_p16x2_kernel"   # more than one round of 512-row tiles: NB = 2, two per CU
-    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 16, 8192) == b"fa_fwd_bf16_x2_p16x2_kernel"    # c4: one full round of two NB = 2 workgroups per CU
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0, 128, 8192) == b"fa_fwd_bf16_x4_pb2_kernel"   # c5's per-GPU shard
     # rows of two stages: the phase-structured kernel (round 3); longer rows keep the one-wave-per-SIMD kernels
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, 0, 1024, 128) == b"fa_fwd_bf16_kernel"
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 32, 1, 1024, 100) == b"fa_fwd_bf16_kernel"
@@ -59,7 +58,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_kernel_ids_match_the_header_and_the_python_names():
     hdr = open(os.path.join(ROOT, "include", "flashattn_amd.h")).read()
-    for name in ("FA_KERNEL_AUTO", "FA_KERNEL_NAIVE", "FA_KERNEL_MFMA", "FA_KERNEL_SPLIT", "FA_KERNEL_P16", "FA_KERNEL_P16X2", "FA_DTYPE_F32", "FA_DTYPE_BF16",
+    for name in ("FA_KERNEL_AUTO", "FA_KERNEL_NAIVE", "FA_KERNEL_MFMA", "FA_KERNEL_SPLIT", "FA_KERNEL_P16", "FA_KERNEL_P16X2", "FA_KERNEL_PB2", "FA_DTYPE_F32", "FA_DTYPE_BF16",
                  "FA_DTYPE_BF16_OUT_F32"):
         m = re.search(name + r"\s*=\s*(\d+)\b", hdr)
         assert m and int(m.group(1)) == getattr(_cabi, name), name
@@ -67,7 +66,7 @@ def test_kernel_ids_match_the_header_and_the_python_names():
     assert flash._kernel_id("split:4") == _cabi.FA_KERNEL_SPLIT | (4 << 8)
     assert flash._kernel_id("exact") == flash._kernel_id("mfma") == _cabi.FA_KERNEL_MFMA
     assert flash._kernel_id("auto") == _cabi.FA_KERNEL_AUTO
-    assert flash._kernel_id("p16") == _cabi.FA_KERNEL_P16 and flash._kernel_id("p16x2") == _cabi.FA_KERNEL_P16X2
+    assert flash._kernel_id("p16") == _cabi.FA_KERNEL_P16 and flash._kernel_id("p16x2") == _cabi.FA_KERNEL_P16X2 and flash._kernel_id("pb2") == _cabi.FA_KERNEL_PB2
     with pytest.raises(ValueError):
         flash._kernel_id("fast")
     L = _cabi.lib()
@@ -80,12 +79,12 @@ def test_workspace_sizes_are_host_arithmetic():
     L = _cabi.lib()
     B16, B16F, F32 = _cabi.FA_DTYPE_BF16, _cabi.FA_DTYPE_BF16_OUT_F32, _cabi.FA_DTYPE_F32
     A = _cabi.FA_KERNEL_AUTO
-    assert L.fa_workspace_bytes(16, 8192, 64, 0, F32, A) == 0                       # fp32 tensors: the guarded chain keeps its word in a device slot
+    assert L.fa_workspace_bytes(16, 8192, 64, 0, F32, A) == 256                     # fp32 tensors: the guarded chain's verdict word (header only)
+    assert L.fa_workspace_bytes(16, 8192, 64, 0, F32, _cabi.FA_KERNEL_SPLIT) == 0 and L.fa_workspace_bytes(16, 8192, 64, 0, F32, _cabi.FA_KERNEL_MFMA) == 0
     assert L.fa_workspace_bytes(16, 8192, 64, 0, B16, A) == 0                       # c4, bf16 output: one launch
-    assert L.fa_workspace_bytes(16, 8192, 64, 0, B16F, A) == 256 + 16 * 8192 * 64 * 2   # c4, fp32 output: the fp16 copy of V behind the header
-    assert L.fa_workspace_bytes(16, 8192, 64, 1, B16F, A) == 256 + 16 * 8192 * 64 * 2
-    assert L.fa_workspace_bytes(16, 1024, 64, 0, B16F, A) == 256 + 16 * 1024 * 64 * 2   # small launches too: the data-independent kernel
-    assert L.fa_workspace_bytes(128, 8192, 64, 0, B16F, A) == 256 + 128 * 8192 * 64 * 2   # c5's per-GPU shard
+    for shape in ((16, 8192, 64, 0), (16, 8192, 64, 1), (16, 1024, 64, 0), (128, 8192, 64, 0), (4, 300, 32, 0), (16, 8192, 128, 1)):
+        assert L.fa_workspace_bytes(*shape, B16F, A) == 0                           # fp32 output (round 4): P as two bf16 terms -- one launch, no scratch
+        assert L.fa_workspace_bytes(*shape, B16F, _cabi.FA_KERNEL_PB2) == 0
     part = lambda S, bh, n, d: S * bh * n * d * 4 + S * bh * n * 4
     assert L.fa_workspace_bytes(1, 8192, 64, 0, B16, A) == 256 + part(8, 1, 8192, 64)         # idle grid: key-split partials
     assert L.fa_workspace_bytes(2, 8192, 64, 0, B16, A) == 256 + part(4, 2, 8192, 64)
@@ -94,16 +93,18 @@ def test_workspace_sizes_are_host_arithmetic():
     assert L.fa_workspace_bytes(8, 8192, 64, 0, B16, A) == 0 and L.fa_workspace_bytes(16, 8192, 64, 1, B16, A) == 0
     assert L.fa_workspace_bytes(1, 8192, 64, 0, F32, A) == 256 + part(8, 1, 8192, 64)         # fp32 tensors: the split kernel over key shares
     assert L.fa_workspace_bytes(1, 8192, 64, 1, F32, A) == 256 + part(8, 1, 8192, 64)         # ... causal too
-    assert L.fa_workspace_bytes(16, 8192, 64, 1, F32, A) == 0 and L.fa_workspace_bytes(1, 8192, 64, 0, F32, _cabi.FA_KERNEL_MFMA) == 0
-    assert L.fa_workspace_bytes(1, 8192, 64, 0, B16F, A) == 256 + 8192 * 64 * 2 + part(8, 1, 8192, 64)   # both
+    assert L.fa_workspace_bytes(16, 8192, 64, 1, F32, A) == 256 and L.fa_workspace_bytes(1, 8192, 64, 0, F32, _cabi.FA_KERNEL_MFMA) == 0
+    assert L.fa_workspace_bytes(1, 8192, 64, 0, B16F, A) == 256 + part(8, 1, 8192, 64)        # the accurate path splits idle grids the same way
+    assert L.fa_workspace_bytes(1, 8192, 64, 0, B16F, _cabi.FA_KERNEL_PB2) == 256 + part(8, 1, 8192, 64)
     assert L.fa_workspace_bytes(1, 8192, 64, 0, B16, _cabi.FA_KERNEL_SPLIT) == 0
-    assert L.fa_workspace_bytes(4, 300, 32, 0, B16F, _cabi.FA_KERNEL_P16) == 256 + ((4 * 300 * 32 * 2 + 255) // 256) * 256   # explicit: any size
-    assert L.fa_workspace_bytes(4, 300, 32, 0, B16F, _cabi.FA_KERNEL_P16X2) == 256 + ((4 * 300 * 32 * 2 + 255) // 256) * 256
+    # the fp16-P kernels left the product library in round 4 (ablation library only): a size query answers 0, a forward FA_ERR_UNSUPPORTED
+    assert L.fa_workspace_bytes(4, 300, 32, 0, B16F, _cabi.FA_KERNEL_P16) == 0 and L.fa_workspace_bytes(4, 300, 32, 0, B16F, _cabi.FA_KERNEL_P16X2) == 0
     # arguments fa_forward_ws would reject size to 0 and leave fa_last_error alone
     assert L.fa_workspace_bytes(0, 8192, 64, 0, B16F, A) == 0 and L.fa_workspace_bytes(16, 8192, 48, 0, B16F, A) == 0
-    assert L.fa_workspace_bytes(16, 8192, 64, 0, 7, A) == 0 and L.fa_workspace_bytes(16, 8192, 64, 0, F32, _cabi.FA_KERNEL_P16) == 0
+    assert L.fa_workspace_bytes(16, 8192, 64, 0, 7, A) == 0 and L.fa_workspace_bytes(16, 8192, 64, 0, F32, _cabi.FA_KERNEL_PB2) == 0
     import torch
-    assert fa.workspace_bytes(16, 8192, 64, dtype=torch.bfloat16, out_dtype=torch.float32) == 256 + 16 * 8192 * 64 * 2
+    assert fa.workspace_bytes(16, 8192, 64, dtype=torch.bfloat16, out_dtype=torch.float32) == 0
+    assert fa.workspace_bytes(1, 8192, 64, dtype=torch.bfloat16, out_dtype=torch.float32) == 256 + part(8, 1, 8192, 64)
 
 
 def test_fp32_auto_choice_follows_the_environment_switch():
@@ -147,9 +148,14 @@ def test_cabi_rejects_bad_arguments_without_touching_a_device():
     assert L.fa_forward(p, k, v, o, 1, 32, 48, 1.0, 0, 0, None) == 2
     assert b"48" in L.fa_last_error()
     assert L.fa_forward_ex(p, k, v, o, None, 1, 32, 64, 1.0, 0, 0, 9, None) == 2
-    # the fp16-P kernels exist for bf16 tensors only (head dims 32, 64, 128)
-    assert L.fa_forward_ex(p, k, v, o, None, 1, 32, 64, 1.0, 0, _cabi.FA_DTYPE_F32, _cabi.FA_KERNEL_P16, None) == 2
-    assert L.fa_forward_ex(p, k, v, o, None, 1, 32, 48, 1.0, 0, _cabi.FA_DTYPE_BF16, _cabi.FA_KERNEL_P16, None) == 2
+    # the two-term-P kernel exists for bf16 tensors only (head dims 32, 64, 128); the fp16-P kernels are not in the product library
+    assert L.fa_forward_ex(p, k, v, o, None, 1, 32, 64, 1.0, 0, _cabi.FA_DTYPE_F32, _cabi.FA_KERNEL_PB2, None) == 2
+    assert L.fa_forward_ex(p, k, v, o, None, 1, 32, 48, 1.0, 0, _cabi.FA_DTYPE_BF16, _cabi.FA_KERNEL_PB2, None) == 2
+    assert L.fa_forward_ex(p, k, v, o, None, 1, 32, 64, 1.0, 0, _cabi.FA_DTYPE_BF16, _cabi.FA_KERNEL_P16X2, None) == 2
+    assert b"ablation" in L.fa_last_error()
+    st = _cabi.FaStats()
+    assert L.fa_get_stats(ctypes.byref(st)) == 0 and st.eager_slots_per_device == 8192 and st.chains_degraded == 0
+    assert L.fa_get_stats(None) == 1
     assert L.fa_forward_packed_qkv(p, o, 1, 8, 96, 5, None) == 1      # C % NH != 0
     assert L.fa_forward_packed_qkv(p, o, 1, 8, 96, 2, None) == 2      # hs = 48 not instantiated
     ms = ctypes.c_float()
