@@ -11,6 +11,10 @@ hipcc cross-compiles for gfx950 without a GPU present.
 ``--ablation`` additionally builds ``libflashattn_amd_ablation.so`` (+ ``fa_driver_ablation``): the same sources compiled with
 ``-DFA_ABLATION=1`` plus the timing-only ablation instantiations quoted in DESIGN.md section 4 (results are garbage by design).
 They are NOT part of the product library: its ``fa_forward_ex`` rejects their variant numbers.
+``--sanitize`` builds ``libflashattn_amd_asan.so``: the host side of ``fa_api.cpp`` recompiled with ``-fsanitize=address,undefined``
+(device code and every other object unchanged) and ``-DFA_HOST_TEST=1``, which adds ``fa_host_selftest()`` -- plans over a shape grid,
+key-split arithmetic and the verdict-slot table from several threads, none of which needs a device.  ``sanitize_selfcheck()`` runs it (and
+the no-device validation paths through ctypes) in a child process with the ASan runtime preloaded; ``__graft_entry__.build()`` calls it.
 ``--torch-binding`` builds ``flash_torch_binding*.so``, the compiled pybind translation unit of INTEGRATION.md section 1
 (``torch::Tensor forward(Q, K, V, bool causal)``, /root/reference/src/main.cpp:3-6) against the installed torch-ROCm.
 """
@@ -126,6 +130,73 @@ def build(force: bool = False, jobs: int = 8, verbose: bool = False, ablation: b
     return LIB_PATH
 
 
+ASAN_LIB_PATH = os.path.join(PKG_DIR, "libflashattn_amd_asan.so")
+SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined", "-g"]
+
+
+def build_sanitized(force: bool = False) -> str:
+    """libflashattn_amd_asan.so: fa_api.cpp's host code under ASan + UBSan (no GPU sanitizer: not available on this pool), with the
+    host self-test compiled in; every other object is the product's."""
+    build(force=False)
+    src = os.path.join(CSRC, "fa_api.cpp")
+    obj = os.path.join(OBJ_DIR, "fa_api.asan.o")
+    if force or _mtime(obj) < max(_mtime(src), _newest_dep()):
+        cmd = [hipcc(), *[f for f in COMMON_FLAGS if f != "-O3"], "-O1", "-DFA_ABLATION=0", "-DFA_HOST_TEST=1", *SAN_FLAGS, "-x", "hip", "-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"sanitizer build of fa_api.cpp failed:\n{r.stdout}\n{r.stderr}")
+    objs = [os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(s))[0] + ".o") for s in LIB_SOURCES if s != "fa_api.cpp"] + [obj]
+    if force or _mtime(ASAN_LIB_PATH) < max(_mtime(o) for o in objs):
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-o", ASAN_LIB_PATH, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link of the sanitizer library failed:\n{r.stdout}\n{r.stderr}")
+    return ASAN_LIB_PATH
+
+
+def asan_runtime() -> str:
+    clang = os.path.join(os.path.dirname(os.path.realpath(hipcc())), "..", "lib", "llvm", "bin", "clang")
+    if not os.path.exists(clang):
+        clang = "/opt/rocm/lib/llvm/bin/clang"
+    return subprocess.run([clang, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True, check=True).stdout.strip()
+
+
+_SELFCHECK = r"""
+import ctypes, sys
+L = ctypes.CDLL(sys.argv[1])
+L.fa_host_selftest.restype = ctypes.c_int
+rc = L.fa_host_selftest()
+assert rc == 0, f"fa_host_selftest: check {rc} failed"
+# the no-device paths of the ABI through ctypes, as tests/test_host_logic.py drives them
+L.fa_workspace_bytes.restype = ctypes.c_size_t
+L.fa_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+assert L.fa_workspace_bytes(1, 8192, 64, 0, 1, 0) == 256 + 8 * 8192 * 64 * 4 + 8 * 8192 * 4
+L.fa_kernel_name_for.restype = ctypes.c_char_p
+L.fa_kernel_name_for.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64]
+for dt in (0, 1, 2):
+    for d in (32, 64, 128, 48):
+        for c in (0, 1):
+            for bh in (1, 16, 130, 70000):
+                for n in (1, 700, 8192, 40000, 1 << 24):
+                    L.fa_kernel_name_for(dt, d, c, bh, n)
+L.fa_last_error.restype = ctypes.c_char_p
+assert L.fa_forward(None, None, None, None, 1, 1, 64, ctypes.c_float(1.0), 0, 0, None) == 1 and b"null" in L.fa_last_error()
+print("sanitizer self-check ok")
+"""
+
+
+def sanitize_selfcheck(force: bool = False) -> str:
+    """Build the sanitizer library and run its host self-test under ASan + UBSan in a child process (a finding aborts it: non-zero
+    exit, the report on stderr).  No device is needed or touched."""
+    lib = build_sanitized(force)
+    env = dict(os.environ, LD_PRELOAD=asan_runtime(), ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1",
+               HIP_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, "-c", _SELFCHECK, lib], env=env, capture_output=True, text=True, timeout=900)
+    if r.returncode != 0 or "self-check ok" not in r.stdout:
+        raise RuntimeError(f"sanitizer self-check failed (rc {r.returncode}):\n{r.stdout[-3000:]}\n{r.stderr[-6000:]}")
+    return r.stdout.strip()
+
+
 TORCH_BINDING_NAME = "flash_torch_binding"
 
 
@@ -167,6 +238,9 @@ if __name__ == "__main__":
     ap.add_argument("--jobs", type=int, default=8)
     ap.add_argument("--ablation", action="store_true", help="also build libflashattn_amd_ablation.so + fa_driver_ablation")
     ap.add_argument("--torch-binding", action="store_true", help="also build the pybind11 module of INTEGRATION.md section 1")
+    ap.add_argument("--sanitize", action="store_true", help="also build libflashattn_amd_asan.so (host ASan + UBSan) and run its self-check")
     a = ap.parse_args()
     build(force=a.force, jobs=a.jobs, verbose=True, ablation=a.ablation, torch_binding=a.torch_binding)
+    if a.sanitize:
+        print(sanitize_selfcheck(force=a.force))
     sys.exit(0)

@@ -1011,6 +1011,17 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
         const float lt = st[blk].lacc[0];
         const float inv = 1.0f / lt;
         const int qi = q0 + 32 * blk + lq;
+        if constexpr (OPT) {
+            // The optimistic mix keeps P near 2^-kBias, so the accumulators hold ~2^-100 |O| l: products p v of the terms that matter
+            // reach fp32's subnormal range when |v| is below ~2^-26.  A lane whose accumulators are ALL tiny (but not all zero) sends
+            // the tile to the rescaled redo (p <= 1 there): V of such magnitudes is computed correctly, twice as slowly.
+            float amax = 0.0f;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) amax = fmaxf(fmaxf(amax, fabsf(o[blk][db][r])), fabsf(o[blk][db][r + 1]));
+            bad = bad || (amax > 0.0f && amax < kOptTinyAcc && qi < n);
+        }
         if (qi < n && idle) {   // empty causal key share: only its log-sum-exp (-inf) is stored; the combine never reads its O
             if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = -INFINITY;
         } else if (qi < n) {

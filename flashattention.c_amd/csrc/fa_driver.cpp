@@ -20,7 +20,7 @@
 //       first bh % N shards one slab longer), one fa_forward_sharded call per iteration, per-device milliseconds from events on each
 //       device's stream and their maximum (the job time: no collective on the path).  FA_ALLOW_SAME_DEVICE=1 lets N exceed the number
 //       of devices (shards then share devices round-robin): the only way to exercise N > 1 on a one-GPU box.
-//   --kernel auto|mfma|split|p16|p16x2 and --out_f32 1 choose the kernel family / an fp32 output for bf16 tensors in rand and sweep mode.
+//   --kernel auto|mfma|split|pb2 (ablation driver: also p16|p16x2) and --out_f32 1 choose the kernel family / an fp32 output for bf16 tensors in rand and sweep mode.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

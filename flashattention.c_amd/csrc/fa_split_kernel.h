@@ -17,7 +17,8 @@
 // its own query rows; it tracks max |k| element-wise while converting K (one v_max3_f32 per four values) and the 2-norms of its
 // Q rows, and when  max_rows |q|_2 * max |k|_inf * scale  exceeds kGuardLimit (= 100: twice what unit-variance data reach at
 // d = 64, scale 1) it raises the chain's flag word -- the exact fp32 kernel queued behind this one then recomputes the launch
-// (fa_api.cpp).  Callers who know better select FA_KERNEL_SPLIT (no guard) or FA_KERNEL_MFMA.  fp32 range is kept (bf16 exponent).
+// (fa_api.cpp).  Callers who know better select FA_KERNEL_SPLIT (no guard) or FA_KERNEL_MFMA.  fp32 range is kept for Q, K, V (bf16
+// exponent) and, through the redo of rows whose accumulators come out tiny, for O.
 //
 //   workgroup   NWAVES waves x QB blocks of 32 query rows; K/V tiles of 32 keys.
 //   HBM -> LDS  fp32 K/V rows are loaded into registers (two 16-byte loads per 8 values), split there, and written as FOUR
@@ -50,6 +51,7 @@ namespace fa {
 
 constexpr int kKvSplit = 32;         // keys per tile
 constexpr float kSplitLimit = 0x1p100f;  // optimistic pass: a row sum below this proves that no term overflowed
+constexpr float kSplitTinyAcc = 0x1p-116f;   // sum of a row's unnormalised accumulators below this (and not zero): products near the subnormals
 constexpr float kGuardLimit = 100.0f;    // |q|_2 * |k|_inf * scale above which 16-bit operand terms no longer hold 1e-3 (see header)
 
 // running maximum of |a|, |b|: one instruction (abs as source modifiers)
@@ -563,9 +565,14 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     // in ONE basic block of plain builtins, which hipcc's scheduler interleaves (sched_group_barrier pins the rhythm).
     // K(j+2) replaces K(j) and V(j) replaces V(j-2) in their two-stage LDS rings at the end of the iteration; one barrier per
     // tile.  A causal wave does not skip the (at most 2*QB*NWAVES - 1) tiles above its diagonal, it masks them: no branches.
-    // fp32 P, l and O have 2^127 of head room either way: a row whose sum ends up in (2^-100, 2^100) with finite outputs
-    // provably lost nothing; any other row sends its workgroup to the textbook redo above.
+    // The exponent reference of round 3 puts every P near 2^-B (B = 109 - ceil(log2 n): 96 at n = 8192): a row whose sum ends up in
+    // (2^-(B + 2), 2^100) with finite outputs lost nothing to RANGE at the top; at the bottom the accumulators hold ~2^-B l |O|, so the
+    // products of the terms that matter stay normal fp32 numbers only while |v| is above ~2^-30 -- a row whose unnormalised accumulators
+    // are all tiny (kSplitTinyAcc) but not zero is sent to the textbook redo as well, like any row outside the window.
     // -----------------------------------------------------------------------------------------------------------------
+    // the fast pass's exponent bias B = 109 - ceil(log2 n) (set_reference) and the smallest healthy row sum, 2^-(B + 2)
+    const float fast_bias = 109.0f - (float)(32 - __builtin_clz((unsigned)max(n - 1, 1)));
+    const float lt_floor = __builtin_amdgcn_exp2f(-(fast_bias + 2.0f));
     auto run_fast = [&]() -> bool {
         f32x16 o[QB][DB];
         float la[QB], lb[QB];   // two partial row sums per block (even / odd score registers)
@@ -672,7 +679,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
         // the reference of every row from the scores of tile 0 (in `c0`) and, when it needs no mask, tile 1 (`c1`): both were computed
         // from a zero accumulator and are shifted here, once; every later product starts from minit
         auto set_reference = [&](f32x16 (&c0)[QB], f32x16 (&c1)[QB], bool mask0, bool have1, bool use1) {
-            const float bias = 109.0f - (float)(32 - __builtin_clz((unsigned)max(n - 1, 1)));   // B = 109 - ceil(log2 n)
+            const float bias = fast_bias;   // B = 109 - ceil(log2 n)
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 if (mask0) {
@@ -943,7 +950,11 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                         store4(p, o_off + db * 32 + 8 * g, pk);
                     }
                 if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (mref[qb] + __builtin_amdgcn_logf(lt)) * kLn2;
-                ok = ok && (lt > 1.0f / kSplitLimit) && (lt < kSplitLimit) && (mag < INFINITY);   // false for NaN as well
+                // lt: the row's own reference term 2^-B is in the sum, so a healthy row sum never falls below 2^-(B + 1) (B = 101 for n <= 256:
+                // round 3 tested against a fixed 2^-100 there and redid every tile whose reference key held most of a row's mass);
+                // mag * lt = the sum of the unnormalised accumulators: tiny but not zero means the products p v of the terms that matter
+                // were near fp32's subnormal range (|v| below ~2^-30): the textbook redo (p <= 1) takes those
+                ok = ok && (lt > lt_floor) && (lt < kSplitLimit) && (mag < INFINITY) && !(mag * lt > 0.0f && mag * lt < kSplitTinyAcc);   // false for NaN as well
                 if (GUARD) saw_nan = saw_nan || (lt != lt) || (mag != mag);
             }
         }

@@ -141,8 +141,7 @@ def main():
     else:
         print(f"[Correctness] attn values sanity check: FAILED (max abs err {err:.2e} >= {tol:g})")
     if args.dtype == "bf16":
-        # the accurate bf16 path: same tensors, fp32 output -> FA_KERNEL_AUTO carries P as two fp16 terms (or, for small launches, hi + lo bf16 terms)
-        # (head dims 32, 128) -- held to the fp32 bar
+        # the accurate bf16 path: same tensors, fp32 output -> FA_KERNEL_AUTO carries P as two bf16 terms (one launch) -- held to the fp32 bar
         o32 = torch.empty(qd.shape, dtype=torch.float32, device=qd.device)
         acc = minimal_flash.forward(qd, kd, vd, args.masking, scale=args.scale, out=o32)
         ms_acc = fa.time_forward(qd, kd, vd, args.masking, scale=args.scale, warmup=args.warmup, iters=args.iters, out=o32)
