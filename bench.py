@@ -589,11 +589,11 @@ def c4_side_measurements(fa, _cabi, q, k, v, causal, args, device):
                              iters=4 if name == "c3" else 20, out=o2)
             ms2 = st2["median"]
             tf2 = fl2 / (ms2 * 1e-3) / 1e12
+            r = fa.last_forward_route()   # (before the check below launches the rung-0 kernel: the route is this thread's LAST forward's)
             chk2 = validate_output(fa, q2, k2, v2, o2, causal, args.scale, TOLERANCE["f32"], f"{name}.{label}")
             ent[label] = {"ms": round(ms2, 4), "ms_min_median_p90": [st2["min"], st2["median"], st2["p90"]], "tflops": round(tf2, 2),
                           "max_abs_err": chk2["max_abs_err"], "tolerance": chk2["tolerance"]}
             if label == "auto":
-                r = fa.last_forward_route()
                 ent[label].update(arithmetic="3 bf16 MFMA products of hi/lo splits, fp32 accumulate, logit-width guard + conditional exact launch "
                                              "included in the time" if r == 1 else "exact fp32 (guard fired)", route=r,
                                   frac_bf16_mfma_peak_at_3x_flop=round(3.0 * tf2 / PEAK_TFLOPS["bf16"], 4))

@@ -236,7 +236,7 @@ constexpr float kLazyThr = 64.0f;
 // 32 keys by a factor 2^200 before its tile is redone with the lazily rescaled softmax -- which keeps every input correct.
 constexpr float kOptBias = 100.0f;
 constexpr float kOptLimit = 0x1p100f;
-constexpr float kOptTinyAcc = 0x1p-116f;   // an accumulator row below this (and not zero) had its dominant products near fp32's subnormals
+constexpr float kOptTinyAcc = 0x1p-116f;   // an accumulator row below this had its dominant products near (or below) fp32's subnormals
 
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 

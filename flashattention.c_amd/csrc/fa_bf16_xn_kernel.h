@@ -400,6 +400,13 @@ __device__ __host__ constexpr XTable xn_make_table(bool opt)
     return t;
 }
 
+// the unit list and the dealing table of an instantiated schedule, evaluated once (every slot and every unit of a step refers to them:
+// re-deriving them per use made the two-term schedules a minute of constant evaluation per translation unit)
+template <int NB, int PF, bool OPT>
+inline constexpr XUnitList xn_units_v = xn_make_units<NB, PF>(OPT);
+template <int D, int NB, int PF, bool OPT>
+inline constexpr XTable xn_table_v = xn_make_table<D, NB, PF>(OPT);
+
 // index of the unit that completes the P fragment MFMA slot sl reads: the pack of fragment tt (hi term), the second lo half (lo term;
 // PF = 3: its packs)
 template <int D, int NB, int PF = 0>
@@ -415,13 +422,12 @@ __device__ __host__ constexpr int xn_producer_unit(XSlot sl, bool opt)
 }
 // A VALU result needs two wait states before an MFMA reads it, and an asm MFMA is not padded by hipcc: when the dealing rule
 // puts the last VALU instruction of a P fragment into the slot right in front of the first MFMA that reads it, that MFMA gets an s_nop 1.
-template <int D, int NB, int PF = 0>
-__device__ __host__ constexpr bool xn_needs_pad(int i, bool opt)
+template <int D, int NB, int PF, bool OPT>
+__device__ __host__ constexpr bool xn_needs_pad(int i)
 {
     const XSlot sl = xn_slot<D, NB, PF>(i);
     if (sl.kind == 0 || i == 0) return false;
-    const XTable t = xn_make_table<D, NB, PF>(opt);
-    return xn_producer_unit<D, NB, PF>(sl, opt) >= t.ub[i - 1];
+    return xn_producer_unit<D, NB, PF>(sl, OPT) >= xn_table_v<D, NB, PF, OPT>.ub[i - 1];
 }
 // Compile-time check of every dependency of a step's static schedule (round 1 and 2 re-derived the tables offline,
 // profiles/r01_x4_schedule_check.py):
@@ -510,7 +516,7 @@ struct XCtx {
 template <int D, int NB, bool OPT, int U, int ABL = 0, int PF = 0>
 __device__ __forceinline__ void xn_unit(XCtx<D, NB>& x)
 {
-    constexpr XUnit un = xn_make_units<NB, PF>(OPT).u[U];
+    constexpr XUnit un = xn_units_v<NB, PF, OPT>.u[U];
     if constexpr (un.kind == 0 && (ABL & 256)) {
         // timing-only ablation: the exponential replaced by a plain VALU instruction of the same data flow
         const float t = fmaf(x.sc[un.blk][un.idx], x.c, -x.off[un.blk]);
@@ -548,7 +554,7 @@ __device__ __forceinline__ void xn_unit(XCtx<D, NB>& x)
 template <int D, int NB, bool OPT, int U, int ABL, int PF, int PASS>
 __device__ __forceinline__ void xn_unit_pass(XCtx<D, NB>& x)
 {
-    constexpr bool is_dot = PF == 3 && xn_make_units<NB, PF>(OPT).u[U].kind == 4;
+    constexpr bool is_dot = PF == 3 && xn_units_v<NB, PF, OPT>.u[U].kind == 4;
     if constexpr (PASS == 0 || (PASS == 1 && !is_dot) || (PASS == 2 && is_dot)) xn_unit<D, NB, OPT, U, ABL, PF>(x);
 }
 template <int D, int NB, bool OPT, int ABL, int PF, int U0, int... Us>
@@ -617,12 +623,12 @@ __device__ __forceinline__ void xn_slot_body(XCtx<D, NB>& x)
 {
     using S = XShape<D, NB, PF>;
     constexpr XSlot sl = xn_slot<D, NB, PF>(I);
-    constexpr XTable tab = xn_make_table<D, NB, PF>(OPT);
+    constexpr XTable tab = xn_table_v<D, NB, PF, OPT>;
     xn_wait_v_frags<D, NB, I, ABL, PF>(x);
     if constexpr (I < S::NV && !(ABL & 16)) load_v_frag_asm<D, KB_C, I>(x.v_addr, x.vlo[I], x.vhi[I]);  // ABL & 16: no LDS fragment reads
     if constexpr (I < S::NV && (ABL & 16)) asm volatile("" : "=v"(x.vlo[I]), "=v"(x.vhi[I]));
     if constexpr (I < S::NV && (ABL & 32)) load_v_frag_asm<D, KB_C, I>(x.v_addr, x.vlo[I], x.vhi[I]);  // ABL & 32: every fragment read issued twice
-    if constexpr (xn_needs_pad<D, NB, PF>(I, OPT)) asm volatile("s_nop 1");
+    if constexpr (xn_needs_pad<D, NB, PF, OPT>(I)) asm volatile("s_nop 1");
     if constexpr (ABL & 1) {
         // timing-only ablation: no matrix instructions
     } else if constexpr (sl.kind == 0) {
@@ -1013,14 +1019,15 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
         const int qi = q0 + 32 * blk + lq;
         if constexpr (OPT) {
             // The optimistic mix keeps P near 2^-kBias, so the accumulators hold ~2^-100 |O| l: products p v of the terms that matter
-            // reach fp32's subnormal range when |v| is below ~2^-26.  A lane whose accumulators are ALL tiny (but not all zero) sends
-            // the tile to the rescaled redo (p <= 1 there): V of such magnitudes is computed correctly, twice as slowly.
+            // reach fp32's subnormal range when |v| is below ~2^-26 -- and vanish altogether below ~2^-50.  A lane whose accumulators
+            // are ALL tiny or zero sends the tile to the rescaled redo (p <= 1 there): V of such magnitudes (and an all-zero V) is
+            // computed correctly, twice as slowly -- down to |v| ~ 2^-62: the redo keeps the row maximum within 2^-64 of 1.
             float amax = 0.0f;
 #pragma unroll
             for (int db = 0; db < DB; ++db)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) amax = fmaxf(fmaxf(amax, fabsf(o[blk][db][r])), fabsf(o[blk][db][r + 1]));
-            bad = bad || (amax > 0.0f && amax < kOptTinyAcc && qi < n);
+            bad = bad || (amax < kOptTinyAcc && qi < n && !idle);
         }
         if (qi < n && idle) {   // empty causal key share: only its log-sum-exp (-inf) is stored; the combine never reads its O
             if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = -INFINITY;
@@ -1311,37 +1318,26 @@ static hipError_t launch_x2_p16(const FwdParams& p0, int causal, int out_f32, hi
     return e;
 }
 
-template <bool CAUSAL, bool OPTIMISTIC = true>
-static hipError_t launch_x4_pb2(const FwdParams& p0, int out_f32, hipStream_t stream)
+// (one output type per translation unit: the two-term schedules are the longest compiles of the library)
+template <bool CAUSAL, bool OUT_F32, bool OPTIMISTIC = true>
+static hipError_t launch_x4_pb2(const FwdParams& p0, hipStream_t stream)
 {
     FwdParams p;
     dim3 grid, block;
     if (!xn_grid<4>(p0, p, grid, block)) return hipErrorInvalidValue;
-    if (out_f32)
-        hipLaunchKernelGGL((fa_fwd_bf16_x4_pb2_kernel<4, CAUSAL, true, 2, 0, OPTIMISTIC>), grid, block, 0, stream, p);
-    else
-        hipLaunchKernelGGL((fa_fwd_bf16_x4_pb2_kernel<4, CAUSAL, false, 2, 0, OPTIMISTIC>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((fa_fwd_bf16_x4_pb2_kernel<4, CAUSAL, OUT_F32, 2, 0, OPTIMISTIC>), grid, block, 0, stream, p);
     return hipGetLastError();
 }
-template <int D, bool OPTIMISTIC = true>
-static hipError_t launch_x2_pb2(const FwdParams& p0, int causal, int out_f32, hipStream_t stream)
+template <int D, bool OUT_F32, bool OPTIMISTIC = true>
+static hipError_t launch_x2_pb2(const FwdParams& p0, int causal, hipStream_t stream)
 {
     FwdParams p;
     dim3 grid, block;
     if (!xn_grid<2>(p0, p, grid, block)) return hipErrorInvalidValue;
     const unsigned solo = xn_launch_order<D, 2>(p, grid, causal, D <= 64);
     auto go = [&](unsigned dyn_lds) {
-        if (causal) {
-            if (out_f32)
-                hipLaunchKernelGGL((fa_fwd_bf16_x2_pb2_kernel<D, 4, true, true, 2, 0, OPTIMISTIC>), grid, block, dyn_lds, stream, p);
-            else
-                hipLaunchKernelGGL((fa_fwd_bf16_x2_pb2_kernel<D, 4, true, false, 2, 0, OPTIMISTIC>), grid, block, dyn_lds, stream, p);
-        } else {
-            if (out_f32)
-                hipLaunchKernelGGL((fa_fwd_bf16_x2_pb2_kernel<D, 4, false, true, 2, 0, OPTIMISTIC>), grid, block, 0, stream, p);
-            else
-                hipLaunchKernelGGL((fa_fwd_bf16_x2_pb2_kernel<D, 4, false, false, 2, 0, OPTIMISTIC>), grid, block, 0, stream, p);
-        }
+        if (causal) hipLaunchKernelGGL((fa_fwd_bf16_x2_pb2_kernel<D, 4, true, OUT_F32, 2, 0, OPTIMISTIC>), grid, block, dyn_lds, stream, p);
+        else hipLaunchKernelGGL((fa_fwd_bf16_x2_pb2_kernel<D, 4, false, OUT_F32, 2, 0, OPTIMISTIC>), grid, block, 0, stream, p);
         return hipGetLastError();
     };
     hipError_t e = go(solo);

@@ -562,10 +562,11 @@ bool bf16_pb2_uses_x4(int64_t bh, int64_t n, int causal) { return choose_bf16(bh
 hipError_t launch_bf16_pb2(const FwdParams& p, int d, int causal, int out_f32, int variant, hipStream_t stream)
 {
     if (!bf16_p16_supported(p, d) || variant < 0 || variant > 2) return hipErrorInvalidValue;
-    if (d == 32) return launch_bf16_x2_pb2_d32(p, causal, out_f32, stream);
-    if (d == 128) return launch_bf16_x2_pb2_d128(p, causal, out_f32, stream);
-    if (variant == 2 || (variant == 0 && bf16_pb2_uses_x4(p.bh, p.n, causal))) return launch_bf16_x4_pb2(p, causal, out_f32, stream);
-    return launch_bf16_x2_pb2_d64(p, causal, out_f32, stream);
+    if (d == 32) return out_f32 ? launch_bf16_x2_pb2_d32_f32out(p, causal, stream) : launch_bf16_x2_pb2_d32_bf16out(p, causal, stream);
+    if (d == 128) return out_f32 ? launch_bf16_x2_pb2_d128_f32out(p, causal, stream) : launch_bf16_x2_pb2_d128_bf16out(p, causal, stream);
+    if (variant == 2 || (variant == 0 && bf16_pb2_uses_x4(p.bh, p.n, causal)))
+        return out_f32 ? launch_bf16_x4_pb2_f32out(p, causal, stream) : launch_bf16_x4_pb2_bf16out(p, causal, stream);
+    return out_f32 ? launch_bf16_x2_pb2_d64_f32out(p, causal, stream) : launch_bf16_x2_pb2_d64_bf16out(p, causal, stream);
 }
 
 hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, int variant, hipStream_t stream)

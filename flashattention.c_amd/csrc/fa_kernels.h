@@ -37,10 +37,12 @@ hipError_t launch_bf16_x2_p16x2_d128(const FwdParams& p, int causal, int out_f32
 // P as bf16 hi + bf16 lo (fa_fwd_bf16_x{4,2}_pb2_kernel): one launch, p.v = the caller's bf16 V, any layout the bf16-P kernels take
 hipError_t launch_bf16_pb2(const FwdParams& p, int d, int causal, int out_f32, int variant, hipStream_t stream);
 bool bf16_pb2_uses_x4(int64_t bh, int64_t n, int causal);
-hipError_t launch_bf16_x4_pb2(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
-hipError_t launch_bf16_x2_pb2_d32(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
-hipError_t launch_bf16_x2_pb2_d64(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
-hipError_t launch_bf16_x2_pb2_d128(const FwdParams& p, int causal, int out_f32, hipStream_t stream);
+#define FA_PB2_DECL(name) hipError_t name##_f32out(const FwdParams& p, int causal, hipStream_t stream); hipError_t name##_bf16out(const FwdParams& p, int causal, hipStream_t stream)
+FA_PB2_DECL(launch_bf16_x4_pb2);
+FA_PB2_DECL(launch_bf16_x2_pb2_d32);
+FA_PB2_DECL(launch_bf16_x2_pb2_d64);
+FA_PB2_DECL(launch_bf16_x2_pb2_d128);
+#undef FA_PB2_DECL
 hipError_t launch_cvt_v_f16(const void* src, void* dst, int64_t count, uint32_t* flag, uint32_t serial, hipStream_t stream);
 // combine of a key-split launch: partial outputs fp32 [S][bh][n][d], partial log-sum-exps [bh][S][n] -> p.o (and p.lse)
 hipError_t launch_combine_splits(const FwdParams& p, const float* o_part, const float* lse_part, int S, int d, int out_f32, hipStream_t stream);

@@ -51,7 +51,7 @@ namespace fa {
 
 constexpr int kKvSplit = 32;         // keys per tile
 constexpr float kSplitLimit = 0x1p100f;  // optimistic pass: a row sum below this proves that no term overflowed
-constexpr float kSplitTinyAcc = 0x1p-116f;   // sum of a row's unnormalised accumulators below this (and not zero): products near the subnormals
+constexpr float kSplitTinyAcc = 0x1p-116f;   // sum of a row's unnormalised accumulators below this: products near (or below) the subnormals
 constexpr float kGuardLimit = 100.0f;    // |q|_2 * |k|_inf * scale above which 16-bit operand terms no longer hold 1e-3 (see header)
 
 // running maximum of |a|, |b|: one instruction (abs as source modifiers)
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     // The exponent reference of round 3 puts every P near 2^-B (B = 109 - ceil(log2 n): 96 at n = 8192): a row whose sum ends up in
     // (2^-(B + 2), 2^100) with finite outputs lost nothing to RANGE at the top; at the bottom the accumulators hold ~2^-B l |O|, so the
     // products of the terms that matter stay normal fp32 numbers only while |v| is above ~2^-30 -- a row whose unnormalised accumulators
-    // are all tiny (kSplitTinyAcc) but not zero is sent to the textbook redo as well, like any row outside the window.
+    // are all tiny (kSplitTinyAcc) or zero is sent to the textbook redo as well, like any row outside the window.
     // -----------------------------------------------------------------------------------------------------------------
     // the fast pass's exponent bias B = 109 - ceil(log2 n) (set_reference) and the smallest healthy row sum, 2^-(B + 2)
     const float fast_bias = 109.0f - (float)(32 - __builtin_clz((unsigned)max(n - 1, 1)));
@@ -952,9 +952,9 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                 if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (mref[qb] + __builtin_amdgcn_logf(lt)) * kLn2;
                 // lt: the row's own reference term 2^-B is in the sum, so a healthy row sum never falls below 2^-(B + 1) (B = 101 for n <= 256:
                 // round 3 tested against a fixed 2^-100 there and redid every tile whose reference key held most of a row's mass);
-                // mag * lt = the sum of the unnormalised accumulators: tiny but not zero means the products p v of the terms that matter
-                // were near fp32's subnormal range (|v| below ~2^-30): the textbook redo (p <= 1) takes those
-                ok = ok && (lt > lt_floor) && (lt < kSplitLimit) && (mag < INFINITY) && !(mag * lt > 0.0f && mag * lt < kSplitTinyAcc);   // false for NaN as well
+                // mag * lt = the sum of the unnormalised accumulators: tiny or zero means the products p v of the terms that matter
+                // were near (or below) fp32's subnormal range (|v| below ~2^-30): the textbook redo (p <= 1) takes those -- an all-zero V too
+                ok = ok && (lt > lt_floor) && (lt < kSplitLimit) && (mag < INFINITY) && !(mag * lt < kSplitTinyAcc);   // false for NaN as well
                 if (GUARD) saw_nan = saw_nan || (lt != lt) || (mag != mag);
             }
         }

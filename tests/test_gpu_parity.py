@@ -1131,7 +1131,9 @@ def test_tiny_v_magnitudes_survive_the_optimistic_mixes(vmag):
     """The optimistic mixes keep P near 2^-100 (bf16 tensors) / 2^-96 (fp32 tensors, N = 8192), so their accumulators hold ~2^-100 |O| l:
     with |v| below ~2^-26 the products that matter would sit in fp32's subnormal range (round 3 accepted such tiles: outputs below
     ~1e-9 lost relative accuracy silently).  A row whose accumulators come out tiny but not zero now sends its tile to the rescaled
-    redo (p <= 1).  Relative error against the rung-0 kernel on V scaled down to 1e-30."""
+    redo (p <= 1).  Relative error against the rung-0 kernel on V scaled down to 1e-30 for fp32 tensors (their redo keeps the true running
+    maximum: p <= 1 exactly) and to 1e-20 for bf16 tensors (their redo keeps the row maximum within 2^-64 of 1: products stay normal
+    fp32 numbers down to |v| ~ 2^-62; below that bf16 V values are outside what this path promises)."""
     g = torch.Generator().manual_seed(7)
     for bh, n, d in ((4, 2048, 64), (2, 8192, 64), (3, 700, 128)):
         q, k, v = (torch.randn(bh, n, d, generator=g) for _ in range(3))
@@ -1145,6 +1147,8 @@ def test_tiny_v_magnitudes_survive_the_optimistic_mixes(vmag):
             rel = float((o - ref).abs().max()) / vmag
             OBSERVED.append((f"tiny V {vmag:g} fp32 tensors {kern} bh={bh} n={n} d={d}", rel, TOL_F32))
             assert rel < TOL_F32, (kern, bh, n, d, rel)
+        if vmag < 1e-20:
+            continue
         qb, kb, vb = (t.bfloat16() for t in (qd, kd, vd))
         refb = fa.forward(qb.float(), kb.float(), vb.float(), False, kernel="naive")
         for kern, odt, tol in (("auto", torch.float32, TOL_PB2), ("mfma", torch.float32, bf16_tol(1.0, True)), ("auto", torch.bfloat16, bf16_tol(1.0, False))):
