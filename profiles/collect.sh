@@ -22,7 +22,7 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_
     --kernel-trace -d $OUT/pmc_c3_sq -- python3 $BENCH3 > $OUT/pmc_c3_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_c3_fetch -- python3 $BENCH3 > $OUT/pmc_c3_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_c3_write -- python3 $BENCH3 > $OUT/pmc_c3_write.log 2>&1
-# the accurate bf16 path (fp32 output: V -> fp16 copy, fp16-P kernel, conditional split kernel): durations and matrix-pipe counters
+# the accurate bf16 path (fp32 output: P as bf16 hi + bf16 lo, ONE launch per forward): durations and matrix-pipe counters
 BENCHA="$R/bench.py --accurate --steps 20 --warmup 3 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats -d $OUT/stats_acc -- python3 $BENCHA > $OUT/stats_acc.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES \
@@ -41,6 +41,9 @@ shape_pass c2_exact --bh 128 --n 1024 --d 64 --dtype f32
 shape_pass d32_n1024_bf16 --bh 128 --n 1024 --d 32 --dtype bf16
 shape_pass d32_n8192_bf16 --bh 16 --n 8192 --d 32 --dtype bf16
 shape_pass c4_causal --bh 16 --n 8192 --d 64 --dtype bf16 --causal 1
+# round 4: the accurate path (two bf16 terms of P) beyond c4 -- causal, d = 128
+shape_pass acc_causal --bh 16 --n 8192 --d 64 --dtype bf16 --kernel pb2 --out_f32 1 --causal 1
+shape_pass acc_d128 --bh 16 --n 8192 --d 128 --dtype bf16 --kernel pb2 --out_f32 1
 cd $R
 # first summary: writes profiles/pmc_traffic.json (with this library's sha256) from the PMC passes above, so that the bench lines below --
 # which print `traffic` only for the library the counters were collected on -- carry it; the second one at the end checks the kernel names

@@ -25,8 +25,8 @@ $D --mode rand --bh 16 --n 8192 --d 32 --dtype f32s --warmup 60 --iters 20 --che
 echo "== fp32 tensors, exact fp32 arithmetic: c3, c2"
 $D --mode rand --bh 16 --n 8192 --d 64 --dtype f32 --warmup 20 --iters 10 --check 0
 $D --mode rand --bh 128 --n 1024 --d 64 --dtype f32 --warmup 100 --iters 30 --check 0
-echo "== two-term fp16-P kernels (FA_KERNEL_AUTO for an fp32 output): --kernel p16x2 --out_f32 1  (c4 at scale 1, 0.5, 1/sqrt(d); causal; bh=128; d=128; d=32; c2 shape)"
-P="--dtype bf16 --kernel p16x2 --out_f32 1 --warmup 100 --iters 30 --check 0"
+echo "== two-term bf16-P kernels (FA_KERNEL_AUTO for an fp32 output, one launch): --kernel pb2 --out_f32 1  (c4 at scale 1, 0.5, 1/sqrt(d); causal; bh=128; d=128; d=128 causal; d=32; c2 shape; c4 through the NB = 2 tiling; bh=128 through NB = 2)"
+P="--dtype bf16 --kernel pb2 --out_f32 1 --warmup 100 --iters 30 --check 0"
 for sc in 1 0.5 0.125; do $D --mode rand --bh 16 --n 8192 --d 64 $P --scale $sc; done
 $D --mode rand --bh 16 --n 8192 --d 64 $P --causal 1
 $D --mode rand --bh 128 --n 8192 --d 64 $P --iters 10
@@ -34,6 +34,17 @@ $D --mode rand --bh 16 --n 8192 --d 128 $P
 $D --mode rand --bh 16 --n 8192 --d 128 $P --causal 1
 $D --mode rand --bh 16 --n 8192 --d 32 $P
 $D --mode rand --bh 128 --n 1024 --d 64 $P
+$D --mode rand --bh 16 --n 8192 --d 64 $P --variant 1
+$D --mode rand --bh 128 --n 8192 --d 64 $P --iters 10 --variant 1
+echo "== round 3 accurate path, ablation library (V -> fp16 copy, two fp16 terms of P, empty fallback launch): --kernel p16x2 --out_f32 1  (c4; causal; bh=128; d=128; d=128 causal; d=32; c2 shape)"
+P="--dtype bf16 --kernel p16x2 --out_f32 1 --warmup 100 --iters 30 --check 0"
+$DA --mode rand --bh 16 --n 8192 --d 64 $P
+$DA --mode rand --bh 16 --n 8192 --d 64 $P --causal 1
+$DA --mode rand --bh 128 --n 8192 --d 64 $P --iters 10
+$DA --mode rand --bh 16 --n 8192 --d 128 $P
+$DA --mode rand --bh 16 --n 8192 --d 128 $P --causal 1
+$DA --mode rand --bh 16 --n 8192 --d 32 $P
+$DA --mode rand --bh 128 --n 1024 --d 64 $P
 echo "== hi + lo bf16 terms (--kernel split --out_f32 1): c4"
 $D --mode rand --bh 16 --n 8192 --d 64 --dtype bf16 --kernel split --out_f32 1 --warmup 100 --iters 30 --check 0
 echo "== key-split launches (grids that leave the chip idle): bf16 non-causal / causal BH = 1, 2, 4, 8; fp32 BH = 1, 2; fp32 causal BH = 1, 2, 4"
@@ -48,15 +59,15 @@ for b in 1 2 4; do $D --mode rand --bh $b --n 8192 --d 64 $U; done
 for b in 1 2 4 8; do $D --mode rand --bh $b --n 8192 --d 64 $U --causal 1; done
 for b in 1 2; do $D --mode rand --bh $b --n 8192 --d 64 --dtype f32s --kernel split --warmup 100 --iters 50 --check 0; done
 for b in 1 2 4; do $D --mode rand --bh $b --n 8192 --d 64 --dtype f32s --kernel split --warmup 100 --iters 50 --check 0 --causal 1; done
-echo "== one-term fp16-P kernels (explicit only): --kernel p16 --out_f32 1  (c4 at scale 1, 0.5, 1/sqrt(d); causal; bh=128; d=128; d=32; c2 shape)"
+echo "== one-term fp16-P kernels (ablation library): --kernel p16 --out_f32 1  (c4 at scale 1, 0.5, 1/sqrt(d); causal; bh=128; d=128; d=32; c2 shape)"
 P="--dtype bf16 --kernel p16 --out_f32 1 --warmup 100 --iters 30 --check 0"
-for sc in 1 0.5 0.125; do $D --mode rand --bh 16 --n 8192 --d 64 $P --scale $sc; done
-$D --mode rand --bh 16 --n 8192 --d 64 $P --causal 1
-$D --mode rand --bh 128 --n 8192 --d 64 $P --iters 10
-$D --mode rand --bh 16 --n 8192 --d 128 $P
-$D --mode rand --bh 16 --n 8192 --d 128 $P --causal 1
-$D --mode rand --bh 16 --n 8192 --d 32 $P
-$D --mode rand --bh 128 --n 1024 --d 64 $P
+for sc in 1 0.5 0.125; do $DA --mode rand --bh 16 --n 8192 --d 64 $P --scale $sc; done
+$DA --mode rand --bh 16 --n 8192 --d 64 $P --causal 1
+$DA --mode rand --bh 128 --n 8192 --d 64 $P --iters 10
+$DA --mode rand --bh 16 --n 8192 --d 128 $P
+$DA --mode rand --bh 16 --n 8192 --d 128 $P --causal 1
+$DA --mode rand --bh 16 --n 8192 --d 32 $P
+$DA --mode rand --bh 128 --n 1024 --d 64 $P
 echo "== llm.c harness size"
 $D --mode llmc | tail -1
 H="python3 -m flashattention_c_amd.harness.bench_flashattention --iters 50 --warmup 100"

@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEYS = [("c4", "== c4 non-causal"), ("bh128", "== bh=128"), ("causal", "== causal c4"), ("dims", "== d=32, d=128"), ("f32s", "== fp32 tensors, split kernel"),
-        ("exact", "== fp32 tensors, exact"), ("p16x2", "== two-term"), ("split", "== hi + lo"), ("ks", "== key-split"), ("unsplit", "== the same launches without"),
+        ("exact", "== fp32 tensors, exact"), ("pb2", "== two-term"), ("p16x2", "== round 3 accurate"), ("split", "== hi + lo"), ("ks", "== key-split"), ("unsplit", "== the same launches without"),
         ("p16", "== one-term"), ("llmc", "== llm.c")]
 
 
@@ -59,7 +59,9 @@ def main():
     b3 = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_bench_line_c3.json")))
     ba = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_bench_line_accurate.json")))
     ex = b4["extra"]
-    c4, bh, ca, dm, f3, exa, x2, sp, ks, us, p1 = (s[k] for k in ("c4", "bh128", "causal", "dims", "f32s", "exact", "p16x2", "split", "ks", "unsplit", "p16"))
+    c4, bh, ca, dm, f3, exa, x2, r3, sp, ks, us, p1 = (s[k] for k in ("c4", "bh128", "causal", "dims", "f32s", "exact", "pb2", "p16x2", "split", "ks", "unsplit", "p16"))
+    # pb2 section order: c4 at scale 1, 0.5, 1/sqrt(d); causal; bh=128; d=128; d=128 causal; d=32; c2 shape; c4 NB=2; bh=128 NB=2
+    # p16x2 (ablation library) order: c4; causal; bh=128; d=128; d=128 causal; d=32; c2 shape
     llmc = s["llmc"][-1]
     c5 = ex["c5"]
     third = 2500.0 / 3.0
@@ -68,13 +70,14 @@ def main():
         "|---|---|---|---|---|",
         f"| **c4** B=2 H=8 N=8192 d=64 bf16 | `fa_fwd_bf16_x4_kernel` (optimistic mix, sampled reference) | {ms(c4[0], 4)} (bench line of the call: {b4['roofline']['kernel_ms']:.4f}) | **{tf(c4[0])}** ({b4['roofline']['achieved']:.0f}) | **{fr(c4[0])}** ({b4['roofline']['frac']:.3f}) |",
         f"| same through the two-wave kernel / lazily rescaled mix only (ablation library) | `fa_fwd_bf16_pp3_kernel` / `x4` variant 42 | {ms(c4[1])} / {ms(c4[2])} | {tf(c4[1])} / {tf(c4[2])} | {fr(c4[1])} / {fr(c4[2])} |",
-        f"| **c4, fp32 output = the accurate path (two fp16 terms of P)**: V copy + kernel + empty fallback launch; at scale 0.5; at 1/√d | `fa_fwd_bf16_x2_p16x2_kernel` | {ms(x2[0])}; {ms(x2[1])}; {ms(x2[2])} (bench `--accurate`: {ba['roofline']['kernel_ms']:.3f}) | **{tf(x2[0])}**; {tf(x2[1])}; {tf(x2[2])} | **{fr(x2[0])}**; {fr(x2[1])}; {fr(x2[2])} |",
-        f"| same, ONE fp16 term (`kernel=\"p16\"`, explicit only: ≈ 1e-3) | `fa_fwd_bf16_x4_p16_kernel` | {ms(p1[0])} | {tf(p1[0])} | {fr(p1[0])} |",
-        f"| same, hi + lo bf16 terms of P and Q′ (`kernel=\"split\"`: the no-scratch choice) | `fa_fwd_f32_split_kernel<…, IN_BF16>` | {ms(sp[0])} | {tf(sp[0])} | {fr(sp[0], 1250.0)} of peak at 2× FLOP |",
-        f"| c5 per-GPU shard BH=128 (bf16 P / two fp16 terms / one); all 1024 slabs on one GPU (bench `extra.c5`) | x4 / x2 p16x2 / x2 p16 (two workgroups per CU); x4 | {ms(bh[0])} / {ms(x2[4], 2)} / {ms(p1[4], 2)}; {c5['ms_per_step']:.2f} | **{tf(bh[0])}** / {tf(x2[4])} / {tf(p1[4])}; {c5['tflops']:.0f} | **{fr(bh[0])}** / {fr(x2[4])} / {fr(p1[4])}; {c5['frac_bf16_mfma_peak_per_gpu']:.3f} |",
-        f"| c4 shape, causal (bf16 P / two fp16 terms / one); BH=128 causal | `fa_fwd_bf16_x2_kernel<64>` / `x2_p16x2` / `x2_p16` (paired tile order, §4.4); `x2` | {ms(ca[0], 4)} / {ms(x2[3])} / {ms(p1[3])}; {ms(ca[1])} | {tf(ca[0])} / {tf(x2[3])} / {tf(p1[3])}; {tf(ca[1])} | {fr(ca[0])} / {fr(x2[3])} / {fr(p1[3])}; {fr(ca[1])} |",
-        f"| **d=128** (BH=16, N=8192), non-causal / causal; two fp16 terms; one | `fa_fwd_bf16_x2_kernel<128>`; `x2_p16x2`; `x2_p16` | {ms(dm[1])} / {ms(dm[2])}; {ms(x2[5])} / {ms(x2[6])}; {ms(p1[5])} / {ms(p1[6])} | **{tf(dm[1])}** / {tf(dm[2])}; {tf(x2[5])} / {tf(x2[6])}; {tf(p1[5])} / {tf(p1[6])} | **{fr(dm[1])}** / {fr(dm[2])}; {fr(x2[5])} / {fr(x2[6])}; {fr(p1[5])} / {fr(p1[6])} |",
-        f"| d=32 (bf16 P; two fp16 terms; one) | `fa_fwd_bf16_x2_kernel<32>`; `x2_p16x2`; `x2_p16` | {ms(dm[0])}; {ms(x2[7])}; {ms(p1[7])} | {tf(dm[0])}; {tf(x2[7])}; {tf(p1[7])} | {fr(dm[0])}; {fr(x2[7])}; {fr(p1[7])} |",
+        f"| **c4, fp32 output = the accurate path (P as bf16 hi + bf16 lo, ONE launch)**; at scale 0.5; at 1/√d; through the NB = 2 tiling | `fa_fwd_bf16_x4_pb2_kernel` (`x2_pb2`) | {ms(x2[0])}; {ms(x2[1])}; {ms(x2[2])}; {ms(x2[9])} (bench `--accurate`: {ba['roofline']['kernel_ms']:.3f}) | **{tf(x2[0])}**; {tf(x2[1])}; {tf(x2[2])}; {tf(x2[9])} | **{fr(x2[0])}**; {fr(x2[1])}; {fr(x2[2])}; {fr(x2[9])} |",
+        f"| same through round 3's accurate path (ablation library: V → fp16 copy + two fp16 terms of P + empty fallback launch), same run | `fa_fwd_bf16_x2_p16x2_kernel` | {ms(r3[0])} | {tf(r3[0])} | {fr(r3[0])} |",
+        f"| same, ONE fp16 term (ablation library, `kernel=\"p16\"`: ≈ 1e-3, at the bar) | `fa_fwd_bf16_x4_p16_kernel` | {ms(p1[0])} | {tf(p1[0])} | {fr(p1[0])} |",
+        f"| same, hi + lo bf16 terms of P and Q′ in the split kernel (`kernel=\"split\"`: slabs beyond 4 GiB) | `fa_fwd_f32_split_kernel<…, IN_BF16>` | {ms(sp[0])} | {tf(sp[0])} | {fr(sp[0], 1250.0)} of peak at 2× FLOP |",
+        f"| c5 per-GPU shard BH=128 (bf16 P / two bf16 terms, NB = 4 and NB = 2 / round 3's chain); all 1024 slabs on one GPU (bench `extra.c5`) | x4 / x4_pb2, x2_pb2 / x2_p16x2; x4 | {ms(bh[0])} / {ms(x2[4], 2)}, {ms(x2[10], 2)} / {ms(r3[2], 2)}; {c5['ms_per_step']:.2f} | **{tf(bh[0])}** / {tf(x2[4])}, {tf(x2[10])} / {tf(r3[2])}; {c5['tflops']:.0f} | **{fr(bh[0])}** / {fr(x2[4])}, {fr(x2[10])} / {fr(r3[2])}; {c5['frac_bf16_mfma_peak_per_gpu']:.3f} |",
+        f"| c4 shape, causal (bf16 P / two bf16 terms / round 3's chain); BH=128 causal | `fa_fwd_bf16_x2_kernel<64>` / `x2_pb2` / `x2_p16x2` (paired tile order, §4.4); `x2` | {ms(ca[0], 4)} / {ms(x2[3])} / {ms(r3[1])}; {ms(ca[1])} | {tf(ca[0])} / {tf(x2[3])} / {tf(r3[1])}; {tf(ca[1])} | {fr(ca[0])} / {fr(x2[3])} / {fr(r3[1])}; {fr(ca[1])} |",
+        f"| **d=128** (BH=16, N=8192), non-causal / causal; two bf16 terms; round 3's chain | `fa_fwd_bf16_x2_kernel<128>`; `x2_pb2`; `x2_p16x2` | {ms(dm[1])} / {ms(dm[2])}; {ms(x2[5])} / {ms(x2[6])}; {ms(r3[3])} / {ms(r3[4])} | **{tf(dm[1])}** / {tf(dm[2])}; {tf(x2[5])} / {tf(x2[6])}; {tf(r3[3])} / {tf(r3[4])} | **{fr(dm[1])}** / {fr(dm[2])}; {fr(x2[5])} / {fr(x2[6])}; {fr(r3[3])} / {fr(r3[4])} |",
+        f"| d=32 (bf16 P; two bf16 terms; round 3's chain); c2's shape 128 × 1024 (two bf16 terms; round 3's chain) | `fa_fwd_bf16_x2_kernel<32>`; `x2_pb2`; `x2_p16x2` | {ms(dm[0])}; {ms(x2[7])}; {ms(r3[5])}; {ms(x2[8])}; {ms(r3[6])} | {tf(dm[0])}; {tf(x2[7])}; {tf(r3[5])}; {tf(x2[8])}; {tf(r3[6])} | {fr(dm[0])}; {fr(x2[7])}; {fr(r3[5])}; {fr(x2[8])}; {fr(r3[6])} |",
         f"| one slab, BH=1 N=8192 d=64 bf16, non-causal / causal (key-split launches, §8) | `fa_fwd_bf16_x2_kernel<64>` × 8 key shares + `fa_combine_splits_kernel` | {ms(ks[0])} / {ms(ks[3])} ({ms(us[0])} / {ms(us[3])} unsplit) | {tf(ks[0])} / {tf(ks[3])} | {fr(ks[0])} / {fr(ks[3])} |",
         f"| BH=2, 4 non-causal; BH=2, 4, 8 causal (key-split) | same | {ms(ks[1])}, {ms(ks[2])} ({ms(us[1])}, {ms(us[2])} unsplit); {ms(ks[4])}, {ms(ks[5])}, {ms(ks[6])} ({ms(us[4])}, {ms(us[5])}, {ms(us[6])} unsplit) | {tf(ks[1])}, {tf(ks[2])}; {tf(ks[4])}, {tf(ks[5])}, {tf(ks[6])} | {fr(ks[1])}, {fr(ks[2])}; {fr(ks[4])}, {fr(ks[5])}, {fr(ks[6])} |",
         f"| BH=1, 2 fp32 tensors N=8192, non-causal; BH=1, 2, 4 causal (key-split inside the guarded chain: round 3) | `fa_fwd_f32_split_kernel` × 8 / 4 / 2 key shares + combine + conditional exact launch | {ms(ks[7])}, {ms(ks[8])} ({ms(us[7])}, {ms(us[8])} unsplit, unguarded); {ms(ks[9])}, {ms(ks[10])}, {ms(ks[11])} ({ms(us[9])}, {ms(us[10])}, {ms(us[11])}) | {tf(ks[7])}, {tf(ks[8])}; {tf(ks[9])}, {tf(ks[10])}, {tf(ks[11])} | — |",
@@ -104,10 +107,11 @@ def main():
 
     readme = (
         f"Measured on MI355X (steady clocks, ONE run of the final binary on one box — `profiles/{tag}_config_table.txt`, generated by\n"
-        f"`profiles/make_tables.py`; identical binaries differ by ±4 % between boxes of the pool, c4 has read 0.225–0.251 ms this round):\n"
+        f"`profiles/make_tables.py`; identical binaries differ by ±4 % between boxes of the pool, c4 has read 0.2245–0.2374 ms this round):\n"
         f"B=2 H=8 N=8192 d=64 — bf16 {ms(c4[0])} ms ({tf(c4[0])} TFLOP/s, {100 * c4[0]['tflops'] / 2500:.0f} % of the dense bf16 MFMA peak; d=128: {tf(dm[1])} TFLOP/s,\n"
-        f"{100 * dm[1]['tflops'] / 2500:.0f} %); bf16 tensors with fp32 output (P as fp16 hi + fp16 lo: **≤ 4e-5 of the fp32 reference at scale 1**, where bf16 P shows\n"
-        f"5e-3 and round 2's one-term fp16 P sat at 1e-3) {ms(x2[0])} ms = {100 * x2[0]['tflops'] / 2500:.0f} %; fp32 tensors {ms(f3[0])} ms ({tf(f3[0])} TFLOP/s: both contractions as\n"
+        f"{100 * dm[1]['tflops'] / 2500:.0f} %) at {b4['roofline']['max_abs_err']:.1e} max-abs of the fp32 reference (bf16 P, bf16 output, the reference's scale 1; {ex['c4_scale_rsqrt_d']['max_abs_err']:.1e} at 1/√d);\n"
+        f"bf16 tensors with fp32 output (P as bf16 hi + bf16 lo in one launch: **{ba['roofline']['max_abs_err']:.1e} of the fp32 reference at scale 1**) {ms(x2[0])} ms =\n"
+        f"{100 * x2[0]['tflops'] / 2500:.0f} % — the `roofline_at_1e-3` block of the bench line; fp32 tensors {ms(f3[0])} ms ({tf(f3[0])} TFLOP/s: both contractions as\n"
         f"three bf16 MFMA products of hi/lo splits, within 2.5e-4 of the fp64 oracle at scale 1, wide-logit launches handed to the exact kernel\n"
         f"on the device; `kernel=\"exact\"`, fp32 arithmetic: {ms(exa[0], 2)} ms, {100 * exa[0]['tflops'] / 157.3:.0f} % of the fp32 MFMA peak); causal {ms(ca[0])} ms — causal launches\n"
         f"choose which tiles share a CU (`DESIGN.md` §4.4); grids that leave the chip idle are key-split (one slab of that length: {ms(ks[0])} ms\n"
