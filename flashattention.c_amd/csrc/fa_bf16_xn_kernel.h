@@ -35,7 +35,7 @@
 #endif
 // dealing limits of the PF = 3 step schedules (half-slots; see XShape), overridable for the offline search's A/B builds
 #ifndef FA_WEND_OPT3_X4
-#define FA_WEND_OPT3_X4 102
+#define FA_WEND_OPT3_X4 103
 #endif
 #ifndef FA_WEND_RSC3_X4
 #define FA_WEND_RSC3_X4 112
@@ -50,13 +50,22 @@
 #define FA_WEND_OPT3_64 47
 #endif
 #ifndef FA_WEND_RSC3_64
-#define FA_WEND_RSC3_64 52
+#define FA_WEND_RSC3_64 53
 #endif
 #ifndef FA_WEND_OPT3_128
 #define FA_WEND_OPT3_128 90
 #endif
 #ifndef FA_WEND_RSC3_128
-#define FA_WEND_RSC3_128 98
+#define FA_WEND_RSC3_128 99
+#endif
+// dots per unit of the PF = 3 schedules: 4 (half a fragment) or 8 (a fragment).  A dot waits until the MFMA issued before it has LEFT
+// the matrix pipe -- ~50 cycles after that MFMA's issue (profiles/r04_ubench_dot2b.txt: the first dot behind an MFMA costs 23 cycles,
+// every further one 4) -- so every group of dots pays that wait at most once: fewer, larger groups pay it less often (c4, one box:
+// 0.3689 ms with 8 dots per unit, 0.3755 with 4).  Issuing the MFMA of a dot slot a slot early, back to back with its predecessor, so
+// that ~70 cycles of VALU work separate the dots from the last MFMA, was built and measured too: +-0 (0.3687 / 0.3689) -- the wave then
+// waits at the second MFMA instead ("a wave waiting to issue an MFMA holds the vector issue port"); profiles/r04_experiments.txt.
+#ifndef FA_PB2_DOTS_PER_UNIT
+#define FA_PB2_DOTS_PER_UNIT 8
 #endif
 #ifndef FA_PB2_DOTS_LAST
 #define FA_PB2_DOTS_LAST 1   // 0: experiment switch -- a slot's VALU units in list order
@@ -97,7 +106,7 @@ struct XShape {
     // VALU units per block: 16 exponentials + 2 packs; the lo term of P adds 4 half fragments (PF = 2: one v_fma_mix per element packs
     // as it goes) or 4 + 4 (PF = 3: the dots of a half fragment and its packs are separate units, see lo_dots_bf16); rescaled mixes:
     // 3 lane-max micro-steps per block and the test
-    static constexpr int kLoUnits = PF == 2 ? 4 : PF == 3 ? 8 : 0;
+    static constexpr int kLoUnits = PF == 2 ? 4 : PF == 3 ? (FA_PB2_DOTS_PER_UNIT == 8 ? 4 : 8) : 0;
     static constexpr int kUnitsOpt = NB * (18 + kLoUnits), kUnitsRsc = NB * (21 + kLoUnits) + 1;
     // VALU units are dealt out over the first kWend half-slots of the step (largest values that put every pack in front of the first MFMA
     // reading it, found offline -- profiles/r04_xn_schedule_check.py -- and re-checked at compile time: xn_schedule_ok); NB = 4 with one
@@ -344,22 +353,33 @@ __device__ __host__ constexpr XUnitList xn_make_units(bool opt)
                 --npend;
             }
             if (e == 9) l.u[n++] = {1, b, 0, 16};
-            if (PF >= 2 && e == 10) l.u[n++] = {4, b, 0, 16};
-            if (PF >= 2 && e == 11) l.u[n++] = {4, b, 1, 16};
-            if (PF == 3 && e == 12) l.u[n++] = {5, b, 0, 8};
-            if (PF == 3 && e == 13) l.u[n++] = {5, b, 1, 8};
+            if constexpr (PF == 3 && FA_PB2_DOTS_PER_UNIT == 8) {   // whole fragments: the unit carries the index of the fragment's second half
+                if (e == 11) l.u[n++] = {4, b, 1, 32};
+                if (e == 13) l.u[n++] = {5, b, 1, 16};
+            } else {
+                if (PF >= 2 && e == 10) l.u[n++] = {4, b, 0, 16};
+                if (PF >= 2 && e == 11) l.u[n++] = {4, b, 1, 16};
+                if (PF == 3 && e == 12) l.u[n++] = {5, b, 0, 8};
+                if (PF == 3 && e == 13) l.u[n++] = {5, b, 1, 8};
+            }
         }
         pend[0] = {1, b, 1, 16};
         npend = 1;
-        if (PF >= 2) {
-            pend[1] = {4, b, 2, 16};
-            pend[2] = {4, b, 3, 16};
+        if constexpr (PF == 3 && FA_PB2_DOTS_PER_UNIT == 8) {
+            pend[1] = {4, b, 3, 32};
+            pend[2] = {5, b, 3, 16};
             npend = 3;
-        }
-        if (PF == 3) {
-            pend[3] = {5, b, 2, 8};
-            pend[4] = {5, b, 3, 8};
-            npend = 5;
+        } else {
+            if (PF >= 2) {
+                pend[1] = {4, b, 2, 16};
+                pend[2] = {4, b, 3, 16};
+                npend = 3;
+            }
+            if (PF == 3) {
+                pend[3] = {5, b, 2, 8};
+                pend[4] = {5, b, 3, 8};
+                npend = 5;
+            }
         }
     }
     if (opt) {
@@ -468,7 +488,8 @@ __device__ __host__ constexpr bool xn_schedule_ok(bool opt)
         if (un.kind == 5) {   // packs of a lo half: behind its dots, with a whole unit between (a dot result is readable three wait states
                               // later) and in a later slot (a slot's dots are emitted behind its other units: xn_units)
             const int ud = pos[un.blk][4 + un.idx];
-            if (PF != 3 || ud == 0 || u < ud + 2) return false;
+            // (whole-fragment units may be neighbours: pack k reads dots 2k, 2k + 1 and has the fragment's 6 - 2k later dots and k packs between)
+            if (PF != 3 || ud == 0 || u < ud + (FA_PB2_DOTS_PER_UNIT == 8 ? 1 : 2)) return false;
             int sd = 0, sp = 0;
             while (sd < S::kSlots && !(t.ub[sd] <= ud && ud < t.ub[sd + 1])) ++sd;
             while (sp < S::kSlots && !(t.ub[sp] <= u && u < t.ub[sp + 1])) ++sp;
@@ -532,8 +553,10 @@ __device__ __forceinline__ void xn_unit(XCtx<D, NB>& x)
         x.pf[un.blk][un.idx] = pack_p16x8<PF>(x.sc[un.blk], 8 * un.idx);
         asm volatile("" : "+v"(x.pf[un.blk][un.idx]));
     } else if constexpr (un.kind == 4 && PF == 3) {
+        if constexpr (FA_PB2_DOTS_PER_UNIT == 8) lo_dots_bf16(x.sc[un.blk], un.idx / 2, 0, x.pf[un.blk][un.idx / 2]);
         lo_dots_bf16(x.sc[un.blk], un.idx / 2, un.idx % 2, x.pf[un.blk][un.idx / 2]);
     } else if constexpr (un.kind == 5) {
+        if constexpr (FA_PB2_DOTS_PER_UNIT == 8) lo_packs_bf16(x.sc[un.blk], un.idx / 2, 0, x.pl[un.blk][un.idx / 2]);
         lo_packs_bf16(x.sc[un.blk], un.idx / 2, un.idx % 2, x.pl[un.blk][un.idx / 2]);
     } else if constexpr (un.kind == 4) {
         lo_half(x.sc[un.blk], un.idx / 2, un.idx % 2, x.pf[un.blk][un.idx / 2], x.pl[un.blk][un.idx / 2]);
@@ -618,12 +641,13 @@ __device__ __forceinline__ void xn_wait_v_frags(XCtx<D, NB>& x)
     }
 }
 
+// the matrix instruction of slot I with everything tied to it: the waits for its V^T fragments, the fragment reads that start in its slot,
+// the pad behind a VALU producer, the K reads of the next step
 template <int D, int NB, int KB_C, int I, int ABL, bool OPT, int PF>
-__device__ __forceinline__ void xn_slot_body(XCtx<D, NB>& x)
+__device__ __forceinline__ void xn_slot_mfma(XCtx<D, NB>& x)
 {
     using S = XShape<D, NB, PF>;
     constexpr XSlot sl = xn_slot<D, NB, PF>(I);
-    constexpr XTable tab = xn_table_v<D, NB, PF, OPT>;
     xn_wait_v_frags<D, NB, I, ABL, PF>(x);
     if constexpr (I < S::NV && !(ABL & 16)) load_v_frag_asm<D, KB_C, I>(x.v_addr, x.vlo[I], x.vhi[I]);  // ABL & 16: no LDS fragment reads
     if constexpr (I < S::NV && (ABL & 16)) asm volatile("" : "=v"(x.vlo[I]), "=v"(x.vhi[I]));
@@ -651,6 +675,12 @@ __device__ __forceinline__ void xn_slot_body(XCtx<D, NB>& x)
         else asm volatile("ds_read_b128 %0, %1" : "=v"(x.kf[ks]) : "v"(a));
         if constexpr (ABL & 32) asm volatile("ds_read_b128 %0, %1" : "=v"(x.kf[ks]) : "v"(a));
     }
+}
+template <int D, int NB, int KB_C, int I, int ABL, bool OPT, int PF>
+__device__ __forceinline__ void xn_slot_body(XCtx<D, NB>& x)
+{
+    constexpr XTable tab = xn_table_v<D, NB, PF, OPT>;
+    xn_slot_mfma<D, NB, KB_C, I, ABL, OPT, PF>(x);
     if constexpr (!(ABL & 2))   // ABL & 2: no VALU work
         xn_units<D, NB, OPT, ABL, PF, tab.ub[I]>(x, std::make_integer_sequence<int, tab.ub[I + 1] - tab.ub[I]>{});
     if constexpr (!(ABL & 128)) __builtin_amdgcn_sched_barrier(0);  // ABL & 128: slots not pinned (hipcc schedules the step)

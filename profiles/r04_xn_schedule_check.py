@@ -12,8 +12,9 @@ at least one other unit between them (a dot result may be read by another VALU i
 import sys
 
 # dealing limits of the PF = 3 schedules: (D, NB, 3, optimistic) -> kWend (the FA_WEND_* defaults of csrc/fa_bf16_xn_kernel.h)
-WEND3 = {(64, 4, 3, True): 102, (64, 4, 3, False): 112, (32, 2, 3, True): 26, (32, 2, 3, False): 30, (64, 2, 3, True): 47, (64, 2, 3, False): 52,
-         (128, 2, 3, True): 90, (128, 2, 3, False): 98}
+DOTS_PER_UNIT = 8   # FA_PB2_DOTS_PER_UNIT of the header: dots per unit of the PF = 3 schedules (4 = half a fragment, 8 = a fragment)
+WEND3 = {(64, 4, 3, True): 103, (64, 4, 3, False): 112, (32, 2, 3, True): 26, (32, 2, 3, False): 30, (64, 2, 3, True): 47, (64, 2, 3, False): 53,
+         (128, 2, 3, True): 90, (128, 2, 3, False): 99}
 
 
 def shape(D, NB, PF):
@@ -53,11 +54,18 @@ def units(NB, PF, opt):
             u.append(('exp', b, e, 12))
             if pend and 1 <= e <= 5: u.append(pend.pop(0))
             if e == 9: u.append(('pack', b, 0, 16))
-            if PF >= 2 and e == 10: u.append(('lo', b, 0, 16))
-            if PF >= 2 and e == 11: u.append(('lo', b, 1, 16))
-            if PF == 3 and e == 12: u.append(('lopk', b, 0, 8))
-            if PF == 3 and e == 13: u.append(('lopk', b, 1, 8))
-        pend = [('pack', b, 1, 16)] + ([('lo', b, 2, 16), ('lo', b, 3, 16)] if PF >= 2 else []) + ([('lopk', b, 2, 8), ('lopk', b, 3, 8)] if PF == 3 else [])
+            if PF == 3 and DOTS_PER_UNIT == 8:     # whole fragments, indexed by the fragment's second half
+                if e == 11: u.append(('lo', b, 1, 32))
+                if e == 13: u.append(('lopk', b, 1, 16))
+            else:
+                if PF >= 2 and e == 10: u.append(('lo', b, 0, 16))
+                if PF >= 2 and e == 11: u.append(('lo', b, 1, 16))
+                if PF == 3 and e == 12: u.append(('lopk', b, 0, 8))
+                if PF == 3 and e == 13: u.append(('lopk', b, 1, 8))
+        if PF == 3 and DOTS_PER_UNIT == 8:
+            pend = [('pack', b, 1, 16), ('lo', b, 3, 32), ('lopk', b, 3, 16)]
+        else:
+            pend = [('pack', b, 1, 16)] + ([('lo', b, 2, 16), ('lo', b, 3, 16)] if PF >= 2 else []) + ([('lopk', b, 2, 8), ('lopk', b, 3, 8)] if PF == 3 else [])
     if opt:
         return u + pend
     for b in range(NB):
@@ -111,7 +119,7 @@ def check(D, NB, PF, opt, wend=None, verbose=False):
             dots = [i for i, y in enumerate(un) if y[0] == 'lo' and y[1] == x[1] and y[2] == x[2]][0]
             sd = [i for i in range(S['kSlots']) if ub[i] <= dots < ub[i + 1]][0]
             sp = [i for i in range(S['kSlots']) if ub[i] <= j < ub[i + 1]][0]
-            if j < dots + 2 or (D >= 64 and sp <= sd):   # (a slot's dots are emitted behind its other units)
+            if j < dots + (1 if DOTS_PER_UNIT == 8 else 2) or (D >= 64 and sp <= sd):   # (a slot's dots are emitted behind its other units)
                 ok = False
                 if verbose: print('  VIOLATED: packs of lo half', x, 'right behind their dots / in their slot')
         if x[0] == 'max' and x[2] == 0:
