@@ -13,7 +13,7 @@ FA_KERNEL_AUTO, FA_KERNEL_NAIVE, FA_KERNEL_MFMA, FA_KERNEL_SPLIT, FA_KERNEL_P16,
 
 # every symbol include/flashattn_amd.h declares
 EXPORTED_SYMBOLS = (
-    "fa_forward", "fa_forward_ex", "fa_workspace_bytes", "fa_forward_ws", "fa_forward_sharded", "fa_forward_packed_qkv", "fa_time_forward", "fa_time_forward_graph",
+    "fa_forward", "fa_forward_ex", "fa_workspace_bytes", "fa_forward_ws", "fa_forward_sharded", "fa_forward_sharded_ex", "fa_forward_packed_qkv", "fa_time_forward", "fa_time_forward_graph",
     "fa_last_forward_route", "fa_get_stats", "fa_last_error", "fa_device_count", "fa_version", "fa_kernel_name", "fa_kernel_name_for",
 )
 
@@ -52,6 +52,10 @@ def lib() -> ctypes.CDLL:
     L.fa_forward_sharded.argtypes = [i32, ctypes.POINTER(i32), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
                                      ctypes.POINTER(vp), ctypes.POINTER(i64), i64, i32, f32, i32, i32, ctypes.POINTER(vp)]
     L.fa_forward_sharded.restype = ctypes.c_int
+    L.fa_forward_sharded_ex.argtypes = [i32, ctypes.POINTER(i32), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                        ctypes.POINTER(vp), ctypes.POINTER(i64), i64, i32, f32, i32, i32, i32, ctypes.POINTER(vp),
+                                        ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(vp)]
+    L.fa_forward_sharded_ex.restype = ctypes.c_int
     L.fa_forward_packed_qkv.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     L.fa_forward_packed_qkv.restype = ctypes.c_int
     L.fa_time_forward.argtypes = [vp, vp, vp, vp, i64, i64, i32, f32, i32, i32, i32, vp, i32, i32, ctypes.POINTER(f32)]

@@ -10,6 +10,8 @@
 
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -861,6 +863,93 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
     return FA_OK;
 }
 
+// ---- fa_forward_sharded: one persistent host thread per shard index -----------------------------------------------------------------
+// A forward can be a chain of launches plus a pool allocation; enqueued from one thread the last device would start a whole table's
+// worth of host time behind the first.  Round 3 created and joined a std::thread per shard on every call (tens of microseconds each on
+// the path of a ~0.3 ms launch: ADVICE r03); now worker i is created on first use, sleeps on a condition variable between calls and is
+// never destroyed (the pool is leaked on purpose: no join at process exit, where HIP may already be gone).  One sharded call at a
+// time uses the pool (g_shard_call); a second caller runs meanwhile on threads of its own, as before.
+struct ShardWorker {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, done = false, started = false;
+    std::thread th;
+    void loop()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return has_job; });
+            std::function<void()> j = std::move(job);
+            has_job = false;
+            lk.unlock();
+            j();
+            lk.lock();
+            done = true;
+            cv.notify_all();
+        }
+    }
+};
+struct ShardPool {
+    std::mutex call_mu;                      // one sharded call at a time
+    ShardWorker workers[kMaxDevices];
+};
+ShardPool* shard_pool()
+{
+    static ShardPool* pool = new ShardPool();   // never freed
+    return pool;
+}
+// run work(i) for every index in `idx`, each on its own thread, and wait for all of them
+void run_on_shard_threads(const std::vector<int>& idx, const std::function<void(int)>& work)
+{
+    ShardPool* pool = shard_pool();
+    std::unique_lock<std::mutex> call(pool->call_mu, std::try_to_lock);
+    if (!call.owns_lock() || (int)idx.size() > kMaxDevices) {   // the pool is busy with another caller's shards: threads of our own
+        std::vector<std::thread> th;
+        for (int i : idx) {
+            try {
+                th.emplace_back(work, i);
+            } catch (const std::exception&) {   // no thread to be had (nothing may cross the extern "C" boundary): this shard from here
+                work(i);
+            }
+        }
+        for (auto& t : th) t.join();
+        return;
+    }
+    std::vector<int> queued;
+    for (size_t k = 0; k < idx.size(); ++k) {
+        ShardWorker& w = pool->workers[k];
+        const int i = idx[k];
+        bool ok = true;
+        if (!w.started) {
+            try {
+                w.th = std::thread([&w] { w.loop(); });
+                w.th.detach();
+                w.started = true;
+            } catch (const std::exception&) {
+                ok = false;
+            }
+        }
+        if (!ok) {
+            work(i);
+            continue;
+        }
+        {
+            std::lock_guard<std::mutex> lk(w.mu);
+            w.job = [&work, i] { work(i); };
+            w.has_job = true;
+            w.done = false;
+        }
+        w.cv.notify_all();
+        queued.push_back((int)k);
+    }
+    for (int k : queued) {
+        ShardWorker& w = pool->workers[k];
+        std::unique_lock<std::mutex> lk(w.mu);
+        w.cv.wait(lk, [&] { return w.done; });
+    }
+}
+
 }  // namespace
 
 #if FA_HOST_TEST
@@ -1015,13 +1104,15 @@ int fa_forward_ws(const void* q, const void* k, const void* v, void* o, float* l
     return launch(p, d, causal, dtype, kernel, static_cast<hipStream_t>(stream), workspace, workspace_bytes, true);
 }
 
-int fa_forward_sharded(int32_t n_shards, const int32_t* device_ids, const void* const* q, const void* const* k, const void* const* v,
-                       void* const* o, const int64_t* bh, int64_t n, int32_t d, float scale, int32_t causal, int32_t dtype,
-                       void* const* streams)
+int fa_forward_sharded_ex(int32_t n_shards, const int32_t* device_ids, const void* const* q, const void* const* k, const void* const* v,
+                          void* const* o, float* const* lse, const int64_t* bh, int64_t n, int32_t d, float scale, int32_t causal, int32_t dtype,
+                          int32_t kernel, void* const* workspaces, const size_t* workspace_bytes, void* const* streams)
 {
     g_err[0] = 0;
     if (n_shards < 1 || !device_ids || !q || !k || !v || !o || !bh)
         return fail(FA_ERR_INVALID_ARGUMENT, "fa_forward_sharded: bad shard table");
+    if ((workspaces == nullptr) != (workspace_bytes == nullptr))
+        return fail(FA_ERR_INVALID_ARGUMENT, "fa_forward_sharded_ex: workspaces and workspace_bytes come together (both NULL: the convenience path's private pools)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(FA_ERR_NO_DEVICE, "no HIP device visible");
     // a shard table that names one device twice is almost always a bug of the caller (two shards then queue up behind each other
@@ -1042,44 +1133,39 @@ int fa_forward_sharded(int32_t n_shards, const int32_t* device_ids, const void* 
     if (hipGetDevice(&prev) != hipSuccess) return fail(FA_ERR_HIP, "hipGetDevice failed");
     t_last_chain = 0;   // the shards' chains belong to their worker threads: fa_last_forward_route() of this thread reports "no chain"
     t_last_route = -1;
-    // One host thread per shard: a forward may be a chain of launches plus a stream-ordered allocation, and enqueued from one
-    // thread the last device would start a whole chain's worth of host time behind the first.  The current device is per host
-    // thread in HIP, so the workers do not disturb the caller's; each worker's scratch comes from its own device's private pool.
+    // One host thread per shard (run_on_shard_threads).  The current device is per host thread in HIP, so the workers do not disturb the
+    // caller's; each worker's scratch comes from its shard's workspace, or from its own device's private pool.
     std::vector<int> rcs((size_t)n_shards, FA_OK);
     std::vector<std::string> msgs((size_t)n_shards);
-    auto work = [&](int i) {
+    const std::function<void(int)> work = [&](int i) {
         const hipError_t e = hipSetDevice(device_ids[i]);
         if (e != hipSuccess) {
             rcs[i] = fail(FA_ERR_HIP, "hipSetDevice(%d): %s", device_ids[i], hipGetErrorString(e));
         } else {
-            const fa::FwdParams p = make_params(q[i], k[i], v[i], o[i], nullptr, bh[i], n, d, scale);
-            rcs[i] = launch(p, d, causal, dtype, FA_KERNEL_AUTO, streams ? static_cast<hipStream_t>(streams[i]) : nullptr);
+            const fa::FwdParams p = make_params(q[i], k[i], v[i], o[i], lse ? lse[i] : nullptr, bh[i], n, d, scale);
+            hipStream_t st = streams ? static_cast<hipStream_t>(streams[i]) : nullptr;
+            if (workspaces != nullptr) rcs[i] = launch(p, d, causal, dtype, kernel, st, workspaces[i], workspace_bytes[i], true);
+            else rcs[i] = launch(p, d, causal, dtype, kernel, st);
         }
         if (rcs[i] != FA_OK) msgs[i] = g_err;
     };
-    int active = 0, last = -1;
+    std::vector<int> active;
     for (int i = 0; i < n_shards; ++i)
-        if (bh[i] > 0) ++active, last = i;   // bh[i] == 0: more devices than slabs, this shard is empty
-    if (active == 1) {
-        work(last);
-        t_last_chain = 0;
-    } else if (active > 1) {
-        std::vector<std::thread> th;
-        for (int i = 0; i < n_shards; ++i) {
-            if (bh[i] <= 0) continue;
-            try {
-                th.emplace_back(work, i);
-            } catch (const std::exception&) {   // no thread to be had (nothing may cross the extern "C" boundary): this shard from here
-                work(i);
-            }
-        }
-        for (auto& t : th) t.join();
-        t_last_chain = 0;
-    }
+        if (bh[i] > 0) active.push_back(i);   // bh[i] == 0: more devices than slabs, this shard is empty
+    if (active.size() == 1) work(active[0]);
+    else if (active.size() > 1) run_on_shard_threads(active, work);
+    t_last_chain = 0;
     (void)hipSetDevice(prev);
     for (int i = 0; i < n_shards; ++i)
         if (rcs[i] != FA_OK) return fail(rcs[i], "shard %d (device %d): %s", i, device_ids[i], msgs[i].c_str());
     return FA_OK;
+}
+
+int fa_forward_sharded(int32_t n_shards, const int32_t* device_ids, const void* const* q, const void* const* k, const void* const* v,
+                       void* const* o, const int64_t* bh, int64_t n, int32_t d, float scale, int32_t causal, int32_t dtype,
+                       void* const* streams)
+{
+    return fa_forward_sharded_ex(n_shards, device_ids, q, k, v, o, nullptr, bh, n, d, scale, causal, dtype, FA_KERNEL_AUTO, nullptr, nullptr, streams);
 }
 
 int fa_forward_packed_qkv(const float* inp, float* out, int32_t B, int32_t T, int32_t C, int32_t NH, void* stream)

@@ -32,13 +32,24 @@ def shard_sizes(bh: int, world: int) -> List[int]:
 
 
 def forward_sharded(qs: Sequence[torch.Tensor], ks: Sequence[torch.Tensor], vs: Sequence[torch.Tensor],
-                    causal: bool = False, *, scale: float = 1.0) -> List[torch.Tensor]:
-    """Single-process multi-device forward: shard i lives on ``qs[i].device``; returns the per-device outputs."""
+                    causal: bool = False, *, scale: float = 1.0, return_lse: bool = False, kernel="auto",
+                    out_dtype=None):
+    """Single-process multi-device forward: shard i lives on ``qs[i].device``; returns the per-device outputs (and, with
+    ``return_lse``, the per-device (bh_i, N) log-sum-exps).  Goes through ``fa_forward_sharded_ex``: every shard gets a ``torch.empty``
+    workspace of ``fa_workspace_bytes`` on its own device (nothing is allocated inside the C ABI), an explicit ``kernel`` and
+    ``out_dtype=torch.float32`` for bf16 shards (the accurate path) work as in ``forward``."""
+    from .flash import _kernel_id
     n_sh = len(qs)
     if not (n_sh == len(ks) == len(vs)) or n_sh < 1:
         raise ValueError("qs, ks, vs must be equally long, non-empty lists")
     n, d, dt = qs[0].shape[1], qs[0].shape[2], qs[0].dtype
-    outs, streams, devs = [], [], []
+    odt = dt if out_dtype is None else out_dtype
+    if odt != dt and not (dt == torch.bfloat16 and odt == torch.float32):
+        raise TypeError(f"out_dtype {odt} not supported for {dt} inputs")
+    dtype_id = {torch.float32: _cabi.FA_DTYPE_F32, torch.bfloat16: _cabi.FA_DTYPE_BF16}[dt] if odt == dt else _cabi.FA_DTYPE_BF16_OUT_F32
+    kid = _kernel_id(kernel)
+    L = _cabi.lib()
+    outs, lses, wss, streams, devs = [], [], [], [], []
     for q, k, v in zip(qs, ks, vs):
         if not (q.is_cuda and q.shape == k.shape == v.shape and q.dtype == k.dtype == v.dtype == dt):
             raise ValueError("every shard needs matching GPU tensors")
@@ -47,17 +58,22 @@ def forward_sharded(qs: Sequence[torch.Tensor], ks: Sequence[torch.Tensor], vs: 
         if q.shape[1] != n or q.shape[2] != d:
             raise ValueError("all shards must share seq_len and head_dim")
         # the kernel writes a dense row-major (bh, n, d) shard whatever the strides of q are
-        outs.append(torch.empty(q.shape, dtype=q.dtype, device=q.device))
+        outs.append(torch.empty(q.shape, dtype=odt, device=q.device))
+        lses.append(torch.empty(q.shape[:2], dtype=torch.float32, device=q.device) if return_lse else None)
+        need = int(L.fa_workspace_bytes(q.shape[0], n, d, int(bool(causal)), dtype_id, kid)) if q.shape[0] else 0
+        with torch.cuda.device(q.device):
+            wss.append(torch.empty(need, dtype=torch.uint8, device=q.device) if need else None)
         devs.append(q.device.index)
         streams.append(torch.cuda.current_stream(q.device).cuda_stream)
     # contiguous copies (if any were needed) stay referenced until the launches are enqueued; torch's caching allocator keeps a
     # block alive for work already queued on the stream it was allocated on
     qc, kc, vc = ([t.contiguous() for t in ts] for ts in (qs, ks, vs))
     vp = ctypes.c_void_p
-    arr = lambda ts: (vp * n_sh)(*[t.data_ptr() if t.shape[0] else None for t in ts])  # noqa: E731
-    rc = _cabi.lib().fa_forward_sharded(
-        n_sh, (ctypes.c_int32 * n_sh)(*devs), arr(qc), arr(kc), arr(vc), arr(outs), (ctypes.c_int64 * n_sh)(*[q.shape[0] for q in qs]),
-        n, d, float(scale), int(bool(causal)), {torch.float32: 0, torch.bfloat16: 1}[dt], (vp * n_sh)(*streams))
+    arr = lambda ts: (vp * n_sh)(*[t.data_ptr() if (t is not None and t.numel()) else None for t in ts])  # noqa: E731
+    rc = L.fa_forward_sharded_ex(
+        n_sh, (ctypes.c_int32 * n_sh)(*devs), arr(qc), arr(kc), arr(vc), arr(outs), arr(lses) if return_lse else None,
+        (ctypes.c_int64 * n_sh)(*[q.shape[0] for q in qs]), n, d, float(scale), int(bool(causal)), dtype_id, kid,
+        arr(wss), (ctypes.c_size_t * n_sh)(*[w.numel() if w is not None else 0 for w in wss]), (vp * n_sh)(*streams))
     del qc, kc, vc
     _cabi.check(rc)
-    return outs
+    return (outs, lses) if return_lse else outs

@@ -152,13 +152,25 @@ int fa_forward_ws(const void* q, const void* k, const void* v, void* o, float* l
  *                   (FA_ALLOW_SAME_DEVICE=1 in the environment lifts the check: single-GPU test boxes)
  *   q/k/v/o[i]      device pointers of shard i, (bh[i], n, d)
  *   streams[i]      hipStream_t on device_ids[i] (NULL entries / NULL array = null stream)
- * Each shard is enqueued by its own host thread (a forward can be a chain of launches: one thread would start the last device a
- * whole table's worth of host time behind the first) without synchronising; the caller's current device is untouched.
+ * Each shard is enqueued by its own (persistent) host thread (a forward can be a chain of launches: one thread would start the last
+ * device a whole table's worth of host time behind the first) without synchronising; the caller's current device is untouched.
  */
 int fa_forward_sharded(int32_t n_shards, const int32_t* device_ids,
                        const void* const* q, const void* const* k, const void* const* v, void* const* o,
                        const int64_t* bh, int64_t n, int32_t d, float scale, int32_t causal,
                        int32_t dtype, void* const* streams);
+/*
+ * fa_forward_sharded_ex -- the same with what fa_forward_ws has per shard: lse[i] (NULL array or NULL entries: none), an explicit
+ *                          `kernel`, and caller-owned scratch -- workspaces[i] / workspace_bytes[i], each at least
+ *                          fa_workspace_bytes(bh[i], n, d, causal, dtype, kernel) (both arrays NULL: scratch from each device's private
+ *                          pool, as fa_forward_sharded).  With workspaces nothing is allocated and the call is legal while the shards'
+ *                          streams are capturing.  The worker threads are persistent (created on first use, one per shard index).
+ */
+int fa_forward_sharded_ex(int32_t n_shards, const int32_t* device_ids,
+                          const void* const* q, const void* const* k, const void* const* v, void* const* o, float* const* lse,
+                          const int64_t* bh, int64_t n, int32_t d, float scale, int32_t causal,
+                          int32_t dtype, int32_t kernel, void* const* workspaces, const size_t* workspace_bytes,
+                          void* const* streams);
 
 /*
  * fa_forward_packed_qkv -- llm.c layout entry, replaces attention_forward6

@@ -645,6 +645,30 @@ def test_sharded_entry_point_on_one_device(monkeypatch):
     outs = fa.forward_sharded([qd[b0:e0], qd[b1:e1]], [kd[b0:e0], kd[b1:e1]], [vd[b0:e0], vd[b1:e1]], True)
     torch.cuda.synchronize()
     check(torch.cat(outs), ref, TOL_F32)
+    # fa_forward_sharded_ex: LSE, explicit kernel, per-shard caller-owned workspaces (key-split shards: BH = 1 each at 4 200 keys),
+    # the accurate path for bf16 shards; persistent worker threads: many calls in a row, then the raw entry with its refusals
+    L = _cabi.lib()
+    q2, k2, v2 = (orc.round_to_bf16(randn(s, 2, 4200, 64)) for s in (25, 26, 27))
+    ref2, lse2 = orc.attention_f64(q2, k2, v2, return_lse=True)
+    qb, kb, vb = to_dev(q2, k2, v2, dtype=torch.bfloat16)
+    assert fa.workspace_bytes(1, 4200, 64, dtype=torch.bfloat16, out_dtype=torch.float32) > 256
+    for _ in range(20):
+        outs, lses = fa.forward_sharded([qb[:1], qb[1:]], [kb[:1], kb[1:]], [vb[:1], vb[1:]], False, return_lse=True, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    check(torch.cat(outs), ref2, TOL_PB2, "sharded, accurate path, key-split shards")
+    check(torch.cat(lses), lse2, 1e-4, "sharded lse")
+    outs = fa.forward_sharded([qb[:1], qb[1:]], [kb[:1], kb[1:]], [vb[:1], vb[1:]], False, kernel="split", out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    check(torch.cat(outs), ref2, TOL_ACC, "sharded, explicit kernel")
+    outs = fa.forward_sharded([qd[b0:e0], qd[b1:e1], qd[:0]], [kd[b0:e0], kd[b1:e1], kd[:0]], [vd[b0:e0], vd[b1:e1], vd[:0]], True)   # an empty shard
+    torch.cuda.synchronize()
+    check(torch.cat(outs), ref, TOL_F32, "sharded with an empty shard")
+    vp = ctypes.c_void_p
+    one = (vp * 1)(qd.data_ptr())
+    o1 = torch.empty_like(qd)
+    assert L.fa_forward_sharded_ex(1, (ctypes.c_int32 * 1)(0), one, (vp * 1)(kd.data_ptr()), (vp * 1)(vd.data_ptr()), (vp * 1)(o1.data_ptr()), None,
+                                   (ctypes.c_int64 * 1)(5), 200, 64, 1.0, 1, 0, 0, (vp * 1)(None), None, None) == 1   # workspaces without their sizes
+    assert b"come together" in L.fa_last_error()
 
 
 def test_runs_on_callers_stream_without_sync():
