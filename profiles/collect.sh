@@ -48,6 +48,7 @@ cd $R
 # first summary: writes profiles/pmc_traffic.json (with this library's sha256) from the PMC passes above, so that the bench lines below --
 # which print `traffic` only for the library the counters were collected on -- carry it; the second one at the end checks the kernel names
 python3 profiles/summarize_rocpd.py $OUT $TAG --out $OUT > /dev/null 2>&1 || true
+cp $OUT/pmc_traffic.json profiles/pmc_traffic.json 2>/dev/null || true   # (this box's copy of the tree: what bench.py reads)
 python3 bench.py --accurate --no-cpu-baseline --no-extras > $OUT/bench_line_accurate.json 2> $OUT/bench_acc.err
 python3 bench.py --workload c3 --no-cpu-baseline > $OUT/bench_line_c3.json 2> $OUT/bench_c3.err
 python3 bench.py > $OUT/bench_line.json 2> $OUT/bench.err
