@@ -103,6 +103,16 @@ def main():
     sec7 = (f"c4 from the final passes (`{tag}`): {avg_ns / 1e3:.1f} µs average of {calls} dispatches under the profiler, `SQ_VALU_MFMA_BUSY_CYCLES` ÷ (1024 SIMDs ×\n"
             f"{gui / 1e3:.1f} k cycles) = {k4['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * gui):.2f} of the matrix pipe, {gui / avg_ns:.2f} GHz, HBM traffic {traffic['c4_hbm_bytes_per_launch'] / 1e6:.2f} MB against 67.11 MB\n"
             f"algorithmic, `SQ_LDS_BANK_CONFLICT` {k4['SQ_LDS_BANK_CONFLICT']:.0f}; the bench line of that call: {b4['roofline']['kernel_ms']:.4f} ms = **{b4['roofline']['frac']:.3f}**.\n")
+    # ... and of the accurate path (pass stats_acc: one dispatch per forward; pmc_acc_sq: its counters)
+    ka = next((v for k, v in pmc.items() if "fa_fwd_bf16_x4_pb2_kernel" in k), None)
+    ma = re.search(r"== pass stats_acc: kernel durations.*?\n.*?\n\s*(\d+)\s+(\d+)\s+\d+\s+\d+\s+\d+\s+void fa::fa_fwd_bf16_x4_pb2_kernel", summ, re.S)
+    if ka is not None and ma is not None:
+        calls_a, avg_a = int(ma.group(1)), int(ma.group(2))
+        gui_a = ka["GRBM_GUI_ACTIVE"] / 8.0
+        sec7 += (f"The accurate path in the same collection: {avg_a / 1e3:.1f} µs average of {calls_a} dispatches of `fa_fwd_bf16_x4_pb2_kernel` (one per forward; round 3's\n"
+                 f"chain was three), {gui_a / 1e3:.1f} k cycles = {gui_a / 256 / 1e3 * 1.0:.2f} k per four-block step (256 steps per tile; the issue model of section 4.6 gives 2.6 k), `SQ_VALU_MFMA_BUSY_CYCLES` ÷ (1024 × cycles) = "
+                 f"{ka['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * gui_a):.2f} of the pipe,\n{gui_a / avg_a:.2f} GHz, {ka['SQ_INSTS_VALU'] / ka['SQ_INSTS_MFMA']:.2f} VALU instructions per MFMA; "
+                 f"the bench line (`--accurate`): {ba['roofline']['kernel_ms']:.4f} ms = **{ba['roofline']['frac']:.3f}** at {ba['roofline']['max_abs_err']:.1e}.\n")
     replace_block(os.path.join(ROOT, "DESIGN.md"), sec7, "profile7")
 
     readme = (
