@@ -67,6 +67,9 @@
 #ifndef FA_PB2_DOTS_PER_UNIT
 #define FA_PB2_DOTS_PER_UNIT 8
 #endif
+#ifndef FA_PB2_DOT_SLOT_EXTRA
+#define FA_PB2_DOT_SLOT_EXTRA 1
+#endif
 #ifndef FA_PB2_DOTS_LAST
 #define FA_PB2_DOTS_LAST 1   // 0: experiment switch -- a slot's VALU units in list order
 #endif
@@ -417,6 +420,21 @@ __device__ __host__ constexpr XTable xn_make_table(bool opt)
         t.ub[i] = n;
     }
     t.ub[kS] = nu;
+    // PF = 3: a slot that holds a dot unit takes FA_PB2_DOT_SLOT_EXTRA more (non-dot) units from the slot behind it.  The dots of a slot
+    // are emitted last and need the matrix pipe EMPTY (~50 cycles after the slot's MFMA); the dot unit alone fills a slot's share of the
+    // VALU work, so without this the dots start ~35 cycles behind the MFMA and wait out the rest, eight times per step.
+    if (PF == 3 && pb2_dots_last(D) && FA_PB2_DOT_SLOT_EXTRA > 0) {
+        for (int i = 0; i + 2 <= kS; ++i) {
+            bool dots = false;
+            for (int u = t.ub[i]; u < t.ub[i + 1]; ++u) dots = dots || l.u[u].kind == 4;
+            if (!dots) continue;
+            for (int k = 0; k < FA_PB2_DOT_SLOT_EXTRA; ++k) {
+                const int u = t.ub[i + 1];
+                if (u >= t.ub[i + 2] || u >= nu || l.u[u].kind == 4 || l.u[u].kind == 5) break;   // nothing left / never another dot or lo-pack unit
+                ++t.ub[i + 1];
+            }
+        }
+    }
     return t;
 }
 

@@ -12,6 +12,7 @@ at least one other unit between them (a dot result may be read by another VALU i
 import sys
 
 # dealing limits of the PF = 3 schedules: (D, NB, 3, optimistic) -> kWend (the FA_WEND_* defaults of csrc/fa_bf16_xn_kernel.h)
+DOT_SLOT_EXTRA = 1  # FA_PB2_DOT_SLOT_EXTRA of the header
 DOTS_PER_UNIT = 8   # FA_PB2_DOTS_PER_UNIT of the header: dots per unit of the PF = 3 schedules (4 = half a fragment, 8 = a fragment)
 WEND3 = {(64, 4, 3, True): 103, (64, 4, 3, False): 112, (32, 2, 3, True): 26, (32, 2, 3, False): 30, (64, 2, 3, True): 47, (64, 2, 3, False): 53,
          (128, 2, 3, True): 90, (128, 2, 3, False): 99}
@@ -95,6 +96,13 @@ def table(D, NB, PF, opt, wend=None):
         while n < len(un) and cum[n + 1] <= target: n += 1
         ub.append(n)
     ub[kS] = len(un)
+    if PF == 3 and D >= 64 and DOT_SLOT_EXTRA > 0:   # a slot that holds a dot unit takes more (non-dot) units from the slot behind it
+        for i in range(kS - 1):
+            if not any(x[0] == 'lo' for x in un[ub[i]:ub[i + 1]]): continue
+            for _ in range(DOT_SLOT_EXTRA):
+                u = ub[i + 1]
+                if u >= ub[i + 2] or u >= len(un) or un[u][0] in ('lo', 'lopk'): break
+                ub[i + 1] += 1
     return S, un, ub, w
 
 
