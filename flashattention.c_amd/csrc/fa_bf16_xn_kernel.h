@@ -35,37 +35,39 @@
 #endif
 // dealing limits of the PF = 3 step schedules (half-slots; see XShape), overridable for the offline search's A/B builds
 #ifndef FA_WEND_OPT3_X4
-#define FA_WEND_OPT3_X4 103
+#define FA_WEND_OPT3_X4 96
 #endif
 #ifndef FA_WEND_RSC3_X4
-#define FA_WEND_RSC3_X4 112
+#define FA_WEND_RSC3_X4 107
 #endif
 #ifndef FA_WEND_OPT3_32
-#define FA_WEND_OPT3_32 26
+#define FA_WEND_OPT3_32 25
 #endif
 #ifndef FA_WEND_RSC3_32
-#define FA_WEND_RSC3_32 30
+#define FA_WEND_RSC3_32 27
 #endif
 #ifndef FA_WEND_OPT3_64
 #define FA_WEND_OPT3_64 47
 #endif
 #ifndef FA_WEND_RSC3_64
-#define FA_WEND_RSC3_64 53
+#define FA_WEND_RSC3_64 49
 #endif
 #ifndef FA_WEND_OPT3_128
-#define FA_WEND_OPT3_128 90
+#define FA_WEND_OPT3_128 89
 #endif
 #ifndef FA_WEND_RSC3_128
-#define FA_WEND_RSC3_128 99
+#define FA_WEND_RSC3_128 92
 #endif
-// dots per unit of the PF = 3 schedules: 4 (half a fragment) or 8 (a fragment).  A dot waits until the MFMA issued before it has LEFT
+// dots per unit of the PF = 3 schedules: 4 (half a fragment), 8 (a fragment) or 16 (a block: both fragments, behind the second one's pack,
+// with both hi runs of the block's P.V group in front of the lo runs).  The dealing limits FA_WEND_* below belong to 16 (8: 103 / 112,
+// 47 / 53, 90 / 99, 26 / 30; 4: 102 / 112, 47 / 52, 90 / 98, 26 / 30 -- a wrong pairing fails xn_schedule_ok at compile time).  A dot waits until the MFMA issued before it has LEFT
 // the matrix pipe -- ~50 cycles after that MFMA's issue (profiles/r04_ubench_dot2b.txt: the first dot behind an MFMA costs 23 cycles,
 // every further one 4) -- so every group of dots pays that wait at most once: fewer, larger groups pay it less often (c4, one box:
-// 0.3689 ms with 8 dots per unit, 0.3755 with 4).  Issuing the MFMA of a dot slot a slot early, back to back with its predecessor, so
+// 0.3689 ms with 8 dots per unit, 0.3755 with 4; another box: 0.3550 with 16, 0.3578 with 8).  Issuing the MFMA of a dot slot a slot early, back to back with its predecessor, so
 // that ~70 cycles of VALU work separate the dots from the last MFMA, was built and measured too: +-0 (0.3687 / 0.3689) -- the wave then
 // waits at the second MFMA instead ("a wave waiting to issue an MFMA holds the vector issue port"); profiles/r04_experiments.txt.
 #ifndef FA_PB2_DOTS_PER_UNIT
-#define FA_PB2_DOTS_PER_UNIT 8
+#define FA_PB2_DOTS_PER_UNIT 16
 #endif
 #ifndef FA_PB2_DOT_SLOT_EXTRA
 #define FA_PB2_DOT_SLOT_EXTRA 1
@@ -109,7 +111,7 @@ struct XShape {
     // VALU units per block: 16 exponentials + 2 packs; the lo term of P adds 4 half fragments (PF = 2: one v_fma_mix per element packs
     // as it goes) or 4 + 4 (PF = 3: the dots of a half fragment and its packs are separate units, see lo_dots_bf16); rescaled mixes:
     // 3 lane-max micro-steps per block and the test
-    static constexpr int kLoUnits = PF == 2 ? 4 : PF == 3 ? (FA_PB2_DOTS_PER_UNIT == 8 ? 4 : 8) : 0;
+    static constexpr int kLoUnits = PF == 2 ? 4 : PF == 3 ? (FA_PB2_DOTS_PER_UNIT == 16 ? 3 : FA_PB2_DOTS_PER_UNIT == 8 ? 4 : 8) : 0;
     static constexpr int kUnitsOpt = NB * (18 + kLoUnits), kUnitsRsc = NB * (21 + kLoUnits) + 1;
     // VALU units are dealt out over the first kWend half-slots of the step (largest values that put every pack in front of the first MFMA
     // reading it, found offline -- profiles/r04_xn_schedule_check.py -- and re-checked at compile time: xn_schedule_ok); NB = 4 with one
@@ -272,7 +274,9 @@ __device__ __host__ constexpr XSlot xn_pv_group(int blk, int j)
     using S = XShape<D, NB, PF>;
     constexpr int H = S::DB + 1;                 // slots of one (term, tt) run: DB P.V + one row sum
     const int run = j / H, w = j % H;            // run = tt * NT + term
-    const int tt = run / S::NT, term = run % S::NT;
+    // (PF = 3 with a whole block's dots in one unit: both hi runs first -- the lo fragments are complete later)
+    const bool hi_first = PF == 3 && FA_PB2_DOTS_PER_UNIT == 16;
+    const int tt = hi_first ? run % 2 : run / S::NT, term = hi_first ? run / 2 : run % S::NT;
     if (w == S::DB) return {2, blk, tt, term};
     return {1, blk, tt * S::DB + w, term};
 }
@@ -356,7 +360,9 @@ __device__ __host__ constexpr XUnitList xn_make_units(bool opt)
                 --npend;
             }
             if (e == 9) l.u[n++] = {1, b, 0, 16};
-            if constexpr (PF == 3 && FA_PB2_DOTS_PER_UNIT == 8) {   // whole fragments: the unit carries the index of the fragment's second half
+            if constexpr (PF == 3 && FA_PB2_DOTS_PER_UNIT == 16) {
+                // a whole block's sixteen dots in ONE unit, behind the second fragment's pack (in the next block's first exponentials)
+            } else if constexpr (PF == 3 && FA_PB2_DOTS_PER_UNIT == 8) {   // whole fragments: the unit carries the index of the fragment's second half
                 if (e == 11) l.u[n++] = {4, b, 1, 32};
                 if (e == 13) l.u[n++] = {5, b, 1, 16};
             } else {
@@ -368,7 +374,12 @@ __device__ __host__ constexpr XUnitList xn_make_units(bool opt)
         }
         pend[0] = {1, b, 1, 16};
         npend = 1;
-        if constexpr (PF == 3 && FA_PB2_DOTS_PER_UNIT == 8) {
+        if constexpr (PF == 3 && FA_PB2_DOTS_PER_UNIT == 16) {
+            pend[1] = {4, b, 3, 64};
+            pend[2] = {5, b, 1, 16};
+            pend[3] = {5, b, 3, 16};
+            npend = 4;
+        } else if constexpr (PF == 3 && FA_PB2_DOTS_PER_UNIT == 8) {
             pend[1] = {4, b, 3, 32};
             pend[2] = {5, b, 3, 16};
             npend = 3;
@@ -505,9 +516,9 @@ __device__ __host__ constexpr bool xn_schedule_ok(bool opt)
         }
         if (un.kind == 5) {   // packs of a lo half: behind its dots, with a whole unit between (a dot result is readable three wait states
                               // later) and in a later slot (a slot's dots are emitted behind its other units: xn_units)
-            const int ud = pos[un.blk][4 + un.idx];
+            const int ud = pos[un.blk][4 + (FA_PB2_DOTS_PER_UNIT == 16 ? 3 : un.idx)];
             // (whole-fragment units may be neighbours: pack k reads dots 2k, 2k + 1 and has the fragment's 6 - 2k later dots and k packs between)
-            if (PF != 3 || ud == 0 || u < ud + (FA_PB2_DOTS_PER_UNIT == 8 ? 1 : 2)) return false;
+            if (PF != 3 || ud == 0 || u < ud + (FA_PB2_DOTS_PER_UNIT >= 8 ? 1 : 2)) return false;
             int sd = 0, sp = 0;
             while (sd < S::kSlots && !(t.ub[sd] <= ud && ud < t.ub[sd + 1])) ++sd;
             while (sp < S::kSlots && !(t.ub[sp] <= u && u < t.ub[sp + 1])) ++sp;
@@ -571,10 +582,14 @@ __device__ __forceinline__ void xn_unit(XCtx<D, NB>& x)
         x.pf[un.blk][un.idx] = pack_p16x8<PF>(x.sc[un.blk], 8 * un.idx);
         asm volatile("" : "+v"(x.pf[un.blk][un.idx]));
     } else if constexpr (un.kind == 4 && PF == 3) {
-        if constexpr (FA_PB2_DOTS_PER_UNIT == 8) lo_dots_bf16(x.sc[un.blk], un.idx / 2, 0, x.pf[un.blk][un.idx / 2]);
+        if constexpr (FA_PB2_DOTS_PER_UNIT == 16) {
+            lo_dots_bf16(x.sc[un.blk], 0, 0, x.pf[un.blk][0]);
+            lo_dots_bf16(x.sc[un.blk], 0, 1, x.pf[un.blk][0]);
+        }
+        if constexpr (FA_PB2_DOTS_PER_UNIT >= 8) lo_dots_bf16(x.sc[un.blk], un.idx / 2, 0, x.pf[un.blk][un.idx / 2]);
         lo_dots_bf16(x.sc[un.blk], un.idx / 2, un.idx % 2, x.pf[un.blk][un.idx / 2]);
     } else if constexpr (un.kind == 5) {
-        if constexpr (FA_PB2_DOTS_PER_UNIT == 8) lo_packs_bf16(x.sc[un.blk], un.idx / 2, 0, x.pl[un.blk][un.idx / 2]);
+        if constexpr (FA_PB2_DOTS_PER_UNIT >= 8) lo_packs_bf16(x.sc[un.blk], un.idx / 2, 0, x.pl[un.blk][un.idx / 2]);
         lo_packs_bf16(x.sc[un.blk], un.idx / 2, un.idx % 2, x.pl[un.blk][un.idx / 2]);
     } else if constexpr (un.kind == 4) {
         lo_half(x.sc[un.blk], un.idx / 2, un.idx % 2, x.pf[un.blk][un.idx / 2], x.pl[un.blk][un.idx / 2]);

@@ -12,10 +12,11 @@ at least one other unit between them (a dot result may be read by another VALU i
 import sys
 
 # dealing limits of the PF = 3 schedules: (D, NB, 3, optimistic) -> kWend (the FA_WEND_* defaults of csrc/fa_bf16_xn_kernel.h)
+G16 = True          # FA_PB2_DOTS_PER_UNIT == 16 of the header: a block's sixteen dots in one unit, both hi runs of its P.V group first
 DOT_SLOT_EXTRA = 1  # FA_PB2_DOT_SLOT_EXTRA of the header
 DOTS_PER_UNIT = 8   # FA_PB2_DOTS_PER_UNIT of the header: dots per unit of the PF = 3 schedules (4 = half a fragment, 8 = a fragment)
-WEND3 = {(64, 4, 3, True): 103, (64, 4, 3, False): 112, (32, 2, 3, True): 26, (32, 2, 3, False): 30, (64, 2, 3, True): 47, (64, 2, 3, False): 53,
-         (128, 2, 3, True): 90, (128, 2, 3, False): 99}
+WEND3 = {(64, 4, 3, True): 96, (64, 4, 3, False): 107, (32, 2, 3, True): 25, (32, 2, 3, False): 27, (64, 2, 3, True): 47, (64, 2, 3, False): 49,
+         (128, 2, 3, True): 89, (128, 2, 3, False): 92}
 
 
 def shape(D, NB, PF):
@@ -28,7 +29,10 @@ def shape(D, NB, PF):
 def pv_group(S, blk, j):
     H = S['DB'] + 1
     run, w = divmod(j, H)
-    tt, term = divmod(run, S['NT'])
+    if G16 and S['NT'] == 2:
+        term, tt = divmod(run, 2)      # (tt0 hi)(tt1 hi)(tt0 lo)(tt1 lo)
+    else:
+        tt, term = divmod(run, S['NT'])
     if w == S['DB']:
         return (2, blk, tt, term)
     return (1, blk, tt * S['DB'] + w, term)
@@ -55,7 +59,9 @@ def units(NB, PF, opt):
             u.append(('exp', b, e, 12))
             if pend and 1 <= e <= 5: u.append(pend.pop(0))
             if e == 9: u.append(('pack', b, 0, 16))
-            if PF == 3 and DOTS_PER_UNIT == 8:     # whole fragments, indexed by the fragment's second half
+            if PF == 3 and G16:
+                pass
+            elif PF == 3 and DOTS_PER_UNIT == 8:     # whole fragments, indexed by the fragment's second half
                 if e == 11: u.append(('lo', b, 1, 32))
                 if e == 13: u.append(('lopk', b, 1, 16))
             else:
@@ -63,7 +69,9 @@ def units(NB, PF, opt):
                 if PF >= 2 and e == 11: u.append(('lo', b, 1, 16))
                 if PF == 3 and e == 12: u.append(('lopk', b, 0, 8))
                 if PF == 3 and e == 13: u.append(('lopk', b, 1, 8))
-        if PF == 3 and DOTS_PER_UNIT == 8:
+        if PF == 3 and G16:
+            pend = [('pack', b, 1, 16), ('lo', b, 3, 64), ('lopk', b, 1, 16), ('lopk', b, 3, 16)]
+        elif PF == 3 and DOTS_PER_UNIT == 8:
             pend = [('pack', b, 1, 16), ('lo', b, 3, 32), ('lopk', b, 3, 16)]
         else:
             pend = [('pack', b, 1, 16)] + ([('lo', b, 2, 16), ('lo', b, 3, 16)] if PF >= 2 else []) + ([('lopk', b, 2, 8), ('lopk', b, 3, 8)] if PF == 3 else [])
@@ -124,7 +132,7 @@ def check(D, NB, PF, opt, wend=None, verbose=False):
             pads += 1
     for j, x in enumerate(un):
         if x[0] == 'lopk':
-            dots = [i for i, y in enumerate(un) if y[0] == 'lo' and y[1] == x[1] and y[2] == x[2]][0]
+            dots = [i for i, y in enumerate(un) if y[0] == 'lo' and y[1] == x[1] and (G16 or y[2] == x[2])][0]
             sd = [i for i in range(S['kSlots']) if ub[i] <= dots < ub[i + 1]][0]
             sp = [i for i in range(S['kSlots']) if ub[i] <= j < ub[i + 1]][0]
             if j < dots + (1 if DOTS_PER_UNIT == 8 else 2) or (D >= 64 and sp <= sd):   # (a slot's dots are emitted behind its other units)
