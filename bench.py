@@ -406,8 +406,9 @@ def main():
         # while the kernel it was measured on is still the kernel this run launches
         # ... AND while the library loaded here is the very binary the passes ran on (sha256 recorded by profiles/collect.sh)
         sha = lib_sha256()
-        traffic = (pmc.get(f"{args.workload}_hbm_bytes_per_launch")
-                   if pmc.get(f"{args.workload}_kernel") == kname and pmc.get("lib_sha256") == sha and not causal else None)
+        tkey = args.workload + ("acc" if (args.accurate and dtype == "bf16") else "")
+        traffic = (pmc.get(f"{tkey}_hbm_bytes_per_launch")
+                   if pmc.get(f"{tkey}_kernel") == kname and pmc.get("lib_sha256") == sha and not causal else None)
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_source": (f"profiles/pmc_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
@@ -479,6 +480,10 @@ def main():
             line["roofline_at_1e-3"] = {"bound": "mfma", "achieved": acc["tflops"], "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
                                         "frac": acc["frac_mfma_peak"], "kernel": acc.get("kernel"), "kernel_ms": acc["kernel_ms"],
                                         "max_abs_err": acc.get("max_abs_err"), "tolerance": acc.get("tolerance"),
+                                        "traffic": ((load_pmc_traffic() or {}).get("c4acc_hbm_bytes_per_launch")
+                                                    if args.workload == "c4" and not causal and (load_pmc_traffic() or {}).get("c4acc_kernel") == acc.get("kernel")
+                                                    and (load_pmc_traffic() or {}).get("lib_sha256") == lib_sha256() else None),
+                                        "algorithmic_hbm_bytes_per_launch": algorithmic_bytes(bh, n, d, 2) + bh * n * d * 2.0,   # fp32 output: 2 more bytes per element
                                         "what": "same tensors, fp32 output through FA_KERNEL_AUTO (P as bf16 hi + lo, one launch): the figure to "
                                                 "hold against BASELINE.json's '>= 60 % of peak within 1e-3'"}
         line["validation"] = {"status": "FAILED" if VALIDATION_FAILURES else "ok", "failures": list(VALIDATION_FAILURES),

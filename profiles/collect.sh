@@ -27,6 +27,8 @@ BENCHA="$R/bench.py --accurate --steps 20 --warmup 3 --no-cpu-baseline --no-extr
 rocprofv3 --kernel-trace --stats -d $OUT/stats_acc -- python3 $BENCHA > $OUT/stats_acc.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES \
     --kernel-trace -d $OUT/pmc_acc_sq -- python3 $BENCHA > $OUT/pmc_acc_sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_acc_fetch -- python3 $BENCHA > $OUT/pmc_acc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_acc_write -- python3 $BENCHA > $OUT/pmc_acc_write.log 2>&1
 # shapes that had no profile before round 3: BASELINE config 2 (fp32 tensors, N = 1024; AUTO and exact arithmetic) and the README's d = 32 rows,
 # through the C driver (one kernel family per pass; 200 launches each)
 DRV=$R/flashattention.c_amd/fa_driver

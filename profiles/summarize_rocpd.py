@@ -55,7 +55,8 @@ def main(src: str, tag: str, out: str = None):
                           "--no-cpu-baseline --no-extras` (profiles/collect.sh)",
                "_method": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per dispatch of the dominant kernel"}
     bad = []
-    for wl, fpass, wpass, line_file in (("c4", "pmc_fetch", "pmc_write", "bench_line.json"), ("c3", "pmc_c3_fetch", "pmc_c3_write", "bench_line_c3.json")):
+    for wl, fpass, wpass, line_file in (("c4", "pmc_fetch", "pmc_write", "bench_line.json"), ("c3", "pmc_c3_fetch", "pmc_c3_write", "bench_line_c3.json"),
+                                        ("c4acc", "pmc_acc_fetch", "pmc_acc_write", "bench_line_accurate.json")):
         if fpass in per_pass and wpass in per_pass:
             kf, cf, _ = per_pass[fpass]
             kw, cw, _ = per_pass[wpass]
