@@ -1091,6 +1091,58 @@ def test_verdict_slots_survive_ten_thousand_streams_and_nine_thousand_captured_g
     assert fa.forward(q, k, v, False) is not None and fa.last_forward_route() == 1
 
 
+def test_host_threads_feed_their_own_streams_concurrently():
+    """Four host threads, each with its own stream, enqueue fp32 chains (verdict words from the slot table: fa_forward_ex, no workspace),
+    key-split launches from the private pool and accurate-path launches side by side -- ctypes releases the GIL, so the slot table, the
+    pool and the thread-local chain state really are used concurrently.  Two of the threads feed wide logits (route 2), two ordinary
+    ones (route 1); every result is checked."""
+    import threading
+    L = _cabi.lib()
+    q, k, v = (torch.randn(4, 1024, 64, device=dev()) for _ in range(3))
+    kw = k.clone()
+    kw[1, 33] *= 40.0
+    ref, ref_w = fa.forward(q, k, v, False, kernel="exact"), fa.forward(q, kw, v, False, kernel="exact")
+    qb, kb, vb = (torch.randn(1, 4096, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
+    refb = fa.forward(qb.float(), kb.float(), vb.float(), False, kernel="naive")
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(tid):
+        try:
+            wide = tid % 2 == 1
+            kk, rr = (kw, ref_w) if wide else (k, ref)
+            st = torch.cuda.Stream()
+            sp = ctypes.c_void_p(st.cuda_stream)
+            o = torch.zeros_like(q)
+            ob = torch.zeros(qb.shape, dtype=torch.float32, device=dev())
+            for it in range(150):
+                assert L.fa_forward_ex(q.data_ptr(), kk.data_ptr(), v.data_ptr(), o.data_ptr(), None, 4, 1024, 64, 1.0, 0, _cabi.FA_DTYPE_F32, _cabi.FA_KERNEL_AUTO, sp) == 0
+                if it % 10 == 9:
+                    r = ctypes.c_int32(-1)
+                    assert L.fa_last_forward_route(sp, ctypes.byref(r)) == 0
+                    assert r.value == (2 if wide else 1), (tid, it, r.value)
+                    assert float((o - rr).abs().max()) < (1e-4 if wide else TOL_F32), (tid, it)
+                    o.zero_()
+                # a key-split launch of the accurate path through the convenience entry (scratch from the private pool, on this stream)
+                assert L.fa_forward_ex(qb.data_ptr(), kb.data_ptr(), vb.data_ptr(), ob.data_ptr(), None, 1, 4096, 64, 1.0, 0, _cabi.FA_DTYPE_BF16_OUT_F32, _cabi.FA_KERNEL_AUTO, sp) == 0
+            st.synchronize()
+            assert float((ob - refb).abs().max()) < TOL_PB2, tid
+        except BaseException as e:   # noqa: BLE001 -- reported by the main thread
+            errors.append((tid, repr(e)))
+
+    before = fa.stats()
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    after = fa.stats()
+    assert after["chains_degraded"] == before["chains_degraded"]
+    assert after["chains"] - before["chains"] == 4 * 150
+
+
 def test_scratch_paths_on_concurrent_streams():
     """Two streams, each issuing key-split launches (bf16 P and two-term P) and plain launches back to back (every call with its own
     workspace tensor from torch's caching allocator): neither may see the other's partial outputs."""
