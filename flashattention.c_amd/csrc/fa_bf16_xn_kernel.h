@@ -33,59 +33,26 @@
 #ifndef FA_OPT_SAMPLE
 #define FA_OPT_SAMPLE 1   // 0: experiment switch -- the optimistic mix takes its exponent reference from the first sub-tile only (round 2)
 #endif
-// dealing limits of the PF = 3 step schedules (half-slots; see XShape), overridable for the offline search's A/B builds
-#ifndef FA_WEND_OPT3_X4
-#define FA_WEND_OPT3_X4 96
-#endif
-#ifndef FA_WEND_RSC3_X4
-#define FA_WEND_RSC3_X4 107
-#endif
-#ifndef FA_WEND_OPT3_32
-#define FA_WEND_OPT3_32 25
-#endif
-#ifndef FA_WEND_RSC3_32
-#define FA_WEND_RSC3_32 27
-#endif
-#ifndef FA_WEND_OPT3_64
-#define FA_WEND_OPT3_64 47
-#endif
-#ifndef FA_WEND_RSC3_64
-#define FA_WEND_RSC3_64 49
-#endif
-#ifndef FA_WEND_OPT3_128
-#define FA_WEND_OPT3_128 89
-#endif
-#ifndef FA_WEND_RSC3_128
-#define FA_WEND_RSC3_128 92
-#endif
-// dots per unit of the PF = 3 schedules: 4 (half a fragment), 8 (a fragment) or 16 (a block: both fragments, behind the second one's pack,
-// with both hi runs of the block's P.V group in front of the lo runs).  The dealing limits FA_WEND_* below belong to 16 (8: 103 / 112,
-// 47 / 53, 90 / 99, 26 / 30; 4: 102 / 112, 47 / 52, 90 / 98, 26 / 30 -- a wrong pairing fails xn_schedule_ok at compile time).  A dot waits until the MFMA issued before it has LEFT
-// the matrix pipe -- ~50 cycles after that MFMA's issue (profiles/r04_ubench_dot2b.txt: the first dot behind an MFMA costs 23 cycles,
-// every further one 4) -- so every group of dots pays that wait at most once: fewer, larger groups pay it less often (c4, one box:
-// 0.3689 ms with 8 dots per unit, 0.3755 with 4; another box: 0.3550 with 16, 0.3578 with 8).  Issuing the MFMA of a dot slot a slot early, back to back with its predecessor, so
-// that ~70 cycles of VALU work separate the dots from the last MFMA, was built and measured too: +-0 (0.3687 / 0.3689) -- the wave then
-// waits at the second MFMA instead ("a wave waiting to issue an MFMA holds the vector issue port"); profiles/r04_experiments.txt.
-#ifndef FA_PB2_DOTS_PER_UNIT
-#define FA_PB2_DOTS_PER_UNIT 16
-#endif
-#ifndef FA_PB2_DOT_SLOT_EXTRA
-#define FA_PB2_DOT_SLOT_EXTRA 1
-#endif
-#ifndef FA_PB2_DOTS_LAST
-#define FA_PB2_DOTS_LAST 1   // 0: experiment switch -- a slot's VALU units in list order
-#endif
 namespace fa {
-// (D = 32: 52 units in 20 slots -- no dealing keeps every pack out of its dots' slot; list order there)
-constexpr bool pb2_dots_last(int D) { return FA_PB2_DOTS_LAST != 0 && D >= 64; }
+// ---- the two-term-P (PF = 3) step schedules: what round 4 measured its way to (profiles/r04_experiments.txt, r04_pb2_ab.txt) ----------
+// A v_dot2c waits until the MFMA issued before it has LEFT the matrix pipe -- ~50 cycles after that MFMA's issue
+// (profiles/r04_ubench_dot2b.txt: the first dot behind an MFMA costs 23 cycles, every further one 4) -- so:
+//   * a slot's dots are emitted behind its other VALU work (pb2_dots_last; D = 32 has 42 units in 20 slots -- no dealing keeps every
+//     pack out of its dots' slot -- and keeps list order);
+//   * a block's sixteen dots are ONE unit, behind the second fragment's pack, and the block's P.V group runs (hi, hi, lo, lo) so that
+//     the lo fragments may complete later: every group of dots pays the wait at most once (c4: 4 dots per unit 0.3755 ms, 8: 0.3689;
+//     another box 8: 0.3578, 16: 0.3550);
+//   * a slot that holds dots takes kDotSlotExtra more non-dot units from the slot behind it (c4 +0.5 %, through NB = 2 +2.6 %);
+//   * issuing the MFMA of a dot slot a slot early (70 cycles of VALU between it and the dots) bought nothing: the wave then waits at the
+//     second of the two back-to-back MFMAs instead ("a wave waiting to issue an MFMA holds the vector issue port").
+constexpr bool pb2_dots_last(int D) { return D >= 64; }
+constexpr int kDotSlotExtra = 1;
+// workgroups of the NB = 2 two-term kernel a CU is asked to hold (register budget 512 / this per lane).  Asked for two at d = 64, hipcc
+// spills: 17 registers to scratch in the causal instantiation, ~20 VGPRs into AGPRs inside the loop in the non-causal one (659
+// v_accvgpr_read in the binary); asked for one they come out at 252 - 256 registers without either and fit a CU twice anyway -- like the
+// bf16-P NB = 2 kernel, see xn_launch_order; tests/test_code_objects.py pins that on the binary.
+constexpr int pb2_wgs_per_cu(int D) { return D == 32 ? 2 : 1; }
 }  // namespace fa
-// workgroups of the NB = 2 pb2 kernel a CU is asked to hold (register budget 512 / this per lane)
-// (asked for two at d = 64, hipcc spills: 17 registers to scratch in the causal instantiation, ~20 VGPRs into AGPRs inside the loop in the
-// non-causal one -- 659 v_accvgpr_read in the binary; asked for one they come out at 252 / 256 registers without either and fit a CU
-// twice anyway -- like the bf16-P NB = 2 kernel, see xn_launch_order; tests/test_code_objects.py pins that on the binary)
-#ifndef FA_PB2_WGS_PER_CU
-#define FA_PB2_WGS_PER_CU(D, CAUSAL) ((D) == 32 ? 2 : 1)
-#endif
 
 namespace fa {
 
@@ -111,16 +78,16 @@ struct XShape {
     // VALU units per block: 16 exponentials + 2 packs; the lo term of P adds 4 half fragments (PF = 2: one v_fma_mix per element packs
     // as it goes) or 4 + 4 (PF = 3: the dots of a half fragment and its packs are separate units, see lo_dots_bf16); rescaled mixes:
     // 3 lane-max micro-steps per block and the test
-    static constexpr int kLoUnits = PF == 2 ? 4 : PF == 3 ? (FA_PB2_DOTS_PER_UNIT == 16 ? 3 : FA_PB2_DOTS_PER_UNIT == 8 ? 4 : 8) : 0;
+    static constexpr int kLoUnits = PF == 2 ? 4 : PF == 3 ? 3 : 0;
     static constexpr int kUnitsOpt = NB * (18 + kLoUnits), kUnitsRsc = NB * (21 + kLoUnits) + 1;
     // VALU units are dealt out over the first kWend half-slots of the step (largest values that put every pack in front of the first MFMA
     // reading it, found offline -- profiles/r04_xn_schedule_check.py -- and re-checked at compile time: xn_schedule_ok); NB = 4 with one
     // term of P: see weight_end()
-    static constexpr int kWendOpt2 = PF == 3 ? (D == 128 ? FA_WEND_OPT3_128 : D == 64 ? FA_WEND_OPT3_64 : FA_WEND_OPT3_32) : (D == 128 ? 58 : D == 64 ? 30 : 16);
-    static constexpr int kWendRsc2 = PF == 3   ? (D == 128 ? FA_WEND_RSC3_128 : D == 64 ? FA_WEND_RSC3_64 : FA_WEND_RSC3_32)
+    static constexpr int kWendOpt2 = PF == 3 ? (D == 128 ? 89 : D == 64 ? 47 : 25) : (D == 128 ? 58 : D == 64 ? 30 : 16);
+    static constexpr int kWendRsc2 = PF == 3   ? (D == 128 ? 92 : D == 64 ? 49 : 27)
                                      : PF == 2 ? (D == 128 ? 99 : D == 64 ? 52 : 29)
                                                : (D == 128 ? 64 : D == 64 ? 34 : 18);
-    static constexpr int kWendOpt4 = FA_WEND_OPT3_X4, kWendRsc4 = FA_WEND_RSC3_X4;   // NB = 4, PF = 3
+    static constexpr int kWendOpt4 = 96, kWendRsc4 = 107;   // NB = 4, PF = 3
 };
 // ---- matrix instructions with explicit register files ------------------------------------------------------------------
 // With one wave per SIMD the wave owns 256 architectural VGPRs and 256 accumulation registers (AGPRs).  VALU instructions
@@ -274,8 +241,8 @@ __device__ __host__ constexpr XSlot xn_pv_group(int blk, int j)
     using S = XShape<D, NB, PF>;
     constexpr int H = S::DB + 1;                 // slots of one (term, tt) run: DB P.V + one row sum
     const int run = j / H, w = j % H;            // run = tt * NT + term
-    // (PF = 3 with a whole block's dots in one unit: both hi runs first -- the lo fragments are complete later)
-    const bool hi_first = PF == 3 && FA_PB2_DOTS_PER_UNIT == 16;
+    // (PF = 3: a whole block's dots are one unit behind the second fragment's pack: both hi runs first -- the lo fragments are complete later)
+    const bool hi_first = PF == 3;
     const int tt = hi_first ? run % 2 : run / S::NT, term = hi_first ? run / 2 : run % S::NT;
     if (w == S::DB) return {2, blk, tt, term};
     return {1, blk, tt * S::DB + w, term};
@@ -335,10 +302,11 @@ struct XTable {
 // instruction that reads the result of a transcendental issued just before it costs a wait state (hipcc pads an s_nop).
 // PF = 2: the two halves of a fragment's lo term follow its pack, one exp unit apart (they read the pack's result and the
 // exponentials the pack read).
-// PF = 3: the four dots of a half fragment (kind 4) and its two packs (kind 5) are separate units, two positions apart at least.
+// PF = 3: the sixteen dots of a block (kind 4, one unit behind the second fragment's pack) and the four packs of each lo fragment (kind 5)
+// are separate units; idx carries the number of the last half fragment a unit covers (3; 1 and 3).
 struct XUnit {
-    int kind;  // 0 = exp of one element, 1 = pack of one fragment, 2 = lane-max micro-step, 3 = rescale test, 4 = half a lo fragment
-               // (PF = 2: complete; PF = 3: its dots), 5 = the packs of half a lo fragment (PF = 3)
+    int kind;  // 0 = exp of one element, 1 = pack of one fragment, 2 = lane-max micro-step, 3 = rescale test, 4 = PF = 2: half a lo fragment
+               // (complete), PF = 3: the block's dots, 5 = the packs of one lo fragment (PF = 3)
     int blk, idx, cost;
 };
 struct XUnitList {
@@ -360,40 +328,23 @@ __device__ __host__ constexpr XUnitList xn_make_units(bool opt)
                 --npend;
             }
             if (e == 9) l.u[n++] = {1, b, 0, 16};
-            if constexpr (PF == 3 && FA_PB2_DOTS_PER_UNIT == 16) {
-                // a whole block's sixteen dots in ONE unit, behind the second fragment's pack (in the next block's first exponentials)
-            } else if constexpr (PF == 3 && FA_PB2_DOTS_PER_UNIT == 8) {   // whole fragments: the unit carries the index of the fragment's second half
-                if (e == 11) l.u[n++] = {4, b, 1, 32};
-                if (e == 13) l.u[n++] = {5, b, 1, 16};
-            } else {
-                if (PF >= 2 && e == 10) l.u[n++] = {4, b, 0, 16};
-                if (PF >= 2 && e == 11) l.u[n++] = {4, b, 1, 16};
-                if (PF == 3 && e == 12) l.u[n++] = {5, b, 0, 8};
-                if (PF == 3 && e == 13) l.u[n++] = {5, b, 1, 8};
+            if constexpr (PF == 2) {   // fp16 hi + lo (ablation library): half a lo fragment per unit, one v_fma_mix per element packs as it goes
+                if (e == 10) l.u[n++] = {4, b, 0, 16};
+                if (e == 11) l.u[n++] = {4, b, 1, 16};
             }
+            // (PF = 3: the block's sixteen dots are ONE unit, behind the second fragment's pack -- in the next block's first exponentials)
         }
         pend[0] = {1, b, 1, 16};
         npend = 1;
-        if constexpr (PF == 3 && FA_PB2_DOTS_PER_UNIT == 16) {
+        if constexpr (PF == 3) {   // dots of both fragments (the unit carries the index of the block's last half), then the packs of each lo fragment
             pend[1] = {4, b, 3, 64};
             pend[2] = {5, b, 1, 16};
             pend[3] = {5, b, 3, 16};
             npend = 4;
-        } else if constexpr (PF == 3 && FA_PB2_DOTS_PER_UNIT == 8) {
-            pend[1] = {4, b, 3, 32};
-            pend[2] = {5, b, 3, 16};
+        } else if constexpr (PF == 2) {
+            pend[1] = {4, b, 2, 16};
+            pend[2] = {4, b, 3, 16};
             npend = 3;
-        } else {
-            if (PF >= 2) {
-                pend[1] = {4, b, 2, 16};
-                pend[2] = {4, b, 3, 16};
-                npend = 3;
-            }
-            if (PF == 3) {
-                pend[3] = {5, b, 2, 8};
-                pend[4] = {5, b, 3, 8};
-                npend = 5;
-            }
         }
     }
     if (opt) {
@@ -431,15 +382,15 @@ __device__ __host__ constexpr XTable xn_make_table(bool opt)
         t.ub[i] = n;
     }
     t.ub[kS] = nu;
-    // PF = 3: a slot that holds a dot unit takes FA_PB2_DOT_SLOT_EXTRA more (non-dot) units from the slot behind it.  The dots of a slot
+    // PF = 3: a slot that holds a dot unit takes kDotSlotExtra more (non-dot) units from the slot behind it.  The dots of a slot
     // are emitted last and need the matrix pipe EMPTY (~50 cycles after the slot's MFMA); the dot unit alone fills a slot's share of the
     // VALU work, so without this the dots start ~35 cycles behind the MFMA and wait out the rest, eight times per step.
-    if (PF == 3 && pb2_dots_last(D) && FA_PB2_DOT_SLOT_EXTRA > 0) {
+    if (PF == 3 && pb2_dots_last(D)) {
         for (int i = 0; i + 2 <= kS; ++i) {
             bool dots = false;
             for (int u = t.ub[i]; u < t.ub[i + 1]; ++u) dots = dots || l.u[u].kind == 4;
             if (!dots) continue;
-            for (int k = 0; k < FA_PB2_DOT_SLOT_EXTRA; ++k) {
+            for (int k = 0; k < kDotSlotExtra; ++k) {
                 const int u = t.ub[i + 1];
                 if (u >= t.ub[i + 2] || u >= nu || l.u[u].kind == 4 || l.u[u].kind == 5) break;   // nothing left / never another dot or lo-pack unit
                 ++t.ub[i + 1];
@@ -516,9 +467,9 @@ __device__ __host__ constexpr bool xn_schedule_ok(bool opt)
         }
         if (un.kind == 5) {   // packs of a lo half: behind its dots, with a whole unit between (a dot result is readable three wait states
                               // later) and in a later slot (a slot's dots are emitted behind its other units: xn_units)
-            const int ud = pos[un.blk][4 + (FA_PB2_DOTS_PER_UNIT == 16 ? 3 : un.idx)];
-            // (whole-fragment units may be neighbours: pack k reads dots 2k, 2k + 1 and has the fragment's 6 - 2k later dots and k packs between)
-            if (PF != 3 || ud == 0 || u < ud + (FA_PB2_DOTS_PER_UNIT >= 8 ? 1 : 2)) return false;
+            const int ud = pos[un.blk][4 + 3];   // the block's one dot unit
+            // (they may be neighbours: a pack reads dots that have the block's later dots and the earlier packs between -- three at least)
+            if (PF != 3 || ud == 0 || u < ud + 1) return false;
             int sd = 0, sp = 0;
             while (sd < S::kSlots && !(t.ub[sd] <= ud && ud < t.ub[sd + 1])) ++sd;
             while (sp < S::kSlots && !(t.ub[sp] <= u && u < t.ub[sp + 1])) ++sp;
@@ -582,15 +533,13 @@ __device__ __forceinline__ void xn_unit(XCtx<D, NB>& x)
         x.pf[un.blk][un.idx] = pack_p16x8<PF>(x.sc[un.blk], 8 * un.idx);
         asm volatile("" : "+v"(x.pf[un.blk][un.idx]));
     } else if constexpr (un.kind == 4 && PF == 3) {
-        if constexpr (FA_PB2_DOTS_PER_UNIT == 16) {
-            lo_dots_bf16(x.sc[un.blk], 0, 0, x.pf[un.blk][0]);
-            lo_dots_bf16(x.sc[un.blk], 0, 1, x.pf[un.blk][0]);
-        }
-        if constexpr (FA_PB2_DOTS_PER_UNIT >= 8) lo_dots_bf16(x.sc[un.blk], un.idx / 2, 0, x.pf[un.blk][un.idx / 2]);
-        lo_dots_bf16(x.sc[un.blk], un.idx / 2, un.idx % 2, x.pf[un.blk][un.idx / 2]);
+        lo_dots_bf16(x.sc[un.blk], 0, 0, x.pf[un.blk][0]);   // both fragments, both halves: sixteen dots
+        lo_dots_bf16(x.sc[un.blk], 0, 1, x.pf[un.blk][0]);
+        lo_dots_bf16(x.sc[un.blk], 1, 0, x.pf[un.blk][1]);
+        lo_dots_bf16(x.sc[un.blk], 1, 1, x.pf[un.blk][1]);
     } else if constexpr (un.kind == 5) {
-        if constexpr (FA_PB2_DOTS_PER_UNIT >= 8) lo_packs_bf16(x.sc[un.blk], un.idx / 2, 0, x.pl[un.blk][un.idx / 2]);
-        lo_packs_bf16(x.sc[un.blk], un.idx / 2, un.idx % 2, x.pl[un.blk][un.idx / 2]);
+        lo_packs_bf16(x.sc[un.blk], un.idx / 2, 0, x.pl[un.blk][un.idx / 2]);   // one lo fragment: four packs
+        lo_packs_bf16(x.sc[un.blk], un.idx / 2, 1, x.pl[un.blk][un.idx / 2]);
     } else if constexpr (un.kind == 4) {
         lo_half(x.sc[un.blk], un.idx / 2, un.idx % 2, x.pf[un.blk][un.idx / 2], x.pl[un.blk][un.idx / 2]);
     } else if constexpr (un.kind == 2) {
@@ -602,7 +551,7 @@ __device__ __forceinline__ void xn_unit(XCtx<D, NB>& x)
         x.need = t > XSoft<false, PF>::kThr;  // off = m + kBias
     }
 }
-// PASS: 0 = every unit of the slot in list order; PF = 3 (FA_PB2_DOTS_LAST): 1 = all but the dot units, 2 = the dot units.  The dot
+// PASS: 0 = every unit of the slot in list order; PF = 3 (pb2_dots_last): 1 = all but the dot units, 2 = the dot units.  The dot
 // product unit shares the matrix pipe: a v_dot2c issued behind an MFMA waits until that MFMA has left the pipe (four of them beside one
 // 32-cycle MFMA: 63.8 cycles against 33.5 for four v_fma_f32, profiles/r04_ubench_dot2.txt), so a slot's dots go behind its other VALU
 // work, where the pipe has (nearly) drained.  Legal because nothing in a slot depends on its dots: their packs sit in a later slot
@@ -1229,7 +1178,7 @@ __global__ __launch_bounds__(NWAVES* kWave, 1) void fa_fwd_bf16_x4_pb2_kernel(Fw
     xn_kernel_body<64, 4, NWAVES, CAUSAL, OUT_F32, G, ABL, OPTIMISTIC, 3>(p, smem);
 }
 template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL = 0, bool OPTIMISTIC = true>
-__global__ __launch_bounds__(NWAVES* kWave, FA_PB2_WGS_PER_CU(D, CAUSAL)) void fa_fwd_bf16_x2_pb2_kernel(FwdParams p)
+__global__ __launch_bounds__(NWAVES* kWave, pb2_wgs_per_cu(D)) void fa_fwd_bf16_x2_pb2_kernel(FwdParams p)
 {
     __shared__ __attribute__((aligned(1024))) char smem[4 * G * Bf16Cfg<D, NWAVES>::kTileBytes];
     xn_kernel_body<D, 2, NWAVES, CAUSAL, OUT_F32, G, ABL, OPTIMISTIC, 3>(p, smem);

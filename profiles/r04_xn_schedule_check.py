@@ -6,15 +6,15 @@ the NB = 2 shapes, which limits kWend of XShape keep every dependency, and shows
     python profiles/r04_xn_schedule_check.py            # all instantiated shapes
     python profiles/r04_xn_schedule_check.py 64 2 3     # D NB PF: search the dealing limit
 
-Round 4: PF = 3 (bf16 hi + bf16 lo): the four v_dot2c of half a lo fragment ('lo') and its two packs ('lopk') are separate units with
-at least one other unit between them (a dot result may be read by another VALU instruction three wait states later at the earliest).
+Round 4: PF = 3 (bf16 hi + bf16 lo): the sixteen v_dot2c of a block ('lo', one unit behind the second fragment's pack) and the four packs of
+each lo fragment ('lopk') are separate units (a dot result may be read by another VALU instruction three wait states later at the earliest);
+slots that hold dots take DOT_SLOT_EXTRA more units and emit their dots last (D >= 64).
 """
 import sys
 
 # dealing limits of the PF = 3 schedules: (D, NB, 3, optimistic) -> kWend (the FA_WEND_* defaults of csrc/fa_bf16_xn_kernel.h)
-G16 = True          # FA_PB2_DOTS_PER_UNIT == 16 of the header: a block's sixteen dots in one unit, both hi runs of its P.V group first
+PF3_HI_FIRST = True   # the P.V group of a block runs (hi, hi, lo, lo) for PF = 3
 DOT_SLOT_EXTRA = 1  # FA_PB2_DOT_SLOT_EXTRA of the header
-DOTS_PER_UNIT = 8   # FA_PB2_DOTS_PER_UNIT of the header: dots per unit of the PF = 3 schedules (4 = half a fragment, 8 = a fragment)
 WEND3 = {(64, 4, 3, True): 96, (64, 4, 3, False): 107, (32, 2, 3, True): 25, (32, 2, 3, False): 27, (64, 2, 3, True): 47, (64, 2, 3, False): 49,
          (128, 2, 3, True): 89, (128, 2, 3, False): 92}
 
@@ -23,13 +23,13 @@ def shape(D, NB, PF):
     KS, DB = D // 16, D // 32
     NV, NT = 2 * DB, (2 if PF >= 2 else 1)
     GRP = NT * (NV + 2)
-    return dict(KS=KS, DB=DB, NV=NV, NT=NT, GRP=GRP, kSlots=NB * (KS + GRP))
+    return dict(KS=KS, DB=DB, NV=NV, NT=NT, GRP=GRP, kSlots=NB * (KS + GRP), PF=PF)
 
 
 def pv_group(S, blk, j):
     H = S['DB'] + 1
     run, w = divmod(j, H)
-    if G16 and S['NT'] == 2:
+    if PF3_HI_FIRST and S['NT'] == 2 and S.get('PF') == 3:
         term, tt = divmod(run, 2)      # (tt0 hi)(tt1 hi)(tt0 lo)(tt1 lo)
     else:
         tt, term = divmod(run, S['NT'])
@@ -59,22 +59,12 @@ def units(NB, PF, opt):
             u.append(('exp', b, e, 12))
             if pend and 1 <= e <= 5: u.append(pend.pop(0))
             if e == 9: u.append(('pack', b, 0, 16))
-            if PF == 3 and G16:
-                pass
-            elif PF == 3 and DOTS_PER_UNIT == 8:     # whole fragments, indexed by the fragment's second half
-                if e == 11: u.append(('lo', b, 1, 32))
-                if e == 13: u.append(('lopk', b, 1, 16))
-            else:
-                if PF >= 2 and e == 10: u.append(('lo', b, 0, 16))
-                if PF >= 2 and e == 11: u.append(('lo', b, 1, 16))
-                if PF == 3 and e == 12: u.append(('lopk', b, 0, 8))
-                if PF == 3 and e == 13: u.append(('lopk', b, 1, 8))
-        if PF == 3 and G16:
+            if PF == 2 and e == 10: u.append(('lo', b, 0, 16))
+            if PF == 2 and e == 11: u.append(('lo', b, 1, 16))
+        if PF == 3:    # the block's sixteen dots in one unit behind the second fragment's pack, then the packs of each lo fragment
             pend = [('pack', b, 1, 16), ('lo', b, 3, 64), ('lopk', b, 1, 16), ('lopk', b, 3, 16)]
-        elif PF == 3 and DOTS_PER_UNIT == 8:
-            pend = [('pack', b, 1, 16), ('lo', b, 3, 32), ('lopk', b, 3, 16)]
         else:
-            pend = [('pack', b, 1, 16)] + ([('lo', b, 2, 16), ('lo', b, 3, 16)] if PF >= 2 else []) + ([('lopk', b, 2, 8), ('lopk', b, 3, 8)] if PF == 3 else [])
+            pend = [('pack', b, 1, 16)] + ([('lo', b, 2, 16), ('lo', b, 3, 16)] if PF == 2 else [])
     if opt:
         return u + pend
     for b in range(NB):
@@ -132,10 +122,10 @@ def check(D, NB, PF, opt, wend=None, verbose=False):
             pads += 1
     for j, x in enumerate(un):
         if x[0] == 'lopk':
-            dots = [i for i, y in enumerate(un) if y[0] == 'lo' and y[1] == x[1] and (G16 or y[2] == x[2])][0]
+            dots = [i for i, y in enumerate(un) if y[0] == 'lo' and y[1] == x[1]][0]
             sd = [i for i in range(S['kSlots']) if ub[i] <= dots < ub[i + 1]][0]
             sp = [i for i in range(S['kSlots']) if ub[i] <= j < ub[i + 1]][0]
-            if j < dots + (1 if DOTS_PER_UNIT == 8 else 2) or (D >= 64 and sp <= sd):   # (a slot's dots are emitted behind its other units)
+            if j < dots + 1 or (D >= 64 and sp <= sd):   # (a slot's dots are emitted behind its other units)
                 ok = False
                 if verbose: print('  VIOLATED: packs of lo half', x, 'right behind their dots / in their slot')
         if x[0] == 'max' and x[2] == 0:
