@@ -7,6 +7,8 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+// ALT: 0 = dots behind 32x32x16 MFMAs, 1 = the dot-free residual behind them, 2 = dots behind 16x16x32 MFMAs (the row-sum shape: 16 cycles of pipe)
 template <int M, int N, int F, int ALT>
 __global__ __launch_bounds__(256, 1) void k(float* out, unsigned long long* cyc, const float* seed, int iters)
 {
@@ -22,6 +24,7 @@ __global__ __launch_bounds__(256, 1) void k(float* out, unsigned long long* cyc,
 #pragma unroll
     for (int i = 0; i < 8; ++i) u[i] = __float_as_uint(r[i]);
     f32x16 acc[2];
+    f32x4 small[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.0f;
     __syncthreads();
@@ -30,10 +33,13 @@ __global__ __launch_bounds__(256, 1) void k(float* out, unsigned long long* cyc,
 #pragma unroll
         for (int rep = 0; rep < 8; ++rep) {
 #pragma unroll
-            for (int m = 0; m < M; ++m) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[m & 1]) : "v"(a), "a"(b));
+            for (int m = 0; m < M; ++m) {
+                if constexpr (ALT == 2) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(small[m & 1]) : "v"(a), "a"(b));
+                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[m & 1]) : "v"(a), "a"(b));
+            }
 #pragma unroll
             for (int f = 0; f < F; ++f) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[(f + 8) % 16]) : "v"(r[(f + 3) % 16]), "v"(r[(f + 5) % 16]));
-            if constexpr (ALT == 0) {
+            if constexpr (ALT == 0 || ALT == 2) {
 #pragma unroll
                 for (int n = 0; n < N; ++n) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(r[n % 8]) : "s"(0x0000bf80u), "v"(u[n % 8]));
             } else {   // the dot-free residual: unpack hi (shift / and), subtract
@@ -52,6 +58,7 @@ __global__ __launch_bounds__(256, 1) void k(float* out, unsigned long long* cyc,
     float s = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += r[i] + acc[0][i] + acc[1][i];
+    s += small[0][0] + small[1][1];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += __uint_as_float(u[i]);
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
@@ -87,5 +94,8 @@ int main()
     ROW(1, 0, 8); ROW(1, 4, 8); ROW(1, 8, 8);
     ROW(2, 0, 0); ROW(2, 4, 0); ROW(2, 8, 0); ROW(2, 16, 0);
     ROW(4, 0, 0); ROW(4, 4, 0); ROW(4, 16, 0);
+    printf("behind 16x16x32 MFMAs (16 cycles of pipe): M MFMAs, F fmas, N dots\n");
+#define ROW2(M, N, F) printf("%d MFMA 16x16x32, %2d fma, %2d dots : %7.2f cycles\n", M, F, N, run<M, N, F, 2>(out, cyc, seed))
+    ROW2(1, 0, 0); ROW2(1, 1, 0); ROW2(1, 4, 0); ROW2(1, 16, 0); ROW2(1, 0, 4); ROW2(1, 4, 4); ROW2(1, 16, 4); ROW2(1, 4, 8); ROW2(2, 0, 0); ROW2(2, 4, 0);
     return 0;
 }
