@@ -428,8 +428,21 @@ int keysplit_rows(const fa::FwdParams& p, int S, int32_t causal)   // keys per s
     const int unit = causal ? 256 : 64;
     return ((p.n + S - 1) / S + unit - 1) / unit * unit;
 }
-int keysplit_factor(const fa::FwdParams& p, int32_t d, int32_t causal, bool f32 = false)
+int keysplit_factor(const fa::FwdParams& p, int32_t d, int32_t causal, bool f32 = false, bool pb2 = false)
 {
+    // Two-term P (FA_KERNEL_PB2; AUTO for an fp32 output), non-causal rows of 1024 .. 4095 keys on at most 64 tiles: its only tiling is the
+    // 256-row workgroup, so such a launch leaves three quarters of the chip idle where the bf16-P dispatch has finer tilings to fall back
+    // on.  Shares of >= 256 keys, up to 256 workgroups -- ms unsplit / key-split at d = 64, BH x N: 4 x 2048 0.045 / 0.024, 8 x 1024
+    // 0.026 / 0.019, 8 x 2048 0.045 / 0.030, 16 x 1024 0.026 / 0.024, 16 x 2048 0.047 / 0.044, 1 x 2048 0.045 / 0.016; d = 32 8 x 1024 0.021 / 0.013;
+    // d = 128 8 x 2048 0.070 / 0.049; from 128 tiles on the split loses (32 x 1024 0.028 / 0.033): profiles/r04_experiments.txt, fourth part.
+    if (pb2 && !causal && dense_layout(p, d) && p.n >= 1024 && p.n < 4096) {
+        const int64_t tiles = (int64_t)p.bh * ((p.n + 255) / 256);
+        if (tiles > 64 || (d == 128 && p.n < 2048 && tiles > 32)) return 1;   // (d = 128, 16 x 1024: 0.040 / 0.042)
+        int S = 1;
+        while (S < 8 && tiles * (2 * S) <= 256 && p.n / (2 * S) >= 256) S *= 2;
+        while (S > 1 && (int64_t)(S - 1) * keysplit_rows(p, S, causal) >= p.n) --S;
+        return S;
+    }
     if (!dense_layout(p, d) || p.n < 4096) return 1;
     if (((int64_t)(p.n - 1) * p.kv_row_stride + d) * 2 >= (int64_t)0xffffffffLL) return 1;   // the NB = 2 kernels' 32-bit slab offsets
     const int64_t tiles = (int64_t)p.bh * ((p.n + 255) / 256);
@@ -558,7 +571,8 @@ Plan make_plan(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype,
         pl.status = fail(FA_ERR_UNSUPPORTED, "FA_KERNEL_PB2 addresses a slab with 32-bit byte offsets (slabs below 4 GiB; got n = %d, d = %d)", p.n, d);
         return pl;
     }
-    const int S = (scratch_ok && sel.variant == 0) ? keysplit_factor(p, d, causal) : 1;
+    const bool pb2_route = sel.kind == FA_KERNEL_PB2 || (sel.kind == FA_KERNEL_AUTO && out_f32 && sel.variant == 0 && fa::bf16_p16_supported(p, d));
+    const int S = (scratch_ok && sel.variant == 0) ? keysplit_factor(p, d, causal, false, pb2_route) : 1;
     // AUTO for an fp32 output (round 4): hi + lo bf16 terms of P in the one-wave-per-SIMD kernel -- one launch, V as it is, any layout
     // (slabs beyond 32-bit byte offsets: the split kernel below)
     if (sel.kind == FA_KERNEL_PB2 || (sel.kind == FA_KERNEL_AUTO && out_f32 && sel.variant == 0 && fa::bf16_p16_supported(p, d))) {
@@ -964,7 +978,7 @@ extern "C" int fa_host_selftest(void)
     // ---- plans
     const int dtypes[] = {FA_DTYPE_F32, FA_DTYPE_BF16, FA_DTYPE_BF16_OUT_F32};
     const int kinds[] = {FA_KERNEL_AUTO, FA_KERNEL_MFMA, FA_KERNEL_SPLIT, FA_KERNEL_PB2, FA_KERNEL_NAIVE, FA_KERNEL_P16X2, 9};
-    const int64_t bhs[] = {1, 2, 3, 8, 16, 33, 128, 1024, 70000}, ns[] = {1, 31, 300, 1024, 4096, 5000, 8192, 16384, 40000, 1 << 24};
+    const int64_t bhs[] = {1, 2, 3, 8, 16, 33, 128, 1024, 70000}, ns[] = {1, 31, 300, 1024, 1100, 2048, 4095, 4096, 5000, 8192, 16384, 40000, 1 << 24};
     for (int dt : dtypes) for (int kind : kinds) for (int d : {32, 64, 128, 48}) for (int causal : {0, 1}) for (int64_t bh : bhs) for (int64_t n : ns) {
         const fa::FwdParams p = make_params(nullptr, nullptr, nullptr, nullptr, nullptr, bh, n, d, 1.0f);
         for (bool scratch_ok : {false, true}) {
@@ -1365,7 +1379,7 @@ const char* fa_kernel_name_for(int32_t dtype, int32_t d, int32_t causal, int64_t
     if (dtype == FA_DTYPE_BF16_OUT_F32) {   // the accurate P (see fa_dtype): hi + lo bf16 terms in the one-wave-per-SIMD kernel (slabs below 4 GiB)
         if (((n - 1) * d + d) * 2 >= 0xffffffffLL) return "fa_fwd_f32_split_kernel";
         const fa::FwdParams pk = make_params(nullptr, nullptr, nullptr, nullptr, nullptr, bh, n, d, 1.0f);
-        if (keysplit_factor(pk, d, causal) > 1) return "fa_fwd_bf16_x2_pb2_kernel";   // small grids: key-split launch of the NB = 2 kernel
+        if (keysplit_factor(pk, d, causal, false, true) > 1) return "fa_fwd_bf16_x2_pb2_kernel";   // small grids: key-split launch of the NB = 2 kernel
         return d == 64 && fa::bf16_pb2_uses_x4(bh, n, causal) ? "fa_fwd_bf16_x4_pb2_kernel" : "fa_fwd_bf16_x2_pb2_kernel";
     }
     return nullptr;

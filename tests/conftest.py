@@ -32,6 +32,20 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _seed_per_test(request):
+    """Tests that draw device tensors from torch's global generators get the same data whatever ran before them (the seed is a
+    function of the test's id): a premise like "the two arithmetic paths are distinguishable on this input" must not depend on the
+    order or the selection of the run."""
+    try:
+        import torch
+        import zlib
+        torch.manual_seed(zlib.crc32(request.node.nodeid.encode()))
+    except ImportError:
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN_DIR

@@ -537,6 +537,38 @@ def test_key_split_launch_for_grids_that_leave_the_chip_idle(bh, n, d):
     check(out[sl], ref, bf16_tol(1.0, False), "vs fp64 oracle")
 
 
+@pytest.mark.parametrize("bh,n,d", [(1, 1024, 64), (4, 2048, 64), (8, 1024, 64), (16, 1024, 64), (8, 2048, 64), (3, 1100, 64), (5, 3000, 64), (2, 1025, 32),
+                                    (6, 1500, 128), (5, 1500, 128), (1, 4095, 64), (16, 1023, 64), (17, 1024, 64)])
+def test_short_row_key_split_of_the_two_term_kernel(bh, n, d):
+    """Round 4: the two-term-P kernel has one tiling (256-row workgroups), so non-causal rows of 1024 .. 4095 keys on at most 64 tiles run as
+    S = 2 .. 8 key shares of >= 256 keys + combine (fa_api.cpp: keysplit_factor, pb2).  Ragged lengths (a last share shorter than the
+    reference sample), every head dim, the LSE, a dominant key inside one share, NaN-poisoned output; the shapes outside the rule
+    (1023 keys; 17 slabs = 68 tiles; d = 128 below 2048 keys on more than 32 tiles) run unsplit and need no workspace."""
+    q, k, v = (orc.round_to_bf16(randn(s, bh, n, d)) for s in (191, 192, 193))
+    k[0, n // 3] = 6.0 * q[0, 17] / np.linalg.norm(q[0, 17])
+    k = orc.round_to_bf16(k)                                          # (the fp64 oracle below sees the tensor the device sees)
+    qd, kd, vd = to_dev(q, k, v, dtype=torch.bfloat16)
+    ref_dev, lse_ref = fa.forward(qd.float(), kd.float(), vd.float(), False, kernel="naive", return_lse=True)
+    tiles = bh * ((n + 255) // 256)
+    split = 1024 <= n < 4096 and tiles <= 64 and not (d == 128 and n < 2048 and tiles > 32)
+    need = fa.workspace_bytes(bh, n, d, False, dtype=torch.bfloat16, out_dtype=torch.float32)
+    assert (need > 256) == split, f"workspace {need} bytes for bh={bh} n={n}"
+    for kern in ("auto", "pb2"):
+        out = torch.full((bh, n, d), float("nan"), dtype=torch.float32, device=dev())
+        _, lse = fa.forward(qd, kd, vd, False, out=out, return_lse=True, kernel=kern)
+        assert fa.last_forward_route() == 0
+        assert not torch.isnan(out).any()
+        err = float((out - ref_dev).abs().max())
+        OBSERVED.append((f"short-row key split, two bf16 terms of P ({kern}), bh={bh} n={n} d={d}", err, TOL_PB2))
+        assert err < TOL_PB2, f"{kern}: {err:.3e}"
+        assert float((lse - lse_ref).abs().max()) < 1e-4
+    sl = [0]
+    check(out[sl], orc.attention_f64(q[sl], k[sl], v[sl], causal=False), TOL_PB2, "vs fp64 oracle")
+    # the same launch unsplit (an explicit tiling never splits): the two must agree to the combine's rounding
+    ou = fa.forward(qd, kd, vd, False, out_dtype=torch.float32, kernel="pb2:1")
+    assert float((ou - out).abs().max()) < TOL_PB2
+
+
 @pytest.mark.parametrize("bh,n,d", [(1, 8192, 64), (2, 8192, 64), (4, 8192, 64), (8, 8192, 64), (3, 5000, 64), (1, 16384, 64), (2, 7777, 32),
                                     (1, 8192, 128), (5, 4200, 128), (7, 4097, 64), (1, 4096, 32)])
 def test_causal_key_split_launch(bh, n, d):
@@ -930,13 +962,14 @@ def test_torch_graph_capture_of_a_launch_chain_and_independent_replays():
     out = torch.zeros_like(q)
     ref_wide = fa.forward(q, kwide, v, False, kernel="exact")
     ref = fa.forward(q, k, v, False, kernel="exact")
-    assert float((fa.forward(q, kwide, v, False, kernel="split") - ref_wide).abs().max()) > 2e-4   # the two arithmetic paths differ on this input
+    apart = float((fa.forward(q, kwide, v, False, kernel="split") - ref_wide).abs().max())
+    assert apart > 5e-5                                                                          # the two arithmetic paths differ on this input
 
     def replays(graph, read_route):
         out.zero_()
         graph.replay()
         assert read_route() == 2
-        assert float((out - ref_wide).abs().max()) < 1e-4
+        assert float((out - ref_wide).abs().max()) < 0.2 * apart
         kbuf.copy_(k)
         out.zero_()
         graph.replay()
@@ -945,7 +978,7 @@ def test_torch_graph_capture_of_a_launch_chain_and_independent_replays():
         kbuf.copy_(kwide)
         graph.replay()
         assert read_route() == 2
-        assert float((out - ref_wide).abs().max()) < 1e-4
+        assert float((out - ref_wide).abs().max()) < 0.2 * apart
 
     fa.forward(q, kbuf, v, False, out=out)          # warm-up outside the capture
     torch.cuda.synchronize()
@@ -1003,12 +1036,14 @@ def test_a_replayed_graph_keeps_its_verdict_while_thousands_of_chains_run_on_ano
     have a raised word overwritten by an eager chain 4096 calls later, between its primary and its fallback kernel.  Now a captured
     chain owns a slot nobody else is given and eager chains take the slot of their (device, stream).  A captured fp32 chain whose
     guard FIRES (wide logits: the exact kernel must produce the output) is replayed while another stream enqueues 4300 quiet chains."""
-    q, k, v = (torch.randn(8, 1024, 64, device=dev()) for _ in range(3))
+    gen = torch.Generator(device=dev()).manual_seed(1042)     # (seeded: the premise below is a property of the data)
+    q, k, v = (torch.randn(8, 1024, 64, device=dev(), generator=gen) for _ in range(3))
     kw = k.clone()
     kw[3, 77] *= 40.0
     exact = fa.forward(q, kw, v, False, kernel="exact")
     split = fa.forward(q, kw, v, False, kernel="split")
-    assert float((split - exact).abs().max()) > 2e-4          # the two arithmetic paths are distinguishable on this input
+    apart = float((split - exact).abs().max())
+    assert apart > 5e-5                                       # the two arithmetic paths are distinguishable on this input
     out = torch.zeros_like(q)
     fa.forward(q, kw, v, False, out=out)
     torch.cuda.synchronize()
@@ -1027,7 +1062,7 @@ def test_a_replayed_graph_keeps_its_verdict_while_thousands_of_chains_run_on_ano
         torch.cuda.current_stream().synchronize()
         worst = max(worst, float((out - exact).abs().max()))
     torch.cuda.synchronize()
-    assert worst < 1e-4, f"a replay kept the split kernel's output: {worst:.3e}"
+    assert worst < 0.2 * apart, f"a replay kept the split kernel's output: {worst:.3e} (split kernel: {apart:.3e} from the exact one)"
 
 
 def test_verdict_slots_survive_ten_thousand_streams_and_nine_thousand_captured_graphs():

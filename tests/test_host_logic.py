@@ -82,7 +82,7 @@ def test_workspace_sizes_are_host_arithmetic():
     assert L.fa_workspace_bytes(16, 8192, 64, 0, F32, A) == 256                     # fp32 tensors: the guarded chain's verdict word (header only)
     assert L.fa_workspace_bytes(16, 8192, 64, 0, F32, _cabi.FA_KERNEL_SPLIT) == 0 and L.fa_workspace_bytes(16, 8192, 64, 0, F32, _cabi.FA_KERNEL_MFMA) == 0
     assert L.fa_workspace_bytes(16, 8192, 64, 0, B16, A) == 0                       # c4, bf16 output: one launch
-    for shape in ((16, 8192, 64, 0), (16, 8192, 64, 1), (16, 1024, 64, 0), (128, 8192, 64, 0), (4, 300, 32, 0), (16, 8192, 128, 1)):
+    for shape in ((16, 8192, 64, 0), (16, 8192, 64, 1), (32, 1024, 64, 0), (16, 1024, 64, 1), (16, 1023, 64, 0), (128, 8192, 64, 0), (4, 300, 32, 0), (16, 8192, 128, 1)):
         assert L.fa_workspace_bytes(*shape, B16F, A) == 0                           # fp32 output (round 4): P as two bf16 terms -- one launch, no scratch
         assert L.fa_workspace_bytes(*shape, B16F, _cabi.FA_KERNEL_PB2) == 0
     part = lambda S, bh, n, d: S * bh * n * d * 4 + S * bh * n * 4
@@ -97,6 +97,11 @@ def test_workspace_sizes_are_host_arithmetic():
     assert L.fa_workspace_bytes(1, 8192, 64, 0, B16F, A) == 256 + part(8, 1, 8192, 64)        # the accurate path splits idle grids the same way
     assert L.fa_workspace_bytes(1, 8192, 64, 0, B16F, _cabi.FA_KERNEL_PB2) == 256 + part(8, 1, 8192, 64)
     assert L.fa_workspace_bytes(1, 8192, 64, 0, B16, _cabi.FA_KERNEL_SPLIT) == 0
+    # the two-term kernel has one tiling: short non-causal rows (1024 .. 4095 keys) on at most 64 tiles are key-split too (shares >= 256 keys)
+    assert L.fa_workspace_bytes(16, 1024, 64, 0, B16F, A) == 256 + part(4, 16, 1024, 64)
+    assert L.fa_workspace_bytes(8, 2048, 128, 0, B16F, _cabi.FA_KERNEL_PB2) == 256 + part(4, 8, 2048, 128)
+    assert L.fa_workspace_bytes(1, 1024, 32, 0, B16F, A) == 256 + part(4, 1, 1024, 32)        # (shares of 256 keys at least)
+    assert L.fa_workspace_bytes(16, 1024, 64, 0, B16, A) == 0                                  # bf16 P has finer tilings for these
     # the fp16-P kernels left the product library in round 4 (ablation library only): a size query answers 0, a forward FA_ERR_UNSUPPORTED
     assert L.fa_workspace_bytes(4, 300, 32, 0, B16F, _cabi.FA_KERNEL_P16) == 0 and L.fa_workspace_bytes(4, 300, 32, 0, B16F, _cabi.FA_KERNEL_P16X2) == 0
     # arguments fa_forward_ws would reject size to 0 and leave fa_last_error alone
