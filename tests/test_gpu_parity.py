@@ -1237,6 +1237,36 @@ def test_guarded_fp32_chain_survives_graph_capture_and_other_streams():
     assert float((o2 - fa.forward(q, kw, v, False, kernel="exact")).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("first", [0, 5000])
+@pytest.mark.parametrize("b0", [3.0, 4.0, 4.25, 4.5, 4.59375, 4.75, 5.0, 6.0])
+def test_tail_mass_below_fp32_epsilon(b0, first):
+    """The adversarial row for any fp32-accumulating softmax: ONE dominant key and 8191 keys exactly `gap` binades below it, V = +4 on the
+    dominant key and -4 elsewhere, so the tail's whole mass (n - 1) 2^-gap moves the output by 8 mass.  Each tail term is below fp32's
+    epsilon relative to the dominant one: an fp32 accumulator absorbs part of it (the rung-0 kernel reads up to 5.8e-4 from the analytic
+    result here, the reference's fp32 registers do the same), and the optimistic mix drops terms more than 126 - bias binades below its
+    exponent reference outright (fa_bf16_xn_kernel.h: the dropped mass is bounded by n 2^-(126 - bias) <= 2^-13).  Asserted: the accurate
+    path stays inside the north star's 1e-3 on this input, and never loses more than the whole tail + its ordinary 5e-5.
+    Measured (scratch probe of round 4, n = 8192): gap 24.5 -> 2.1e-4, 26.5 -> 6.9e-4 (all of the tail), 28.9 -> 1.3e-4, 34.6 -> 2e-6."""
+    bh, n, d = 2, 8192, 64
+    q = torch.zeros(bh, n, d)
+    k = torch.zeros(bh, n, d)
+    v = torch.full((bh, n, d), -4.0)
+    q[:, :, 0] = 4.0
+    k[:, first, 0] = b0
+    v[:, first, :] = 4.0
+    gap = 4.0 * b0 * np.log2(np.e)
+    mass = (n - 1) * 2.0 ** (-gap)
+    true = (4.0 - 4.0 * mass) / (1.0 + mass)          # every row the same, analytically
+    whole_tail = 8.0 * mass / (1.0 + mass)
+    qd, kd, vd = (t.to(dev(), torch.bfloat16) for t in (q, k, v))
+    for kern in ("auto", "pb2:1"):
+        o = fa.forward(qd, kd, vd, False, kernel=kern, out_dtype=torch.float32)
+        err = float((o - true).abs().max())
+        OBSERVED.append((f"tail mass below fp32 epsilon, gap {gap:.1f} binades, dominant key {first}, {kern}", err, TOL_F32))
+        assert err < TOL_F32, f"{kern}: {err:.3e}"
+        assert err < whole_tail + 5e-5, f"{kern}: {err:.3e} with a tail worth {whole_tail:.3e}"
+
+
 @pytest.mark.parametrize("vmag", [1e-6, 1e-12, 1e-20, 1e-30])
 def test_tiny_v_magnitudes_survive_the_optimistic_mixes(vmag):
     """The optimistic mixes keep P near 2^-100 (bf16 tensors) / 2^-96 (fp32 tensors, N = 8192), so their accumulators hold ~2^-100 |O| l:
