@@ -806,26 +806,21 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
         case kRouteNaive: e = fa::launch_naive_f32(p, d, c, stream); break;
         case kRouteF32Exact: e = fa::launch_fwd_f32(p, d, c, sel.variant, stream); break;
         case kRouteF32Split: e = fa::launch_f32_split(p, d, c, sel.variant, stream); break;
-        case kRouteF32Guarded: {   // split products behind the logit-width guard, exact kernel as the conditional fallback
-            FlagRef f;
-            if (!chain_flag(f)) {   // no slot to be had for this (device, stream): the always-correct kernel alone
-                e = fa::launch_fwd_f32(p, d, c, 0, stream);
-                break;
-            }
+        case kRouteF32Guarded: {   // split products behind the logit-width guard: ONE launch (round 4) -- a workgroup whose logits are too wide
+            FlagRef f;              // for 16-bit operand terms redoes its own rows in fp32 arithmetic inside the kernel (flag_mode 4).  The word
+            const bool have = chain_flag(f);   // only REPORTS that (fa_last_forward_route); without one the launch is the same
             fa::FwdParams pg = p;
-            pg.flag = f.word;
-            pg.flag_serial = f.serial;
-            pg.flag_mode = 3;
-            if (pl.S > 1) e = launch_f32_keysplit(pg, d, causal, pl.S, scratch + pl.part_off, stream);
+            pg.flag = have ? f.word : nullptr;
+            pg.flag_serial = have ? f.serial : 0u;
+            pg.flag_mode = 4;
+            if (pl.S > 1) e = launch_f32_keysplit(pg, d, causal, pl.S, scratch + pl.part_off, stream);   // (every share guards its own keys)
             else e = fa::launch_f32_split(pg, d, c, 0, stream);
-            if (e == hipSuccess) {
-                pg.flag_mode = 2;
-                e = fa::launch_fwd_f32(pg, d, c, 0, stream);
-            }
-            chain_enqueued(f, stream);
-            if (e == hipSuccess) {
-                t_last_flag = f;
-                t_last_chain = 1;
+            if (have) {
+                chain_enqueued(f, stream);
+                if (e == hipSuccess) {
+                    t_last_flag = f;
+                    t_last_chain = 1;
+                }
             }
             break;
         }

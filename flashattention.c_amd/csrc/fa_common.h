@@ -51,6 +51,8 @@ struct FwdParams {
     // (serials are unique per call, so the word never needs clearing).
     //   flag_mode 0  ignore the word;   1  run only while the word is NOT set;   2  run only if the word IS set;
     //   flag_mode 3  (fp32 split kernel) always run, and set the word when the logits are too wide for 16-bit operands.
+    //   flag_mode 4  (fp32 split kernel, FA_KERNEL_AUTO) always run; a workgroup whose logits are too wide redoes its own rows in fp32
+    //                arithmetic on the spot (fa_f32_exact.h) and sets the word, if there is one (flag may be null), as a report.
     uint32_t* flag;
     uint32_t flag_serial;
     int32_t flag_mode;

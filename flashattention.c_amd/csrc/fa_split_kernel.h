@@ -39,6 +39,7 @@
 //               rejected tile is simply overwritten.
 #pragma once
 #include "fa_bf16_common.h"
+#include "fa_f32_exact.h"
 #include "fa_kernels.h"
 #include <type_traits>
 #include <utility>
@@ -966,14 +967,29 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     if constexpr (PIPE) ok = run_fast();
     else ok = run_tile(std::true_type{});
     if constexpr (GUARD) {   // every thread converted its share of every K tile: fold the shares into the workgroup's maximum
-        if (p.flag_mode == 3) atomicMax(&s_kmax, __float_as_uint(kmax));   // non-negative floats order like their bit patterns
+        if (p.flag_mode >= 3) atomicMax(&s_kmax, __float_as_uint(kmax));   // non-negative floats order like their bit patterns
     }
     const bool redo = __syncthreads_or(!ok);
     if constexpr (GUARD) {
         // |q'|_2 carries scale * log2(e); +-inf on either side fails the comparison, a NaN is caught through the first attempt's
-        // results (saw_nan): either way the exact kernel then produces the output in fp32 arithmetic
-        if (p.flag_mode == 3 && (saw_nan || !(sqrtf(qn2) * __uint_as_float(s_kmax) <= kGuardLimit * kLog2e)))
-            __hip_atomic_store(p.flag, p.flag_serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // results (saw_nan): either way the output is then produced in fp32 arithmetic --
+        //   flag_mode 4 (FA_KERNEL_AUTO, round 4): by THIS workgroup, for its own rows, right here (fa_f32_exact.h: the body of the exact
+        //               kernel over the same keys, in the LDS this kernel is done with); the word, if the caller has one, only reports it;
+        //   flag_mode 3 (the ablation library's chains): by the exact kernel queued behind this launch, for the whole grid.
+        const bool wide = p.flag_mode >= 3 && (saw_nan || !(sqrtf(qn2) * __uint_as_float(s_kmax) <= kGuardLimit * kLog2e));
+        if (p.flag_mode == 3) {
+            if (wide) __hip_atomic_store(p.flag, p.flag_serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (p.flag_mode == 4) {   // (uniform)
+            if (__syncthreads_or(wide)) {   // ... which is also the barrier behind the last LDS read of the attempt
+                if (p.flag != nullptr && tid == 0) __hip_atomic_store(p.flag, p.flag_serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 1
+                for (int qb = 0; qb < QB; ++qb) {
+                    if (qb > 0) __syncthreads();   // every wave is out of the previous block's last tile
+                    f32_exact_rows<D, NWAVES, CAUSAL, false>(p, smem, qg, kg, vg, o_slab, slab, q0 + qb * 32, kbeg, nk, kv_end, wave, lane);
+                }
+                return;
+            }
+        }
     }
     if (redo) run_tile(std::false_type{});
 }
