@@ -93,28 +93,28 @@ fa::FwdParams make_params(const void* q, const void* k, const void* v, void* o, 
     return p;
 }
 
-// ---- conditional launch chains ------------------------------------------------------------------------------------------------
-// The FA_KERNEL_AUTO path of fp32 tensors is a chain of launches on the caller's stream in which a later kernel runs or skips itself
-// depending on what an earlier one found on the device (nothing is read back, nothing synchronises):
-//   fp32 tensors   split kernel (bf16 pipe, 16-bit operand terms; raises the word when the logits are too wide for that)
-//                  -> exact fp32 kernel, only if the word is raised.
-// (bf16 tensors with an fp32 output were a chain too until round 4 -- V -> fp16 copy, fp16-P kernel, split kernel as the fallback; P as
-// two bf16 terms made that one unconditional launch.  The fp16 chain lives on in the ablation library.)
+// ---- the report word of a forward (and the ablation library's conditional launch chains) ---------------------------------------------
+// Until round 4 the FA_KERNEL_AUTO path of fp32 tensors was a chain of launches in which the exact fp32 kernel, queued behind the split
+// kernel, ran or skipped itself depending on a device word the split kernel raised when its logits were too wide for 16-bit operand
+// terms.  Now the split kernel redoes such a workgroup's rows in fp32 arithmetic itself (flag_mode 4; fa_split_kernel.h) -- ONE launch,
+// and a hostile slab costs its own tiles only -- and the word merely REPORTS that some workgroup did (fa_last_forward_route).  The
+// machinery below is what keeps two calls from ever sharing a word; the ablation library's chains (fp16-P kernels, the static-slot fp32
+// kernel) still depend on it for correctness, the product for the truth of its report:
 // "Raised" means "the word equals this call's serial number" (serials are unique per call), so a word never needs clearing between
-// eager calls.  WHERE the word lives is what keeps two chains from ever sharing one:
-//   * a chain that runs with a caller-owned workspace (fa_forward_ws; fa_workspace_bytes() reports at least the 256-byte header for
-//     every chained call) keeps its word in the first bytes of that workspace -- the caller's buffer, in use by one forward at a time
+// eager calls.  WHERE the word lives:
+//   * a call that runs with a caller-owned workspace (fa_forward_ws; fa_workspace_bytes() reports at least the 256-byte header for
+//     every such call) keeps its word in the first bytes of that workspace -- the caller's buffer, in use by one forward at a time
 //     like every other buffer of the call;
-//   * every other eager chain takes the slot of its (device, stream) pair from a per-device table, and the table's mutex is held while
-//     the chain is enqueued: chains that share a slot are on one stream, one after the other, so the second chain's first kernel
-//     runs after the first chain's last.  An event recorded behind each chain tells when its slot may change hands: when the table is
-//     full the least recently used slot whose last chain has COMPLETED is given to the new stream (a long-running host that creates and
-//     destroys streams never runs out; round 3 handed slots out once and degraded to the slow kernel after 8192 streams);
-//   * a chain enqueued while its stream is CAPTURING takes a slot of its own and starts with a memset node that clears the word, so
-//     replays of the graph are independent of each other (round 3 left the verdict of an earlier replay standing).  The slot goes back
-//     to the table when the graph -- and every executable instantiated from it -- has been destroyed (a hipUserObject retained by
-//     the capturing graph; where the runtime refuses that, the slot is simply never reused).
-// When no slot can be had the always-correct kernel of the chain is launched alone; fa_get_stats() counts those calls.
+//   * every other eager call takes the slot of its (device, stream) pair from a per-device table, and the table's mutex is held while
+//     the call is enqueued: calls that share a slot are on one stream, one after the other.  An event recorded behind each call tells
+//     when its slot may change hands: when the table is full the least recently used slot whose last call has COMPLETED is given to the
+//     new stream (a long-running host that creates and destroys streams never runs out; round 3 handed slots out once);
+//   * a call enqueued while its stream is CAPTURING takes a slot of its own and starts with a memset node that clears the word, so
+//     replays of the graph report independently of each other.  The slot goes back to the table when the graph -- and every executable
+//     instantiated from it -- has been destroyed (a hipUserObject retained by the capturing graph; where the runtime refuses that, the
+//     slot is simply never reused).
+// When no slot can be had the product launches the same kernel without a word (route 0 is reported; fa_get_stats() counts those calls);
+// a chain of the ablation library launches its always-correct kernel alone.
 // (Round 2 indexed a 4096-slot ring with serial % 4096: a chain whose serial was congruent -- every 4096th eager call, or a replayed
 // graph -- could overwrite a raised word between the other chain's primary and its fallback kernel.)
 constexpr int kFlagSlots = 16384;          // eager slots [0, kEagerSlots), capture slots behind them

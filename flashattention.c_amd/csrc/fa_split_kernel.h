@@ -13,11 +13,12 @@
 // three products still beat v_mfma_f32_32x32x2_f32 by 5x on the matrix pipe, and the result stays within ~2e-4 of the fp64
 // oracle on unit-variance data at scale 1 (~1e-5 at 1/sqrt(d)) -- inside the 1e-3 fp32 tolerance of the path, two orders of
 // magnitude tighter than bf16 tensors.  The error of a score is ~2^-17.6 * sqrt(sum (q_i k_i)^2) <= 5e-6 |q|_2 |k|_inf scale.
-// LOGIT-WIDTH GUARD (fp32 tensors under FA_KERNEL_AUTO, FwdParams::flag_mode = 3): every workgroup sees all keys of its slab and
+// LOGIT-WIDTH GUARD (fp32 tensors under FA_KERNEL_AUTO, FwdParams::flag_mode = 4): every workgroup sees all keys of its slab and
 // its own query rows; it tracks max |k| element-wise while converting K (one v_max3_f32 per four values) and the 2-norms of its
 // Q rows, and when  max_rows |q|_2 * max |k|_inf * scale  exceeds kGuardLimit (= 100: twice what unit-variance data reach at
-// d = 64, scale 1) it raises the chain's flag word -- the exact fp32 kernel queued behind this one then recomputes the launch
-// (fa_api.cpp).  Callers who know better select FA_KERNEL_SPLIT (no guard) or FA_KERNEL_MFMA.  fp32 range is kept for Q, K, V (bf16
+// d = 64, scale 1) the workgroup redoes its own rows in exact fp32 arithmetic before it exits (f32_exact_rows, fa_f32_exact.h: the body
+// of the exact kernel, in the LDS this kernel is done with) and sets the caller's report word.  Round 3 raised a flag instead and the exact
+// kernel, queued behind every launch, recomputed the whole grid (flag_mode = 3: still what the ablation library's chains do).  Callers who know better select FA_KERNEL_SPLIT (no guard) or FA_KERNEL_MFMA.  fp32 range is kept for Q, K, V (bf16
 // exponent) and, through the redo of rows whose accumulators come out tiny, for O.
 //
 //   workgroup   NWAVES waves x QB blocks of 32 query rows; K/V tiles of 32 keys.

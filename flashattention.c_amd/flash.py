@@ -79,14 +79,15 @@ def forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = Fa
 
     Kernel choice (include/flashattn_amd.h has the full rules).  fp32 tensors: ``kernel="auto"`` runs both contractions on
     the bf16 matrix pipe as three products of two-term bf16 splits (within 1e-3 of the fp32 reference) behind a device-side
-    guard that hands launches with too wide logits to the exact fp32 kernel; ``"split"`` is the same without the guard,
+    guard: a workgroup whose logits are too wide for that redoes its rows in exact fp32 arithmetic inside the same launch;
+    ``"split"`` is the same without the guard,
     ``"exact"`` (= ``"mfma"``) computes in fp32 arithmetic.  bf16 tensors: ``out_dtype=torch.float32`` stores the fp32
     accumulator (FA_DTYPE_BF16_OUT_F32) and, under ``"auto"``, selects the accurate P -- bf16 hi + bf16 lo terms in one launch
     (``"pb2"``), within 1e-4 of the fp32 reference at scale 1 (2.4e-5 on B=2 H=8 d=64 N=8192); a bf16 output keeps the fastest
     kernels (bf16 P, ``"mfma"``: ~8e-3 in the accumulator at scale 1, ~1.5e-2 after the output's own rounding; 4e-4 at 1/sqrt(d)).
     ``"p16"`` / ``"p16x2"`` (P in fp16, round 3) exist in the ablation library only.  ``out`` must not overlap q, k or v.
 
-    The call goes through ``fa_forward_ws``: scratch (key-split partials, the verdict word of the fp32 launch chain), when the call
+    The call goes through ``fa_forward_ws``: scratch (key-split partials, the report word of an fp32 ``"auto"`` forward), when the call
     needs any, is a ``torch.empty`` byte tensor from torch's caching allocator on the current stream -- the C ABI itself allocates
     nothing, which also makes every kernel family legal under ``torch.cuda.graph`` capture.  ``workspace`` may pass a preallocated
     ``torch.uint8`` tensor of at least ``workspace_bytes(...)`` bytes instead.
@@ -123,7 +124,7 @@ def forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = Fa
                              workspace.data_ptr() if workspace is not None else None,
                              workspace.numel() if workspace is not None else 0, ctypes.c_void_p(stream))
     _cabi.check(rc)
-    # the launch chain's verdict word lives in the workspace: keep the buffer referenced until this thread's next forward, so that
+    # the forward's report word lives in the workspace: keep the buffer referenced until this thread's next forward, so that
     # last_forward_route() reads the word and not whatever the caching allocator put there since
     _tls.last_workspace = workspace
     return (out, lse) if return_lse else out
@@ -192,9 +193,9 @@ def time_forward(q, k, v, causal: bool = False, *, scale: float = 1.0, kernel: U
 
 
 def last_forward_route(stream: Optional[torch.cuda.Stream] = None) -> int:
-    """Which kernel of a conditional launch chain produced this thread's most recent forward (blocking; diagnostics):
-    0 = single unconditional launch (every bf16 path), 1 = primary kernel (fp32 tensors: split products), 2 = fallback (fp32 tensors: the
-    logit-width guard fired and the exact kernel ran)."""
+    """Which arithmetic produced this thread's most recent forward (blocking; diagnostics): 0 = nothing to report (every bf16 path,
+    explicit kernels), 1 = fp32 tensors under ``"auto"``: split products throughout, 2 = the logit-width guard fired and at least one
+    workgroup redid its rows in exact fp32 arithmetic (inside the same launch)."""
     r = ctypes.c_int32(0)
     s = (stream or torch.cuda.current_stream()).cuda_stream
     _cabi.check(_cabi.lib().fa_last_forward_route(ctypes.c_void_p(s), ctypes.byref(r)))
@@ -202,8 +203,8 @@ def last_forward_route(stream: Optional[torch.cuda.Stream] = None) -> int:
 
 
 def stats() -> dict:
-    """Process-wide counters of the launch machinery (``fa_get_stats``): forwards, launch chains, chains that found no verdict slot and
-    ran their always-correct kernel alone, re-plans without scratch, slot evictions, recycled capture slots."""
+    """Process-wide counters of the launch machinery (``fa_get_stats``): forwards, forwards with a report word (fp32 ``"auto"``), those
+    that found no slot for it, re-plans without scratch, slot evictions, recycled capture slots."""
     st = _cabi.FaStats()
     _cabi.check(_cabi.lib().fa_get_stats(ctypes.byref(st)))
     return {n: int(getattr(st, n)) for n, _ in _cabi.FaStats._fields_}

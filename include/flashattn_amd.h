@@ -22,12 +22,12 @@
  *   ownership   the caller owns every buffer; nothing is allocated, freed or zero-filled by fa_forward_ws, the entry point of this
  *               boundary proper (the reference allocates O and a dead O_l inside forward(), :608-609).  Scratch is needed only for
  *               key-split launches (rows of 4096 keys and more on grids that leave the chip idle: the partial outputs of the key
- *               shares) and, 256 bytes of it, for the verdict word of the fp32 FA_KERNEL_AUTO launch chain: fa_workspace_bytes()
- *               sizes it, fa_forward_ws() takes it.  The convenience entry points (fa_forward, fa_forward_ex, fa_forward_sharded,
+ *               shares) and, 256 bytes of it, for the report word of an fp32 FA_KERNEL_AUTO forward (fa_last_forward_route):
+ *               fa_workspace_bytes() sizes it, fa_forward_ws() takes it.  The convenience entry points (fa_forward, fa_forward_ex, fa_forward_sharded,
  *               fa_forward_packed_qkv) draw the key-split scratch from a PRIVATE stream-ordered pool of the device
  *               (hipMemPoolCreate; hipMallocFromPoolAsync / hipFreeAsync on `stream`; the device's default pool is never touched) --
  *               except while `stream` is capturing (graph allocations proved unreliable on ROCm 7.2): the launch then runs unsplit.
- *               A failed pool allocation has the same effect.  Their verdict words live in a per-device slot table (see fa_get_stats)
+ *               A failed pool allocation has the same effect.  Their report words live in a per-device slot table (see fa_get_stats)
  *   aliasing    o must not overlap q, k or v (a tile that fails its verification is recomputed from q, k, v after o was
  *               written): overlapping ranges are rejected with FA_ERR_INVALID_ARGUMENT
  *   ordering    the kernel is enqueued on `stream` and the call returns without synchronising
@@ -60,10 +60,11 @@ typedef enum fa_dtype {
     FA_DTYPE_F32 = 0, /* fp32 in, fp32 out -- the reference's dtype.  FA_KERNEL_AUTO: both contractions as three bf16 MFMA
                          products of two-term bf16 splits of the fp32 operands (16 significant bits per operand, fp32
                          accumulate; max-abs error against fp64 ~2e-4 on unit-variance data at scale 1, ~1e-5 at 1/sqrt(d),
-                         2.6x faster than fp32 arithmetic) BEHIND A GUARD: the kernel bounds the logit width of its launch,
-                         max |q|_2 * max |k|_inf * scale, and when that exceeds 100 (16-bit operand terms then no longer hold
-                         1e-3) the exact fp32 kernel enqueued behind it recomputes the launch -- on the device, no host
-                         round trip; fa_last_forward_route() tells which one produced the output.  FA_KERNEL_SPLIT: the split
+                         2.6x faster than fp32 arithmetic) BEHIND A GUARD: every workgroup bounds the logit width of its rows,
+                         max |q|_2 * max |k|_inf * scale over the keys it reads, and when that exceeds 100 (16-bit operand terms
+                         then no longer hold 1e-3) it redoes its rows in exact fp32 arithmetic before it exits -- ONE launch
+                         (round 4; a second, conditional launch before), no host round trip, and a hostile slab costs its own
+                         tiles only; fa_last_forward_route() tells whether any workgroup did.  FA_KERNEL_SPLIT: the split
                          products without the guard.  FA_KERNEL_MFMA: exact fp32 arithmetic (v_mfma_f32_32x32x2_f32: ~2e-5 /
                          ~1e-6), bit-for-bit an fmaf chain; FA_F32_AUTO=exact in the environment makes that the
                          FA_KERNEL_AUTO choice for the whole process */
@@ -127,17 +128,16 @@ int fa_forward_ex(const void* q, const void* k, const void* v, void* o, float* l
 
 /*
  * fa_workspace_bytes -- bytes of caller-owned scratch THIS call needs (0 = none; also 0 for arguments fa_forward_ws would reject).
- *                       Same (bh, n, d, causal, dtype, kernel) as the forward it sizes; the figure covers every kernel the call's
- *                       launch chain may run, so it is an upper bound of what is touched.
+ *                       Same (bh, n, d, causal, dtype, kernel) as the forward it sizes; an upper bound of what is touched.
  * fa_forward_ws      -- fa_forward_ex that never allocates: the non-allocating form of the boundary
  *                       (ownership as in /root/reference/src/flashattention.cu:608-609 inverted: caller owns all buffers).
  *   workspace        device pointer, 256-byte aligned, at least fa_workspace_bytes() bytes, not overlapping q, k, v, o; NULL is fine
  *                    when the call needs none.  In use until the forward has completed on `stream`; one forward at a time per
- *                    workspace (its first bytes hold the launch chain's verdict word).  Contents need no initialisation.
+ *                    workspace (its first bytes hold the forward's report word).  Contents need no initialisation.
  *                    NULL with FA_KERNEL_AUTO when the call would use one: the forward runs without scratch (unsplit launch; the
- *                    chain's verdict word from the slot table) instead of failing -- a binder that skips fa_workspace_bytes() works.
- *   capture          legal while `stream` is capturing, with every kernel family (a chain clears its verdict word with a memset
- *                    node, so replays of the graph are independent of each other -- with or without a workspace).
+ *                    report word from the slot table) instead of failing -- a binder that skips fa_workspace_bytes() works.
+ *   capture          legal while `stream` is capturing, with every kernel family (an fp32 FA_KERNEL_AUTO forward clears its report
+ *                    word with a memset node, so replays of the graph report independently -- with or without a workspace).
  */
 size_t fa_workspace_bytes(int64_t bh, int64_t n, int32_t d, int32_t causal, int32_t dtype, int32_t kernel);
 int fa_forward_ws(const void* q, const void* k, const void* v, void* o, float* lse,
@@ -152,7 +152,7 @@ int fa_forward_ws(const void* q, const void* k, const void* v, void* o, float* l
  *                   (FA_ALLOW_SAME_DEVICE=1 in the environment lifts the check: single-GPU test boxes)
  *   q/k/v/o[i]      device pointers of shard i, (bh[i], n, d)
  *   streams[i]      hipStream_t on device_ids[i] (NULL entries / NULL array = null stream)
- * Each shard is enqueued by its own (persistent) host thread (a forward can be a chain of launches: one thread would start the last
+ * Each shard is enqueued by its own (persistent) host thread (a forward can be several launches and a pool allocation: one thread would start the last
  * device a whole table's worth of host time behind the first) without synchronising; the caller's current device is untouched.
  */
 int fa_forward_sharded(int32_t n_shards, const int32_t* device_ids,
@@ -205,26 +205,28 @@ int fa_time_forward_graph(const void* q, const void* k, const void* v, void* o,
                           int32_t kernel, int32_t warmup, int32_t iters, float* ms_per_forward);
 
 /*
- * fa_last_forward_route -- which kernel of a conditional launch chain produced the output of this thread's most recent
- *                          forward.  Blocking (waits for `stream`, reads one word back): diagnostics and benchmarks only.
- *   *route  0 = the call was a single unconditional launch (every bf16 path; explicit kernels);  1 = the primary kernel (fp32 tensors:
- *           split products);  2 = the fallback (fp32 tensors: exact fp32 arithmetic -- the logit-width guard fired)
+ * fa_last_forward_route -- which arithmetic produced the output of this thread's most recent forward.  Blocking (waits for
+ *                          `stream`, reads one word back): diagnostics and benchmarks only.
+ *   *route  0 = nothing to report (every bf16 path; explicit kernels; an fp32 forward that found no report word);  1 = fp32 tensors under
+ *           FA_KERNEL_AUTO: split products throughout;  2 = the logit-width guard fired: at least one workgroup redid its rows in exact
+ *           fp32 arithmetic (inside the same launch)
  */
 int fa_last_forward_route(void* stream, int32_t* route);
 
 /*
  * fa_get_stats -- process-wide counters of the launch machinery (never fails for a non-NULL pointer; cheap; no device access).
- * The verdict word of a launch chain that has no caller-owned workspace comes from a per-device table: one slot per (device, stream)
- * for eager chains -- when all eager_slots_per_device are taken, the least recently used slot whose last chain has completed changes
- * hands (slot_evictions) --, one slot per captured chain, returned when the graph and its executables are destroyed
+ * The report word of an fp32 FA_KERNEL_AUTO forward that has no caller-owned workspace comes from a per-device table: one slot per
+ * (device, stream) for eager calls -- when all eager_slots_per_device are taken, the least recently used slot whose last forward has
+ * completed changes hands (slot_evictions) --, one slot per captured forward, returned when the graph and its executables are destroyed
  * (capture_slots_recycled; on a runtime that refuses the user-object hook a capture slot is used once, and capture_slots_per_device
- * captures without a workspace exhaust them).  chains_degraded counts the forwards that found no slot and ran the chain's
- * always-correct kernel alone (fp32 FA_KERNEL_AUTO: the exact kernel, ~3x slower): non-zero means "pass a workspace".
+ * captures without a workspace exhaust them).  chains_degraded counts the forwards that found no slot: since round 4 they run exactly
+ * as fast and as accurately as the others (the fallback is inside the kernel) and only report route 0; in the ablation library, whose
+ * chains of launches still depend on the word, such a call runs the chain's always-correct kernel alone.
  */
 typedef struct fa_stats {
     uint64_t forwards;                 /* forwards enqueued through any entry point                          */
-    uint64_t chains;                   /* ... of which conditional launch chains                             */
-    uint64_t chains_degraded;          /* chains that ran their always-correct kernel alone: no verdict slot */
+    uint64_t chains;                   /* ... of which forwards with a report word (fp32 FA_KERNEL_AUTO)     */
+    uint64_t chains_degraded;          /* ... that found no slot for the word (see above)                    */
     uint64_t scratch_replans;          /* forwards re-planned without scratch (NULL workspace / pool failure) */
     uint64_t slot_evictions;           /* eager slots that changed hands                                     */
     uint64_t capture_slots_recycled;   /* capture slots returned by destroyed graphs                         */

@@ -80,7 +80,7 @@ def main():
         f"| d=32 (bf16 P; two bf16 terms; round 3's chain); c2's shape 128 × 1024 (two bf16 terms; round 3's chain) | `fa_fwd_bf16_x2_kernel<32>`; `x2_pb2`; `x2_p16x2` | {ms(dm[0])}; {ms(x2[7])}; {ms(r3[5])}; {ms(x2[8])}; {ms(r3[6])} | {tf(dm[0])}; {tf(x2[7])}; {tf(r3[5])}; {tf(x2[8])}; {tf(r3[6])} | {fr(dm[0])}; {fr(x2[7])}; {fr(r3[5])}; {fr(x2[8])}; {fr(r3[6])} |",
         f"| one slab, BH=1 N=8192 d=64 bf16, non-causal / causal (key-split launches, §8) | `fa_fwd_bf16_x2_kernel<64>` × 8 key shares + `fa_combine_splits_kernel` | {ms(ks[0])} / {ms(ks[3])} ({ms(us[0])} / {ms(us[3])} unsplit) | {tf(ks[0])} / {tf(ks[3])} | {fr(ks[0])} / {fr(ks[3])} |",
         f"| BH=2, 4 non-causal; BH=2, 4, 8 causal (key-split) | same | {ms(ks[1])}, {ms(ks[2])} ({ms(us[1])}, {ms(us[2])} unsplit); {ms(ks[4])}, {ms(ks[5])}, {ms(ks[6])} ({ms(us[4])}, {ms(us[5])}, {ms(us[6])} unsplit) | {tf(ks[1])}, {tf(ks[2])}; {tf(ks[4])}, {tf(ks[5])}, {tf(ks[6])} | {fr(ks[1])}, {fr(ks[2])}; {fr(ks[4])}, {fr(ks[5])}, {fr(ks[6])} |",
-        f"| BH=1, 2 fp32 tensors N=8192, non-causal; BH=1, 2, 4 causal (key-split inside the guarded chain: round 3) | `fa_fwd_f32_split_kernel` × 8 / 4 / 2 key shares + combine + conditional exact launch | {ms(ks[7])}, {ms(ks[8])} ({ms(us[7])}, {ms(us[8])} unsplit, unguarded); {ms(ks[9])}, {ms(ks[10])}, {ms(ks[11])} ({ms(us[9])}, {ms(us[10])}, {ms(us[11])}) | {tf(ks[7])}, {tf(ks[8])}; {tf(ks[9])}, {tf(ks[10])}, {tf(ks[11])} | — |",
+        f"| BH=1, 2 fp32 tensors N=8192, non-causal; BH=1, 2, 4 causal (key-split, every share guarded: round 3) | `fa_fwd_f32_split_kernel` × 8 / 4 / 2 key shares + combine | {ms(ks[7])}, {ms(ks[8])} ({ms(us[7])}, {ms(us[8])} unsplit, unguarded); {ms(ks[9])}, {ms(ks[10])}, {ms(ks[11])} ({ms(us[9])}, {ms(us[10])}, {ms(us[11])}) | {tf(ks[7])}, {tf(ks[8])}; {tf(ks[9])}, {tf(ks[10])}, {tf(ks[11])} | — |",
         f"| **c3** B=2 H=8 N=8192 d=64 fp32 | `fa_fwd_f32_split_kernel` (3 bf16 products of hi/lo splits, exponent reference in the accumulator init; AUTO adds the guard's empty exact launch: {b3['ms_per_step']:.3f} bench) | {ms(f3[0])} | **{tf(f3[0])}** | {fr(f3[0], third)} of bf16 peak at 3× FLOP |",
         f"| same, **fp32 arithmetic** (`FA_KERNEL_MFMA` — the figure to quote for \"c3 fp32\" in the reference's sense: bench `extra.c3.reference_arithmetic`) | `fa_fwd_f32_kernel` | {ms(exa[0])} | {exa[0]['tflops']:.1f} | **{fr(exa[0], 157.3)}** of fp32 peak |",
         f"| c3 shape causal; d=128; d=32 (fp32 tensors, split) | `fa_fwd_f32_split_kernel` | {ms(f3[4])}; {ms(f3[6])}; {ms(f3[7])} | {tf(f3[4])}; {tf(f3[6])}; {tf(f3[7])} | — |",
@@ -122,7 +122,7 @@ def main():
         f"{100 * dm[1]['tflops'] / 2500:.0f} %) at {b4['roofline']['max_abs_err']:.1e} max-abs of the fp32 reference (bf16 P, bf16 output, the reference's scale 1; {ex['c4_scale_rsqrt_d']['max_abs_err']:.1e} at 1/√d);\n"
         f"bf16 tensors with fp32 output (P as bf16 hi + bf16 lo in one launch: **{ba['roofline']['max_abs_err']:.1e} of the fp32 reference at scale 1**) {ms(x2[0])} ms =\n"
         f"{100 * x2[0]['tflops'] / 2500:.0f} % — the `roofline_at_1e-3` block of the bench line; fp32 tensors {ms(f3[0])} ms ({tf(f3[0])} TFLOP/s: both contractions as\n"
-        f"three bf16 MFMA products of hi/lo splits, within 2.5e-4 of the fp64 oracle at scale 1, wide-logit launches handed to the exact kernel\n"
+        f"three bf16 MFMA products of hi/lo splits, within 2.5e-4 of the fp64 oracle at scale 1, wide-logit workgroups redone in fp32 arithmetic inside the launch\n"
         f"on the device; `kernel=\"exact\"`, fp32 arithmetic: {ms(exa[0], 2)} ms, {100 * exa[0]['tflops'] / 157.3:.0f} % of the fp32 MFMA peak); causal {ms(ca[0])} ms — causal launches\n"
         f"choose which tiles share a CU (`DESIGN.md` §4.4); grids that leave the chip idle are key-split (one slab of that length: {ms(ks[0])} ms\n"
         f"instead of {ms(us[0])}, causal {ms(ks[3])} instead of {ms(us[3])}, fp32 {ms(ks[7])} instead of {ms(us[7])}, fp32 causal {ms(ks[9])} instead of {ms(us[9])}).\n")

@@ -5,7 +5,7 @@
 Every case draws (bh, n, d, causal, scale, dtype, data shape) and compares FA_KERNEL_AUTO -- bf16 tensors with bf16 and with fp32
 output, fp32 tensors -- with the rung-0 kernel (one thread per query row, fp32) on the same inputs, with the tolerances of
 tests/test_gpu_parity.py.  Lengths are drawn around the tiling boundaries (multiples of 32 .. 512, +-1), the data from several
-families: N(0,1); wide logits (x3: the fp32 guard hands the launch to the exact kernel, the bf16 kernels rescale); planted dominant
+families: N(0,1); wide logits (x3: the fp32 guard sends the affected workgroups to fp32 arithmetic, the bf16 kernels rescale); planted dominant
 keys; a constant V; zero Q; values at the bf16 / fp16 range ends for V.  Exit code 1 on the first mismatch or NaN.
 """
 import argparse

@@ -597,7 +597,7 @@ def test_causal_key_split_launch(bh, n, d):
 @pytest.mark.parametrize("bh,n,d", [(1, 8192, 64), (2, 8192, 64), (3, 5000, 64), (1, 16384, 64), (2, 7777, 32), (1, 8192, 128), (4, 4100, 64)])
 def test_fp32_key_split_launch(bh, n, d, causal):
     """fp32 tensors, grids that leave the chip idle: the split kernel over key shares + combine inside the guarded AUTO chain (every
-    share bounds the logit width of its own keys; any share raising the verdict hands the launch to the exact kernel).  Causal: shares
+    share bounds the logit width of its own keys and falls back to fp32 arithmetic on its own keys).  Causal: shares
     are multiples of the tile height, shares above a tile's diagonal are empty (lse = -inf, weight 0 in the combine)."""
     q, k, v = (randn(s, bh, n, d) for s in (97, 98, 99))
     qd, kd, vd = to_dev(q, k, v)
