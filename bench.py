@@ -425,7 +425,7 @@ def main():
         if abs(ratio - 1.0) > 0.03:
             roof["timing_warning"] = (f"kernel_ms (median of {kstats['reps']} event-timed loops) and ms_per_step differ by {abs(ratio - 1.0) * 100:.1f} %: "
                                       f"min / median / p90 of the loops = {kstats['min']} / {kstats['median']} / {kstats['p90']} ms; "
-                                      "expect ms_per_step above kernel_ms when a forward is a launch chain (host enqueue per launch) and "
+                                      "expect ms_per_step above kernel_ms when a forward is several launches (key shares + combine: host enqueue per launch) and "
                                       "either one high right after an idle period (clock ramp)")
         if dtype == "f32":
             roof["arithmetic"] = {0: "single launch", 1: "split products on the bf16 pipe (guard quiet)",
