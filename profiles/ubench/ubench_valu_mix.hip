@@ -61,6 +61,13 @@ __global__ __launch_bounds__(256, 1) void kmix(float* out, unsigned long long* c
                 else if constexpr (KIND == 23) asm volatile("v_mov_b32 %0, %1" : "=v"(u[i]) : "v"(u[i2]));
                 else if constexpr (KIND == 24) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(u[i]) : "v"(r[k]));
                 else if constexpr (KIND == 25) asm volatile("v_exp_f32 %0, %0 mul:2" : "+v"(r[k]));
+                else if constexpr (KIND == 26) asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(u[i]) : "v"(u[i2]));
+                else if constexpr (KIND == 27) asm volatile("v_alignbit_b32 %0, %1, %2, 16" : "=v"(u[i]) : "v"(r[k]), "v"(r[(k + 5) % 16]));
+                else if constexpr (KIND == 28) asm volatile("v_bfi_b32 %0, %3, %1, %2" : "=v"(u[i]) : "v"(r[k]), "v"(r[(k + 5) % 16]), "s"(0xffff0000u));
+                else if constexpr (KIND == 29) asm volatile("v_and_or_b32 %0, %1, %3, %2" : "=v"(u[i]) : "v"(r[k]), "v"(r[(k + 5) % 16]), "s"(0xffff0000u));
+                else if constexpr (KIND == 30) asm volatile("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(u[i]) : "v"(r[k]), "v"(r[(k + 5) % 16]));
+                else if constexpr (KIND == 31) asm volatile("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(u[i]) : "v"(r[k]), "v"(r[(k + 5) % 16]));
+                else if constexpr (KIND == 32) asm volatile("v_add_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(r[k]) : "v"(r[(k + 3) % 16]), "v"(r[(k + 5) % 16]));
                 // dependent pairs: the second instruction reads what the first wrote
                 else if constexpr (KIND == 10) { if (v & 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(u[i]) : "v"(r[(k + 15) % 16])); else asm volatile("v_sub_f32 %0, %1, %0" : "+v"(r[k]) : "v"(r[(k + 5) % 16])); }
                 else if constexpr (KIND == 11) { if (v & 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(r[(k + 7) % 16]) : "v"(r[(k + 15) % 16])); else asm volatile("v_exp_f32 %0, %0" : "+v"(r[k])); }
@@ -128,6 +135,13 @@ int main()
     run<21>("v_pk_mul_f16", out, cyc, seed);
     run<20>("v_max3_f32", out, cyc, seed);
     run<22>("v_mul_f32", out, cyc, seed);
+    run<26>("v_mov_b32_sdwa WORD_1 -> WORD_0 keep", out, cyc, seed);
+    run<31>("v_or_b32_sdwa src0 WORD_1", out, cyc, seed);
+    run<32>("v_add_f32_sdwa (dword sels)", out, cyc, seed);
+    run<27>("v_alignbit_b32", out, cyc, seed);
+    run<28>("v_bfi_b32", out, cyc, seed);
+    run<29>("v_and_or_b32", out, cyc, seed);
+    run<30>("v_lshl_or_b32", out, cyc, seed);
     run<23>("v_mov_b32", out, cyc, seed);
     run<24>("v_accvgpr_write_b32", out, cyc, seed);
     run<10>("(v_sub_f32 -> v_cvt_pk dependent) / 2", out, cyc, seed);
