@@ -68,6 +68,16 @@ __global__ __launch_bounds__(256, 1) void kmix(float* out, unsigned long long* c
                 else if constexpr (KIND == 30) asm volatile("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(u[i]) : "v"(r[k]), "v"(r[(k + 5) % 16]));
                 else if constexpr (KIND == 31) asm volatile("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(u[i]) : "v"(r[k]), "v"(r[(k + 5) % 16]));
                 else if constexpr (KIND == 32) asm volatile("v_add_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(r[k]) : "v"(r[(k + 3) % 16]), "v"(r[(k + 5) % 16]));
+                // the softmax element (fma, then exp of its result) in three orders: adjacent pairs, two by two, four by four
+                else if constexpr (KIND == 40) asm volatile("v_fma_f32 %1, %0, %2, %3\n\tv_exp_f32 %0, %1" : "+v"(r[k]), "=&v"(u[i]) : "v"(k0), "v"(k1));
+                else if constexpr (KIND == 41) { if (v == 0) asm volatile("v_fma_f32 %4, %0, %8, %9\n\tv_fma_f32 %5, %1, %8, %9\n\tv_fma_f32 %6, %2, %8, %9\n\tv_fma_f32 %7, %3, %8, %9\n\t"
+                                                                            "v_exp_f32 %0, %4\n\tv_exp_f32 %1, %5\n\tv_exp_f32 %2, %6\n\tv_exp_f32 %3, %7"
+                                                                            : "+v"(r[k]), "+v"(r[(k + 1) % 16]), "+v"(r[(k + 2) % 16]), "+v"(r[(k + 3) % 16]), "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]) : "v"(k0), "v"(k1)); }
+                else if constexpr (KIND == 42) { if ((v & 1) == 0) asm volatile("v_fma_f32 %2, %0, %4, %5\n\tv_fma_f32 %3, %1, %4, %5\n\tv_exp_f32 %0, %2\n\tv_exp_f32 %1, %3"
+                                                                            : "+v"(r[k]), "+v"(r[(k + 1) % 16]), "=&v"(u[0]), "=&v"(u[1]) : "v"(k0), "v"(k1)); }
+                else if constexpr (KIND == 43) { if (v == 0) asm volatile("v_fma_f32 %4, %0, %8, %9\n\tv_fma_f32 %5, %1, %8, %9\n\tv_exp_f32 %0, %4\n\tv_fma_f32 %6, %2, %8, %9\n\tv_exp_f32 %1, %5\n\tv_fma_f32 %7, %3, %8, %9\n\t"
+                                                                            "v_exp_f32 %2, %6\n\tv_exp_f32 %3, %7"
+                                                                            : "+v"(r[k]), "+v"(r[(k + 1) % 16]), "+v"(r[(k + 2) % 16]), "+v"(r[(k + 3) % 16]), "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]) : "v"(k0), "v"(k1)); }
                 // dependent pairs: the second instruction reads what the first wrote
                 else if constexpr (KIND == 10) { if (v & 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(u[i]) : "v"(r[(k + 15) % 16])); else asm volatile("v_sub_f32 %0, %1, %0" : "+v"(r[k]) : "v"(r[(k + 5) % 16])); }
                 else if constexpr (KIND == 11) { if (v & 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(r[(k + 7) % 16]) : "v"(r[(k + 15) % 16])); else asm volatile("v_exp_f32 %0, %0" : "+v"(r[k])); }
@@ -135,6 +145,10 @@ int main()
     run<21>("v_pk_mul_f16", out, cyc, seed);
     run<20>("v_max3_f32", out, cyc, seed);
     run<22>("v_mul_f32", out, cyc, seed);
+    run<40>("(fma, exp of it) adjacent      [8 instr]", out, cyc, seed);
+    run<42>("(fma, fma, exp, exp)           [8 instr]", out, cyc, seed);
+    run<41>("(4 fma, 4 exp)                 [8 instr]", out, cyc, seed);
+    run<43>("(fma fma exp fma exp fma exp exp)", out, cyc, seed);
     run<26>("v_mov_b32_sdwa WORD_1 -> WORD_0 keep", out, cyc, seed);
     run<31>("v_or_b32_sdwa src0 WORD_1", out, cyc, seed);
     run<32>("v_add_f32_sdwa (dword sels)", out, cyc, seed);
