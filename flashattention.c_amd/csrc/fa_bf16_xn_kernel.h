@@ -556,15 +556,66 @@ __device__ __forceinline__ void xn_unit(XCtx<D, NB>& x)
 // 32-cycle MFMA: 63.8 cycles against 33.5 for four v_fma_f32, profiles/r04_ubench_dot2.txt), so a slot's dots go behind its other VALU
 // work, where the pipe has (nearly) drained.  Legal because nothing in a slot depends on its dots: their packs sit in a later slot
 // (xn_schedule_ok), and the dots read a pack of an earlier unit, which the reordering keeps in front of them.
+// D = 32 only: the exponentials of a slot, all fmas first, then all v_exp_f32 (profiles/r04_ubench_valu_mix.txt: a v_exp_f32 issued right
+// behind the v_fma_f32 whose result it reads costs the pair 16.0 cycles, four fmas followed by their four exponentials 13.6 each, and hipcc,
+// left to order a slot's units, puts most exponentials directly behind their fma).  A scheduling barrier between the two groups holds the
+// order; the instructions stay hipcc's own, so its hazard padding stays exact (as inline asm the groups cost an s_nop at every boundary).
+// d = 32 is the one head dimension whose loop is bound by issue slots (+1.5 %, two-term +1.6 %); at d >= 64 the same change took ~4 % of
+// the issue cycles out of the loops and no time -- they run at the board's power cap (DESIGN.md section 4.2, r04_experiments.txt part 7).
+constexpr bool xn_group_exps(int D) { return D == 32; }
+struct XExpList {
+    int n;
+    int blk[8], idx[8];
+};
+// the exp units among units [u0, u0 + cnt) of the step, from the skip-th one on (eight at most)
+template <int NB, int PF, bool OPT>
+__device__ __host__ constexpr XExpList xn_slot_exps(int u0, int cnt, int skip)
+{
+    XExpList l{};
+    int seen = 0;
+    for (int u = u0; u < u0 + cnt; ++u) {
+        const XUnit un = xn_units_v<NB, PF, OPT>.u[u];
+        if (un.kind != 0) continue;
+        if (seen++ < skip || l.n == 8) continue;
+        l.blk[l.n] = un.blk;
+        l.idx[l.n] = un.idx;
+        ++l.n;
+    }
+    return l;
+}
+template <int D, int NB, bool OPT, int PF, int U0, int CNT, int SKIP>
+__device__ __forceinline__ void xn_exp_group(XCtx<D, NB>& x)
+{
+    constexpr XExpList L = xn_slot_exps<NB, PF, OPT>(U0, CNT, SKIP);
+    if constexpr (L.n > 0) {
+        float t[8];
+#define FA_E(i) x.sc[L.blk[i]][L.idx[i]]
+#define FA_T(i) if constexpr (L.n > i) t[i] = fmaf(FA_E(i), x.c, -x.off[L.blk[i]]);
+        FA_T(0) FA_T(1) FA_T(2) FA_T(3) FA_T(4) FA_T(5) FA_T(6) FA_T(7)
+        if constexpr (L.n > 1) __builtin_amdgcn_sched_barrier(0);   // every fma of the slot in front of its first exponential
+        // (clamp: as in xn_unit)
+#define FA_X(i) if constexpr (L.n > i) FA_E(i) = (OPT || pf_f16(PF)) ? fast_exp2(t[i]) : exp2_clamp01(t[i]);
+        FA_X(0) FA_X(1) FA_X(2) FA_X(3) FA_X(4) FA_X(5) FA_X(6) FA_X(7)
+#undef FA_X
+#undef FA_T
+#undef FA_E
+    }
+}
 template <int D, int NB, bool OPT, int U, int ABL, int PF, int PASS>
 __device__ __forceinline__ void xn_unit_pass(XCtx<D, NB>& x)
 {
     constexpr bool is_dot = PF == 3 && xn_units_v<NB, PF, OPT>.u[U].kind == 4;
-    if constexpr (PASS == 0 || (PASS == 1 && !is_dot) || (PASS == 2 && is_dot)) xn_unit<D, NB, OPT, U, ABL, PF>(x);
+    constexpr bool grouped_exp = xn_group_exps(D) && !(ABL & 256) && xn_units_v<NB, PF, OPT>.u[U].kind == 0;   // (emitted by xn_exp_group)
+    if constexpr (!grouped_exp && (PASS == 0 || (PASS == 1 && !is_dot) || (PASS == 2 && is_dot))) xn_unit<D, NB, OPT, U, ABL, PF>(x);
 }
 template <int D, int NB, bool OPT, int ABL, int PF, int U0, int... Us>
 __device__ __forceinline__ void xn_units(XCtx<D, NB>& x, std::integer_sequence<int, Us...>)
 {
+    if constexpr (xn_group_exps(D) && !(ABL & 256)) {
+        xn_exp_group<D, NB, OPT, PF, U0, (int)sizeof...(Us), 0>(x);
+        xn_exp_group<D, NB, OPT, PF, U0, (int)sizeof...(Us), 8>(x);
+        static_assert(xn_slot_exps<NB, PF, OPT>(U0, (int)sizeof...(Us), 16).n == 0, "more than sixteen exponentials in one slot");
+    }
     if constexpr (PF == 3 && pb2_dots_last(D)) {
         (xn_unit_pass<D, NB, OPT, U0 + Us, ABL, PF, 1>(x), ...);
         (xn_unit_pass<D, NB, OPT, U0 + Us, ABL, PF, 2>(x), ...);
