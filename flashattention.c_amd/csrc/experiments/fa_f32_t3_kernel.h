@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_f32_t3_kernel(FwdParams p)
         const unsigned long long kw = p.stats[0], qw = p.stats[1];
         const float kmax = (unsigned)(kw >> 32) == p.flag_serial ? __uint_as_float((unsigned)kw) : INFINITY;
         const float qn2 = (unsigned)(qw >> 32) == p.flag_serial ? __uint_as_float((unsigned)qw) : INFINITY;
-        if (!(sqrtf(qn2) * kmax <= 100.0f * kLog2e)) {   // kGuardLimit of fa_split_kernel.h; false for NaN as well
+        if (!(sqrtf(qn2) * kmax <= 100.0f * kLog2e)) {   // (kGuardLimit of fa_split_kernel.h as it was in round 3; false for NaN as well)
             if (threadIdx.x == 0) __hip_atomic_store(p.flag, p.flag_serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }

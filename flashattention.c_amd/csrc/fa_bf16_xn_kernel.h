@@ -797,10 +797,16 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
     const int nst = (kv_end + kKvBlk - 1) / kKvBlk;  // 64-key stages
     const int nsub = (kv_end + 31) / 32;             // 32-key sub-tiles
     const int q0r = q0 - kbeg;                       // first row of block 0 in local key coordinates (causal: local key <= local row)
-    // The optimistic mix drops every term more than 126 - bias binades below the row's reference (bf16 underflow: the exact zeros the
-    // clock likes).  For the accurate P (PF = 3) the dropped mass is bounded by the row length: nk * 2^-(126 - bias) <= 2^-13 of the
-    // reference term -- bias = 100 up to 8192 keys, one less per doubling beyond (the range test at the end of the tile is unchanged).
-    const float kBias = (OPT && PF == 3) ? kBiasC - (float)max(0, 32 - __builtin_clz(max(nk, 2) - 1) - 13) : kBiasC;
+    // The optimistic mix drops every term more than 126 - bias binades below the row's reference (bf16 underflow: exact zeros).  Zeros are
+    // what the power budget likes (these loops run at the board's cap, and a sparser P buys clock on an unchanged
+    // instruction stream), so the bias is as high as the accuracy of the P format allows -- the dropped mass is bounded by nk 2^-T:
+    //   bf16 P (PF = 0)    T = 10 + ceil(log2 nk)   dropped mass <= 2^-10 of the reference term, half of what rounding P to 8 bits may cost
+    //                      (nk = 8192: bias 103, T = 23; round 4: +1.2 % on every bf16-P shape against T = 26, errors on random data unchanged
+    //                      to the last digit -- profiles/r04_experiments.txt, part 8; T = 22: +1.5 %, T = 24: +1.0 %, T = 26: the form before);
+    //   two bf16 terms     T = 26 up to 8192 keys, one more per doubling beyond: <= 2^-13 (the range test at the end of the tile is unchanged).
+    const int lg_nk = 32 - __builtin_clz(max(nk, 2) - 1);   // ceil(log2 nk)
+    const float kBias = (OPT && PF == 3) ? kBiasC - (float)max(0, lg_nk - 13) : (OPT && PF == 0) ? kBiasC + (float)max(0, 26 - (10 + lg_nk)) : kBiasC;
+    const float tiny_acc = (OPT && PF == 0) ? __builtin_amdgcn_exp2f(-(kBias + 16.0f)) : kOptTinyAcc;   // (kOptTinyAcc = 2^-(100 + 16))
 
     auto k_slot = [&](int j) { return k_ring + (j & (KR - 1)) * T; };
     auto v_slot = [&](int j) { return v_ring + (j & (VR - 1)) * T; };
@@ -1090,7 +1096,7 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
             for (int db = 0; db < DB; ++db)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) amax = fmaxf(fmaxf(amax, fabsf(o[blk][db][r])), fabsf(o[blk][db][r + 1]));
-            bad = bad || (amax < kOptTinyAcc && qi < n && !idle);
+            bad = bad || (amax < tiny_acc && qi < n && !idle);
         }
         if (qi < n && idle) {   // empty causal key share: only its log-sum-exp (-inf) is stored; the combine never reads its O
             if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = -INFINITY;

@@ -15,8 +15,8 @@
 // magnitude tighter than bf16 tensors.  The error of a score is ~2^-17.6 * sqrt(sum (q_i k_i)^2) <= 5e-6 |q|_2 |k|_inf scale.
 // LOGIT-WIDTH GUARD (fp32 tensors under FA_KERNEL_AUTO, FwdParams::flag_mode = 4): every workgroup sees all keys of its slab and
 // its own query rows; it tracks max |k| element-wise while converting K (one v_max3_f32 per four values) and the 2-norms of its
-// Q rows, and when  max_rows |q|_2 * max |k|_inf * scale  exceeds kGuardLimit (= 100: twice what unit-variance data reach at
-// d = 64, scale 1) the workgroup redoes its own rows in exact fp32 arithmetic before it exits (f32_exact_rows, fa_f32_exact.h: the body
+// Q rows, and when  max_rows |q|_2 * max |k|_inf * scale  exceeds kGuardLimit (= 90; unit-variance data reach 55 at
+// d = 64, scale 1, and 78 at d = 128) the workgroup redoes its own rows in exact fp32 arithmetic before it exits (f32_exact_rows, fa_f32_exact.h: the body
 // of the exact kernel, in the LDS this kernel is done with) and sets the caller's report word.  Round 3 raised a flag instead and the exact
 // kernel, queued behind every launch, recomputed the whole grid (flag_mode = 3: still what the ablation library's chains do).  Callers who know better select FA_KERNEL_SPLIT (no guard) or FA_KERNEL_MFMA.  fp32 range is kept for Q, K, V (bf16
 // exponent) and, through the redo of rows whose accumulators come out tiny, for O.
@@ -54,7 +54,12 @@ namespace fa {
 constexpr int kKvSplit = 32;         // keys per tile
 constexpr float kSplitLimit = 0x1p100f;  // optimistic pass: a row sum below this proves that no term overflowed
 constexpr float kSplitTinyAcc = 0x1p-116f;   // sum of a row's unnormalised accumulators below this: products near (or below) the subnormals
-constexpr float kGuardLimit = 100.0f;    // |q|_2 * |k|_inf * scale above which 16-bit operand terms no longer hold 1e-3 (see header)
+// |q|_2 * |k|_inf * scale above which 16-bit operand terms no longer hold 1e-3.  100 until the fallback became per workgroup (round 4): a
+// launch whose widest rows raised the old flag was redone as a whole, rows just under the limit included -- now those stay on the bf16 pipe,
+// and rows at 95 .. 100 read up to 1.19e-3 in the LSE (soak seed 101 case 297; sweep over 126 launches, worst |O| / |lse| error of rows under
+// L: 60 -> 3.6e-4 / 5.0e-4, 75 -> 5.9e-4 / 7.1e-4, 100 -> 7.0e-4 / 8.2e-4, 125 -> 8.4e-4 / 1.05e-3: profiles/r04_experiments.txt part 9)
+// 75 would put unit-variance data at d = 128, scale 1 (up to 78) on the fallback: 90.
+constexpr float kGuardLimit = 90.0f;
 
 // running maximum of |a|, |b|: one instruction (abs as source modifiers)
 __device__ __forceinline__ void absmax2(float& m, float a, float b)

@@ -61,7 +61,7 @@ typedef enum fa_dtype {
                          products of two-term bf16 splits of the fp32 operands (16 significant bits per operand, fp32
                          accumulate; max-abs error against fp64 ~2e-4 on unit-variance data at scale 1, ~1e-5 at 1/sqrt(d),
                          2.6x faster than fp32 arithmetic) BEHIND A GUARD: every workgroup bounds the logit width of its rows,
-                         max |q|_2 * max |k|_inf * scale over the keys it reads, and when that exceeds 100 (16-bit operand terms
+                         max |q|_2 * max |k|_inf * scale over the keys it reads, and when that exceeds 90 (16-bit operand terms
                          then no longer hold 1e-3) it redoes its rows in exact fp32 arithmetic before it exits -- ONE launch
                          (round 4; a second, conditional launch before), no host round trip, and a hostile slab costs its own
                          tiles only; fa_last_forward_route() tells whether any workgroup did.  FA_KERNEL_SPLIT: the split
