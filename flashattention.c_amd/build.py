@@ -21,6 +21,7 @@ the no-device validation paths through ctypes) in a child process with the ASan 
 from __future__ import annotations
 
 import argparse
+import glob
 import os
 import shutil
 import subprocess
@@ -53,8 +54,8 @@ ABLATION_DEPENDENT = ["fa_fwd_bf16.hip", "fa_fwd_bf16_x4.hip", "fa_fwd_bf16_pipe
                       "fa_split_f32_d32.hip", "fa_split_f32_d64.hip"]
 ABL_LIB_PATH = os.path.join(PKG_DIR, "libflashattn_amd_ablation.so")
 ABL_DRIVER_PATH = os.path.join(PKG_DIR, "fa_driver_ablation")
-HEADERS = ["fa_common.h", "fa_kernels.h", "fa_bf16_common.h", "fa_split_kernel.h", "fa_bf16_xn_kernel.h", "experiments/fa_f32_t3_kernel.h", "fa_bf16_step.h",
-           os.path.join(ROOT, "include", "flashattn_amd.h")]
+# every header under csrc/ (globbed: a new header cannot be forgotten -- ADVICE r04) plus the C ABI
+HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "experiments", "*.h"))) + [os.path.join(ROOT, "include", "flashattn_amd.h")]
 COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
                 "-I", os.path.join(ROOT, "include"), "-I", CSRC]
 # per-source extras.  The split kernel keeps its fp32 arithmetic scalar: the SLP vectoriser would pair it into
