@@ -462,6 +462,22 @@ int keysplit_factor(const fa::FwdParams& p, int32_t d, int32_t causal, bool f32 
     return S;
 }
 
+// Exact fp32 arithmetic (FA_KERNEL_MFMA; 128-row workgroups, one per CU already reads 0.78 of the fp32 MFMA peak -- BH x N = 4 x 8192
+// 0.559 ms, 8 x 8192 1.055, 16 x 8192 2.061): a grid of fewer than 256 tiles leaves CUs idle, so its rows are cut into S <= 8 key shares
+// of >= 1024 keys until the launch has 256 .. 512 workgroups (round 5: 1 x 8192 took 0.555 ms unsplit, as long as 4 x 8192).
+int keysplit_factor_exact(const fa::FwdParams& p, int32_t d, int32_t causal)
+{
+    if (!dense_layout(p, d) || p.n < 2048) return 1;
+    const int64_t tiles = (int64_t)p.bh * ((p.n + 127) / 128);
+    // (a causal launch of one tile per CU lasts as long as its heaviest tile -- 4 x 8192 causal 0.552 ms, the non-causal launch's 0.559 --:
+    // a full round of causal tiles is still split)
+    if (tiles > (causal ? 256 : 255)) return 1;
+    int S = 1;
+    while (S < 8 && tiles * (2 * S) <= (causal ? 1024 : 512) && p.n / (2 * S) >= 1024) S *= 2;
+    while (S > 1 && (int64_t)(S - 1) * keysplit_rows(p, S, causal) >= p.n) --S;   // every share owns at least one key
+    return S;
+}
+
 // FA_KERNEL_AUTO, bf16 tensors, fp32 output (round 4): P as bf16 hi + bf16 lo in the one-wave-per-SIMD kernel (FA_KERNEL_PB2) -- one launch,
 // V as it is, no scratch, at every launch size: ms at BH x N x d against round 3's chain (V -> fp16 copy, two fp16 terms of P, empty
 // fallback launch), same box: 16 x 8192 x 64 0.352 / 0.367, 128 x 8192 x 64 2.78 / 2.79, causal 16 x 8192 x 64 0.205 / 0.227, 16 x 8192 x 128
@@ -518,7 +534,16 @@ Plan make_plan(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype,
     if (dtype == FA_DTYPE_F32) {
         if (sel.kind == FA_KERNEL_P16 || sel.kind == FA_KERNEL_P16X2 || sel.kind == FA_KERNEL_PB2)
             pl.status = fail(FA_ERR_UNSUPPORTED, "FA_KERNEL_P16 / FA_KERNEL_P16X2 / FA_KERNEL_PB2 are bf16-tensor kernels");
-        else if (sel.kind == FA_KERNEL_MFMA || (sel.kind == FA_KERNEL_AUTO && f32_auto_is_exact())) pl.route = kRouteF32Exact;
+        else if (sel.kind == FA_KERNEL_MFMA || (sel.kind == FA_KERNEL_AUTO && f32_auto_is_exact())) {
+            pl.route = kRouteF32Exact;
+            const int S = (scratch_ok && sel.variant == 0) ? keysplit_factor_exact(p, d, causal) : 1;
+            if (S > 1) {   // idle grids: key shares + combine
+                pl.S = S;
+                pl.part_off = kWsHeader;
+                pl.part_bytes = (size_t)S * p.bh * p.n * d * 4u + (size_t)S * p.bh * p.n * 4u;
+                pl.total = pl.part_off + align256(pl.part_bytes);
+            }
+        }
         else if (sel.kind == FA_KERNEL_AUTO && sel.variant == 0) {
             pl.route = kRouteF32Guarded;
             if (scratch_ok) pl.total = kWsHeader;   // the chain's verdict word (a caller-owned workspace keeps it off the slot table)
@@ -650,7 +675,7 @@ hipError_t launch_bf16_keysplit(const fa::FwdParams& p0, int32_t d, int32_t caus
 
 // fp32 tensors, key-split launch of the split kernel: p0 carries the chain's flag fields (flag_mode 3: every share bounds the logit
 // width of its own keys)
-hipError_t launch_f32_keysplit(const fa::FwdParams& p0, int32_t d, int32_t causal, int S, char* part, hipStream_t stream)
+hipError_t launch_f32_keysplit(const fa::FwdParams& p0, int32_t d, int32_t causal, int S, char* part, hipStream_t stream, bool exact = false)
 {
     const int n_kv = keysplit_rows(p0, S, causal);
     const size_t o_bytes = (size_t)S * p0.bh * p0.n * d * 4u;
@@ -668,7 +693,7 @@ hipError_t launch_f32_keysplit(const fa::FwdParams& p0, int32_t d, int32_t causa
     p.lse = lse_part;
     p.n_kv = n_kv;
     p.n_kv_total = p0.n;
-    hipError_t e = fa::launch_f32_split(p, d, causal ? 1 : 0, 0, stream);
+    hipError_t e = exact ? fa::launch_fwd_f32(p, d, causal ? 1 : 0, 0, stream) : fa::launch_f32_split(p, d, causal ? 1 : 0, 0, stream);
     fa::FwdParams pc = p0;
     pc.flag_mode = 0;
     if (e == hipSuccess) e = fa::launch_combine_splits(pc, o_part, lse_part, S, d, 1, stream);
@@ -804,7 +829,10 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
     };
     switch (pl.route) {
         case kRouteNaive: e = fa::launch_naive_f32(p, d, c, stream); break;
-        case kRouteF32Exact: e = fa::launch_fwd_f32(p, d, c, sel.variant, stream); break;
+        case kRouteF32Exact:
+            if (pl.S > 1) e = launch_f32_keysplit(p, d, causal, pl.S, scratch + pl.part_off, stream, true);
+            else e = fa::launch_fwd_f32(p, d, c, sel.variant, stream);
+            break;
         case kRouteF32Split: e = fa::launch_f32_split(p, d, c, sel.variant, stream); break;
         case kRouteF32Guarded: {   // split products behind the logit-width guard: ONE launch (round 4) -- a workgroup whose logits are too wide
             FlagRef f;              // for 16-bit operand terms redoes its own rows in fp32 arithmetic inside the kernel (flag_mode 4).  The word

@@ -20,11 +20,18 @@
 
 namespace fa {
 
-template <int D, int NWAVES, bool CAUSAL, int MINWAVES>
+// PAIRED (causal only): one workgroup computes TWO q-tiles, the heavy tile T - 1 - i and then the light tile i of its slab, so that every
+// workgroup of the launch does the same T + 1 tile-steps of work whatever its position (round 5).  Unpaired, a causal launch is a bag
+// of tiles of 1 .. T steps on three to four co-resident workgroups per CU: c3-causal read 0.67 of the fp32 MFMA peak where the
+// non-causal launch reads 0.85, all of it load imbalance (the masked diagonal costs ~1 %).
+// Key shares (FwdParams::n_kv > 0, round 5): as in the split kernel -- the "head" index of a slab is the share, kv_head_stride carries the
+// key offset, the kernel works in the share's local key coordinates and leaves a normalised partial + its log-sum-exp for the combine.
+template <int D, int NWAVES, bool CAUSAL, int MINWAVES, bool PAIRED>
 __global__ __launch_bounds__(NWAVES* kWave, MINWAVES) void fa_fwd_f32_kernel(FwdParams p)
 {
     using C = F32Cfg<D, NWAVES>;
     constexpr int BM = NWAVES * 32;
+    static_assert(CAUSAL || !PAIRED, "pairing balances causal launches only");
 
     __shared__ __attribute__((aligned(1024))) char smem[2 * C::kStageBytes];
 
@@ -33,55 +40,88 @@ __global__ __launch_bounds__(NWAVES* kWave, MINWAVES) void fa_fwd_f32_kernel(Fwd
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    const int total = p.bh * p.q_tiles;
+    const int total = p.bh * p.q_tiles;   // PAIRED: q_tiles counts pairs
     const int w = xcd_remap(blockIdx.x, total);
     const int slab = w / p.q_tiles;
     int qt = w % p.q_tiles;
-    if (CAUSAL) qt = causal_tile(p, qt);
     const int n = p.n;
-    const int q0 = qt * BM + wave * 32;
+    const int tiles = (n + BM - 1) / BM;
+    if (CAUSAL && !PAIRED) qt = causal_tile(p, qt);
 
     const int b = slab / p.heads, h = slab % p.heads;
     const float* qg = (const float*)p.q + b * p.q_batch_stride + h * p.q_head_stride;
     const float* kg = (const float*)p.k + b * p.kv_batch_stride + h * p.kv_head_stride;
     const float* vg = (const float*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
     const int64_t o_slab = b * p.o_batch_stride + h * p.o_head_stride;
+    const int kbeg = p.n_kv > 0 ? h * p.n_kv : 0;
+    const int nk = p.n_kv > 0 ? min(p.n_kv, p.n_kv_total - kbeg) : n;
 
-    int kv_end = n;
-    if (CAUSAL) kv_end = min(n, qt * BM + BM);
-    f32_exact_rows<D, NWAVES, CAUSAL>(p, smem, qg, kg, vg, o_slab, slab, q0, 0, n, kv_end, wave, lane);
+#pragma unroll 1
+    for (int half = 0; half < (PAIRED ? 2 : 1); ++half) {
+        int t = qt;
+        if constexpr (PAIRED) {
+            t = half == 0 ? tiles - 1 - qt : qt;
+            if (half == 1) {
+                if (qt == tiles - 1 - qt) break;   // odd tile count: the middle tile is its own pair
+                __syncthreads();                   // every wave is out of the heavy tile's last stage
+            }
+        }
+        const int q0 = t * BM + wave * 32;
+        int kv_end = nk;
+        if (CAUSAL) kv_end = min(nk, t * BM + BM - kbeg);
+        if (CAUSAL && kv_end <= 0) {   // a key share entirely above this tile: weight 0 in the combine (workgroup-uniform)
+            const int qi = q0 + (lane & 31);
+            if (qi < n && p.lse != nullptr && lane < 32) p.lse[(int64_t)slab * n + qi] = -INFINITY;
+            continue;
+        }
+        f32_exact_rows<D, NWAVES, CAUSAL>(p, smem, qg, kg, vg, o_slab, slab, q0, kbeg, nk, kv_end, wave, lane);
+    }
 }
 
 // MINWAVES_C: the occupancy hint of the causal instantiation (the mask code needs a few registers more: at 4 waves per SIMD, i.e.
 // 128 registers, the D = 64 causal kernel spilled 56 bytes per lane)
+// order: 0 = the product choice, 1 = one tile per workgroup, 2 = paired tiles (causal only)
 template <int D, int NWAVES, int MINWAVES, int MINWAVES_C = MINWAVES>
-static hipError_t launch_cfg_f32(const FwdParams& p0, int causal, hipStream_t stream)
+static hipError_t launch_cfg_f32(const FwdParams& p0, int causal, int order, hipStream_t stream)
 {
     FwdParams p = p0;
     constexpr int BM = NWAVES * 32;
-    p.q_tiles = (p.n + BM - 1) / BM;
+    const int tiles = (p.n + BM - 1) / BM;
+    // Pairing halves the number of workgroups and makes them equally long.  Sweep over 190 causal shapes (profiles/r05_exact_causal_sweep.txt,
+    // ms paired / one tile per workgroup): from ~480 pairs on it wins or ties at every head dim (d = 64: 768 pairs 0.73-0.78, 1024 0.73-0.87,
+    // 2048 0.87-0.91, 8192 0.97; c3-causal, 512 pairs: 1.00; d = 128 16 x 8192 0.87); one round of pairs on most of the CUs (144 .. 256) is
+    // never more than 3 % behind and up to 1.5x ahead where the alternating order of single tiles lands badly (32 x 1500 0.67, 12 x 4096 0.71,
+    // 40 x 1500 0.68); fewer pairs than that leave CUs idle (1.05-1.28), and in between (257 .. 479) single tiles are 2-6 % ahead.
+    // Key shares (n_kv > 0) are short rows on an idle chip: one tile per workgroup.
+    const int pairs = (tiles + 1) / 2;
+    const int64_t npairs = (int64_t)p.bh * pairs;
+    const bool pair_auto = npairs >= 480 || (npairs >= 144 && npairs <= 256 && tiles >= 8);
+    const bool paired = causal && p.n_kv == 0 && (order == 2 || (order == 0 && pair_auto));
+    p.q_tiles = paired ? pairs : tiles;
     const int64_t total = (int64_t)p.bh * p.q_tiles;
     if (total > 0x7fffffffLL) return hipErrorInvalidValue;
     dim3 grid((unsigned)total), block(NWAVES * kWave);
-    // Three to six workgroups share a CU here.  Dealing a slab's tiles alternately from the heavy and the light end (causal_tile:
-    // even rounds of an XCD's workgroups heavy, odd rounds light) evens out what the co-resident workgroups of a CU add up to.
+    // Unpaired causal launches: three to six workgroups share a CU.  Dealing a slab's tiles alternately from the heavy and the light end
+    // (causal_tile: even rounds of an XCD's workgroups heavy, odd rounds light) evens out what the co-resident workgroups of a CU add up to.
     // Measured, causal, ms plain -> alternating: 16 x 4096 d = 64 0.538 -> 0.328, 8 x 8192 0.787 -> 0.617, 12 x 8192 1.321 -> 1.073,
     // 16 x 8192 d = 32 0.848 -> 0.630, 16 x 8192 d = 64 1.338 -> 1.308, 128 x 1024 0.248 -> 0.236, d = 128 2.45 -> 2.47.
-    p.alt_order = causal ? 1 : 0;
-    if (causal)
-        hipLaunchKernelGGL((fa_fwd_f32_kernel<D, NWAVES, true, MINWAVES_C>), grid, block, 0, stream, p);
+    p.alt_order = (causal && !paired) ? 1 : 0;
+    if (paired)
+        hipLaunchKernelGGL((fa_fwd_f32_kernel<D, NWAVES, true, MINWAVES_C, true>), grid, block, 0, stream, p);
+    else if (causal)
+        hipLaunchKernelGGL((fa_fwd_f32_kernel<D, NWAVES, true, MINWAVES_C, false>), grid, block, 0, stream, p);
     else
-        hipLaunchKernelGGL((fa_fwd_f32_kernel<D, NWAVES, false, MINWAVES>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((fa_fwd_f32_kernel<D, NWAVES, false, MINWAVES, false>), grid, block, 0, stream, p);
     return hipGetLastError();
 }
 
 hipError_t launch_fwd_f32(const FwdParams& p, int d, int causal, int variant, hipStream_t stream)
 {
-    (void)variant;
+    if (variant < 0 || variant > 2 || (variant == 2 && !causal)) return hipErrorInvalidValue;   // 1 / 2: one tile per workgroup / paired tiles
     switch (d) {
-        case 32: return launch_cfg_f32<32, 4, 4>(p, causal, stream);
-        case 64: return launch_cfg_f32<64, 4, 4, 3>(p, causal, stream);
-        case 128: return launch_cfg_f32<128, 4, 2>(p, causal, stream);
+        case 32: return launch_cfg_f32<32, 4, 4>(p, causal, variant, stream);
+        case 64: return launch_cfg_f32<64, 4, 4, 3>(p, causal, variant, stream);
+        case 128: return launch_cfg_f32<128, 4, 2>(p, causal, variant, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -48,6 +48,9 @@
 #ifndef FA_SPLIT_REF
 #define FA_SPLIT_REF 1   // 0: experiment switch -- the fast pass runs reference-free (p = exp2(s), round 2)
 #endif
+#ifndef FA_SPLIT_QK16
+#define FA_SPLIT_QK16 1  // 0: experiment switch -- K and Q' of fp32 tensors as two BF16 terms (16 bits: rounds 1-4) instead of two FP16 terms
+#endif
 
 namespace fa {
 
@@ -59,7 +62,10 @@ constexpr float kSplitTinyAcc = 0x1p-116f;   // sum of a row's unnormalised accu
 // and rows at 95 .. 100 read up to 1.19e-3 in the LSE (soak seed 101 case 297; sweep over 126 launches, worst |O| / |lse| error of rows under
 // L: 60 -> 3.6e-4 / 5.0e-4, 75 -> 5.9e-4 / 7.1e-4, 100 -> 7.0e-4 / 8.2e-4, 125 -> 8.4e-4 / 1.05e-3: profiles/r04_experiments.txt part 9)
 // 75 would put unit-variance data at d = 128, scale 1 (up to 78) on the fallback: 90.
-constexpr float kGuardLimit = 90.0f;
+constexpr float kGuardLimit = 90.0f;   // (FA_SPLIT_QK16 = 0 builds only: the bf16-term form of rounds 1-4)
+// fp16-term form (round 5): D * max|k| + sqrt(D) * max|q'|_2 above which the subnormal lo terms of small elements could add more than
+// 2^-25 * 2048 = 2^-14 (4e-5 nat) to a logit; unit-variance data: ~520 at d = 64, ~860 at d = 128 (scale 1)
+constexpr float kSubnormalBudget = 2048.0f;
 
 // running maximum of |a|, |b|: one instruction (abs as source modifiers)
 __device__ __forceinline__ void absmax2(float& m, float a, float b)
@@ -108,29 +114,49 @@ __device__ __forceinline__ void split2c(float a, float b, bf16x2& hi, bf16x2& lo
     const f32x2_t lv = {a - hf[0], b - hf[1]};
     lo = __builtin_convertvector(lv, bf16x2);
 }
-__device__ __forceinline__ void split8c(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo)
+// Two-term FP16 split of a pair of fp32 values (the operands of K.Q'^T for fp32 tensors, round 5): hi = f16(x) to nearest even, lo =
+// f16(x - hi) -- 22 significant bits where two bf16 terms hold 16, on the same matrix pipe at the same rate (v_mfma_f32_32x32x16_f16).
+// x - hi is ONE instruction: v_fma_mix_f32 reads the packed f16 half directly (fma(hi, -1, x), exact); v_cvt_pk_f16_f32 rounds to nearest
+// even and keeps fp16 subnormals.  The pair travels in a bf16x2-typed register (bits only; the matrix instruction gives them their meaning).
+// Range: |x| >= 65520 makes hi = inf and lo = -inf, whose products are NaN -- caught by the guard (see the kernel); |x - hi| < 2^-14 makes
+// lo a subnormal with an absolute error <= 2^-25, bounded by the guard as well.
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ void split2h(float a, float b, bf16x2& hi, bf16x2& lo)
+{
+    const f32x2_t ab = {a, b};
+    const f16x2_t h = __builtin_convertvector(ab, f16x2_t);
+    const unsigned hp = __builtin_bit_cast(unsigned, h);
+    f32x2_t lv;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lv[0]) : "v"(hp), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lv[1]) : "v"(hp), "v"(b));
+    const f16x2_t l = __builtin_convertvector(lv, f16x2_t);
+    hi = __builtin_bit_cast(bf16x2, h);
+    lo = __builtin_bit_cast(bf16x2, l);
+}
+// F16 = the fp16 split (K and Q' of fp32 tensors), else the bf16 split (V, P; everything for bf16 tensors); ASM = the form whose four
+// middle instructions are asm (the phase-structured pass), else plain C++ (the slot-scheduled pass)
+template <bool F16, bool ASM>
+__device__ __forceinline__ void split2x(float a, float b, bf16x2& hi, bf16x2& lo)
+{
+    if constexpr (F16) split2h(a, b, hi, lo);
+    else if constexpr (ASM) split2(a, b, hi, lo);
+    else split2c(a, b, hi, lo);
+}
+template <bool F16, bool ASM>
+__device__ __forceinline__ void split8x(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo)
 {
 #pragma unroll
     for (int i = 0; i < 4; i += 2) {
         bf16x2 h, l;
-        split2c(a[i], a[i + 1], h, l);
+        split2x<F16, ASM>(a[i], a[i + 1], h, l);
         hi[i] = h[0], hi[i + 1] = h[1], lo[i] = l[0], lo[i + 1] = l[1];
-        split2c(b[i], b[i + 1], h, l);
+        split2x<F16, ASM>(b[i], b[i + 1], h, l);
         hi[i + 4] = h[0], hi[i + 5] = h[1], lo[i + 4] = l[0], lo[i + 5] = l[1];
     }
 }
-
-__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo)
-{
-#pragma unroll
-    for (int i = 0; i < 4; i += 2) {
-        bf16x2 h, l;
-        split2(a[i], a[i + 1], h, l);
-        hi[i] = h[0], hi[i + 1] = h[1], lo[i] = l[0], lo[i + 1] = l[1];
-        split2(b[i], b[i + 1], h, l);
-        hi[i + 4] = h[0], hi[i + 5] = h[1], lo[i + 4] = l[0], lo[i + 5] = l[1];
-    }
-}
+__device__ __forceinline__ void split8c(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) { split8x<false, false>(a, b, hi, lo); }
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) { split8x<false, true>(a, b, hi, lo); }
 
 __device__ __forceinline__ void split_p(const f32x16& s, int base, bf16x8& hi, bf16x8& lo)
 {
@@ -148,17 +174,31 @@ __device__ __forceinline__ void split_p(const f32x16& s, int base, bf16x8& hi, b
 //   s_nop 1   in front of every product: an operand may have been copied into place (v_accvgpr_read_b32, v_mov_b32) by
 //             the instruction before, and VALU write -> MFMA read needs two wait states;
 //   scores_retire() after the chain, before any VALU instruction may read the scores.
+// F16: the operand registers hold fp16 pairs (split2h) and the product is v_mfma_f32_32x32x16_f16 -- same shape, same rate
+template <bool F16 = false>
 __device__ __forceinline__ void mfma_from(f32x16& d, const bf16x8& a, const bf16x8& b, const f32x16& c)
 {
-    asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    if constexpr (F16) asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    else asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
 }
+template <bool F16 = false>
 __device__ __forceinline__ void mfma_from_zero(f32x16& d, const bf16x8& a, const bf16x8& b)
 {
-    asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    if constexpr (F16) asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    else asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
 }
+template <bool F16 = false>
 __device__ __forceinline__ void mfma_acc(f32x16& d, const bf16x8& a, const bf16x8& b)
 {
-    asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+    if constexpr (F16) asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+    else asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+}
+// the builtin form (slot-scheduled pass)
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_qk(const bf16x8& a, const bf16x8& b, const f32x16& c)
+{
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 // four consecutive output values: fp32, or bf16 when the caller's O is bf16 (p.o_is_bf16, bf16 tensors only)
@@ -183,6 +223,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     using C = SplitCfg<D>;
     using T = std::conditional_t<IN_BF16, __bf16, float>;   // element type of Q, K, V
     constexpr int NPROD = IN_BF16 ? 2 : 3;                  // matrix products per contraction
+    constexpr bool QK16 = !IN_BF16 && FA_SPLIT_QK16;       // K and Q' as two FP16 terms (22 bits), K.Q'^T on v_mfma_f32_32x32x16_f16
     constexpr int KS = D / 16;   // k-steps of S^T = K Q^T
     constexpr int DB = D / 32;   // 32-wide blocks of the head dim in O^T
     constexpr int NT = NWAVES * kWave;
@@ -289,7 +330,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) absmax2(kmax, kst[i][0][e], kst[i][0][e + 1]), absmax2(kmax, kst[i][1][e], kst[i][1][e + 1]);
                 }
-                split8(kst[i][0], kst[i][1], h8, l8);
+                split8x<QK16, true>(kst[i][0], kst[i][1], h8, l8);
                 *(bf16x8*)(stage + g_kdst[i]) = h8;
                 *(bf16x8*)(stage + C::kImageBytes + g_kdst[i]) = l8;
                 split8(vst[i][0], vst[i][1], h8, l8);
@@ -322,7 +363,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
 #pragma unroll
                 for (int e = 0; e < 4; ++e) qs = fmaf(a[e], a[e], fmaf(c[e], c[e], qs));
             }
-            split8(a, c, qh[qb][ks], ql[qb][ks]);
+            split8x<QK16, true>(a, c, qh[qb][ks], ql[qb][ks]);
         }
         if constexpr (GUARD) qn2 = fmaxf(qn2, xhalf_sum(qs));
     }
@@ -364,36 +405,55 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                 for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.0f;
         }
 
-        // scores of one tile for all QB blocks: three products per k-step, the first one starting from minit
+        // scores of one tile for all QB blocks.  ORDER (round 5): the accumulator starts at -m_ref (as large as the row's widest logit) and
+        // every matrix instruction rounds its result at the magnitude the partial sum has THEN -- so the hi.hi products of all k-steps come
+        // first (the partial sum walks from -m_ref down to the score's own small magnitude) and the cross terms, 2^-11 of them, are added
+        // last, where an ulp is small.  Interleaved per k-step (rounds 1-4) two thirds of the roundings happened at full magnitude: the
+        // coherent-input family of tests/adversarial.py read 1.9e-3 at d = 128 from that alone.  Without MREG the chain starts from zero
+        // and grows: there the cross terms go first.
         auto scores = [&](const char* kh_lds, f32x16 (&s)[QB]) {
+            auto hh_pass = [&](bool first_pass) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kfh = *(const bf16x8*)(kh_lds + k_off[ks]);
-                if constexpr (IN_BF16) {
-#pragma unroll
-                    for (int qb = 0; qb < QB; ++qb) {
-                        if (ks == 0) {
-                            if constexpr (MREG) mfma_from(s[qb], kfh, ql[qb][ks], minit[qb]);
-                            else mfma_from_zero(s[qb], kfh, ql[qb][ks]);
-                        } else {
-                            mfma_acc(s[qb], kfh, ql[qb][ks]);
-                        }
-                        mfma_acc(s[qb], kfh, qh[qb][ks]);
-                    }
-                } else {
-                    const bf16x8 kfl = *(const bf16x8*)(kh_lds + C::kImageBytes + k_off[ks]);
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 kfh = *(const bf16x8*)(kh_lds + k_off[ks]);
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) {
-                        if (ks == 0) {
-                            if constexpr (MREG) mfma_from(s[qb], kfl, qh[qb][ks], minit[qb]);
-                            else mfma_from_zero(s[qb], kfl, qh[qb][ks]);
+                        if (first_pass && ks == 0) {
+                            if constexpr (MREG) mfma_from<QK16>(s[qb], kfh, qh[qb][ks], minit[qb]);
+                            else mfma_from_zero<QK16>(s[qb], kfh, qh[qb][ks]);
                         } else {
-                            mfma_acc(s[qb], kfl, qh[qb][ks]);
+                            mfma_acc<QK16>(s[qb], kfh, qh[qb][ks]);
                         }
-                        mfma_acc(s[qb], kfh, ql[qb][ks]);
-                        mfma_acc(s[qb], kfh, qh[qb][ks]);
                     }
                 }
+            };
+            auto cross_pass = [&](bool first_pass) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 kfh = *(const bf16x8*)(kh_lds + k_off[ks]);
+                    if constexpr (IN_BF16) {   // K exact in one term: K . Q'_lo
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) {
+                            if (first_pass && ks == 0) mfma_from_zero(s[qb], kfh, ql[qb][ks]);
+                            else mfma_acc(s[qb], kfh, ql[qb][ks]);
+                        }
+                    } else {
+                        const bf16x8 kfl = *(const bf16x8*)(kh_lds + C::kImageBytes + k_off[ks]);
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) {
+                            if (first_pass && ks == 0) mfma_from_zero<QK16>(s[qb], kfl, qh[qb][ks]);
+                            else mfma_acc<QK16>(s[qb], kfl, qh[qb][ks]);
+                            mfma_acc<QK16>(s[qb], kfh, ql[qb][ks]);
+                        }
+                    }
+                }
+            };
+            if constexpr (MREG) {
+                hh_pass(true);
+                cross_pass(false);
+            } else {
+                cross_pass(true);
+                hh_pass(false);
             }
             // let the last product retire (19 wait states cover its 8 passes), tied to the registers the chain writes
             if constexpr (QB == 1) asm volatile("s_nop 15\n\ts_nop 2" : "+v"(s[0]));
@@ -642,7 +702,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
 #pragma unroll
                         for (int e = 0; e < 4; e += 2) absmax2(kmax, kst[i][0][e], kst[i][0][e + 1]), absmax2(kmax, kst[i][1][e], kst[i][1][e + 1]);
                     }
-                    split8c(kst[i][0], kst[i][1], h8, l8);
+                    split8x<QK16, false>(kst[i][0], kst[i][1], h8, l8);
                     *(bf16x8*)(stage + g_kdst[i]) = h8;
                     *(bf16x8*)(stage + C::kImageBytes + g_kdst[i]) = l8;
                 }
@@ -662,23 +722,25 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                 }
             }
         };
-        auto qk = [&](const char* kh_lds, f32x16 (&s)[QB]) {
+        auto qk = [&](const char* kh_lds, f32x16 (&s)[QB]) {   // hi.hi products of every k-step first, cross terms last: see scores()
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kfh = *(const bf16x8*)(kh_lds + k_off[ks]);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) s[qb] = mfma_qk<QK16>(kfh, qh[qb][ks], ks == 0 ? minit[qb] : s[qb]);
+            }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 kfh = *(const bf16x8*)(kh_lds + k_off[ks]);
                 if constexpr (IN_BF16) {
 #pragma unroll
-                    for (int qb = 0; qb < QB; ++qb) {
-                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, ql[qb][ks], ks == 0 ? minit[qb] : s[qb], 0, 0, 0);
-                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, qh[qb][ks], s[qb], 0, 0, 0);
-                    }
+                    for (int qb = 0; qb < QB; ++qb) s[qb] = mfma_qk<false>(kfh, ql[qb][ks], s[qb]);
                 } else {
                     const bf16x8 kfl = *(const bf16x8*)(kh_lds + C::kImageBytes + k_off[ks]);
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) {
-                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl, qh[qb][ks], ks == 0 ? minit[qb] : s[qb], 0, 0, 0);
-                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, ql[qb][ks], s[qb], 0, 0, 0);
-                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, qh[qb][ks], s[qb], 0, 0, 0);
+                        s[qb] = mfma_qk<QK16>(kfl, qh[qb][ks], s[qb]);
+                        s[qb] = mfma_qk<QK16>(kfh, ql[qb][ks], s[qb]);
                     }
                 }
             }
@@ -820,30 +882,46 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                         }
                     }
                 }
-                constexpr int MPG = NPROD * QB, NG = KS + 2 * DB, NSLOT = NG * MPG;
+                // Groups (round 5: the hi.hi products of ALL k-steps first, the cross terms behind them -- see scores() for why):
+                //   [0, KS)          hi.hi of k-step G, one product per block                        (fragment: K_hi(G))
+                //   [KS, 2 KS)       the cross terms of k-step G - KS, NPROD - 1 per block            (K_hi and, fp32 tensors, K_lo: read again)
+                //   [2 KS, 2 KS + 2 DB)  a (key half, head-dim block) of V^T.P^T, NPROD per block     (V_hi, V_lo)
+                // The fragments of a group are requested TWO groups ahead (three register sets): the hi.hi groups are only QB slots long.
+                constexpr int NQ1 = QB, NQ2 = (NPROD - 1) * QB, NPV = NPROD * QB;
+                constexpr int NG = 2 * KS + 2 * DB, NSLOT = KS * (NQ1 + NQ2) + 2 * DB * NPV;
+                constexpr auto group_start = [](int G) constexpr {
+                    return G < KS ? G * NQ1 : G < 2 * KS ? KS * NQ1 + (G - KS) * NQ2 : KS * (NQ1 + NQ2) + (G - 2 * KS) * NPV;
+                };
+                constexpr auto group_of = [group_start](int I) constexpr {
+                    int G = 0;
+                    while (G + 1 < NG && group_start(G + 1) <= I) ++G;
+                    return G;
+                };
                 constexpr int NU_S = 8 * QB;                                     // score pairs
                 constexpr int NU_C = IN_BF16 ? 2 * GPT : 8 * GPT;               // K/V pieces: plain stores, or half units of the split
                 constexpr int NU = 2 * NU_S + NU_C;                              // half units
-                bf16x8 fh[2], fl[2];       // fragments of the current / next group
+                bf16x8 fh[3], fl[3];       // fragments of the current group and the two behind it
                 bf16x8 ch[2][GPT], cl[2][GPT];   // converted pieces (K, V) being assembled
                 const char* k_img = st_oth;                          // K(j+1) hi (lo at + kImageBytes)
                 const char* v_img = st_oth + 2 * C::kImageBytes;     // V(j-1) hi
                 auto load_frags = [&](auto gc) {
                     constexpr int G = decltype(gc)::value;
                     if constexpr (G < KS) {
-                        fh[G & 1] = *(const bf16x8*)(k_img + k_off[G]);
-                        if constexpr (!IN_BF16) fl[G & 1] = *(const bf16x8*)(k_img + C::kImageBytes + k_off[G]);
+                        fh[G % 3] = *(const bf16x8*)(k_img + k_off[G]);
+                    } else if constexpr (G < 2 * KS) {
+                        fh[G % 3] = *(const bf16x8*)(k_img + k_off[G - KS]);
+                        if constexpr (!IN_BF16) fl[G % 3] = *(const bf16x8*)(k_img + C::kImageBytes + k_off[G - KS]);
                     } else {
-                        constexpr int t = (G - KS) / DB, db = (G - KS) % DB;
+                        constexpr int t = (G - 2 * KS) / DB, db = (G - 2 * KS) % DB;
                         constexpr int off0 = ((4 * t + 0) * (D / 16) + 2 * db) * 128;
                         constexpr int off1 = ((4 * t + 2) * (D / 16) + 2 * db) * 128;
                         const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_img + v_lane_off + off0));
                         const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_img + v_lane_off + off1));
-                        fh[G & 1] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                        fh[G % 3] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
                         if constexpr (!IN_BF16) {
                             const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_img + C::kImageBytes + v_lane_off + off0));
                             const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(v_img + C::kImageBytes + v_lane_off + off1));
-                            fl[G & 1] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                            fl[G % 3] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
                         }
                     }
                 };
@@ -872,7 +950,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                         const f32x4 x = which ? vst[gi][half] : kst[gi][half];
                         if constexpr (GUARD && which == 0) absmax2(kmax, x[2 * H], x[2 * H + 1]);
                         bf16x2 h2, l2;
-                        split2c(x[2 * H], x[2 * H + 1], h2, l2);
+                        split2x<QK16 && which == 0, false>(x[2 * H], x[2 * H + 1], h2, l2);   // K pieces: fp16 terms (fp32 tensors)
                         ch[which][gi][4 * half + 2 * H] = h2[0], ch[which][gi][4 * half + 2 * H + 1] = h2[1];
                         cl[which][gi][4 * half + 2 * H] = l2[0], cl[which][gi][4 * half + 2 * H + 1] = l2[1];
                         if constexpr (half == 1 && H == 1) {   // piece complete: K(j+2) over K(j), V(j) over V(j-2), both in this tile's stage
@@ -883,19 +961,25 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                     }
                 };
                 load_frags(std::integral_constant<int, 0>{});
+                load_frags(std::integral_constant<int, 1>{});
                 auto slot = [&](auto ic) {
                     constexpr int I = decltype(ic)::value;
-                    constexpr int G = I / MPG, M = I % MPG, term = M / QB, qb = M % QB;   // consecutive products alternate accumulators
-                    if constexpr (M == 0 && G + 1 < NG) load_frags(std::integral_constant<int, G + 1>{});
-                    // fp32 tensors: lo.hi, hi.lo, hi.hi; bf16 tensors (K, V exact in one term): hi.lo, hi.hi
-                    constexpr bool a_lo = !IN_BF16 && term == 0, b_lo = IN_BF16 ? term == 0 : term == 1;
-                    const bf16x8& a = a_lo ? fl[G & 1] : fh[G & 1];
-                    if constexpr (G < KS) {
-                        const bf16x8& bq = b_lo ? ql[qb][G] : qh[qb][G];
-                        if constexpr (G == 0 && term == 0) next[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, minit[qb], 0, 0, 0);
-                        else next[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, next[qb], 0, 0, 0);
-                    } else {
-                        constexpr int t = (G - KS) / DB, db = (G - KS) % DB;
+                    constexpr int G = group_of(I), M = I - group_start(G);
+                    if constexpr (M == 0 && G + 2 < NG) load_frags(std::integral_constant<int, G + 2>{});
+                    if constexpr (G < KS) {                    // hi.hi of k-step G; the first one starts from -(m0 + B)
+                        constexpr int qb = M;
+                        if constexpr (G == 0) next[qb] = mfma_qk<QK16>(fh[G % 3], qh[qb][G], minit[qb]);
+                        else next[qb] = mfma_qk<QK16>(fh[G % 3], qh[qb][G], next[qb]);
+                    } else if constexpr (G < 2 * KS) {         // cross terms -- fp32 tensors: K_lo.Q'_hi, K_hi.Q'_lo; bf16 tensors: K.Q'_lo
+                        constexpr int ks = G - KS, term = M / QB, qb = M % QB;
+                        constexpr bool a_lo = !IN_BF16 && term == 0;
+                        const bf16x8& a = a_lo ? fl[G % 3] : fh[G % 3];
+                        const bf16x8& bq = a_lo ? qh[qb][ks] : ql[qb][ks];
+                        next[qb] = mfma_qk<QK16>(a, bq, next[qb]);
+                    } else {                                   // fp32 tensors: lo.hi, hi.lo, hi.hi; bf16 tensors (V exact in one term): hi.lo, hi.hi
+                        constexpr int t = (G - 2 * KS) / DB, db = (G - 2 * KS) % DB, term = M / QB, qb = M % QB;
+                        constexpr bool a_lo = !IN_BF16 && term == 0, b_lo = IN_BF16 ? term == 0 : term == 1;
+                        const bf16x8& a = a_lo ? fl[G % 3] : fh[G % 3];
                         const bf16x8& bp = b_lo ? plp[qb][t] : php[qb][t];
                         o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bp, o[qb][db], 0, 0, 0);
                     }
@@ -982,7 +1066,16 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
         //   flag_mode 4 (FA_KERNEL_AUTO, round 4): by THIS workgroup, for its own rows, right here (fa_f32_exact.h: the body of the exact
         //               kernel over the same keys, in the LDS this kernel is done with); the word, if the caller has one, only reports it;
         //   flag_mode 3 (the ablation library's chains): by the exact kernel queued behind this launch, for the whole grid.
-        const bool wide = p.flag_mode >= 3 && (saw_nan || !(sqrtf(qn2) * __uint_as_float(s_kmax) <= kGuardLimit * kLog2e));
+        bool wide;
+        if constexpr (QK16) {
+            // fp16 terms: what the guard bounds is the RANGE of fp16, not the logit width (3 * 2^-22 * sum |q'_i k_i| is below the rounding
+            // bound of the fp32 FMA chain itself, d * 2^-24 * sum |q'_i k_i|, at every width).  (1) |x| >= 65520 -> hi = inf, lo = -inf ->
+            // NaN scores -> saw_nan (as for NaN / inf inputs).  (2) an element below 2^-3 has a subnormal lo term, absolute error <= 2^-25,
+            // multiplied by its partner: sum <= 2^-25 (|k|_1 + |q'|_1) <= 2^-25 (D |k|_inf + sqrt(D) |q'|_2) per logit; kept <= 2^-14.
+            wide = p.flag_mode >= 3 && (saw_nan || !((float)D * __uint_as_float(s_kmax) + sqrtf((float)D * qn2) <= kSubnormalBudget));
+        } else {
+            wide = p.flag_mode >= 3 && (saw_nan || !(sqrtf(qn2) * __uint_as_float(s_kmax) <= kGuardLimit * kLog2e));
+        }
         if (p.flag_mode == 3) {
             if (wide) __hip_atomic_store(p.flag, p.flag_serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (p.flag_mode == 4) {   // (uniform)

@@ -85,6 +85,20 @@ def randn(seed, *shape):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)).numpy()
 
 
+RANGE_SHIFT = 2.0 ** 13
+
+
+def range_hostile(q, k, slab):
+    """In place: slab `slab` of q times 2^-13, of k times 2^13 -- powers of two, so the logits, the fp64 oracle and the exact kernel's result
+    are what they were, but the fp16 operand terms of the fp32 default (round 5: K and Q' as fp16 hi + lo) lose the small side to fp16
+    subnormals (absolute error 2^-25 per element, times a partner of ~2^13): the input on which the UNGUARDED split products are visibly
+    wrong (~1e-3) and the guard of FA_KERNEL_AUTO (D |k|_inf + sqrt(D) |q'|_2 <= 2048) must hand the workgroup to fp32 arithmetic.  (Until
+    round 4 the hostile input was a wide logit -- one key times 40 --, which two fp16 terms now simply compute correctly.)"""
+    q[slab] *= 1.0 / RANGE_SHIFT
+    k[slab] *= RANGE_SHIFT
+    return q, k
+
+
 def test_extension_is_the_in_tree_library():
     # the product path is the hipcc-built library next to the package, not a fallback
     assert os.path.samefile(_cabi.LIB_PATH, os.path.join(ROOT, "flashattention.c_amd", "libflashattn_amd.so"))
@@ -475,6 +489,54 @@ def test_causal_alternating_tile_order_in_the_exact_kernel(bh, n, d):
     OBSERVED.append((f"exact kernel alternating causal order bh={bh} n={n} d={d}", err, 1e-4))
     assert err < 1e-4, f"{err:.3e}"
 
+
+
+@pytest.mark.parametrize("bh,n,d", [(16, 8192, 64), (128, 1024, 64), (40, 1500, 64), (5, 3000, 64), (13, 777, 64), (33, 129, 32), (7, 1300, 128), (260, 1000, 32), (3, 128, 64),
+                                    (31, 1153, 64)])
+def test_causal_paired_tiles_in_the_exact_kernel(bh, n, d):
+    """Round 5: a workgroup of the causal exact kernel computes the heavy tile T - 1 - i and then the light tile i of its slab (every
+    workgroup T + 1 tile-steps; the launcher pairs from ~480 pairs on and for one round of 144 .. 256).  Forced here (kernel "exact:2") and
+    through the launcher's own choice, against one tile per workgroup ("exact:1"): even and odd tile counts (the middle tile is its own
+    pair), ragged lengths, NaN-poisoned outputs (a bijection or poisoned rows stay), bit-equal results (same arithmetic, same order), LSE."""
+    q, k, v = (randn(s, bh, n, d) for s in (84, 85, 86))
+    qd, kd, vd = to_dev(q, k, v)
+    one, lse_one = fa.forward(qd, kd, vd, True, kernel="exact:1", return_lse=True)
+    for kern in ("exact:2", "exact"):
+        out = torch.full((bh, n, d), float("nan"), dtype=torch.float32, device=dev())
+        _, lse = fa.forward(qd, kd, vd, True, kernel=kern, out=out, return_lse=True)
+        assert not torch.isnan(out).any(), f"unwritten rows ({kern})"
+        if fa.workspace_bytes(bh, n, d, True, kernel=kern) == 0:       # (key shares: other partial sums, merged by the combine)
+            assert torch.equal(out, one) and torch.equal(lse, lse_one), kern
+    ref = fa.forward(qd, kd, vd, True, kernel="naive")
+    err = float((out - ref).abs().max())
+    OBSERVED.append((f"exact kernel paired causal tiles bh={bh} n={n} d={d}", err, 1e-4))
+    assert err < 1e-4, f"{err:.3e}"
+    with pytest.raises(_cabi.FlashAttnError):
+        fa.forward(qd, kd, vd, False, kernel="exact:2")                # pairing is a causal order
+    with pytest.raises(_cabi.FlashAttnError):
+        fa.forward(qd, kd, vd, True, kernel="exact:3")
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("bh,n,d", [(1, 8192, 64), (2, 8192, 64), (3, 5000, 64), (1, 16384, 64), (2, 7777, 32), (1, 4096, 128), (1, 2048, 64), (4, 8192, 64)])
+def test_exact_kernel_key_split_launch(bh, n, d, causal):
+    """Round 5: kernel="exact" on a grid that leaves CUs idle (fewer than 256 tiles of 128 rows; causal: a full round too) runs over S <= 8 key
+    shares + combine, like the split kernel does (1 x 8192: 0.555 -> 0.154 ms).  Against rung 0 and the fp64 oracle, LSE, NaN-poisoned
+    output, ragged lengths; a NULL workspace runs unsplit."""
+    q, k, v = (randn(s, bh, n, d) for s in (87, 88, 89))
+    qd, kd, vd = to_dev(q, k, v)
+    want_split = bh * ((n + 127) // 128) < (257 if causal else 256)
+    assert (fa.workspace_bytes(bh, n, d, causal, kernel="exact") > 0) == want_split
+    ref, lse_ref = fa.forward(qd, kd, vd, causal, kernel="naive", return_lse=True)
+    out = torch.full((bh, n, d), float("nan"), device=dev())
+    _, lse = fa.forward(qd, kd, vd, causal, kernel="exact", out=out, return_lse=True)
+    assert not torch.isnan(out).any() and fa.last_forward_route() == 0
+    err = float((out - ref).abs().max())
+    OBSERVED.append((f"exact key split bh={bh} n={n} d={d} causal={causal}", err, 1e-4))
+    assert err < 1e-4 and float((lse - lse_ref).abs().max()) < 1e-4
+    check(out[:1], orc.attention_f64(q[:1], k[:1], v[:1], causal=causal), 1e-4, "vs fp64 oracle")
+    unsplit = fa.forward(qd, kd, vd, causal, kernel="exact:1")
+    assert float((out - unsplit).abs().max()) < 1e-4
 
 
 @pytest.mark.parametrize("bh,n", [(128, 2048), (256, 1024), (512, 512), (96, 2048), (64, 3072), (48, 3000), (130, 2000)])
@@ -958,14 +1020,14 @@ def test_workspace_sizes_and_validation_of_the_non_allocating_entry():
 
 def test_torch_graph_capture_of_a_launch_chain_and_independent_replays():
     """torch.cuda.graph around fa.forward (workspace = a torch tensor of the graph's pool): the captured fp32 chain clears its verdict word
-    at the start of every replay.  Replay 1 sees a K with logits too wide for 16-bit operand terms (fallback: route 2), replay 2 the same
+    at the start of every replay.  Replay 1 sees a K outside the range of fp16 operand terms (range_hostile; fallback: route 2), replay 2 the same
     buffer with ordinary values (primary: route 1 -- a verdict left standing would keep the slower kernel forever), replay 3 the wide
     one again.  Then the same through fa_forward_ex on a capturing stream WITHOUT a workspace: the word then sits in a capture slot and
     is cleared by the same memset node (round 3 let the verdict of an earlier replay stand there)."""
     L = _cabi.lib()
     q, k, v = (torch.randn(8, 2048, 64, device=dev()) for _ in range(3))
     kwide = k.clone()
-    kwide[3, 77] *= 40.0
+    range_hostile(q, kwide, 3)                      # (q[3] is tiny for both K buffers; only kwide[3] is large)
     kbuf = kwide.clone()
     out = torch.zeros_like(q)
     ref_wide = fa.forward(q, kwide, v, False, kernel="exact")
@@ -1049,7 +1111,7 @@ def test_a_replayed_graph_keeps_its_verdict_while_thousands_of_chains_run_on_ano
     gen = torch.Generator(device=dev()).manual_seed(1042)     # (seeded: the premise below is a property of the data)
     q, k, v = (torch.randn(8, 1024, 64, device=dev(), generator=gen) for _ in range(3))
     kw = k.clone()
-    kw[3, 77] *= 40.0
+    range_hostile(q, kw, 3)
     exact = fa.forward(q, kw, v, False, kernel="exact")
     split = fa.forward(q, kw, v, False, kernel="split")
     apart = float((split[3] - exact[3]).abs().max())          # (slab 3 holds the wide key: the slab whose workgroups fall back)
@@ -1360,14 +1422,14 @@ def test_accurate_mode_holds_the_fp32_bar_on_several_seeds(name, bh, n, d):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# fp32 tensors: the logit-width guard of FA_KERNEL_AUTO
+# fp32 tensors: the range guard of FA_KERNEL_AUTO (rounds 2-4: a logit-width guard in front of 16-bit operand terms)
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("d", [32, 64, 128])
 @pytest.mark.parametrize("causal", [False, True])
-def test_fp32_auto_guard_routes_wide_logits_to_exact_arithmetic(d, causal):
-    """The inputs of the split kernel's redo test (scores up to 2^200 in the exp2 domain, a whole row of sigma-32 scores): with
-    16-bit operand terms they need a 3e-3 tolerance; FA_KERNEL_AUTO has to notice (|q|_2 |k|_inf scale > 90) and hand the
-    launch to the exact kernel, on the device -- 1e-3 holds without the caller knowing anything."""
+def test_fp32_auto_holds_the_bar_on_wide_logits(d, causal):
+    """The inputs of the split kernel's redo test (scores up to 2^200 in the exp2 domain, a whole row of sigma-32 scores).  With 16-bit
+    operand terms (rounds 1-4) they needed a 3e-3 tolerance, and FA_KERNEL_AUTO a logit-width guard that sent them to the exact kernel;
+    with fp16 hi + lo terms (22 bits, round 5) the split products hold 1e-3 on them by themselves -- whichever route the launch reports."""
     bh, n = 2, 1536
     q, k, v = (randn(s, bh, n, d) for s in (41, 42, 43))
     q *= np.sqrt(64.0 / d)
@@ -1378,30 +1440,35 @@ def test_fp32_auto_guard_routes_wide_logits_to_exact_arithmetic(d, causal):
     q[1, 500] *= -4.0
     ref, lse_ref = orc.attention_f64(q, k, v, causal=causal, return_lse=True)
     o, lse = fa.forward(*to_dev(q, k, v), causal, return_lse=True)
-    assert fa.last_forward_route() == 2, "guard did not fire"
+    assert fa.last_forward_route() in (1, 2)
     check(o, ref, TOL_F32, "auto")
     check(lse, lse_ref, TOL_F32, "auto lse")
+    o, lse = fa.forward(*to_dev(q, k, v), causal, return_lse=True, kernel="split")
+    check(o, ref, TOL_F32, "split (unguarded)")
+    check(lse, lse_ref, TOL_F32, "split (unguarded) lse")
 
 
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("bh,n,d", [(16, 8192, 64), (8, 1024, 64), (5, 1500, 64), (4, 2048, 128), (2, 8192, 128), (40, 700, 128), (4, 2048, 32), (3, 4100, 32)])
 def test_fp32_fallback_is_per_workgroup_and_inside_the_kernel(bh, n, d, causal):
-    """Round 4: FA_KERNEL_AUTO for fp32 tensors is ONE launch.  A workgroup of the split kernel whose logits are too wide for 16-bit operand
-    terms (|q'|_2 of its rows x |k|_inf of its slab) redoes its own rows with the body of the exact fp32 kernel (fa_f32_exact.h) before it
+    """Round 4: FA_KERNEL_AUTO for fp32 tensors is ONE launch.  A workgroup of the split kernel whose operands leave the range fp16 terms
+    hold (round 5: D |k|_inf of the keys it reads + sqrt(D) |q'|_2 of its rows > 2048; rounds 2-4: a logit-width bound) redoes its own rows
+    with the body of the exact fp32 kernel (fa_f32_exact.h) before it
     exits; round 3 queued the exact kernel behind every launch (a second dispatch, 3-10 us, that skipped itself) and, when one slab was
     hostile, recomputed ALL of them.  One hostile slab: its rows equal the exact kernel's, every other slab equals the unguarded split
     kernel's bit for bit, the word reports the fallback; every tiling the dispatch picks for these shapes (one and two 32-row blocks per
     wave, four and eight waves), ragged lengths, causal, LSE."""
     q, k, v = (randn(s, bh, n, d) for s in (141, 142, 143))
     hostile = bh // 2
-    k[hostile, n // 3] *= 60.0
-    k[hostile, n - 1] *= 60.0
+    q[hostile] *= 1.0 / RANGE_SHIFT          # (range_hostile, two keys only: tiles that end above the first of them have nothing to fall back for)
+    k[hostile, n // 3] *= RANGE_SHIFT
+    k[hostile, n - 1] *= RANGE_SHIFT
     qd, kd, vd = to_dev(q, k, v)
     out = torch.full((bh, n, d), float("nan"), device=dev())
     _, lse = fa.forward(qd, kd, vd, causal, out=out, return_lse=True)
     assert fa.last_forward_route() == 2
     assert not torch.isnan(out).any()
-    ex, lse_ex = fa.forward(qd, kd, vd, causal, kernel="exact", return_lse=True)
+    ex, lse_ex = fa.forward(qd, kd, vd, causal, kernel="exact:1", return_lse=True)   # (one tile per workgroup, all keys: what the fallback computes)
     sp, lse_sp = fa.forward(qd, kd, vd, causal, kernel="split", return_lse=True)
     key_split = fa.workspace_bytes(bh, n, d, causal) > 256      # idle grids: every share falls back on its own keys, the combine merges
     # causal: a workgroup bounds the logits of the keys it reads -- tiles that end before the first wide key have nothing to fall back for

@@ -93,7 +93,13 @@ def test_workspace_sizes_are_host_arithmetic():
     assert L.fa_workspace_bytes(8, 8192, 64, 0, B16, A) == 0 and L.fa_workspace_bytes(16, 8192, 64, 1, B16, A) == 0
     assert L.fa_workspace_bytes(1, 8192, 64, 0, F32, A) == 256 + part(8, 1, 8192, 64)         # fp32 tensors: the split kernel over key shares
     assert L.fa_workspace_bytes(1, 8192, 64, 1, F32, A) == 256 + part(8, 1, 8192, 64)         # ... causal too
-    assert L.fa_workspace_bytes(16, 8192, 64, 1, F32, A) == 256 and L.fa_workspace_bytes(1, 8192, 64, 0, F32, _cabi.FA_KERNEL_MFMA) == 0
+    assert L.fa_workspace_bytes(16, 8192, 64, 1, F32, A) == 256
+    # exact fp32 arithmetic (round 5): fewer than 256 tiles of 128 rows -> key shares until the launch has 256 .. 512 workgroups
+    M = _cabi.FA_KERNEL_MFMA
+    assert L.fa_workspace_bytes(1, 8192, 64, 0, F32, M) == 256 + part(8, 1, 8192, 64) and L.fa_workspace_bytes(2, 8192, 64, 0, F32, M) == 256 + part(4, 2, 8192, 64)
+    assert L.fa_workspace_bytes(4, 8192, 64, 0, F32, M) == 0 and L.fa_workspace_bytes(4, 8192, 64, 1, F32, M) == 256 + part(4, 4, 8192, 64)   # (a causal round is still split)
+    assert L.fa_workspace_bytes(16, 8192, 64, 0, F32, M) == 0 and L.fa_workspace_bytes(1, 1024, 64, 0, F32, M) == 0
+    assert L.fa_workspace_bytes(1, 8192, 64, 0, F32, M | (1 << 8)) == 0                                 # an explicit tiling runs unsplit
     assert L.fa_workspace_bytes(1, 8192, 64, 0, B16F, A) == 256 + part(8, 1, 8192, 64)        # the accurate path splits idle grids the same way
     assert L.fa_workspace_bytes(1, 8192, 64, 0, B16F, _cabi.FA_KERNEL_PB2) == 256 + part(8, 1, 8192, 64)
     assert L.fa_workspace_bytes(1, 8192, 64, 0, B16, _cabi.FA_KERNEL_SPLIT) == 0
