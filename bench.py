@@ -127,8 +127,8 @@ def timed_region(step_fn, steps: int, warmup: int, sync_fn, world: int, dist=Non
 
 
 PER_RANK_S = []   # seconds of the last timed_region on every rank (filled on all ranks)
-C4_ONE_GPU_TFLOPS = 1180.0   # the c4 headline on one MI355X (BENCH_r01 .. r03: 1138 - 1219)
-C5_ONE_GPU_MS = 14.6   # all 1024 slabs of config 5 on one MI355X (profiles/: 14.57 - 14.77 ms over three rounds' boxes, +- 4 % between boxes)
+C4_ONE_GPU_TFLOPS = 1190.0   # the c4 headline on one MI355X: mean of the driver's four records (BENCH_r01 .. r04: 1164, 1212, 1220, 1171)
+C5_ONE_GPU_MS = 14.6   # all 1024 slabs of config 5 on one MI355X (driver, r04: 14.59 ms; profiles/: 14.57 - 14.77 over three rounds' boxes, +- 4 % between boxes)
 
 
 def make_inputs(bh: int, n: int, d: int, dtype: str, device, seed: int):
@@ -232,7 +232,7 @@ def kernel_peak(kernel_name: str, dtype: str):
     if kernel_name == "fa_fwd_f32_kernel":
         return PEAK_TFLOPS["f32"], "fp32 MFMA (v_mfma_f32_32x32x2_f32), 1x the algorithmic FLOP"
     if kernel_name == "fa_fwd_f32_split_kernel" and dtype == "f32":
-        return PEAK_TFLOPS["bf16"] / 3.0, "bf16 MFMA peak / 3: three bf16 products per contraction (hi/lo splits of fp32 operands)"
+        return PEAK_TFLOPS["bf16"] / 3.0, "16-bit MFMA dense peak / 3: three products per contraction (fp16 hi/lo terms for Q.K^T, bf16 hi/lo terms for P.V)"
     if kernel_name == "fa_fwd_f32_split_kernel":
         return PEAK_TFLOPS["bf16"] / 2.0, "bf16 MFMA peak / 2: two bf16 products per contraction (hi/lo terms of P and Q')"
     return PEAK_TFLOPS["bf16"], "bf16 / fp16 MFMA dense peak, 1x the algorithmic FLOP"
@@ -344,9 +344,29 @@ def main():
                 torch.cuda.synchronize()
 
     prewarm(step)
-    dt = timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, world, dist, device)
+    # The line's two clocks -- K back-to-back forwards from Python between barriers (ms_per_step -> `value`) and the C ABI's event-timed
+    # loops on the launch stream (kernel_ms -> `roofline`) -- are taken in ALTERNATION inside one warm state, and when they disagree by more
+    # than 2 % (a clock ramp, a noisy neighbour on the box: round 4's line read 4.2 % between them) the pair is measured again, in this
+    # process, at most three times.  Every attempt is a complete timed region of exactly K steps; the LAST attempt is the one reported,
+    # all of them are listed in extra.timing_attempts.
+    kiters = max(10, min(args.steps, 50))
+    attempts = []
+    kstats = None
+    for attempt in range(3):
+        dt = timed_region(step, args.steps, args.warmup if attempt == 0 else 2, torch.cuda.synchronize, world, dist, device)
+        per_rank_s = list(PER_RANK_S)
+        agree = torch.zeros(1, dtype=torch.int32, device=device)
+        if rank == 0:
+            kstats = time_stats(fa, (q, k, v), reps=5, causal=causal, scale=args.scale, warmup=3, iters=kiters, out=out)
+            ratio = kstats["median"] / (dt / args.steps * 1e3)
+            attempts.append({"ms_per_step": round(dt / args.steps * 1e3, 4), "kernel_ms": kstats["median"], "kernel_ms_over_ms_per_step": round(ratio, 4)})
+            agree[0] = 1 if abs(ratio - 1.0) <= 0.02 else 0
+        if world > 1:
+            dist.broadcast(agree, src=0)
+        if int(agree.item()) == 1:
+            break
     ms_per_step = dt / args.steps * 1e3
-    per_rank_ms = [round(x / args.steps * 1e3, 4) for x in PER_RANK_S]
+    per_rank_ms = [round(x / args.steps * 1e3, 4) for x in per_rank_s]
     value = fwd_flop(global_bh, n, d, causal) * args.steps / dt / 1e12
     route = fa.last_forward_route()   # 0: single launch; 1 / 2: primary / fallback kernel of a conditional chain (fp32 guard)
     # what the timed launches wrote, checked before anything else runs (rank 0; every rank's shard has the same distribution)
@@ -357,6 +377,11 @@ def main():
                                      oracle_slab=0 if (world == 1 and not args.no_cpu_baseline) else None)
 
     extras = {"per_rank_ms": per_rank_ms} if world > 1 else {}
+    if rank == 0:
+        extras["timing_attempts"] = attempts
+    if world > 1:   # what the collective layer saw, not what the environment said
+        extras["ranks_seen"] = int(dist.get_world_size())
+        extras["dist_backend"] = str(dist.get_backend())
     if world > 1 and args.workload == "c4" and not causal and not args.accurate:
         # weak scaling, no collective: N ranks should read N x the one-GPU value (1130 - 1220 TFLOP/s over three rounds' boxes)
         extras["weak_scaling"] = {"predicted_value": round(world * C4_ONE_GPU_TFLOPS, 1),
@@ -395,9 +420,8 @@ def main():
         dt_id = (_cabi.FA_DTYPE_BF16_OUT_F32 if args.accurate else _cabi.FA_DTYPE_BF16) if dtype == "bf16" else _cabi.FA_DTYPE_F32
         kname = L.fa_kernel_name_for(dt_id, d, int(causal), bh, n).decode()
         if dtype == "f32" and route == 2:
-            kname = "fa_fwd_f32_kernel"   # the logit-width guard sent this workload to the exact kernel
-        kstats = time_stats(fa, (q, k, v), reps=5, causal=causal, scale=args.scale, warmup=3, iters=max(10, min(args.steps, 50)), out=out)
-        kms = kstats["median"]
+            kname = "fa_fwd_f32_kernel"   # the range guard sent (part of) this workload to fp32 arithmetic
+        kms = kstats["median"]   # (of the last attempt above: taken right behind the timed region `value` comes from)
         achieved = fwd_flop(bh, n, d, causal) / (kms * 1e-3) / 1e12
         elem = 2 if dtype == "bf16" else 4
         pmc = load_pmc_traffic() or {}
@@ -410,7 +434,11 @@ def main():
         traffic = (pmc.get(f"{tkey}_hbm_bytes_per_launch")
                    if pmc.get(f"{tkey}_kernel") == kname and pmc.get("lib_sha256") == sha and not causal else None)
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic,
+                "frac": round(achieved / peak, 4),
+                # the same fraction from the line's two clocks (they agree to 2 % or `timing_note` below says how far apart they stayed)
+                "frac_from_kernel_ms": round(achieved / peak, 4),
+                "frac_from_ms_per_step": round(fwd_flop(bh, n, d, causal) / (ms_per_step * 1e-3) / 1e12 / peak, 4),
+                "traffic": traffic,
                 "traffic_source": (f"profiles/pmc_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                                    f"{pmc.get('_tag', '?')}; 2*FETCH_SIZE + WRITE_SIZE)") if traffic is not None else None,
                 "kernel": kname, "kernel_ms": round(kms, 4), "kernel_ms_stats": kstats, "lib_sha256": sha[:16], "peak_note": peak_note,
@@ -422,14 +450,16 @@ def main():
         # the two clocks of this line: K back-to-back forwards from Python (ms_per_step) and the C ABI's event-timed loop (kernel_ms)
         ratio = kms / ms_per_step if ms_per_step > 0 else 0.0
         roof["kernel_ms_over_ms_per_step"] = round(ratio, 4)
-        if abs(ratio - 1.0) > 0.03:
+        roof["timing_note"] = (f"{len(attempts)} attempt(s): " + ("the two clocks agree to 2 %" if abs(ratio - 1.0) <= 0.02 else
+                               f"the two clocks stayed {abs(ratio - 1.0) * 100:.1f} % apart after {len(attempts)} attempts (extra.timing_attempts)"))
+        if abs(ratio - 1.0) > 0.02:
             roof["timing_warning"] = (f"kernel_ms (median of {kstats['reps']} event-timed loops) and ms_per_step differ by {abs(ratio - 1.0) * 100:.1f} %: "
                                       f"min / median / p90 of the loops = {kstats['min']} / {kstats['median']} / {kstats['p90']} ms; "
                                       "expect ms_per_step above kernel_ms when a forward is several launches (key shares + combine: host enqueue per launch) and "
                                       "either one high right after an idle period (clock ramp)")
         if dtype == "f32":
-            roof["arithmetic"] = {0: "single launch", 1: "split products on the bf16 pipe (guard quiet)",
-                                  2: "exact fp32 (logit-width guard fired)"}[route]
+            roof["arithmetic"] = {0: "single launch", 1: "split products on the 16-bit pipes: Q.K^T as fp16 hi + lo terms, P.V as bf16 hi + lo terms (range guard quiet)",
+                                  2: "exact fp32 for some workgroups (range guard fired)"}[route]
         if not args.no_extras:
             # the same launches captured into one hipGraph and replayed (median of three timed replays); reported beside the
             # stream-launch figures above, never instead of them.  per_launch_delta_us = what a graph node costs more (+) or less (-)
@@ -562,7 +592,7 @@ def c4_side_measurements(fa, _cabi, q, k, v, causal, args, device):
     # fp32 tensors, one slab: the split kernel over key shares inside the guarded chain
     qf, kf, vf = make_inputs(1, n, d, "f32", device, seed=5)
     timed("bh1_n8192_f32_keysplit", dict(causal=False, scale=args.scale), fwd_flop(1, n, d, False), tensors=(qf, kf, vf), peak=PEAK_TFLOPS["bf16"] / 3.0,
-          note="B*H = 1, fp32 tensors (FA_KERNEL_AUTO): split kernel over 8 key shares (each guarding its own keys) + combine; frac of bf16 peak / 3", warm=100, iters=50)
+          note="B*H = 1, fp32 tensors (FA_KERNEL_AUTO): split kernel over 8 key shares (each guarding its own keys) + combine; frac of the 16-bit MFMA peak / 3", warm=100, iters=50)
     timed("bh1_n8192_f32_unsplit", dict(causal=False, scale=args.scale, kernel="split"), fwd_flop(1, n, d, False), tensors=(qf, kf, vf), peak=PEAK_TFLOPS["bf16"] / 3.0,
           note="the same tensors through kernel=\"split\" (one launch, no key split, no guard): round 2's path", warm=100, iters=50)
     timed("bh1_n8192_f32_causal_keysplit", dict(causal=True, scale=args.scale), fwd_flop(1, n, d, True), tensors=(qf, kf, vf), peak=PEAK_TFLOPS["bf16"] / 3.0,
@@ -581,36 +611,58 @@ def c4_side_measurements(fa, _cabi, q, k, v, causal, args, device):
               note=f"README shape B={B2} H={H2} d=32 N={n2}, fp32 tensors (FA_KERNEL_AUTO), frac of bf16 peak / 3",
               warm=30 if n2 > 2048 else 200, iters=10 if n2 > 2048 else 100)
         del q2, k2, v2, q3, k3, v3
-    # the same shape with fp32 tensors (config c3) and the README shape (c2): FA_KERNEL_AUTO (split products behind the logit-width
-    # guard; the route says which arithmetic produced the output) and the exact fp32-arithmetic kernel beside it
-    for name in ("c3", "c2"):
-        B2, H2, d2, n2, dt2, _ = WORKLOADS[name]
-        q2, k2, v2 = make_inputs(B2 * H2, n2, d2, dt2, device, seed=1)
-        fl2 = fwd_flop(B2 * H2, n2, d2, causal)
-        ent = {"workload": f"B={B2} H={H2} d={d2} N={n2} {dt2}"}
+    # the same shape with fp32 tensors (config c3) and the README shape (c2): FA_KERNEL_AUTO (round 5: Q.K^T as fp16 hi + lo terms, P.V as
+    # bf16 hi + lo terms, behind the range guard; the route says which arithmetic produced the output) and the fp32-arithmetic kernel beside it
+    AUTO_ARITH = ("Q.K^T: 3 v_mfma_f32_32x32x16_f16 products of fp16 hi/lo splits (22 bits); P.V: 3 v_mfma_f32_32x32x16_bf16 products of bf16 hi/lo "
+                  "splits; fp32 accumulate; range guard with its in-kernel fp32 fallback included in the time")
+
+    def f32_pair(name, workload, q2, k2, v2, caus, warm, iters):
+        fl2 = fwd_flop(q2.shape[0], q2.shape[1], q2.shape[2], caus)
+        ent = {"workload": workload}
         o2 = torch.empty_like(q2)
         for label, kern in (("auto", "auto"), ("exact", "exact")):
-            st2 = time_stats(fa, (q2, k2, v2), reps=5, causal=causal, scale=args.scale, kernel=kern, warmup=30 if name == "c3" else 100,
-                             iters=4 if name == "c3" else 20, out=o2)
+            st2 = time_stats(fa, (q2, k2, v2), reps=5, causal=caus, scale=args.scale, kernel=kern, warmup=warm, iters=iters, out=o2)
             ms2 = st2["median"]
             tf2 = fl2 / (ms2 * 1e-3) / 1e12
             r = fa.last_forward_route()   # (before the check below launches the rung-0 kernel: the route is this thread's LAST forward's)
-            chk2 = validate_output(fa, q2, k2, v2, o2, causal, args.scale, TOLERANCE["f32"], f"{name}.{label}")
+            chk2 = validate_output(fa, q2, k2, v2, o2, caus, args.scale, TOLERANCE["f32"], f"{name}.{label}")
             ent[label] = {"ms": round(ms2, 4), "ms_min_median_p90": [st2["min"], st2["median"], st2["p90"]], "tflops": round(tf2, 2),
                           "max_abs_err": chk2["max_abs_err"], "tolerance": chk2["tolerance"]}
             if label == "auto":
-                ent[label].update(arithmetic="3 bf16 MFMA products of hi/lo splits, fp32 accumulate, logit-width guard with its in-kernel fp32 fallback "
-                                             "included in the time" if r == 1 else "the guard fired: some workgroups in exact fp32", route=r,
-                                  frac_bf16_mfma_peak_at_3x_flop=round(3.0 * tf2 / PEAK_TFLOPS["bf16"], 4))
+                ent[label].update(arithmetic=AUTO_ARITH if r == 1 else "the range guard fired: some workgroups in exact fp32", route=r,
+                                  frac_16bit_mfma_peak_at_3x_flop=round(3.0 * tf2 / PEAK_TFLOPS["bf16"], 4))
             else:
-                ent[label].update(arithmetic="v_mfma_f32_32x32x2_f32 (FA_KERNEL_MFMA)",
+                ws = fa.workspace_bytes(q2.shape[0], q2.shape[1], q2.shape[2], caus, kernel="exact")
+                ent[label].update(arithmetic="v_mfma_f32_32x32x2_f32 (FA_KERNEL_MFMA)" + (", key shares + combine" if ws else "")
+                                  + (", paired causal tiles where the launcher chooses them" if caus else ""),
                                   frac_f32_mfma_peak=round(tf2 / PEAK_TFLOPS["f32"], 4))
         ent["ms"], ent["tflops"] = ent["auto"]["ms"], ent["auto"]["tflops"]
+        ent["default_arithmetic"] = "auto (FA_KERNEL_AUTO): " + AUTO_ARITH
         # the figure to quote for "fp32" in the reference's sense: fp32 ARITHMETIC (v_mfma_f32_32x32x2_f32), against the fp32 MFMA peak
         ent["reference_arithmetic"] = {"ms": ent["exact"]["ms"], "tflops": ent["exact"]["tflops"],
                                        "frac_f32_mfma_peak": ent["exact"]["frac_f32_mfma_peak"], "kernel": "fa_fwd_f32_kernel (kernel=\"exact\")"}
         ex[name] = ent
-        del q2, k2, v2, o2
+
+    for name in ("c3", "c2"):
+        B2, H2, d2, n2, dt2, _ = WORKLOADS[name]
+        q2, k2, v2 = make_inputs(B2 * H2, n2, d2, dt2, device, seed=1)
+        f32_pair(name, f"B={B2} H={H2} d={d2} N={n2} {dt2}", q2, k2, v2, causal, 30 if name == "c3" else 100, 4 if name == "c3" else 20)
+        if name == "c3" and not causal:
+            f32_pair("c3_causal", f"B={B2} H={H2} d={d2} N={n2} {dt2}, causal", q2, k2, v2, True, 30, 6)
+        del q2, k2, v2
+    # fp32 tensors at the other head dims and on one slab (exact arithmetic over key shares): B=2 H=8 N=8192
+    for name, (bh2, n2, d2, caus) in (("f32_d128", (16, 8192, 128, False)), ("f32_d128_causal", (16, 8192, 128, True)), ("f32_d32", (16, 8192, 32, False)),
+                                      ("f32_bh1", (1, 8192, 64, False)), ("f32_bh1_causal", (1, 8192, 64, True))):
+        q2, k2, v2 = make_inputs(bh2, n2, d2, "f32", device, seed=6)
+        f32_pair(name, f"BH={bh2} d={d2} N={n2} f32" + (", causal" if caus else ""), q2, k2, v2, caus, 20, 4 if bh2 > 1 else 20)
+        if bh2 == 1:
+            try:
+                ms1 = time_stats(fa, (q2, k2, v2), reps=3, causal=caus, scale=args.scale, kernel="exact:1", warmup=10, iters=10)["median"]
+                ex[name]["exact"]["unsplit_ms"] = round(ms1, 4)
+                ex[name]["exact"]["speedup_of_key_shares"] = round(ms1 / ex[name]["exact"]["ms"], 2)
+            except Exception as e:  # pragma: no cover - informational only
+                ex[name]["exact"]["unsplit_ms"] = repr(e)
+        del q2, k2, v2
     # llm.c harness size (attention_forward.cu:1217-1220): B=6 T=4096 C=768 NH=12, packed (B, T, 3C) fp32, causal, 1/sqrt(hs); mean of
     # 100 launches like benchmark_kernel (:1279-1288)
     try:

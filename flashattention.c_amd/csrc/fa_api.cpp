@@ -96,7 +96,7 @@ fa::FwdParams make_params(const void* q, const void* k, const void* v, void* o, 
 // ---- the report word of a forward (and the ablation library's conditional launch chains) ---------------------------------------------
 // Until round 4 the FA_KERNEL_AUTO path of fp32 tensors was a chain of launches in which the exact fp32 kernel, queued behind the split
 // kernel, ran or skipped itself depending on a device word the split kernel raised when its logits were too wide for 16-bit operand
-// terms.  Now the split kernel redoes such a workgroup's rows in fp32 arithmetic itself (flag_mode 4; fa_split_kernel.h) -- ONE launch,
+// terms.  Now the split kernel redoes a workgroup's rows in fp32 arithmetic itself when its operands leave the range fp16 terms hold (flag_mode 4; fa_split_kernel.h) -- ONE launch,
 // and a hostile slab costs its own tiles only -- and the word merely REPORTS that some workgroup did (fa_last_forward_route).  The
 // machinery below is what keeps two calls from ever sharing a word; the ablation library's chains (fp16-P kernels, the static-slot fp32
 // kernel) still depend on it for correctness, the product for the truth of its report:
@@ -547,8 +547,8 @@ Plan make_plan(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype,
         else if (sel.kind == FA_KERNEL_AUTO && sel.variant == 0) {
             pl.route = kRouteF32Guarded;
             if (scratch_ok) pl.total = kWsHeader;   // the chain's verdict word (a caller-owned workspace keeps it off the slot table)
-            // grids that leave the chip idle: the split kernel over key shares + combine (the guard's verdict is per share, and any share
-            // raising it sends the whole launch to the exact kernel, which runs unsplit)
+            // grids that leave the chip idle: the split kernel over key shares + combine (flag_mode 4: the workgroups of a share guard the
+            // keys of THAT share and redo their own partial rows in fp32 arithmetic; the combine merges both kinds; the word only reports)
             const int S = scratch_ok ? keysplit_factor(p, d, causal, true) : 1;
             if (S > 1) {
                 pl.S = S;
@@ -834,8 +834,8 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
             else e = fa::launch_fwd_f32(p, d, c, sel.variant, stream);
             break;
         case kRouteF32Split: e = fa::launch_f32_split(p, d, c, sel.variant, stream); break;
-        case kRouteF32Guarded: {   // split products behind the logit-width guard: ONE launch (round 4) -- a workgroup whose logits are too wide
-            FlagRef f;              // for 16-bit operand terms redoes its own rows in fp32 arithmetic inside the kernel (flag_mode 4).  The word
+        case kRouteF32Guarded: {   // split products behind the range guard: ONE launch (round 4) -- a workgroup whose operands leave what fp16
+            FlagRef f;              // terms hold (or met a NaN) redoes its own rows in fp32 arithmetic inside the kernel (flag_mode 4).  The word
             const bool have = chain_flag(f);   // only REPORTS that (fa_last_forward_route); without one the launch is the same
             fa::FwdParams pg = p;
             pg.flag = have ? f.word : nullptr;

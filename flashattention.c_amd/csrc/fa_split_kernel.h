@@ -1,29 +1,35 @@
-// fa_split_kernel.h -- fused flash-attention forward on the bf16 matrix pipe with split (hi + lo) operands (gfx950): the kernel
+// fa_split_kernel.h -- fused flash-attention forward on the 16-bit matrix pipe with split (hi + lo) operands (gfx950): the kernel
 // template instantiated per (dtype, head dim) in fa_split_{f32,bf16}_d{32,64,128}.hip; dispatch in fa_fwd_f32_split.hip (fp32 tensors) and
 // fa_fwd_bf16_split.hip (bf16 tensors, accurate mode).
 //
 // Same contract as fa_fwd_f32.hip (fp32 Q/K/V in, fp32 O out; replaces flash_tiled_coarse{,_causal},
-// /root/reference/src/flashattention.cu:139-579), but both contractions run as THREE v_mfma_f32_32x32x16_bf16 on
-// two-term bf16 splits of their fp32 operands:
+// /root/reference/src/flashattention.cu:139-579), but both contractions run as THREE 16-bit matrix instructions on two-term splits of
+// their fp32 operands, a.b ~= a_hi.b_hi + a_lo.b_hi + a_hi.b_lo, with fp32 accumulation in the matrix core:
 //
-//     x = x_hi + x_lo,   x_hi = bf16(x),  x_lo = bf16(x - x_hi)          (16 significant bits, fp32 exponent range)
-//     a.b ~= a_hi.b_hi + a_lo.b_hi + a_hi.b_lo                            (the dropped a_lo.b_lo is 2^-18 relative)
+//     S = Q'.K^T   FP16 terms (round 5):  x_hi = f16(x),  x_lo = f16(x - x_hi)       22 significant bits; v_mfma_f32_32x32x16_f16
+//     O += P.V     BF16 terms:            x_hi = bf16(x), x_lo = bf16(x - x_hi)      16 significant bits, fp32's exponent range (P = 2^(s - m0 - B)
+//                                                                                    lives near 2^-96); v_mfma_f32_32x32x16_bf16
 //
-// with fp32 accumulation in the matrix core.  The bf16 pipe is 16x the fp32 one on this chip (2.5 PF vs 157 TF dense), so
-// three products still beat v_mfma_f32_32x32x2_f32 by 5x on the matrix pipe, and the result stays within ~2e-4 of the fp64
-// oracle on unit-variance data at scale 1 (~1e-5 at 1/sqrt(d)) -- inside the 1e-3 fp32 tolerance of the path, two orders of
-// magnitude tighter than bf16 tensors.  The error of a score is ~2^-17.6 * sqrt(sum (q_i k_i)^2) <= 5e-6 |q|_2 |k|_inf scale.
-// LOGIT-WIDTH GUARD (fp32 tensors under FA_KERNEL_AUTO, FwdParams::flag_mode = 4): every workgroup sees all keys of its slab and
-// its own query rows; it tracks max |k| element-wise while converting K (one v_max3_f32 per four values) and the 2-norms of its
-// Q rows, and when  max_rows |q|_2 * max |k|_inf * scale  exceeds kGuardLimit (= 90; unit-variance data reach 55 at
-// d = 64, scale 1, and 78 at d = 128) the workgroup redoes its own rows in exact fp32 arithmetic before it exits (f32_exact_rows, fa_f32_exact.h: the body
-// of the exact kernel, in the LDS this kernel is done with) and sets the caller's report word.  Round 3 raised a flag instead and the exact
-// kernel, queued behind every launch, recomputed the whole grid (flag_mode = 3: still what the ablation library's chains do).  Callers who know better select FA_KERNEL_SPLIT (no guard) or FA_KERNEL_MFMA.  fp32 range is kept for Q, K, V (bf16
-// exponent) and, through the redo of rows whose accumulators come out tiny, for O.
+// The 16-bit pipes are 16x the fp32 one on this chip (2.5 PF vs 157 TF dense), so three products still beat v_mfma_f32_32x32x2_f32 by 5x
+// on the matrix pipe.  ERROR of a logit from the operand terms: <= 3 * 2^-22 * sum |q'_i k_i| -- below the rounding bound of the
+// reference's own fp32 FMA chain, d * 2^-24 * sum |q'_i k_i|, for every d >= 12, whatever the data (rounds 1-4 carried K and Q' as two BF16
+// terms: 2^-16.4 * sum |q'_i k_i| in the worst case, 6e-2 in O on coherent inputs that the RMS-model guard of those rounds let through:
+// VERDICT r04).  What is left on wide logits is fp32 ACCUMULATION: every matrix instruction rounds (truncates) its partial sum at the
+// magnitude it has then, so the hi.hi products of ALL k-steps come first -- the accumulator starts at -(m0 + B), as large as the row's widest
+// logit, and walks down to the score's own small magnitude -- and the cross terms are added last, where an ulp is small (scores(), qk(),
+// the slot schedule).  O's terms add <= 3 * 2^-17 * max|v|.  Measured: <= 1e-4 on unit-variance data at scale 1, <= 1.5e-5 at 1/sqrt(d).
+// RANGE GUARD (fp32 tensors under FA_KERNEL_AUTO, FwdParams::flag_mode = 4): fp16 terms hold |x| < 65520 (beyond: hi = inf, lo = -inf, NaN
+// scores) and give elements below 2^-3 a subnormal lo term (absolute error <= 2^-25, times the partner element).  Every workgroup sees all
+// keys of its slab and its own query rows; it tracks max |k| element-wise while converting K (one v_max3_f32 per four values) and the
+// 2-norms of its Q' rows, and when the first attempt produced a NaN or  D * max|k| + sqrt(D) * max|q'|_2  exceeds kSubnormalBudget (2048:
+// the subnormal terms stay below 2^-14 per logit) the workgroup redoes its own rows in exact fp32 arithmetic before it exits
+// (f32_exact_rows, fa_f32_exact.h: the body of the exact kernel, in the LDS this kernel is done with) and sets the caller's report word.
+// Callers who know better select FA_KERNEL_SPLIT (no guard) or FA_KERNEL_MFMA.  fp32 range is kept for V, P (bf16 exponent) and, through
+// the redo of rows whose accumulators come out tiny, for O.
 //
 //   workgroup   NWAVES waves x QB blocks of 32 query rows; K/V tiles of 32 keys.
 //   HBM -> LDS  fp32 K/V rows are loaded into registers (two 16-byte loads per 8 values), split there, and written as FOUR
-//               bf16 images per tile (K_hi, K_lo, V_hi, V_lo) in the layouts of fa_bf16_common.h: K row-major with
+//               16-bit images per tile (K_hi, K_lo in fp16; V_hi, V_lo in bf16) in the layouts of fa_bf16_common.h: K row-major with
 //               XOR-swizzled 16-byte slots (ds_read_b128 A fragments), V as [key/4][col/16][4][16] sub-tiles
 //               (ds_read_b64_tr_b16 hands out V^T fragments).  Rows past the end of the slab are zeros.
 //   S^T = K Q'^T   Q' = Q * scale*log2(e) in fp32 (one rounding per element), then split: scores arrive in the exp2 domain.
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     constexpr int GPT = (C::kGroups + NT - 1) / NT;  // groups per thread and tile
 
     __shared__ __attribute__((aligned(1024))) char smem[2 * C::kStageBytes];
-    __shared__ unsigned s_kmax;   // logit-width guard: max |k| over the slab, as the bits of a non-negative float
+    __shared__ unsigned s_kmax;   // range guard: max |k| over the keys this workgroup reads, as the bits of a non-negative float
 
     if (flag_says_skip(p)) return;   // conditional fallback of a launch chain (bf16 tensors behind the fp16-P kernel)
 
@@ -239,7 +245,8 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 31, hi = lane >> 5;
-    constexpr bool GUARD = !IN_BF16;   // tracked for every fp32 launch (4 VALU per K piece), acted upon under flag_mode 3 only
+    constexpr bool GUARD = !IN_BF16;   // tracked for every fp32 launch (4 VALU per K piece); acted upon under flag_mode 4 (FA_KERNEL_AUTO: the
+                                       // workgroup redoes its rows in fp32 arithmetic on the spot) and 3 (ablation chains: raise the word)
     float kmax = 0.0f;
     if (GUARD && tid == 0) s_kmax = 0u;   // ordered before the first atomic by the barriers of the main loop
 

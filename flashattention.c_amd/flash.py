@@ -77,9 +77,10 @@ def forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = Fa
     enough because every element is written).  ``return_lse=True`` additionally returns the (BH, N) fp32 row
     log-sum-exp -- the quantity the reference's unused ``O_l`` buffer was reserved for.
 
-    Kernel choice (include/flashattn_amd.h has the full rules).  fp32 tensors: ``kernel="auto"`` runs both contractions on
-    the bf16 matrix pipe as three products of two-term bf16 splits (within 1e-3 of the fp32 reference) behind a device-side
-    guard: a workgroup whose logits are too wide for that redoes its rows in exact fp32 arithmetic inside the same launch;
+    Kernel choice (include/flashattn_amd.h has the full rules).  fp32 tensors: ``kernel="auto"`` runs Q.K^T as three matrix products
+    of two-term FP16 splits (22 bits) and P.V as three products of two-term BF16 splits: <= 1e-4 of the fp32 reference on unit-variance
+    data, never further from fp64 than the reference's own fp32 arithmetic on any input, behind a device-side RANGE guard: a workgroup
+    whose operands leave what fp16 terms hold redoes its rows in exact fp32 arithmetic inside the same launch;
     ``"split"`` is the same without the guard,
     ``"exact"`` (= ``"mfma"``) computes in fp32 arithmetic.  bf16 tensors: ``out_dtype=torch.float32`` stores the fp32
     accumulator (FA_DTYPE_BF16_OUT_F32) and, under ``"auto"``, selects the accurate P -- bf16 hi + bf16 lo terms in one launch
@@ -194,8 +195,8 @@ def time_forward(q, k, v, causal: bool = False, *, scale: float = 1.0, kernel: U
 
 def last_forward_route(stream: Optional[torch.cuda.Stream] = None) -> int:
     """Which arithmetic produced this thread's most recent forward (blocking; diagnostics): 0 = nothing to report (every bf16 path,
-    explicit kernels), 1 = fp32 tensors under ``"auto"``: split products throughout, 2 = the logit-width guard fired and at least one
-    workgroup redid its rows in exact fp32 arithmetic (inside the same launch)."""
+    explicit kernels), 1 = fp32 tensors under ``"auto"``: split products throughout, 2 = the range guard fired (operands outside what fp16
+    terms hold, or a NaN) and at least one workgroup redid its rows in exact fp32 arithmetic (inside the same launch)."""
     r = ctypes.c_int32(0)
     s = (stream or torch.cuda.current_stream()).cuda_stream
     _cabi.check(_cabi.lib().fa_last_forward_route(ctypes.c_void_p(s), ctypes.byref(r)))

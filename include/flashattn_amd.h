@@ -21,7 +21,7 @@
  *               flashattention.cu:224-231)
  *   ownership   the caller owns every buffer; nothing is allocated, freed or zero-filled by fa_forward_ws, the entry point of this
  *               boundary proper (the reference allocates O and a dead O_l inside forward(), :608-609).  Scratch is needed only for
- *               key-split launches (rows of 4096 keys and more on grids that leave the chip idle: the partial outputs of the key
+ *               key-split launches (rows of 4096 keys and more -- 2048 for FA_KERNEL_MFMA on fp32 tensors -- on grids that leave the chip idle: the partial outputs of the key
  *               shares) and, 256 bytes of it, for the report word of an fp32 FA_KERNEL_AUTO forward (fa_last_forward_route):
  *               fa_workspace_bytes() sizes it, fa_forward_ws() takes it.  The convenience entry points (fa_forward, fa_forward_ex, fa_forward_sharded,
  *               fa_forward_packed_qkv) draw the key-split scratch from a PRIVATE stream-ordered pool of the device
@@ -57,17 +57,27 @@ typedef enum fa_status {
 } fa_status;
 
 typedef enum fa_dtype {
-    FA_DTYPE_F32 = 0, /* fp32 in, fp32 out -- the reference's dtype.  FA_KERNEL_AUTO: both contractions as three bf16 MFMA
-                         products of two-term bf16 splits of the fp32 operands (16 significant bits per operand, fp32
-                         accumulate; max-abs error against fp64 ~2e-4 on unit-variance data at scale 1, ~1e-5 at 1/sqrt(d),
-                         2.6x faster than fp32 arithmetic) BEHIND A GUARD: every workgroup bounds the logit width of its rows,
-                         max |q|_2 * max |k|_inf * scale over the keys it reads, and when that exceeds 90 (16-bit operand terms
-                         then no longer hold 1e-3) it redoes its rows in exact fp32 arithmetic before it exits -- ONE launch
-                         (round 4; a second, conditional launch before), no host round trip, and a hostile slab costs its own
-                         tiles only; fa_last_forward_route() tells whether any workgroup did.  FA_KERNEL_SPLIT: the split
-                         products without the guard.  FA_KERNEL_MFMA: exact fp32 arithmetic (v_mfma_f32_32x32x2_f32: ~2e-5 /
-                         ~1e-6), bit-for-bit an fmaf chain; FA_F32_AUTO=exact in the environment makes that the
-                         FA_KERNEL_AUTO choice for the whole process */
+    FA_DTYPE_F32 = 0, /* fp32 in, fp32 out -- the reference's dtype.  FA_KERNEL_AUTO (round 5): Q.K^T as three matrix products of two-term
+                         FP16 splits of the fp32 operands (hi = f16(x), lo = f16(x - hi): 22 significant bits; v_mfma_f32_32x32x16_f16,
+                         fp32 accumulate, the hi.hi products of all k-steps first so that the cross terms are added where the partial sum
+                         is small), P.V as three products of two-term BF16 splits (P needs fp32's exponent range); 3.2x faster than fp32
+                         arithmetic.  GUARANTEED: the logit error of the operand terms is <= 3 * 2^-22 * sum |q_i k_i| * scale -- below the
+                         rounding bound d * 2^-24 * sum |q_i k_i| of the reference's own fp32 FMA chain for every d >= 12 -- and the P.V
+                         terms add <= 3 * 2^-17 * max|v|.  CONTRACT (tests/test_gpu_adversarial.py): |O - O_fp64| and |LSE - LSE_fp64| are
+                         <= max(1e-3, E_ref) on every input, E_ref = what the reference's own arithmetic (a k-ordered chain of rounding fp32
+                         FMAs, flashattention.cu:236-252) leaves on that input.  OBSERVED: <= 1e-4 on unit-variance data at scale 1 (c2, c3;
+                         FA_KERNEL_MFMA reads 2e-5 there), <= 1.5e-5 at 1/sqrt(d); on coherent inputs (constant-component rows, v = +-5,
+                         logits ~1500) 2.5e-4 .. 3.5e-3 where FA_KERNEL_MFMA reads 8e-4 .. 5.9e-3: there fp32 ACCUMULATION is the limit.
+                         RANGE GUARD: fp16 terms hold |x| < 65520 and lose elements below 2^-3 to subnormal lo terms (absolute error 2^-25
+                         each); a workgroup whose first attempt produced a NaN, or whose D * max|k| + sqrt(D) * max|q * scale * log2 e|_2
+                         exceeds 2048 (the subnormal terms could then add more than 2^-14 to a logit; unit-variance data: ~520 at d = 64,
+                         ~860 at d = 128), redoes its rows in exact fp32 arithmetic before it exits -- ONE launch, no host round trip;
+                         fa_last_forward_route() tells whether any workgroup did.  (Rounds 1-4 used two BF16 terms, 16 bits, behind a
+                         logit-width guard that bounded an RMS error model: coherent inputs under its limit read up to 6e-2.)
+                         FA_KERNEL_SPLIT: the same products without the guard.  FA_KERNEL_MFMA: fp32 arithmetic (v_mfma_f32_32x32x2_f32),
+                         bit-for-bit an fmaf chain -- the reference's arithmetic, NOT an oracle (see E_ref above); causal launches pair a
+                         heavy with a light tile per workgroup, idle grids run over key shares.  FA_F32_AUTO=exact in the environment makes
+                         that the FA_KERNEL_AUTO choice for the whole process */
     FA_DTYPE_BF16 = 1,        /* bf16 in, bf16 MFMA with fp32 accumulate and fp32 softmax, bf16 out     */
     FA_DTYPE_BF16_OUT_F32 = 2 /* bf16 in, O written as fp32 (the accumulator precision).  Under FA_KERNEL_AUTO this also selects
                                  the ACCURATE P: a caller who wants the fp32 accumulator gets P as two bf16 terms, hi + lo
@@ -84,7 +94,7 @@ typedef enum fa_kernel {
     FA_KERNEL_NAIVE = 1, /* rung-0 scalar kernel: fp32 only, any d <= 256; on-device cross-check        */
     FA_KERNEL_MFMA = 2,  /* the tiled MFMA kernel in the arithmetic of `dtype`: exact fp32 for fp32 tensors, bf16 P for bf16
                             tensors (whatever the output type); d in {32, 64, 128}                        */
-    FA_KERNEL_SPLIT = 3, /* split products on the bf16 matrix pipe.  fp32 tensors: see FA_DTYPE_F32 (unguarded).
+    FA_KERNEL_SPLIT = 3, /* split products on the 16-bit matrix pipe.  fp32 tensors: see FA_DTYPE_F32 (the same products, unguarded).
                             bf16 tensors: K, V exact in one term, Q*scale*log2e and P carried as hi + lo (two products per
                             contraction): max-abs error ~1e-4 against fp64 at scale 1 with FA_DTYPE_BF16_OUT_F32, at ~2x the
                             time of the bf16-P kernels */
@@ -208,8 +218,8 @@ int fa_time_forward_graph(const void* q, const void* k, const void* v, void* o,
  * fa_last_forward_route -- which arithmetic produced the output of this thread's most recent forward.  Blocking (waits for
  *                          `stream`, reads one word back): diagnostics and benchmarks only.
  *   *route  0 = nothing to report (every bf16 path; explicit kernels; an fp32 forward that found no report word);  1 = fp32 tensors under
- *           FA_KERNEL_AUTO: split products throughout;  2 = the logit-width guard fired: at least one workgroup redid its rows in exact
- *           fp32 arithmetic (inside the same launch)
+ *           FA_KERNEL_AUTO: split products throughout;  2 = the range guard fired (operands outside what fp16 terms hold, or a NaN): at
+ *           least one workgroup redid its rows in exact fp32 arithmetic (inside the same launch)
  */
 int fa_last_forward_route(void* stream, int32_t* route);
 
