@@ -11,7 +11,7 @@ hipcc cross-compiles for gfx950 without a GPU present.
 ``--ablation`` additionally builds ``libflashattn_amd_ablation.so`` (+ ``fa_driver_ablation``): the same sources compiled with
 ``-DFA_ABLATION=1`` plus the timing-only ablation instantiations quoted in DESIGN.md section 4 (results are garbage by design).
 They are NOT part of the product library: its ``fa_forward_ex`` rejects their variant numbers.
-``--sanitize`` builds ``libflashattn_amd_asan.so``: the host side of ``fa_api.cpp`` recompiled with ``-fsanitize=address,undefined``
+``--sanitize`` builds ``libflashattn_amd_asan.so``: the host translation units (``fa_plan / fa_slots / fa_launch / fa_shard / fa_timing / fa_api .cpp`` + ``fa_selftest.cpp``) recompiled with ``-fsanitize=address,undefined``
 (device code and every other object unchanged) and ``-DFA_HOST_TEST=1``, which adds ``fa_host_selftest()`` -- plans over a shape grid,
 key-split arithmetic and the verdict-slot table from several threads, none of which needs a device.  ``sanitize_selfcheck()`` runs it (and
 the no-device validation paths through ctypes) in a child process with the ASan runtime preloaded; ``__graft_entry__.build()`` calls it.
@@ -36,13 +36,15 @@ LIB_PATH = os.path.join(PKG_DIR, "libflashattn_amd.so")
 DRIVER_PATH = os.path.join(PKG_DIR, "fa_driver")
 ARCH = "gfx950"
 
+# the host side behind include/flashattn_amd.h (csrc/fa_host.h lists what each holds)
+HOST_SOURCES = ["fa_plan.cpp", "fa_slots.cpp", "fa_launch.cpp", "fa_shard.cpp", "fa_timing.cpp", "fa_api.cpp"]
 # longest translation units first: the thread pool starts them in this order
 LIB_SOURCES = ["fa_fwd_bf16_x4_pb2_f32out.hip", "fa_fwd_bf16_x4_pb2_bf16out.hip", "fa_fwd_bf16_x2.hip", "fa_fwd_bf16_x4.hip",
                "fa_fwd_bf16_x2_pb2_d128_f32out.hip", "fa_fwd_bf16_x2_pb2_d128_bf16out.hip", "fa_fwd_bf16_x2_pb2_d64_f32out.hip", "fa_fwd_bf16_x2_pb2_d64_bf16out.hip",
                "fa_fwd_bf16_pipelined.hip", "fa_split_f32_d64.hip", "fa_split_f32_d128.hip", "fa_split_f32_d32.hip",
                "fa_split_bf16_d64.hip", "fa_split_bf16_d128.hip", "fa_split_bf16_d32.hip", "fa_fwd_bf16.hip", "fa_combine.hip",
                "fa_fwd_bf16_x2_pb2_d32_f32out.hip", "fa_fwd_bf16_x2_pb2_d32_bf16out.hip",
-               "fa_fwd_f32.hip", "fa_fwd_f32_split.hip", "fa_fwd_bf16_split.hip", "fa_naive.hip", "fa_api.cpp"]
+               "fa_fwd_f32.hip", "fa_fwd_f32_split.hip", "fa_fwd_bf16_split.hip", "fa_naive.hip", *HOST_SOURCES]
 # csrc/experiments/: only in libflashattn_amd_ablation.so -- timing-only instantiations (garbage results), superseded kernel generations
 # and the fp16-P families the round-4 accurate path (P as two bf16 terms) replaced (correct, tested through fa_driver_ablation)
 ABLATION_SOURCES = ["experiments/" + f for f in (
@@ -50,7 +52,7 @@ ABLATION_SOURCES = ["experiments/" + f for f in (
     "fa_fwd_bf16_x2_p16_d128.hip", "fa_fwd_bf16_x2_p16_d64.hip", "fa_fwd_bf16_x2_p16_d32.hip", "fa_fwd_bf16_x2_p16x2_d128.hip",
     "fa_fwd_bf16_x2_p16x2_d64.hip", "fa_fwd_bf16_x2_p16x2_d32.hip")]
 # product sources whose text depends on FA_ABLATION (the variant dispatch): recompiled for the ablation library, the rest is shared
-ABLATION_DEPENDENT = ["fa_fwd_bf16.hip", "fa_fwd_bf16_x4.hip", "fa_fwd_bf16_pipelined.hip", "fa_fwd_bf16_x2.hip", "fa_api.cpp",
+ABLATION_DEPENDENT = ["fa_fwd_bf16.hip", "fa_fwd_bf16_x4.hip", "fa_fwd_bf16_pipelined.hip", "fa_fwd_bf16_x2.hip", "fa_plan.cpp", "fa_launch.cpp", "fa_api.cpp",
                       "fa_split_f32_d32.hip", "fa_split_f32_d64.hip"]
 ABL_LIB_PATH = os.path.join(PKG_DIR, "libflashattn_amd_ablation.so")
 ABL_DRIVER_PATH = os.path.join(PKG_DIR, "fa_driver_ablation")
@@ -137,17 +139,20 @@ SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-omit-fra
 
 
 def build_sanitized(force: bool = False) -> str:
-    """libflashattn_amd_asan.so: fa_api.cpp's host code under ASan + UBSan (no GPU sanitizer: not available on this pool), with the
-    host self-test compiled in; every other object is the product's."""
+    """libflashattn_amd_asan.so: the host translation units (HOST_SOURCES + the self-test) under ASan + UBSan (no GPU sanitizer: not
+    available on this pool); every kernel object is the product's."""
     build(force=False)
-    src = os.path.join(CSRC, "fa_api.cpp")
-    obj = os.path.join(OBJ_DIR, "fa_api.asan.o")
-    if force or _mtime(obj) < max(_mtime(src), _newest_dep()):
-        cmd = [hipcc(), *[f for f in COMMON_FLAGS if f != "-O3"], "-O1", "-DFA_ABLATION=0", "-DFA_HOST_TEST=1", *SAN_FLAGS, "-x", "hip", "-c", src, "-o", obj]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"sanitizer build of fa_api.cpp failed:\n{r.stdout}\n{r.stderr}")
-    objs = [os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(s))[0] + ".o") for s in LIB_SOURCES if s != "fa_api.cpp"] + [obj]
+    san_objs = []
+    for name in HOST_SOURCES + ["fa_selftest.cpp"]:
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(OBJ_DIR, os.path.splitext(name)[0] + ".asan.o")
+        if force or _mtime(obj) < max(_mtime(src), _newest_dep()):
+            cmd = [hipcc(), *[f for f in COMMON_FLAGS if f != "-O3"], "-O1", "-DFA_ABLATION=0", "-DFA_HOST_TEST=1", *SAN_FLAGS, "-x", "hip", "-c", src, "-o", obj]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"sanitizer build of {name} failed:\n{r.stdout}\n{r.stderr}")
+        san_objs.append(obj)
+    objs = [os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(s))[0] + ".o") for s in LIB_SOURCES if s not in HOST_SOURCES] + san_objs
     if force or _mtime(ASAN_LIB_PATH) < max(_mtime(o) for o in objs):
         cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-o", ASAN_LIB_PATH, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -234,7 +234,7 @@ constexpr float kLazyThr = 64.0f;
 // (2^-126); the row sum l = sum p < 2^100 at the end of the tile proves that no term exceeded 2^100 (a larger term, +inf or
 // NaN fails the test; fp32 accumulators hold N * 2^100 * |v| comfortably).  A row may thus outgrow the maximum of its first
 // 32 keys by a factor 2^200 before its tile is redone with the lazily rescaled softmax -- which keeps every input correct.
-constexpr float kOptBias = 100.0f;   // (the one-wave-per-SIMD kernels add up to 9 for bf16 P on short rows and subtract for the two-term P on long ones: xn_tile)
+constexpr float kOptBias = 100.0f;   // (the one-wave-per-SIMD kernels add up to 9 -- capped -- for bf16 P on short rows and subtract for the two-term P on long ones: xn_tile)
 constexpr float kOptLimit = 0x1p100f;
 constexpr float kOptTinyAcc = 0x1p-116f;   // an accumulator row below this had its dominant products near (or below) fp32's subnormals
 

@@ -805,8 +805,10 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
     //                      to the last digit -- profiles/r04_experiments.txt, part 8; T = 22: +1.5 %, T = 24: +1.0 %, T = 26: the form before);
     //   two bf16 terms     T = 26 up to 8192 keys, one more per doubling beyond: <= 2^-13 (the range test at the end of the tile is unchanged).
     const int lg_nk = 32 - __builtin_clz(max(nk, 2) - 1);   // ceil(log2 nk)
-    const float kBias = (OPT && PF == 3) ? kBiasC - (float)max(0, lg_nk - 13) : (OPT && PF == 0) ? kBiasC + (float)max(0, 26 - (10 + lg_nk)) : kBiasC;
-    const float tiny_acc = (OPT && PF == 0) ? __builtin_amdgcn_exp2f(-(kBias + 16.0f)) : kOptTinyAcc;   // (kOptTinyAcc = 2^-(100 + 16))
+    const float kBias = (OPT && PF == 3) ? kBiasC - (float)max(0, lg_nk - 13) : (OPT && PF == 0) ? kBiasC + (float)min(9, max(0, 26 - (10 + lg_nk))) : kBiasC;
+    // (the short-row increment stops at 9 -- T = 17 for nk <= 128 --: 2^-(bias + 16) must stay a NORMAL fp32 number, v_exp_f32 flushes
+    // subnormal results to zero and a zero threshold could never send a tiny-V tile to the redo: ADVICE r04)
+    const float tiny_acc = (OPT && PF == 0) ? __builtin_amdgcn_exp2f(-(kBias + 16.0f)) : kOptTinyAcc;   // (kOptTinyAcc = 2^-(100 + 16); >= 2^-125 here)
 
     auto k_slot = [&](int j) { return k_ring + (j & (KR - 1)) * T; };
     auto v_slot = [&](int j) { return v_ring + (j & (VR - 1)) * T; };

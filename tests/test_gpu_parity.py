@@ -1381,6 +1381,26 @@ def test_tiny_v_magnitudes_survive_the_optimistic_mixes(vmag):
             assert rel < tol, (kern, odt, bh, n, d, rel)
 
 
+@pytest.mark.parametrize("n", [9, 16, 32, 100, 128])
+def test_tiny_v_on_short_rows_through_the_one_wave_per_simd_tiling(n):
+    """the bf16-P optimistic bias grows on short rows (more exact zeros in P); the increment is capped at 9 so that the tiny-
+    accumulator threshold 2^-(bias + 16) stays a normal fp32 number -- uncapped (up to +15) it was 2^-127, v_exp_f32 flushed it to zero and a
+    tile of tiny V could never reach the rescaled redo.  FA_KERNEL_AUTO does not send rows this short to this tiling; the explicit tiling
+    number does."""
+    g = torch.Generator().manual_seed(n)
+    q, k, v = (torch.randn(6, n, 64, generator=g) for _ in range(3))
+    for vmag in (1.0, 1e-8, 1e-12):
+        qb, kb, vb = (t.bfloat16().to(dev()) for t in (q, k, v * vmag))
+        ref = fa.forward(qb.float(), kb.float(), vb.float(), False, kernel="naive")
+        for causal in (False, True):
+            if causal:
+                ref = fa.forward(qb.float(), kb.float(), vb.float(), True, kernel="naive")
+            o = fa.forward(qb, kb, vb, causal, kernel="mfma:50", out_dtype=torch.float32)
+            rel = float((o - ref).abs().max()) / vmag
+            OBSERVED.append((f"tiny V {vmag:g} on rows of {n} keys, NB = 2 tiling, causal={causal}", rel, bf16_tol(1.0, True)))
+            assert rel < bf16_tol(1.0, True), (n, vmag, causal, rel)
+
+
 def test_auto_takes_the_two_term_kernel_at_every_launch_size():
     """FA_KERNEL_AUTO for bf16 tensors with an fp32 output: P as two bf16 terms in one launch (route 0) whatever the size -- the kernel
     whose error does not depend on the logit width (Q.K^T of bf16 operands is exact in the fp32 accumulator).  x3 logits, the family on
