@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/make_tables.py TAG -- rewrite the measured-results blocks of DESIGN.md and README.md from ONE collection of the final binary:
+"""profiles/make_tables.py TAG -- rewrite the measured-results blocks of docs/results.md and README.md from ONE collection of the final binary:
 profiles/TAG_config_table.txt (profiles/config_table.sh) and profiles/TAG_bench_line{,_c3,_accurate}.json (profiles/collect.sh).
 
 The blocks sit between `<!-- results:begin -->` / `<!-- results:end -->` markers.  Boxes of the pool differ by +-4 %, so the tables are
@@ -81,15 +81,15 @@ def main():
         f"| one slab, BH=1 N=8192 d=64 bf16, non-causal / causal (key-split launches, §8) | `fa_fwd_bf16_x2_kernel<64>` × 8 key shares + `fa_combine_splits_kernel` | {ms(ks[0])} / {ms(ks[3])} ({ms(us[0])} / {ms(us[3])} unsplit) | {tf(ks[0])} / {tf(ks[3])} | {fr(ks[0])} / {fr(ks[3])} |",
         f"| BH=2, 4 non-causal; BH=2, 4, 8 causal (key-split) | same | {ms(ks[1])}, {ms(ks[2])} ({ms(us[1])}, {ms(us[2])} unsplit); {ms(ks[4])}, {ms(ks[5])}, {ms(ks[6])} ({ms(us[4])}, {ms(us[5])}, {ms(us[6])} unsplit) | {tf(ks[1])}, {tf(ks[2])}; {tf(ks[4])}, {tf(ks[5])}, {tf(ks[6])} | {fr(ks[1])}, {fr(ks[2])}; {fr(ks[4])}, {fr(ks[5])}, {fr(ks[6])} |",
         f"| BH=1, 2 fp32 tensors N=8192, non-causal; BH=1, 2, 4 causal (key-split, every share guarded: round 3) | `fa_fwd_f32_split_kernel` × 8 / 4 / 2 key shares + combine | {ms(ks[7])}, {ms(ks[8])} ({ms(us[7])}, {ms(us[8])} unsplit, unguarded); {ms(ks[9])}, {ms(ks[10])}, {ms(ks[11])} ({ms(us[9])}, {ms(us[10])}, {ms(us[11])}) | {tf(ks[7])}, {tf(ks[8])}; {tf(ks[9])}, {tf(ks[10])}, {tf(ks[11])} | — |",
-        f"| **c3** B=2 H=8 N=8192 d=64 fp32 | `fa_fwd_f32_split_kernel` (3 bf16 products of hi/lo splits, exponent reference in the accumulator init; AUTO adds the guard's empty exact launch: {b3['ms_per_step']:.3f} bench) | {ms(f3[0])} | **{tf(f3[0])}** | {fr(f3[0], third)} of bf16 peak at 3× FLOP |",
+        f"| **c3** B=2 H=8 N=8192 d=64 fp32 | `fa_fwd_f32_split_kernel` (Q·Kᵀ: 3 fp16 products of fp16 hi/lo terms, hi·hi first; P·V: 3 bf16 products of bf16 hi/lo terms; exponent reference in the accumulator init; AUTO = the same launch with the range guard: {b3['ms_per_step']:.3f} bench) | {ms(f3[0])} | **{tf(f3[0])}** | {fr(f3[0], third)} of the 16-bit MFMA peak at 3× FLOP |",
         f"| same, **fp32 arithmetic** (`FA_KERNEL_MFMA` — the figure to quote for \"c3 fp32\" in the reference's sense: bench `extra.c3.reference_arithmetic`) | `fa_fwd_f32_kernel` | {ms(exa[0])} | {exa[0]['tflops']:.1f} | **{fr(exa[0], 157.3)}** of fp32 peak |",
         f"| c3 shape causal; d=128; d=32 (fp32 tensors, split) | `fa_fwd_f32_split_kernel` | {ms(f3[4])}; {ms(f3[6])}; {ms(f3[7])} | {tf(f3[4])}; {tf(f3[6])}; {tf(f3[7])} | — |",
-        f"| **c2** B=8 H=16 N=1024 d=64 fp32 | split (AUTO chain: {ex['c2']['ms']:.3f} bench) / exact (`extra.c2.reference_arithmetic`) | {ms(f3[5])} / {ms(exa[1])} | {tf(f3[5])} / {tf(exa[1])} | {fr(f3[5], third)} of bf16 peak at 3× FLOP / {fr(exa[1], 157.3)} of fp32 peak |",
+        f"| **c2** B=8 H=16 N=1024 d=64 fp32 | split (AUTO: {ex['c2']['ms']:.3f} bench) / exact (`extra.c2.reference_arithmetic`) | {ms(f3[5])} / {ms(exa[1])} | {tf(f3[5])} / {tf(exa[1])} | {fr(f3[5], third)} of bf16 peak at 3× FLOP / {fr(exa[1], 157.3)} of fp32 peak |",
         f"| llm.c harness size B=6 T=4096 C=768 NH=12 fp32, causal, 1/√d (`fa_driver --mode llmc`) | `fa_forward_packed_qkv` → split kernel | {ms(llmc)} | {tf(llmc)} | max-abs {llmc['max_abs_err_vs_naive']:.1e} vs rung 0 (bar 1e-4) |",
     ]
     design = (f"Generated by `python profiles/make_tables.py {tag}` from `profiles/{tag}_config_table.txt` and `profiles/{tag}_bench_line*.json` "
               f"(library sha256 {b4['roofline']['lib_sha256']}…):\n\n" + "\n".join(rows) + "\n")
-    replace_block(os.path.join(ROOT, "DESIGN.md"), design)
+    replace_block(os.path.join(ROOT, "docs", "results.md"), design)
 
     # the c4 sentence of DESIGN.md section 7: profiler passes of the same collection
     pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json")))
@@ -113,21 +113,23 @@ def main():
                  f"chain was three), {gui_a / 1e3:.1f} k cycles = {gui_a / 256 / 1e3 * 1.0:.2f} k per four-block step (256 steps per tile; the issue model of section 4.6 gives 2.6 k), `SQ_VALU_MFMA_BUSY_CYCLES` ÷ (1024 × cycles) = "
                  f"{ka['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * gui_a):.2f} of the pipe,\n{gui_a / avg_a:.2f} GHz, {ka['SQ_INSTS_VALU'] / ka['SQ_INSTS_MFMA']:.2f} VALU instructions per MFMA; "
                  f"the bench line (`--accurate`): {ba['roofline']['kernel_ms']:.4f} ms = **{ba['roofline']['frac']:.3f}** at {ba['roofline']['max_abs_err']:.1e}.\n")
-    replace_block(os.path.join(ROOT, "DESIGN.md"), sec7, "profile7")
+    replace_block(os.path.join(ROOT, "docs", "results.md"), sec7, "profile7")
 
     readme = (
         f"Measured on MI355X (steady clocks, ONE run of the final binary on one box — `profiles/{tag}_config_table.txt`, generated by\n"
-        f"`profiles/make_tables.py`; identical binaries differ by ±4 % between boxes of the pool, c4 has read 0.2245–0.2374 ms this round):\n"
+        f"`profiles/make_tables.py`; identical binaries differ by ±4 % between boxes of the pool: the DRIVER's end-of-round runs have read c4 at\n"
+        f"0.467 / 0.483 / 0.489 / 0.468 of the peak in rounds 1–4, this round's boxes 0.2323–0.2450 ms):\n"
         f"B=2 H=8 N=8192 d=64 — bf16 {ms(c4[0])} ms ({tf(c4[0])} TFLOP/s, {100 * c4[0]['tflops'] / 2500:.0f} % of the dense bf16 MFMA peak; d=128: {tf(dm[1])} TFLOP/s,\n"
         f"{100 * dm[1]['tflops'] / 2500:.0f} %) at {b4['roofline']['max_abs_err']:.1e} max-abs of the fp32 reference (bf16 P, bf16 output, the reference's scale 1; {ex['c4_scale_rsqrt_d']['max_abs_err']:.1e} at 1/√d);\n"
         f"bf16 tensors with fp32 output (P as bf16 hi + bf16 lo in one launch: **{ba['roofline']['max_abs_err']:.1e} of the fp32 reference at scale 1**) {ms(x2[0])} ms =\n"
-        f"{100 * x2[0]['tflops'] / 2500:.0f} % — the `roofline_at_1e-3` block of the bench line; fp32 tensors {ms(f3[0])} ms ({tf(f3[0])} TFLOP/s: both contractions as\n"
-        f"three bf16 MFMA products of hi/lo splits, within 2.5e-4 of the fp64 oracle at scale 1, wide-logit workgroups redone in fp32 arithmetic inside the launch\n"
-        f"on the device; `kernel=\"exact\"`, fp32 arithmetic: {ms(exa[0], 2)} ms, {100 * exa[0]['tflops'] / 157.3:.0f} % of the fp32 MFMA peak); causal {ms(ca[0])} ms — causal launches\n"
-        f"choose which tiles share a CU (`DESIGN.md` §4.4); grids that leave the chip idle are key-split (one slab of that length: {ms(ks[0])} ms\n"
+        f"{100 * x2[0]['tflops'] / 2500:.0f} % — the `roofline_at_1e-3` block of the bench line; fp32 tensors {ms(f3[0])} ms ({tf(f3[0])} TFLOP/s: Q·Kᵀ as three\n"
+        f"fp16 MFMA products of fp16 hi/lo terms, P·V as three bf16 products — within 1e-4 of the fp64 oracle at scale 1 and never further from it than\n"
+        f"the reference's own fp32 arithmetic on any input (`DESIGN.md` §4); workgroups whose operands leave the fp16 range are redone in fp32 arithmetic\n"
+        f"inside the launch; `kernel=\"exact\"`, fp32 arithmetic: {ms(exa[0], 2)} ms, {100 * exa[0]['tflops'] / 157.3:.0f} % of the fp32 MFMA peak, causal {100 * ex['c3_causal']['exact']['frac_f32_mfma_peak']:.0f} %); causal bf16 {ms(ca[0])} ms —\n"
+        f"causal launches choose which tiles share a CU; grids that leave the chip idle are key-split (one slab of that length: {ms(ks[0])} ms\n"
         f"instead of {ms(us[0])}, causal {ms(ks[3])} instead of {ms(us[3])}, fp32 {ms(ks[7])} instead of {ms(us[7])}, fp32 causal {ms(ks[9])} instead of {ms(us[9])}).\n")
     replace_block(os.path.join(ROOT, "README.md"), readme)
-    print("DESIGN.md and README.md results blocks rewritten from", tag)
+    print("docs/results.md and README.md results blocks rewritten from", tag)
 
 
 if __name__ == "__main__":
