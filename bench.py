@@ -299,6 +299,9 @@ def main():
     ap.add_argument("--cpu-stub", action="store_true",
                     help="TEST HOOK (tests/test_distributed_gloo.py): exercise launcher, sharding and timing protocol on CPU ranks with a "
                          "sleep instead of the kernel; the line it prints says so and carries no measurement")
+    ap.add_argument("--same-device", action="store_true",
+                    help="TEST HOOK (tests/test_gpu_dist.py): every rank uses cuda:0 -- two ranks on a one-GPU box (with --backend gloo) exercise "
+                         "the world > 1 code of this script; the line says so")
     args = ap.parse_args()
 
     if args.gpus > 1 and not under_launcher():
@@ -312,6 +315,8 @@ def main():
         return stub_main(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the flash-attention forward has no CPU path")
+    if args.same_device:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = init_dist(world, args.backend) if world > 1 else None
@@ -492,7 +497,7 @@ def main():
             if args.workload in ("c3", "c4") else f"flash-attention fwd achieved TFLOP/s, workload {args.workload}",
             "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": dtype, "data": "synthetic randn (seeded), resident in HBM",
+            "dtype": dtype, "data": "synthetic randn (seeded), resident in HBM" + (" -- TEST HOOK --same-device: all ranks share cuda:0, not a measurement" if args.same_device else ""),
             "config": {"workload": f"{args.workload}: B={B} H={H} d={d} N={n} {dtype}, {'causal' if causal else 'non-causal'}, "
                                    f"scale={args.scale:g}" + (", fp32 output (accurate P)" if args.accurate and dtype == "bf16" else "")
                                    + (" per GPU" if scaling == "weak" and world > 1 else ""),

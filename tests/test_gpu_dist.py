@@ -61,3 +61,24 @@ def test_bench_config_5_under_the_drivers_launch_line_with_one_gpu():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["scaling"] == "strong" and line["config"]["global_bh"] == 1024 and line["config"]["bh_per_gpu"] == 1024
     assert line["value"] > 500.0 and line["roofline"]["kernel"] == "fa_fwd_bf16_x4_kernel"
+
+
+def test_bench_with_two_ranks_on_the_one_gpu():
+    """The world > 1 code of bench.py -- the attempts loop's broadcast, the all-gather of per-rank times, ranks_seen / dist_backend, the
+    c5 split over two ranks, weak-scaling prediction -- with two ranks sharing cuda:0 (--same-device, a test hook) over gloo (RCCL refuses
+    two ranks on one device).  Not a measurement; the first real multi-GPU run is the driver's."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--no-cpu-baseline", "--backend", "gloo", "--same-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    ex = line["extra"]
+    assert line["n_gpus"] == 2 and ex["ranks_seen"] == 2 and ex["dist_backend"] == "gloo" and len(ex["per_rank_ms"]) == 2
+    assert line["config"]["global_bh"] == 32 and line["scaling"] == "weak" and "weak_scaling" in ex
+    assert ex["c5"]["n_gpus"] == 2 and ex["c5"]["bh_per_gpu"] == 512 and len(ex["c5"]["per_rank_ms"]) == 2
+    assert 1 <= len(ex["timing_attempts"]) <= 3 and line["validation"]["status"] == "ok"
+    assert line["roofline"]["frac_from_kernel_ms"] > 0.1 and line["roofline"]["frac_from_ms_per_step"] > 0.05
