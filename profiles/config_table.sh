@@ -22,9 +22,20 @@ $D --mode rand --bh 16 --n 8192 --d 64 --dtype f32s --warmup 60 --iters 20 --che
 $D --mode rand --bh 128 --n 1024 --d 64 --dtype f32s --warmup 200 --iters 50 --check 0
 $D --mode rand --bh 16 --n 8192 --d 128 --dtype f32s --warmup 40 --iters 10 --check 0
 $D --mode rand --bh 16 --n 8192 --d 32 --dtype f32s --warmup 60 --iters 20 --check 0
-echo "== fp32 tensors, exact fp32 arithmetic: c3, c2"
-$D --mode rand --bh 16 --n 8192 --d 64 --dtype f32 --warmup 20 --iters 10 --check 0
-$D --mode rand --bh 128 --n 1024 --d 64 --dtype f32 --warmup 100 --iters 30 --check 0
+echo "== fp32 tensors, exact fp32 arithmetic: c3, c2; round 5: c3 causal (paired tiles), c2 causal, d=128, d=128 causal, d=32, d=32 causal, BH=1 over key shares, BH=1 unsplit (--variant 1), BH=1 causal, BH=4 causal"
+E="--dtype f32 --check 0"
+$D --mode rand --bh 16 --n 8192 --d 64 $E --warmup 20 --iters 10
+$D --mode rand --bh 128 --n 1024 --d 64 $E --warmup 100 --iters 30
+$D --mode rand --bh 16 --n 8192 --d 64 $E --warmup 20 --iters 10 --causal 1
+$D --mode rand --bh 128 --n 1024 --d 64 $E --warmup 100 --iters 30 --causal 1
+$D --mode rand --bh 16 --n 8192 --d 128 $E --warmup 10 --iters 6
+$D --mode rand --bh 16 --n 8192 --d 128 $E --warmup 10 --iters 6 --causal 1
+$D --mode rand --bh 16 --n 8192 --d 32 $E --warmup 20 --iters 10
+$D --mode rand --bh 16 --n 8192 --d 32 $E --warmup 20 --iters 10 --causal 1
+$D --mode rand --bh 1 --n 8192 --d 64 $E --warmup 50 --iters 30
+$D --mode rand --bh 1 --n 8192 --d 64 $E --warmup 50 --iters 30 --variant 1
+$D --mode rand --bh 1 --n 8192 --d 64 $E --warmup 50 --iters 30 --causal 1
+$D --mode rand --bh 4 --n 8192 --d 64 $E --warmup 50 --iters 30 --causal 1
 echo "== two-term bf16-P kernels (FA_KERNEL_AUTO for an fp32 output, one launch): --kernel pb2 --out_f32 1  (c4 at scale 1, 0.5, 1/sqrt(d); causal; bh=128; d=128; d=128 causal; d=32; c2 shape; c4 through the NB = 2 tiling; bh=128 through NB = 2)"
 P="--dtype bf16 --kernel pb2 --out_f32 1 --warmup 100 --iters 30 --check 0"
 for sc in 1 0.5 0.125; do $D --mode rand --bh 16 --n 8192 --d 64 $P --scale $sc; done

@@ -1,8 +1,9 @@
 #!/bin/bash
 # profiles/power_sample.sh -- socket power and shader clock (rocm-smi, four samples a second apart) while fa_driver launches one kernel back to back:
-# evidence for the power-budget reading of DESIGN.md section 4.2.  Run on the GPU box: gpurun -- "bash profiles/power_sample.sh"
-mkdir -p gpurun_out/r04
-out=gpurun_out/r04/power.txt
+# evidence for the power-budget reading of DESIGN.md section 5.  Run on the GPU box: gpurun -- "bash profiles/power_sample.sh"
+TAG=${1:-r05}
+mkdir -p gpurun_out/$TAG
+out=gpurun_out/$TAG/power.txt
 : > $out
 D=./flashattention.c_amd/fa_driver
 sample() {  # label, driver args
@@ -22,7 +23,7 @@ echo "idle:" >> $out; rocm-smi --showpower --showclocks --showmaxpower 2>/dev/nu
 sample "c4 bf16 P (x4)" --dtype bf16 --bh 16 --n 8192 --d 64
 sample "c4 two-term P" --dtype bf16 --out_f32 1 --kernel pb2 --bh 16 --n 8192 --d 64
 sample "c4 at scale 4 (sparser P)" --dtype bf16 --bh 16 --n 8192 --d 64 --scale 4
-sample "c3 fp32 tensors (split kernel)" --dtype f32s --kernel auto --bh 16 --n 8192 --d 64 --iters 12000
+sample "c3 fp32 tensors (split kernel: fp16 terms for Q.K^T since round 5)" --dtype f32s --kernel auto --bh 16 --n 8192 --d 64 --iters 12000
 sample "c3 exact fp32" --dtype f32 --bh 16 --n 8192 --d 64 --iters 4000
 sample "d128" --dtype bf16 --bh 16 --n 8192 --d 128 --iters 20000
 cat $out
