@@ -54,6 +54,9 @@
 #ifndef FA_SPLIT_REF
 #define FA_SPLIT_REF 1   // 0: experiment switch -- the fast pass runs reference-free (p = exp2(s), round 2)
 #endif
+#ifndef FA_SPLIT_CENTER
+#define FA_SPLIT_CENTER 1  // 0: experiment switch -- keys are split as they come (rounds 1-4) instead of relative to a reference key
+#endif
 #ifndef FA_SPLIT_QK16
 #define FA_SPLIT_QK16 1  // 0: experiment switch -- K and Q' of fp32 tensors as two BF16 terms (16 bits: rounds 1-4) instead of two FP16 terms
 #endif
@@ -237,6 +240,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     constexpr int GPT = (C::kGroups + NT - 1) / NT;  // groups per thread and tile
 
     __shared__ __attribute__((aligned(1024))) char smem[2 * C::kStageBytes];
+    __shared__ __attribute__((aligned(16))) float s_kref[D];   // key centering, eight-wave tiling only (no registers to spare): the reference key
     __shared__ unsigned s_kmax;   // range guard: max |k| over the keys this workgroup reads, as the bits of a non-negative float
 
     if (flag_says_skip(p)) return;   // conditional fallback of a launch chain (bf16 tensors behind the fp16-P kernel)
@@ -306,6 +310,42 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
         g_vsrc[i] = vrow * p.kv_row_stride + vc8 * 8;
         g_vdst[i] = 2 * C::kImageBytes + (rq * (D / 16) + c16) * 128 + r4 * 32 + half * 16;
     }
+    // KEY CENTERING (fp32 tensors, round 5).  softmax(q.k_j) = softmax(q.(k_j - kbar)) for ANY fixed vector kbar: the row constant q.kbar
+    // cancels in O and is added back to the log-sum-exp.  What it buys: fp32 accumulation rounds (the matrix core truncates) every partial
+    // sum at the magnitude it has, so a logit of ~1500 carries ~1e-3 of error whatever the operand terms hold -- and when that magnitude is
+    // COMMON MODE (constant-component rows, a broadcast token, inputs with an offset: every key close to every other, the family of
+    // tests/adversarial.py) the softmax only needs the DIFFERENCES, which k_j - kbar delivers exactly (one fp32 subtraction, exact for
+    // nearly equal values) before anything is rounded to 22 bits or accumulated.  kbar = the coordinate-wise MEDIAN of three keys of the
+    // share (first, middle, last): an outlier key (an attention sink in position 0) cannot become the reference, |kbar_c| never exceeds the
+    // second largest of three actual values (centred magnitudes are at most twice the uncentred ones), and it costs three row loads and
+    // one v_med3_f32 per column per workgroup + one v_sub_f32 per converted key element.  Coherent family at d = 128, causal: 3.5e-3 ->
+    // below 1e-4 (profiles/r05_family_centered.txt); the reference's own fp32 FMA chain reads 5.7e-3 there.
+    constexpr bool CENTER = !IN_BF16 && FA_SPLIT_CENTER;
+    const int kref_r1 = nk >> 1, kref_r2 = nk - 1;   // (local key indices of the share)
+    auto kref_at = [&](int col0) {                    // median-of-three reference for columns col0 .. col0 + 3
+        f32x4 r = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (CENTER) {
+            const float* kf = (const float*)kg;
+            const f32x4 a = *(const f32x4*)(kf + col0);
+            const f32x4 b = *(const f32x4*)(kf + (int64_t)kref_r1 * p.kv_row_stride + col0);
+            const f32x4 c = *(const f32x4*)(kf + (int64_t)kref_r2 * p.kv_row_stride + col0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = __builtin_amdgcn_fmed3f(a[e], b[e], c[e]);
+        }
+        return r;
+    };
+    // this thread's K pieces all sit in the same 8 columns (NT is a multiple of D / 8, or kGroups divides it)
+    const int kref_col = ((tid % C::kGroups) % (D / 8)) * 8;
+    // KREF_REG: the thread's eight reference values live in registers; the eight-wave D = 128 tiling (256 registers per lane, all in use)
+    // reads them from LDS in front of every conversion instead -- behind the V piece's conversion, which hides the latency
+    constexpr bool KREF_REG = !(D == 128 && NWAVES == 8);
+    f32x4 kref0 = {0.0f, 0.0f, 0.0f, 0.0f}, kref1 = kref0;
+    if constexpr (CENTER && KREF_REG) {
+        kref0 = kref_at(kref_col), kref1 = kref_at(kref_col + 4);
+    } else if constexpr (CENTER) {
+        if (tid < D / 4) *(f32x4*)&s_kref[tid * 4] = kref_at(tid * 4);
+        __syncthreads();
+    }
     f32x4 kst[GPT][2], vst[GPT][2];
     auto load_tile = [&](int kv0) {
 #pragma unroll
@@ -324,7 +364,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
             }
         }
     };
-    auto store_tile = [&](char* stage) {
+    auto store_tile = [&](char* stage, int kv0) {   // kv0: first key of the tile load_tile fetched
 #pragma unroll
         for (int i = 0; i < GPT; ++i) {
             if (!g_on[i]) continue;
@@ -333,16 +373,22 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                 *(f32x4*)(stage + g_vdst[i]) = vst[i][0];
             } else {
                 bf16x8 h8, l8;
+                f32x4 r0 = kref0, r1 = kref1;
+                if constexpr (CENTER && !KREF_REG) r0 = *(const f32x4*)&s_kref[kref_col], r1 = *(const f32x4*)&s_kref[kref_col + 4];
+                split8(vst[i][0], vst[i][1], h8, l8);
+                *(bf16x8*)(stage + g_vdst[i]) = h8;
+                *(bf16x8*)(stage + C::kImageBytes + g_vdst[i]) = l8;
+                if constexpr (CENTER) kst[i][0] -= r0, kst[i][1] -= r1;
                 if constexpr (GUARD) {
+                    // (key rows past the share were loaded as zeros and are now -kbar: masked in the scores, and kept out of the range guard's max |k|)
+                    if (!CENTER || kv0 + g_krow[i] < nk) {
 #pragma unroll
-                    for (int e = 0; e < 4; e += 2) absmax2(kmax, kst[i][0][e], kst[i][0][e + 1]), absmax2(kmax, kst[i][1][e], kst[i][1][e + 1]);
+                        for (int e = 0; e < 4; e += 2) absmax2(kmax, kst[i][0][e], kst[i][0][e + 1]), absmax2(kmax, kst[i][1][e], kst[i][1][e + 1]);
+                    }
                 }
                 split8x<QK16, true>(kst[i][0], kst[i][1], h8, l8);
                 *(bf16x8*)(stage + g_kdst[i]) = h8;
                 *(bf16x8*)(stage + C::kImageBytes + g_kdst[i]) = l8;
-                split8(vst[i][0], vst[i][1], h8, l8);
-                *(bf16x8*)(stage + g_vdst[i]) = h8;
-                *(bf16x8*)(stage + C::kImageBytes + g_vdst[i]) = l8;
             }
         }
     };
@@ -350,6 +396,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     // ---- Q' fragments (B operand of S^T = K Q'^T), hi and lo: lane (lq, hi) holds Q'[q][16*ks + 8*hi .. +7]
     bf16x8 qh[QB][KS], ql[QB][KS];
     float qn2 = 0.0f;   // guard: largest squared 2-norm of Q' among this lane's rows (its half of each row; halves are added below)
+    const bool want_crow = CENTER && p.lse != nullptr;   // (uniform; key-split launches always carry an lse)
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         float qs = 0.0f;
@@ -374,6 +421,29 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
         }
         if constexpr (GUARD) qn2 = fmaxf(qn2, xhalf_sum(qs));
     }
+    // key centering: q'.kbar of this lane's row (exp2 domain), added back to the log-sum-exp in the epilogues -- with the operand the
+    // matrix core sees (hi + lo, exact in fp32), accumulated in fp64: once per row and tile, and only when an lse is asked for
+    auto crow_of = [&](auto qbc) -> float {   // (compile-time indices: a runtime index into the Q' fragments would put them in scratch)
+        constexpr int qb = decltype(qbc)::value;
+        if (!want_crow) return 0.0f;
+        double cacc = 0.0;
+        for_each_index([&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value;
+            const f32x4 r0 = kref_at(ks * 16 + hi * 8), r1 = kref_at(ks * 16 + hi * 8 + 4);
+            typedef __attribute__((ext_vector_type(8))) float f32x8_t;
+            f32x8_t qe;   // the operand the matrix core sees: hi + lo, exact in fp32
+            if constexpr (QK16) {
+                qe = __builtin_convertvector(__builtin_bit_cast(f16x8, qh[qb][ks]), f32x8_t) + __builtin_convertvector(__builtin_bit_cast(f16x8, ql[qb][ks]), f32x8_t);
+            } else {
+                qe = __builtin_convertvector(qh[qb][ks], f32x8_t) + __builtin_convertvector(ql[qb][ks], f32x8_t);
+            }
+            for_each_index([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                cacc += (double)qe[e] * (double)r0[e] + (double)qe[e + 4] * (double)r1[e];
+            }, std::make_integer_sequence<int, 4>{});
+        }, std::make_integer_sequence<int, KS>{});
+        return xhalf_sum((float)cacc);
+    };
 
     const int k_row_off = lq * C::kRowBytes;
     const int k_g = hi ^ k_swizzle<D>(lq);
@@ -488,7 +558,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
         };
 
         load_tile(0);
-        store_tile(smem);
+        store_tile(smem, 0);
         __syncthreads();
 
         if constexpr (OPT) {
@@ -587,7 +657,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
             }
 
             // stage STG^1 was last read in step j-1; every wave has passed the barrier that ended that step
-            if (more) store_tile(smem + (STG ^ 1) * C::kStageBytes);
+            if (more) store_tile(smem + (STG ^ 1) * C::kStageBytes, (j + 1) * kKvSplit);
             __syncthreads();
         };
 
@@ -600,12 +670,15 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
 
         // ================= epilogue: O / l, store =================
         mfma_drain();  // the loop exit is a branch: the last P.V MFMAs may still be in flight
+        float crows[QB];
+        for_each_index([&](auto qbc) { crows[decltype(qbc)::value] = crow_of(qbc); }, std::make_integer_sequence<int, QB>{});
         bool ok = true;
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             const float lt = xhalf_sum(l[qb]);
             const float inv = 1.0f / lt;
             const int qi = q0 + qb * 32 + lq;
+            const float crow = crows[qb];
             float mag = 0.0f;
             if (qi < n) {
                 const int64_t o_off = o_slab + (int64_t)qi * p.o_row_stride + 4 * hi;
@@ -621,7 +694,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                         }
                         store4(p, o_off + db * 32 + 8 * g, pk);
                     }
-                if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (m[qb] + __builtin_amdgcn_logf(lt)) * kLn2;
+                if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = ((m[qb] + __builtin_amdgcn_logf(lt)) + crow) * kLn2;
                 if (OPT) ok = ok && (lt < kSplitLimit) && (mag < INFINITY);   // false for NaN as well
                 if (GUARD) saw_nan = saw_nan || (lt != lt) || (mag != mag);
             }
@@ -679,13 +752,25 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
         const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kg, 0, slab_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vg, 0, slab_bytes, 0x00020000);
         const unsigned tile_step = (unsigned)kKvSplit * (unsigned)p.kv_row_stride * ES;
+        // key centring: rows past the share (the ragged tail of its last tile, the tiles the pipeline reads ahead of the end) are read as
+        // the share's LAST key instead of the descriptor's zeros -- they are masked or never used, but zeros would leave the centring as
+        // -kbar and raise the range guard's max |k| for nothing.  Offsets grow with the row for a fixed column: one add + one min per piece.
+        unsigned k_last[GPT];
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) k_last[i] = ((unsigned)(nk - 1) * (unsigned)p.kv_row_stride + (unsigned)kref_col) * ES;
         auto load_k = [&](int t) {
             const unsigned soff = (unsigned)t * tile_step;
 #pragma unroll
             for (int i = 0; i < GPT; ++i) {
-                kst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, g_ksrc[i] * ES, soff, 0));
-                if constexpr (!IN_BF16)
-                    kst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, g_ksrc[i] * ES + 16, soff, 0));
+                if constexpr (CENTER) {
+                    const unsigned off = min(g_ksrc[i] * ES + soff, k_last[i]);
+                    kst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, off, 0, 0));
+                    kst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, off + 16, 0, 0));
+                } else {
+                    kst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, g_ksrc[i] * ES, soff, 0));
+                    if constexpr (!IN_BF16)
+                        kst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, g_ksrc[i] * ES + 16, soff, 0));
+                }
             }
         };
         auto load_v = [&](int t) {
@@ -705,6 +790,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                     *(f32x4*)(stage + g_kdst[i]) = kst[i][0];
                 } else {
                     bf16x8 h8, l8;
+                    if constexpr (CENTER) kst[i][0] -= kref0, kst[i][1] -= kref1;
                     if constexpr (GUARD) {
 #pragma unroll
                         for (int e = 0; e < 4; e += 2) absmax2(kmax, kst[i][0][e], kst[i][0][e + 1]), absmax2(kmax, kst[i][1][e], kst[i][1][e + 1]);
@@ -954,7 +1040,8 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                         }
                     } else {
                         constexpr int c = U - NU_S, gi = c / 4, which = (c % 4) / 2, half = c % 2;
-                        const f32x4 x = which ? vst[gi][half] : kst[gi][half];
+                        f32x4 x = which ? vst[gi][half] : kst[gi][half];
+                        if constexpr (CENTER && which == 0) x -= (half ? kref1 : kref0);
                         if constexpr (GUARD && which == 0) absmax2(kmax, x[2 * H], x[2 * H + 1]);
                         bf16x2 h2, l2;
                         split2x<QK16 && which == 0, false>(x[2 * H], x[2 * H + 1], h2, l2);   // K pieces: fp16 terms (fp32 tensors)
@@ -1026,12 +1113,15 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
 
         // ================= epilogue: O / l, store =================
         mfma_drain();  // the last P.V MFMAs may still be in flight
+        float crows[QB];
+        for_each_index([&](auto qbc) { crows[decltype(qbc)::value] = crow_of(qbc); }, std::make_integer_sequence<int, QB>{});
         bool ok = true;
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             const float lt = xhalf_sum(la[qb] + lb[qb]);
             const float inv = 1.0f / lt;
             const int qi = q0 + qb * 32 + lq;
+            const float crow = crows[qb];
             float mag = 0.0f;
             if (qi < n) {
                 const int64_t o_off = o_slab + (int64_t)qi * p.o_row_stride + 4 * hi;
@@ -1047,7 +1137,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                         }
                         store4(p, o_off + db * 32 + 8 * g, pk);
                     }
-                if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (mref[qb] + __builtin_amdgcn_logf(lt)) * kLn2;
+                if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = ((mref[qb] + __builtin_amdgcn_logf(lt)) + crow) * kLn2;
                 // lt: the row's own reference term 2^-B is in the sum, so a healthy row sum never falls below 2^-(B + 1) (B = 101 for n <= 256:
                 // round 3 tested against a fixed 2^-100 there and redid every tile whose reference key held most of a row's mass);
                 // mag * lt = the sum of the unnormalised accumulators: tiny or zero means the products p v of the terms that matter

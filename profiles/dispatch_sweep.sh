@@ -2,7 +2,7 @@
 # profiles/dispatch_sweep.sh PART -- the sweeps behind profiles/r03_short_rows.txt: every tiling of the product library against the
 # dispatch (variant 0) over a grid of shapes, one line per run ("dtype [kernel] d D bh BH n N c CAUSAL [v VARIANT] ms").  Run on the GPU
 # box (gpurun -- 'bash profiles/dispatch_sweep.sh short > gpurun_out/sweep_short.txt'), then python3 profiles/dispatch_sweep_report.py FILE.
-# PART: short (rows of 128 .. 2048 keys, fp32 modes and bf16 variants) | small (bf16, small grids) | mid (bf16 d = 64 mid-size) |
+# PART: f32short (round 5: the fp32 half of short) | short (rows of 128 .. 2048 keys, fp32 modes and bf16 variants) | small (bf16, small grids) | mid (bf16 d = 64 mid-size) |
 #       f32mid (fp32 tensors, mid-size) | f32auto (fp32 AUTO against unsplit) | bf16auto (bf16 AUTO against unsplit / phase) | long (bf16 long rows)
 PART=${1:-short}
 cd "${GRAFT_REPO_ROOT:-.}"
@@ -19,6 +19,11 @@ short)
   done; done; done
   for d in 64 32 128; do for c in 0 1; do for n in 128 256 512 768; do
     bh=$((131072 / n)); for v in 0 1 7 50; do runv --bh $bh --n $n --d $d --dtype bf16 --variant $v --causal $c --warmup 100 --iters 50; done
+  done; done; done ;;
+f32short)   # round 5: the fp32 half of `short` (the split kernel's K.Q'^T went to fp16 terms, hi.hi first: is choose_split() still right?)
+  for d in 64 32 128; do for c in 0 1; do for n in 128 256 384 512 640 768 896 1024 1280 1536 2048; do
+    bh=$((131072 / n)); if [ $d = 128 ]; then vs="1 3 5"; else vs="1 3 4"; fi
+    for v in 0 $vs; do runv --bh $bh --n $n --d $d --dtype f32s --variant $v --causal $c --warmup 100 --iters 50; done
   done; done; done ;;
 small)
   for c in 0 1; do for n in 256 512 1024 1536 2048 3072; do for bh in 2 4 8 16 32; do

@@ -127,6 +127,53 @@ def test_exact_kernel_is_the_reference_arithmetic_not_an_oracle(d):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# fp32 tensors: key centring (k_j - kbar, kbar = the coordinate-wise median of three keys of the share)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [32, 64, 128])
+def test_key_centring_is_robust_to_outlier_reference_candidates(d):
+    """The reference key is the median of keys 0, n/2 and n - 1 of the share: ONE outlier among them (an attention sink in position 0, a huge
+    last key) is rejected, and two outliers only make the centring as good as no centring (|kbar_c| never exceeds the second largest of three
+    actual values).  Asserted on random data with outliers planted in exactly those positions -- scaled up AND anti-aligned with the queries'
+    mean so that the rows' mass stays on the ordinary keys, whose logits a bad reference would spoil -- at the fp32 bar, O and LSE."""
+    rng = np.random.default_rng(d)
+    bh, n = 3, 1000
+    q = rng.standard_normal((bh, n, d)).astype(np.float32) + 0.5
+    k = rng.standard_normal((bh, n, d)).astype(np.float32)
+    v = rng.standard_normal((bh, n, d)).astype(np.float32)
+    sink = (-30.0 * q.mean(axis=1) / np.linalg.norm(q.mean(axis=1), axis=-1, keepdims=True)).astype(np.float32)
+    for planted in ([0], [n - 1], [0, n - 1], [0, n // 2, n - 1]):
+        kk = k.copy()
+        for j in planted:
+            kk[:, j] = sink * (1.0 + 0.01 * j / n)
+        for causal in (False, True):
+            o_ref, l_ref = adv.attention_f64(q, kk, v, causal)
+            ce_o, ce_l = adv.reference_arithmetic_error(q, kk, v, causal)
+            o, lse = run(q, kk, v, causal=causal)
+            record(f"key centring, outliers at {planted}, d={d}, causal={int(causal)}: O", float(np.abs(o - o_ref).max()), max(TOL, REF_SHARE * ce_o))
+            record(f"key centring, outliers at {planted}, d={d}, causal={int(causal)}: LSE", float(np.abs(lse - l_ref).max()), max(TOL, REF_SHARE * ce_l))
+
+
+@pytest.mark.parametrize("n", [500, 512, 8192])
+def test_key_centring_removes_common_mode_and_keeps_the_guard_quiet(n):
+    """Constant-component rows whose UNCENTRED operands would trip the range guard (D max|k| + sqrt(D) |q'|_2 > 2048 at width 205, d = 128):
+    the guard looks at the centred keys, so the default stays on the 16-bit pipes (route 1) -- for a ragged length too (rows past the end are
+    kept out of the guard's max |k|), and over key shares (n = 8192 on one slab: every share centres on its own reference and adds its own
+    row constant back to its log-sum-exp before the combine) -- and reads far below the reference arithmetic's own error."""
+    q, k, v = adv.make("const_two_keys", 128, 205.0, n=n, bh=1, seed=n)
+    rows = np.unique(np.concatenate([[0, 1, 2, n - 1], np.random.default_rng(n).integers(0, n, 200)]))
+    for causal in (False, True):
+        o, lse = run(q, k, v, causal=causal)
+        assert fa.last_forward_route() == 1, (n, causal)
+        o_ref, l_ref = adv.rows_f64(q[0], k[0], v[0], rows, causal)
+        o_ch, l_ch = adv.rows_f64(q[0], k[0], v[0], rows, causal, chain=True)
+        ce_o = float(np.abs(o_ch - o_ref).max())
+        e_o, e_l = float(np.abs(o[0][rows] - o_ref).max()), float(np.abs(lse[0][rows] - l_ref).max())
+        record(f"key centring, const_two_keys d=128 w=205 n={n} causal={int(causal)}: O (fp32 FMA chain: {ce_o:.1e})", e_o, TOL)
+        record(f"key centring, const_two_keys d=128 w=205 n={n} causal={int(causal)}: LSE", e_l, TOL)
+        assert e_o < 0.2 * ce_o, (e_o, ce_o)
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # fp32 tensors: the RANGE of the fp16 operand terms (what the guard of FA_KERNEL_AUTO bounds since round 5)
 # ---------------------------------------------------------------------------------------------------------------
 def test_fp32_default_outside_the_fp16_range():
