@@ -17,7 +17,10 @@
 // VERDICT r04).  What is left on wide logits is fp32 ACCUMULATION: every matrix instruction rounds (truncates) its partial sum at the
 // magnitude it has then, so the hi.hi products of ALL k-steps come first -- the accumulator starts at -(m0 + B), as large as the row's widest
 // logit, and walks down to the score's own small magnitude -- and the cross terms are added last, where an ulp is small (scores(), qk(),
-// the slot schedule).  O's terms add <= 3 * 2^-17 * max|v|.  Measured: <= 1e-4 on unit-variance data at scale 1, <= 1.5e-5 at 1/sqrt(d).
+// the slot schedule).  And the keys are CENTRED before they are split (k_j - kbar, kbar the coordinate-wise median of three keys of the
+// share; the row constant q'.kbar goes back into the log-sum-exp): a magnitude all keys share never reaches a rounded sum -- see KEY
+// CENTERING in the kernel.  O's terms add <= 3 * 2^-17 * max|v|.  Measured: <= 1e-4 on unit-variance data at scale 1, <= 1.5e-5 at
+// 1/sqrt(d), <= 2.7e-4 on the coherent-rounding family of tests/adversarial.py (the reference's own FMA chain: up to 5.9e-3).
 // RANGE GUARD (fp32 tensors under FA_KERNEL_AUTO, FwdParams::flag_mode = 4): fp16 terms hold |x| < 65520 (beyond: hi = inf, lo = -inf, NaN
 // scores) and give elements below 2^-3 a subnormal lo term (absolute error <= 2^-25, times the partner element).  Every workgroup sees all
 // keys of its slab and its own query rows; it tracks max |k| element-wise while converting K (one v_max3_f32 per four values) and the

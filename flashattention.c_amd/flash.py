@@ -78,8 +78,9 @@ def forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = Fa
     log-sum-exp -- the quantity the reference's unused ``O_l`` buffer was reserved for.
 
     Kernel choice (include/flashattn_amd.h has the full rules).  fp32 tensors: ``kernel="auto"`` runs Q.K^T as three matrix products
-    of two-term FP16 splits (22 bits) and P.V as three products of two-term BF16 splits: <= 1e-4 of the fp32 reference on unit-variance
-    data, never further from fp64 than the reference's own fp32 arithmetic on any input, behind a device-side RANGE guard: a workgroup
+    of two-term FP16 splits (22 bits) of Q and of the keys centred on a reference key, P.V as three products of two-term BF16 splits:
+    <= 1e-4 of the fp32 reference on unit-variance data, <= 3e-4 on coherent inputs where fp32 arithmetic itself reads up to 6e-3, never
+    further from fp64 than the reference's own fp32 arithmetic on any input, behind a device-side RANGE guard: a workgroup
     whose operands leave what fp16 terms hold redoes its rows in exact fp32 arithmetic inside the same launch;
     ``"split"`` is the same without the guard,
     ``"exact"`` (= ``"mfma"``) computes in fp32 arithmetic.  bf16 tensors: ``out_dtype=torch.float32`` stores the fp32

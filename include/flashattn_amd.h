@@ -60,16 +60,19 @@ typedef enum fa_dtype {
     FA_DTYPE_F32 = 0, /* fp32 in, fp32 out -- the reference's dtype.  FA_KERNEL_AUTO (round 5): Q.K^T as three matrix products of two-term
                          FP16 splits of the fp32 operands (hi = f16(x), lo = f16(x - hi): 22 significant bits; v_mfma_f32_32x32x16_f16,
                          fp32 accumulate, the hi.hi products of all k-steps first so that the cross terms are added where the partial sum
-                         is small), P.V as three products of two-term BF16 splits (P needs fp32's exponent range); 3.2x faster than fp32
-                         arithmetic.  GUARANTEED: the logit error of the operand terms is <= 3 * 2^-22 * sum |q_i k_i| * scale -- below the
-                         rounding bound d * 2^-24 * sum |q_i k_i| of the reference's own fp32 FMA chain for every d >= 12 -- and the P.V
-                         terms add <= 3 * 2^-17 * max|v|.  CONTRACT (tests/test_gpu_adversarial.py): |O - O_fp64| and |LSE - LSE_fp64| are
-                         <= max(1e-3, E_ref) on every input, E_ref = what the reference's own arithmetic (a k-ordered chain of rounding fp32
-                         FMAs, flashattention.cu:236-252) leaves on that input.  OBSERVED: <= 1e-4 on unit-variance data at scale 1 (c2, c3;
-                         FA_KERNEL_MFMA reads 2e-5 there), <= 1.5e-5 at 1/sqrt(d); on coherent inputs (constant-component rows, v = +-5,
-                         logits ~1500) 2.5e-4 .. 3.5e-3 where FA_KERNEL_MFMA reads 8e-4 .. 5.9e-3: there fp32 ACCUMULATION is the limit.
+                         is small), on keys CENTRED on a reference key (k_j - kbar, kbar = the coordinate-wise median of three keys of
+                         the share: softmax only needs differences, and a magnitude all keys share then never enters a rounded sum; the
+                         row constant q.kbar goes back into the LSE); P.V as three products of two-term BF16 splits (P needs fp32's
+                         exponent range); 3x faster than fp32 arithmetic.  GUARANTEED: the logit error of the operand terms is
+                         <= 3 * 2^-22 * sum |q_i (k_i - kbar_i)| * scale -- below the rounding bound d * 2^-24 * sum |q_i k_i| of the
+                         reference's own fp32 FMA chain for every d >= 12 -- and the P.V terms add <= 3 * 2^-17 * max|v|.  CONTRACT
+                         (tests/test_gpu_adversarial.py): |O - O_fp64| and |LSE - LSE_fp64| are <= max(1e-3, E_ref) on every input, E_ref =
+                         what the reference's own arithmetic (a k-ordered chain of rounding fp32 FMAs, flashattention.cu:236-252) leaves
+                         on that input.  OBSERVED: <= 1e-4 on unit-variance data at scale 1 (c2, c3; FA_KERNEL_MFMA reads 2e-5 there),
+                         <= 1.5e-5 at 1/sqrt(d); <= 2.7e-4 (O and LSE) on coherent inputs (constant-component rows, v = +-5, logits ~1500)
+                         where FA_KERNEL_MFMA reads 8e-4 .. 5.9e-3.
                          RANGE GUARD: fp16 terms hold |x| < 65520 and lose elements below 2^-3 to subnormal lo terms (absolute error 2^-25
-                         each); a workgroup whose first attempt produced a NaN, or whose D * max|k| + sqrt(D) * max|q * scale * log2 e|_2
+                         each); a workgroup whose first attempt produced a NaN, or whose D * max|k - kbar| + sqrt(D) * max|q * scale * log2 e|_2
                          exceeds 2048 (the subnormal terms could then add more than 2^-14 to a logit; unit-variance data: ~520 at d = 64,
                          ~860 at d = 128), redoes its rows in exact fp32 arithmetic before it exits -- ONE launch, no host round trip;
                          fa_last_forward_route() tells whether any workgroup did.  (Rounds 1-4 used two BF16 terms, 16 bits, behind a

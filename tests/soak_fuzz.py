@@ -142,19 +142,22 @@ def run(cases=400, seed=1, out="", only=-1, max_n=0, verbose=True):
             raise AssertionError("FAIL NaN fp32 " + desc)
         qs, ks, vs = q[sb].numpy(), k[sb].numpy(), v[sb].numpy()
         o64, l64 = adv.rows_f64(qs, ks, vs, rows, causal, scale)
-        tol_o = tol_l = TOL_F32
+        tol_o = tol_l = TOL_F32          # (also for the coherent families: the kernel works on centred keys -- observed <= 3e-4 there)
+        ref_o = ref_l = TOL_F32          # what rung 0 (fp32 arithmetic itself) may be off by on this input
         if family in (1, 2) or family >= 6:
-            # wide or coherent logits: where the reference's OWN arithmetic (a rounding fp32 FMA chain, flashattention.cu:236-252) leaves more
-            # than 1e-3 against fp64, the bar is what it leaves (tests/test_gpu_adversarial.py states the contract)
+            # wide or coherent logits: the reference's OWN arithmetic (a rounding fp32 FMA chain, flashattention.cu:236-252) may leave more
+            # than 1e-3 against fp64 there; the general contract is max(1e-3, that) (tests/test_gpu_adversarial.py)
             oc, lc = adv.rows_f64(qs, ks, vs, rows, causal, scale, chain=True)
-            tol_o = max(TOL_F32, float(np.abs(oc - o64).max()) / vmag)
-            tol_l = max(TOL_F32, float(np.abs(lc - l64).max()))
+            ref_o = max(TOL_F32, float(np.abs(oc - o64).max()) / vmag)
+            ref_l = max(TOL_F32, float(np.abs(lc - l64).max()))
+            if family in (1, 2):
+                tol_o, tol_l = ref_o, ref_l
         note("fp32 tensors vs fp64 (sampled rows)", float(np.abs(res[sb].cpu().numpy()[rows] - o64).max()) / vmag, tol_o, desc)
         note("fp32 tensors, LSE vs fp64 (sampled rows)", float(np.abs(lse[sb].cpu().numpy()[rows] - l64).max()), tol_l, desc)
         # rung 0 is fp32 arithmetic itself (its own error against fp64 is the FMA chain's), and it is compared on EVERY slab and row where the
-        # fp64 sample above saw ~200 rows of one: a coverage check (unwritten rows, wrong tiles), at three times the sampled bar
-        note("fp32 tensors vs rung 0", float((res - ref).abs().max()) / vmag, 3.0 * tol_o, desc)
-        note("fp32 tensors, LSE vs rung 0", float((lse - lse_ref).abs().max()), 3.0 * tol_l, desc)
+        # fp64 sample above saw ~200 rows of one: a coverage check (unwritten rows, wrong tiles), at five times the chain's error on the sample
+        note("fp32 tensors vs rung 0", float((res - ref).abs().max()) / vmag, 5.0 * ref_o, desc)
+        note("fp32 tensors, LSE vs rung 0", float((lse - lse_ref).abs().max()), 5.0 * ref_l, desc)
         if pack_nh:    # the llm.c entry: packed (B, T, 3C) fp32, causal, 1/sqrt(d)
             nh = pack_nh
             B, T = max(1, bh // nh), min(n, 2048)

@@ -7,15 +7,14 @@ THE CONTRACT OF THE fp32 DEFAULT (plain ``fa.forward(q32, k32, v32)``; include/f
     where E_ref is the error the REFERENCE'S OWN ARITHMETIC leaves on that input: fp32 operands through a k-ordered chain of rounding fp32
     FMAs (flashattention.cu:236-252; tests/adversarial.py: fma_chain_logits).  In words: inside the north star's 1e-3 wherever the
     reference kernel itself is, and never further from fp64 than the reference kernel's own arithmetic where it is not;
-  * observed on the coherent-rounding family of tests/adversarial.py at logit widths up to 89.5 (the round-4 guard's 90): non-causal
-    <= 4.3e-4 at d <= 64 and <= 9.7e-4 at d = 128 in O, <= 3.5e-4 in the LSE; causal rows that see only a handful of keys are the most
-    sensitive ones (O = 5 tanh of a logit difference): 3.5e-3 at d = 128, 0.62 of the FMA chain's 5.7e-3 there; the LSE of 512 near-equal
-    constant-component keys at d = 128: 1.25e-3, 0.90 of the chain's 1.4e-3 (the matrix core truncates its partial sums, a bias every logit
-    of such a row shares) -- where kernel="exact" (measured) reads the chain's 2.6e-3 / 5.9e-3 in O, and the round-4 default (two BF16
-    terms per operand) read 3e-2 .. 6e-2;
-  * what limits it there is fp32 ACCUMULATION, not the operand terms: a logit of magnitude ~1500 has an ulp of 1.2e-4, and every matrix
-    instruction rounds its partial sum once (D/16 roundings on the hi.hi chain; the cross terms are added where the partial sum is small:
-    csrc/fa_split_kernel.h).
+  * on the coherent-rounding family of tests/adversarial.py (constant-component rows, few-valued rows, a broadcast token, quantised +
+    offset inputs, two dominant keys with v = +-5, many near-equal keys) at logit widths up to 89.5 -- the family VERDICT r04 built against
+    the round-4 default, which read 3e-2 .. 6e-2 on it -- 1e-3 OUTRIGHT, O and LSE, d in {32, 64, 128}, causal or not: observed <= 2.7e-4.
+    kernel="exact" (the reference's arithmetic, measured) reads 2.6e-3 / 5.9e-3 there;
+  * how: K and Q' as two FP16 terms (22 bits; the operand error is below the FMA chain's own rounding bound for d >= 12), the hi.hi products
+    first (the matrix core truncates every partial sum at the magnitude it has then), and KEY CENTRING: the kernel works on k_j - kbar,
+    kbar the coordinate-wise median of three keys of the share, so that a magnitude all keys share never enters a rounded sum -- the
+    softmax only needs differences, and one fp32 subtraction of nearly equal values is exact (csrc/fa_split_kernel.h).
 
 The bf16-P kernels (bf16 tensors, bf16 out) are held to the bound derived from the data: every softmax weight off by 2^-8 with the worst
 signs (tests/adversarial.py: p_rounding_bound) -- not to a typical value of seeded data."""
@@ -35,7 +34,7 @@ import soak_fuzz  # noqa: E402
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 1e-3
-REF_SHARE = 1.0     # of the reference arithmetic's own error, where that exceeds 1e-3: the contract itself (observed: <= 0.65 in O, 0.90 in the LSE)
+REF_SHARE = 1.0     # of the reference arithmetic's own error, where that exceeds 1e-3: the general contract (range cases, outlier keys)
 OBSERVED = []
 
 
@@ -78,8 +77,8 @@ def test_fp32_default_on_coherent_rounding_family(d, family, width):
         o_ref, l_ref = adv.attention_f64(q, k, v, causal)
         ce_o, ce_l = adv.reference_arithmetic_error(q, k, v, causal)
         o, lse = run(q, k, v, causal=causal)
-        record(f"fp32 default, {family} d={d} w={width} causal={int(causal)}: O (fp32 FMA chain: {ce_o:.1e})", float(np.abs(o - o_ref).max()), max(TOL, REF_SHARE * ce_o))
-        record(f"fp32 default, {family} d={d} w={width} causal={int(causal)}: LSE (fp32 FMA chain: {ce_l:.1e})", float(np.abs(lse - l_ref).max()), max(TOL, REF_SHARE * ce_l))
+        record(f"fp32 default, {family} d={d} w={width} causal={int(causal)}: O (fp32 FMA chain: {ce_o:.1e})", float(np.abs(o - o_ref).max()), TOL)
+        record(f"fp32 default, {family} d={d} w={width} causal={int(causal)}: LSE (fp32 FMA chain: {ce_l:.1e})", float(np.abs(lse - l_ref).max()), TOL)
 
 
 @pytest.mark.parametrize("d", [32, 64, 128])
@@ -98,8 +97,8 @@ def test_the_two_cases_of_verdict_r04(d):
     o_ref, l_ref = adv.attention_f64(q, k, v)
     ce_o, ce_l = adv.reference_arithmetic_error(q, k, v)
     o, lse = run(q, k, v)
-    record(f"VERDICT r04 case 1 at d={d}: O (fp32 FMA chain: {ce_o:.1e})", float(np.abs(o - o_ref).max()), max(TOL, REF_SHARE * ce_o))
-    record(f"VERDICT r04 case 1 at d={d}: LSE", float(np.abs(lse - l_ref).max()), max(TOL, REF_SHARE * ce_l))
+    record(f"VERDICT r04 case 1 at d={d}: O (fp32 FMA chain: {ce_o:.1e})", float(np.abs(o - o_ref).max()), TOL)
+    record(f"VERDICT r04 case 1 at d={d}: LSE", float(np.abs(lse - l_ref).max()), TOL)
     rng = np.random.default_rng(d)
     q = np.full((1, 2048, d), a, np.float32)
     k = ((4.42 + rng.uniform(-1e-3, 1e-3, (1, 2048, 1))) * np.ones((1, 1, d))).astype(np.float32)
@@ -107,15 +106,15 @@ def test_the_two_cases_of_verdict_r04(d):
     o_ref, l_ref = adv.attention_f64(q, k, v)
     ce_o, ce_l = adv.reference_arithmetic_error(q, k, v)
     o, lse = run(q, k, v)
-    record(f"VERDICT r04 case 2 at d={d}: O", float(np.abs(o - o_ref).max()), max(TOL, REF_SHARE * ce_o))
-    record(f"VERDICT r04 case 2 at d={d}: LSE (fp32 FMA chain: {ce_l:.1e})", float(np.abs(lse - l_ref).max()), max(TOL, REF_SHARE * ce_l))
+    record(f"VERDICT r04 case 2 at d={d}: O", float(np.abs(o - o_ref).max()), TOL)
+    record(f"VERDICT r04 case 2 at d={d}: LSE (fp32 FMA chain: {ce_l:.1e})", float(np.abs(lse - l_ref).max()), TOL)
 
 
 @pytest.mark.parametrize("d", [64, 128])
 def test_exact_kernel_is_the_reference_arithmetic_not_an_oracle(d):
     """kernel="exact" (v_mfma_f32_32x32x2_f32: a k-ordered fp32 FMA chain) reproduces the reference kernel's OWN rounding on coherent inputs:
-    its error against fp64 is the emulated FMA chain's (both ~2e-3 .. 6e-3 on the two-dominant-key rows at width 89.5), several times the
-    default's.  Documented here so that nobody mistakes "exact" for "error free" again (VERDICT r04 assumed it immune)."""
+    its error against fp64 is the emulated FMA chain's (both ~2e-3 .. 6e-3 on the two-dominant-key rows at width 89.5), 40 .. 60 times the
+    default's (which works on centred keys).  Documented here so that nobody mistakes "exact" for "error free" again (VERDICT r04 assumed it immune)."""
     q, k, v = adv.make("const_two_keys", d, 89.5, n=512, bh=2, seed=d)
     o_ref, _ = adv.attention_f64(q, k, v)
     ce_o, _ = adv.reference_arithmetic_error(q, k, v)
@@ -123,7 +122,7 @@ def test_exact_kernel_is_the_reference_arithmetic_not_an_oracle(d):
     e_auto = float(np.abs(run(q, k, v, "auto")[0] - o_ref).max())
     OBSERVED.append((f"exact kernel on const_two_keys d={d} w=89.5 (fp32 FMA chain emulated: {ce_o:.1e}; default: {e_auto:.1e})", e_exact, 2.0 * ce_o + 1e-4))
     assert 0.3 * ce_o < e_exact < 2.0 * ce_o + 1e-4, (e_exact, ce_o)
-    assert e_auto < 0.6 * e_exact, (e_auto, e_exact)
+    assert e_auto < 0.2 * e_exact, (e_auto, e_exact)
 
 
 # ---------------------------------------------------------------------------------------------------------------
