@@ -1253,18 +1253,27 @@ static int choose_split(const FwdParams& p, int d, int causal, unsigned elem_siz
     // 384 tiles: m3 0.213 / m4 0.239 at d = 64, 0.161 / 0.180 at d = 32)
     const int64_t part = tiles256 % 256;
     const bool rounds256 = tiles256 >= 1024 || part == 0 || part >= 192;
+    // Round 5 (fp16 terms, hi.hi first, centred keys; profiles/r05_sweep_f32short.txt, 131072 rows per launch, ms m1 / m3 / m4-or-m5): the
+    // phase-structured pass lost its edge on short rows of BIG grids -- d=64 N=128 0.0355 / 0.0322, 256 0.0467 / 0.0422, 512 0.0692 / 0.0644
+    // (causal 512 0.0614 / 0.0555); d=128 N=128 0.0740 / 0.0672, N=384 0.1264 / 0.1101 / 0.1260 (round 3: m5 0.124, m3 0.161) --, so from two
+    // full rounds of 128-row workgroups on those go to the pipelined 128-row tiling; small grids keep the pass without a pipeline to fill.
+    const bool big = tiles128 >= 1024;
     if (d == 128) {
-        if (p.n <= 128) return 1;
+        if (p.n <= 128) return big ? 3 : 1;
         // two blocks per wave do not fit the register file; EIGHT waves of one block each (256-row workgroups, two waves per
         // SIMD, phases in sequence) halve the K/V conversion work and the L2 traffic per row
         // causal, ms m3 / m5: 64 x 2048 0.257 / 0.291, 32 x 4096 0.412 / 0.511, 8 x 8192 0.387 / 0.560; 16 x 8192 0.796 / 0.702, 128 x 1024 0.168 / 0.157
         if (causal && p.n > 1536 && (p.n < 8192 || tiles256 < 512)) return 3;
-        return (tiles256 >= 256 && (fits256 || p.n <= 512)) ? 5 : 3;   // (N = 384: 0.124 m5 against 0.161 m3) small grids (BH=4 N=4096: m1 0.231, m3 0.158, m5 0.274 ms): 128-row workgroups, pipelined
+        return (tiles256 >= 256 && fits256) ? 5 : 3;   // small grids (BH=4 N=4096: m1 0.231, m3 0.158, m5 0.274 ms): 128-row workgroups, pipelined
     }
     // rows of a few tiles: the first-tile-reference pass (no pipeline to fill); at d = 64 up to 512 keys once the grid is two rounds deep
-    if (p.n <= 256 || (d == 64 && p.n <= 512 && tiles128 >= 1024)) return 1;
+    if (d == 64 && big) {
+        if (causal && p.n <= 384) return 1;                                // (ties with the pipelined tiling: 0.0499 / 0.0482 at N = 384)
+    } else if (p.n <= 256) {
+        return 1;
+    }
     if (causal) {
-        if (p.n <= (d == 64 ? 512 : 384)) return 1;                        // short rows: skipping tiles beats masking them
+        if (p.n <= (d == 64 ? (big ? 384 : 512) : 384)) return 1;         // short rows: skipping tiles beats masking them
         // 256-row tiles only pay on long rows, and from two rounds on: one round of them lasts as long as its heaviest tile, alone on its
         // CU (8 x 8192: m3 0.220 / m4 0.309 at d = 64, 0.173 / 0.238 at d = 32; 16 x 8192: 0.410 / 0.376)
         return (p.n >= 8192 && tiles256 >= 512) ? 4 : 3;

@@ -1,18 +1,24 @@
 """GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle and the committed golden vectors.
 
-Tolerances (max-abs, stated once here; BASELINE.md section 4 gives the arithmetic behind them):
-  fp32 kernels                                  1e-3  north_star bar; observed <= 3e-5 (exact) / <= 2.5e-4 (split) at scale 1
-  bf16 kernel, fp32 out, scale 1/8, long rows   1e-3  north_star bar with 1/sqrt(d) scaling; observed 4e-4 (non-causal, N >= 1000)
-  bf16 kernel, fp32 out, scale 1/8, short rows  4e-3  rows that attend to few keys (causal head of the sequence, N < 1000) keep the
-                                                      full 2^-9 relative rounding of each bf16 P value un-averaged; observed <= 2.7e-3
-  bf16 kernel, fp32 out, scale 1.0              1.2e-2 unscaled scores: P is near one-hot, so the error tends to 2^-9 * max|v| (one bf16
-                                                      rounding of the dominant P); max|v| ~ 5.4 over 8M randn -> 1.05e-2; observed <= 9.0e-3
-  bf16 kernel, bf16 out                         2.5e-2 adds half a bf16 ulp of |O| (|O| < 4 -> 7.8e-3); observed <= 1.5e-2
-  bf16 tensors, fp32 out, ACCURATE P            1e-3  north_star bar at scale 1, held with a wide margin: FA_KERNEL_AUTO with an fp32 output = P as bf16
-                                                      hi + bf16 lo in ONE launch (kernel="pb2": ~17 significant bits, Q.K^T exact in the fp32 accumulator;
-                                                      observed <= 4e-5 on the BASELINE configs) at every launch size and without scratch; hi + lo bf16
-                                                      terms of P AND Q' (kernel="split": 1 .. 2e-4, growing with the logit width) only for slabs beyond
-                                                      4 GiB.  TOL_PB2 = 2e-4 for the first, TOL_ACC = 5e-4 for the second.
+Tolerances (max-abs).  Two kinds, kept apart since round 5:
+  BOUNDS, derived from the data or from the arithmetic, asserted by tests/test_gpu_adversarial.py on constructed worst cases:
+    fp32 tensors, FA_KERNEL_AUTO     max(1e-3, E_ref), E_ref = the error of the reference's own fp32 FMA chain on the same input; 1e-3 outright
+                                     on the coherent-rounding family (observed <= 2.7e-4)
+    bf16-P kernels                   (2^-8 + 2^-10) * max_row sum_j w_j |v_j - O|  (+ 2^-8 |O| for a bf16 output): every softmax weight off by
+                                     half an ulp of 8 bits with the worst signs, plus the mass the optimistic mix may flush; two equally
+                                     dominant keys with v = +-V give 2^-8 V = 1/4 * 2^-7 * |v1 - v2| (tests/adversarial.py: p_rounding_bound)
+    two bf16 terms of P              2^-17 in P; asserted at TOL_PB2 = 2e-4 (observed <= 1e-4 incl. soak)
+  REGRESSION THRESHOLDS for seeded N(0, 1) data (a typical value with head room; NOT a bound -- planted or adversarial data may exceed them and
+  is held to the bounds above instead):
+    fp32 kernels                                  1e-3  north_star bar; observed <= 3e-5 (exact) / <= 1e-4 (fp16-term split products)
+    bf16 kernel, fp32 out, scale 1/8, long rows   1e-3  north_star bar with 1/sqrt(d) scaling; observed 4e-4 (non-causal, N >= 1000)
+    bf16 kernel, fp32 out, scale 1/8, short rows  4e-3  rows that attend to few keys (causal head of the sequence, N < 1000) keep the
+                                                        full 2^-8 relative rounding of each bf16 P value un-averaged; observed <= 3.0e-3
+    bf16 kernel, fp32 out, scale 1.0              1.2e-2 unscaled scores: P is near one-hot; max|v| ~ 5.4 over 8M randn; observed <= 9.0e-3
+                                                        (the bound for such data is 2^-8 * 5.4 * ~0.8 = 1.7e-2)
+    bf16 kernel, bf16 out                         2.5e-2 adds half a bf16 ulp of |O|; observed <= 1.7e-2 (bound ~3.3e-2)
+    bf16 tensors, fp32 out, ACCURATE P            TOL_PB2 = 2e-4 (kernel="pb2" = FA_KERNEL_AUTO with an fp32 output, one launch, no scratch);
+                                                        TOL_ACC = 5e-4 for kernel="split" (hi + lo bf16 terms of P AND Q': slabs beyond 4 GiB)
   (round 3's fp16-P kernels, kernel="p16" / "p16x2", left the product library: csrc/experiments/, ablation library only)
 "bf16 kernel" above = the bf16-P kernels (kernel="mfma"; FA_KERNEL_AUTO for a bf16 output).
 The bf16 kernels are always compared with the oracle evaluated on the SAME bf16-valued inputs.
