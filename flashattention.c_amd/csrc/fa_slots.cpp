@@ -164,12 +164,16 @@ bool next_flag(FlagRef& f, hipStream_t stream, bool capturing, std::unique_lock<
         EagerSlot& e = tb.eager[slot];
         // A slot found BY KEY whose last chain has not completed: normally the same stream, ordered behind it anyway -- but a stream handle
         // can be recycled (hipStreamDestroy does not wait; the runtime may hand the same value to a new stream while the old stream's last
-        // chain still runs), and two chains in flight must not share a word.  Ordering the new stream behind the slot's event is a no-op in
-        // the normal case and the fix in the other.
+        // chain still runs), and two chains in flight would then share a word.  In the PRODUCT the word only reports (the fallback is
+        // inside the kernel): a recycled handle can at worst misreport one route, and back-to-back forwards on one stream -- the normal
+        // case, where the previous event is never complete yet -- pay nothing.  The ablation library's chains decide launches by the word:
+        // there the new stream is ordered behind the slot's event (a no-op for the same stream).
+#if FA_ABLATION
         if (e.state == 1 && e.done != nullptr && hipEventQuery(e.done) != hipSuccess) {
             (void)hipGetLastError();
             (void)hipStreamWaitEvent(stream, e.done, 0);
         }
+#endif
         if (e.done == nullptr && hipEventCreateWithFlags(&e.done, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             e.done = nullptr;   // without an event the slot can never change hands safely: it simply stays with its stream
