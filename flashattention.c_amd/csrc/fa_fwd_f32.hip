@@ -40,32 +40,43 @@ __global__ __launch_bounds__(NWAVES* kWave, MINWAVES) void fa_fwd_f32_kernel(Fwd
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    const int total = p.bh * p.q_tiles;   // PAIRED: q_tiles counts pairs
-    const int w = xcd_remap(blockIdx.x, total);
-    const int slab = w / p.q_tiles;
-    int qt = w % p.q_tiles;
     const int n = p.n;
     const int tiles = (n + BM - 1) / BM;
-    if (CAUSAL && !PAIRED) qt = causal_tile(p, qt);
-
-    const int b = slab / p.heads, h = slab % p.heads;
-    const float* qg = (const float*)p.q + b * p.q_batch_stride + h * p.q_head_stride;
-    const float* kg = (const float*)p.k + b * p.kv_batch_stride + h * p.kv_head_stride;
-    const float* vg = (const float*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
-    const int64_t o_slab = b * p.o_batch_stride + h * p.o_head_stride;
-    const int kbeg = p.n_kv > 0 ? h * p.n_kv : 0;
-    const int nk = p.n_kv > 0 ? min(p.n_kv, p.n_kv_total - kbeg) : n;
+    // PAIRED over key shares (n_kv > 0): the items of one slab are its S x tiles (share, row tile) pairs, item h * tiles + t; the work of an
+    // item and of its complement (S - 1 - h, tiles - 1 - t) = item N - 1 - idx adds up to n_kv + one tile for EVERY item (a share below a row
+    // tile is full, above it empty, and the partial ones mirror each other), so a workgroup that computes both does the same work as every
+    // other one -- 4 x 8192 causal over 4 shares: 0.526 -> 0.30 ms (profiles/r05_exact_share_pairs.txt).
+    const bool shares = PAIRED && p.n_kv > 0;
+    const int S = shares ? p.heads : 1;
+    const int N = S * tiles;               // items of one unit (unit: a slab; over key shares: a slab with all its shares)
+    int unit, item;
+    {
+        const int total = (shares ? p.bh / p.heads : p.bh) * p.q_tiles;   // PAIRED: q_tiles counts pairs of items
+        const int w = xcd_remap(blockIdx.x, total);
+        unit = w / p.q_tiles;
+        item = w % p.q_tiles;
+        if (CAUSAL && !PAIRED) item = causal_tile(p, item);
+    }
 
 #pragma unroll 1
     for (int half = 0; half < (PAIRED ? 2 : 1); ++half) {
-        int t = qt;
+        int idx = item;
         if constexpr (PAIRED) {
-            t = half == 0 ? tiles - 1 - qt : qt;
+            idx = half == 0 ? N - 1 - item : item;
             if (half == 1) {
-                if (qt == tiles - 1 - qt) break;   // odd tile count: the middle tile is its own pair
-                __syncthreads();                   // every wave is out of the heavy tile's last stage
+                if (item == N - 1 - item) break;   // odd item count: the middle item is its own pair
+                __syncthreads();                   // every wave is out of the first item's last stage
             }
         }
+        const int t = idx % tiles;
+        const int slab = unit * S + idx / tiles;
+        const int b = slab / p.heads, h = slab % p.heads;
+        const float* qg = (const float*)p.q + b * p.q_batch_stride + h * p.q_head_stride;
+        const float* kg = (const float*)p.k + b * p.kv_batch_stride + h * p.kv_head_stride;
+        const float* vg = (const float*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
+        const int64_t o_slab = b * p.o_batch_stride + h * p.o_head_stride;
+        const int kbeg = p.n_kv > 0 ? h * p.n_kv : 0;
+        const int nk = p.n_kv > 0 ? min(p.n_kv, p.n_kv_total - kbeg) : n;
         const int q0 = t * BM + wave * 32;
         int kv_end = nk;
         if (CAUSAL) kv_end = min(nk, t * BM + BM - kbeg);
@@ -92,13 +103,15 @@ static hipError_t launch_cfg_f32(const FwdParams& p0, int causal, int order, hip
     // 2048 0.87-0.91, 8192 0.97; c3-causal, 512 pairs: 1.00; d = 128 16 x 8192 0.87); one round of pairs on most of the CUs (144 .. 256) is
     // never more than 3 % behind and up to 1.5x ahead where the alternating order of single tiles lands badly (32 x 1500 0.67, 12 x 4096 0.71,
     // 40 x 1500 0.68); fewer pairs than that leave CUs idle (1.05-1.28), and in between (257 .. 479) single tiles are 2-6 % ahead.
-    // Key shares (n_kv > 0) are short rows on an idle chip: one tile per workgroup.
-    const int pairs = (tiles + 1) / 2;
-    const int64_t npairs = (int64_t)p.bh * pairs;
-    const bool pair_auto = npairs >= 480 || (npairs >= 144 && npairs <= 256 && tiles >= 8);
-    const bool paired = causal && p.n_kv == 0 && (order == 2 || (order == 0 && pair_auto));
+    // Key shares (n_kv > 0): always paired -- an item with its complement over shares AND row tiles (see the kernel).
+    const bool shares = p.n_kv > 0 && p.heads > 1;
+    const int pairs = shares ? (p.heads * tiles + 1) / 2 : (tiles + 1) / 2;
+    const int64_t units = shares ? p.bh / p.heads : p.bh;
+    const int64_t npairs = units * pairs;
+    const bool pair_auto = shares || npairs >= 480 || (npairs >= 144 && npairs <= 256 && tiles >= 8);
+    const bool paired = causal && (order == 2 || (order == 0 && pair_auto)) && (p.n_kv == 0 || shares);
     p.q_tiles = paired ? pairs : tiles;
-    const int64_t total = (int64_t)p.bh * p.q_tiles;
+    const int64_t total = (paired ? units : (int64_t)p.bh) * p.q_tiles;
     if (total > 0x7fffffffLL) return hipErrorInvalidValue;
     dim3 grid((unsigned)total), block(NWAVES * kWave);
     // Unpaired causal launches: three to six workgroups share a CU.  Dealing a slab's tiles alternately from the heavy and the light end

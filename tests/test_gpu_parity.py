@@ -524,7 +524,8 @@ def test_causal_paired_tiles_in_the_exact_kernel(bh, n, d):
 
 
 @pytest.mark.parametrize("causal", [False, True])
-@pytest.mark.parametrize("bh,n,d", [(1, 8192, 64), (2, 8192, 64), (3, 5000, 64), (1, 16384, 64), (2, 7777, 32), (1, 4096, 128), (1, 2048, 64), (4, 8192, 64)])
+@pytest.mark.parametrize("bh,n,d", [(1, 8192, 64), (2, 8192, 64), (3, 5000, 64), (1, 16384, 64), (2, 7777, 32), (1, 4096, 128), (1, 2048, 64), (4, 8192, 64), (1, 3100, 64),
+                                    (5, 2200, 32)])
 def test_exact_kernel_key_split_launch(bh, n, d, causal):
     """Round 5: kernel="exact" on a grid that leaves CUs idle (fewer than 256 tiles of 128 rows; causal: a full round too) runs over S <= 8 key
     shares + combine, like the split kernel does (1 x 8192: 0.555 -> 0.154 ms).  Against rung 0 and the fp64 oracle, LSE, NaN-poisoned
@@ -535,8 +536,12 @@ def test_exact_kernel_key_split_launch(bh, n, d, causal):
     assert (fa.workspace_bytes(bh, n, d, causal, kernel="exact") > 0) == want_split
     ref, lse_ref = fa.forward(qd, kd, vd, causal, kernel="naive", return_lse=True)
     out = torch.full((bh, n, d), float("nan"), device=dev())
-    _, lse = fa.forward(qd, kd, vd, causal, kernel="exact", out=out, return_lse=True)
-    assert not torch.isnan(out).any() and fa.last_forward_route() == 0
+    # the partials' scratch poisoned as well (0xFF bytes = NaN): a (share, row tile) item nobody computed would surface through the combine --
+    # causal launches pair every item with its complement (S - 1 - h, T - 1 - t) in one workgroup, odd item counts included
+    need = fa.workspace_bytes(bh, n, d, causal, kernel="exact")
+    ws = torch.full((max(need, 1),), 0xFF, dtype=torch.uint8, device=dev())
+    _, lse = fa.forward(qd, kd, vd, causal, kernel="exact", out=out, return_lse=True, workspace=ws if need else None)
+    assert not torch.isnan(out).any() and not torch.isnan(lse).any() and fa.last_forward_route() == 0
     err = float((out - ref).abs().max())
     OBSERVED.append((f"exact key split bh={bh} n={n} d={d} causal={causal}", err, 1e-4))
     assert err < 1e-4 and float((lse - lse_ref).abs().max()) < 1e-4
