@@ -12,7 +12,7 @@
 //     hi/lo splits of P -- the intent was a loop bound by the matrix pipe; measured, it is bound by instruction issue (see below);
 //   * the softmax is the reference-free optimistic one of the split kernel's fast pass: p = exp2(s) with s already in the exp2
 //     domain (Q' = Q * scale * log2 e), fp32 row sums on the VALU.  A row sum outside (2^-100, 2^100) or a non-finite output RAISES
-//     THE LAUNCH CHAIN'S FLAG instead of being redone here: the exact fp32 kernel queued behind recomputes the launch (fa_api.cpp).
+//     THE LAUNCH CHAIN'S FLAG instead of being redone here: the exact fp32 kernel queued behind recomputes the launch (fa_launch.cpp).
 // Scope (everything else stays with fa_split_kernel.h): head dim 64, non-causal, N a multiple of 64, plain (BH, N, d) layout.
 //
 //   step t (32 keys, 48 MFMA slots):  K.Q'^T of sub-tile t+1: 4 k-steps x 3 terms x blocks A, B (24)  |  P.V of A: 12  |  P.V of B: 12

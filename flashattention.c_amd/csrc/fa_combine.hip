@@ -1,13 +1,13 @@
 // fa_combine.hip -- the merge step of a key-split launch (FlashDecoding-style): S workgroups per q-tile have left normalised fp32
 // partial outputs and their log-sum-exps in the workspace; this kernel weighs them together.  Grids that leave the chip idle only
-// (fa_api.cpp: keysplit_factor); counterpart of nothing in the reference, whose grid simply runs any (BH, N)
+// (fa_plan.cpp: keysplit_factor); counterpart of nothing in the reference, whose grid simply runs any (BH, N)
 // (/root/reference/src/flashattention.cu:592,599).
 #include "fa_kernels.h"
 
 namespace fa {
 
 
-// ---- combine of a key-split launch (fa_api.cpp: launch_bf16_keysplit) -------------------------------------------------------
+// ---- combine of a key-split launch (fa_launch.cpp: launch_bf16_keysplit) -------------------------------------------------------
 // S workgroups per q-tile each saw a share of the keys and left a normalised partial output O_s (fp32, [S][bh][n][d]) and the
 // log-sum-exp of its share (natural log, [bh][S][n]; -inf for a causal share that lies entirely above the row).  O = sum_s w_s O_s / sum_s w_s with w_s = exp(lse_s - max_s lse_s);
 // lse = max + log(sum w_s).  One thread per four output columns; HBM-bound and small (S * 4 bytes per output element).

@@ -47,7 +47,7 @@ struct FwdParams {
     int64_t kv_head_stride;
     int64_t o_head_stride;
     int32_t o_is_bf16;      // split kernel only: O is bf16 (bf16 tensors); 0 = fp32
-    // The report word of an fp32 FA_KERNEL_AUTO forward, and the ablation library's conditional launch chains (fa_api.cpp): one 32-bit
+    // The report word of an fp32 FA_KERNEL_AUTO forward, and the ablation library's conditional launch chains (fa_slots.cpp, fa_launch.cpp): one 32-bit
     // device word per call; "set" means *flag == flag_serial
     // (serials are unique per call, so the word never needs clearing).
     //   flag_mode 0  ignore the word;   1  run only while the word is NOT set;   2  run only if the word IS set;

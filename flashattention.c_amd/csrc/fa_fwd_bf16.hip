@@ -463,7 +463,7 @@ static Bf16Choice choose_bf16(int64_t bh, int64_t n, int d, int causal, bool add
     // 8 x 1024 0.0166 / 0.0188 (causal 0.0182 / 0.0236), 32 x 1024 0.0194 / 0.0207 (0.0198 / 0.0246), 8 x 2048 0.0302 / 0.0320
     // (0.0326 / 0.0367), 4 x 3072 0.0423 / 0.0442, 16 x 512 causal 0.0111 / 0.0171; 16 x 2048 (128 tiles) 0.0342 / 0.0345, 32 x 1536 (192)
     // 0.0389 / 0.0306; d = 32: 8 x 1024 0.0123 / 0.0146 (0.0143 / 0.0193), 16 x 1536 0.0187 / 0.0207.  Rows of 4096 keys and more on such
-    // grids are key-split launches of the NB = 2 kernel (fa_api.cpp).
+    // grids are key-split launches of the NB = 2 kernel (fa_plan.cpp, fa_launch.cpp).
     if (n < 4096 && items256 <= 128) return kChoosePhase;
     // d = 32 (TFLOP/s, x2 / pipelined / phase-structured): 16 x 8192 non-causal 780 / 767 / -, causal 428 / 415 / 416; 128 x 8192
     // causal 709 / - / 560

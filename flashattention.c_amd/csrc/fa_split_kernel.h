@@ -271,7 +271,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     const T* vg = (const T*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
     const int64_t o_slab = b * p.o_batch_stride + h * p.o_head_stride;   // elements (fp32 or bf16 output, p.o_is_bf16)
 
-    // keys of this workgroup: all n, or (key-split launches, fa_api.cpp) its share [h * n_kv, min((h + 1) * n_kv, n_kv_total)) --
+    // keys of this workgroup: all n, or (key-split launches, fa_launch.cpp) its share [h * n_kv, min((h + 1) * n_kv, n_kv_total)) --
     // kv_head_stride carries the offset, nk bounds the LOCAL key indices (local key i is key kbeg + i of the slab; causal: local key <=
     // local row q - kbeg).  Causal shares are multiples of the tile height: a share starts at or below the tile's first row (every row sees
     // its first key) or lies entirely above the tile -- an empty share, which stores lse = -inf for its rows (the combine gives it weight

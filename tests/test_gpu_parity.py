@@ -614,7 +614,7 @@ def test_key_split_launch_for_grids_that_leave_the_chip_idle(bh, n, d):
                                     (6, 1500, 128), (5, 1500, 128), (1, 4095, 64), (16, 1023, 64), (17, 1024, 64)])
 def test_short_row_key_split_of_the_two_term_kernel(bh, n, d):
     """Round 4: the two-term-P kernel has one tiling (256-row workgroups), so non-causal rows of 1024 .. 4095 keys on at most 64 tiles run as
-    S = 2 .. 8 key shares of >= 256 keys + combine (fa_api.cpp: keysplit_factor, pb2).  Ragged lengths (a last share shorter than the
+    S = 2 .. 8 key shares of >= 256 keys + combine (fa_plan.cpp: keysplit_factor, pb2).  Ragged lengths (a last share shorter than the
     reference sample), every head dim, the LSE, a dominant key inside one share, NaN-poisoned output; the shapes outside the rule
     (1023 keys; 17 slabs = 68 tiles; d = 128 below 2048 keys on more than 32 tiles) run unsplit and need no workspace."""
     q, k, v = (orc.round_to_bf16(randn(s, bh, n, d)) for s in (191, 192, 193))
