@@ -458,8 +458,10 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
 
     // The whole tile, OPT = optimistic pass (fixed reference m0) or the textbook redo.  Returns whether this lane's rows
     // came out inside the range the optimistic pass can prove.
-    // guard: a NaN in a row sum or an output of the first attempt (the running maxima above drop NaNs: v_max3_f32 and fmaxf return the
-    // other operand) -- a NaN in Q, K or V reaches one of them -- raises the word like a wide logit does
+    // guard: a NaN in a row SUM of the first attempt (the running maxima above drop NaNs: v_max3_f32 and fmaxf return the other operand) -- a
+    // NaN or inf in Q or K, or an fp16 term out of range, reaches it -- sends the workgroup to fp32 arithmetic.  (Round 5: a NaN OUTPUT alone
+    // no longer does: rows that outgrow the optimistic window have l = +inf and O = inf / inf, and belong to the textbook redo on the same
+    // pipes, not to the three times slower fallback; a NaN in V gives the NaN it must give on either path.)
     bool saw_nan = false;
     auto run_tile = [&](auto opt_c) -> bool {
         constexpr bool OPT = decltype(opt_c)::value;
@@ -699,7 +701,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                     }
                 if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = ((m[qb] + __builtin_amdgcn_logf(lt)) + crow) * kLn2;
                 if (OPT) ok = ok && (lt < kSplitLimit) && (mag < INFINITY);   // false for NaN as well
-                if (GUARD) saw_nan = saw_nan || (lt != lt) || (mag != mag);
+                if (GUARD) saw_nan = saw_nan || (lt != lt);   // (a NaN row SUM: NaN logits -- an overflowed window gives +inf, which the redo handles)
             }
         }
         return ok;
@@ -1146,7 +1148,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                 // mag * lt = the sum of the unnormalised accumulators: tiny or zero means the products p v of the terms that matter
                 // were near (or below) fp32's subnormal range (|v| below ~2^-30): the textbook redo (p <= 1) takes those -- an all-zero V too
                 ok = ok && (lt > lt_floor) && (lt < kSplitLimit) && (mag < INFINITY) && !(mag * lt < kSplitTinyAcc);   // false for NaN as well
-                if (GUARD) saw_nan = saw_nan || (lt != lt) || (mag != mag);
+                if (GUARD) saw_nan = saw_nan || (lt != lt);   // (a NaN row SUM: NaN logits -- an overflowed window gives +inf, which the redo handles)
             }
         }
         return ok;
