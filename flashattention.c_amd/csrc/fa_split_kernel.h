@@ -146,6 +146,22 @@ __device__ __forceinline__ void split2h(float a, float b, bf16x2& hi, bf16x2& lo
     hi = __builtin_bit_cast(bf16x2, h);
     lo = __builtin_bit_cast(bf16x2, l);
 }
+// x -= float(h) for four values against two packed fp16 pairs: v_fma_mix_f32 reads the fp16 half directly (fma(h, -1, x): one rounding, like
+// v_sub_f32).  The reference rows of the key / value centring live in registers this way: half the registers of fp32 copies, the same
+// instruction count (any fixed vector is a valid reference, so rounding it to fp16 costs nothing as long as the same values are added back).
+__device__ __forceinline__ void sub_f16x4(f32x4& x, unsigned h01, unsigned h23)
+{
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(x[0]) : "v"(h01));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x[1]) : "v"(h01));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(x[2]) : "v"(h23));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x[3]) : "v"(h23));
+}
+__device__ __forceinline__ unsigned pack_f16(float a, float b)
+{
+    const f32x2_t ab = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(ab, f16x2_t));
+}
+
 // F16 = the fp16 split (K and Q' of fp32 tensors), else the bf16 split (V, P; everything for bf16 tensors); ASM = the form whose four
 // middle instructions are asm (the phase-structured pass), else plain C++ (the slot-scheduled pass)
 template <bool F16, bool ASM>
@@ -244,6 +260,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
 
     __shared__ __attribute__((aligned(1024))) char smem[2 * C::kStageBytes];
     __shared__ __attribute__((aligned(16))) float s_kref[D];   // key centering, eight-wave tiling only (no registers to spare): the reference key
+    __shared__ __attribute__((aligned(16))) float s_vref[D];   // ... and the reference value row
     __shared__ unsigned s_kmax;   // range guard: max |k| over the keys this workgroup reads, as the bits of a non-negative float
 
     if (flag_says_skip(p)) return;   // conditional fallback of a launch chain (bf16 tensors behind the fp16-P kernel)
@@ -333,21 +350,49 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
             const f32x4 b = *(const f32x4*)(kf + (int64_t)kref_r1 * p.kv_row_stride + col0);
             const f32x4 c = *(const f32x4*)(kf + (int64_t)kref_r2 * p.kv_row_stride + col0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = __builtin_amdgcn_fmed3f(a[e], b[e], c[e]);
+            for (int e = 0; e < 4; ++e) r[e] = (float)(_Float16)__builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(a[e], b[e], c[e]), -65504.0f, 65504.0f);
         }
-        return r;
+        return r;   // (rounded to fp16 and clamped to its range: ANY fixed vector is a valid reference; see sub_f16x4)
     };
     // this thread's K pieces all sit in the same 8 columns (NT is a multiple of D / 8, or kGroups divides it)
     const int kref_col = ((tid % C::kGroups) % (D / 8)) * 8;
     // KREF_REG: the thread's eight reference values live in registers; the eight-wave D = 128 tiling (256 registers per lane, all in use)
     // reads them from LDS in front of every conversion instead -- behind the V piece's conversion, which hides the latency
     constexpr bool KREF_REG = !(D == 128 && NWAVES == 8);
-    f32x4 kref0 = {0.0f, 0.0f, 0.0f, 0.0f}, kref1 = kref0;
-    if constexpr (CENTER && KREF_REG) {
-        kref0 = kref_at(kref_col), kref1 = kref_at(kref_col + 4);
-    } else if constexpr (CENTER) {
+    unsigned krefp[4] = {0u, 0u, 0u, 0u}, vrefp[4] = {0u, 0u, 0u, 0u};   // the thread's eight reference values each, as packed fp16 pairs
+    // VALUE CENTERING (round 5).  sum_j w_j v_j = vbar + sum_j w_j (v_j - vbar) for softmax weights (they add up to one): the kernel splits
+    // v_j - vbar into its two bf16 terms, so the 16 bits cover the SPREAD of V and not an offset all values share -- V = 100 + N(0, 1) under a
+    // peaked softmax read 1.6e-3 (the terms' 3 * 2^-17 * max|v|) where the reference's own fp32 recurrence reads 1.4e-4, V = 1000 + N(0, 1)
+    // 1.6e-2 (profiles/r05_v_offset.txt) -- and vbar, the same median of three rows as for the keys, is added back to O in the epilogue.
+    // A V that is CONSTANT over the share is all zeros after centring: such a tile takes the redo of the all-zero-V case (twice the time).
+    auto vref_at = [&](int col0) {
+        f32x4 r = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (CENTER) {
+            const float* vf = (const float*)vg;
+            const f32x4 a = *(const f32x4*)(vf + col0);
+            const f32x4 b = *(const f32x4*)(vf + (int64_t)kref_r1 * p.kv_row_stride + col0);
+            const f32x4 c = *(const f32x4*)(vf + (int64_t)kref_r2 * p.kv_row_stride + col0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = (float)(_Float16)__builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(a[e], b[e], c[e]), -65504.0f, 65504.0f);
+        }
+        return r;
+    };
+    // this thread's V pieces all sit in the same 8 columns: (c16 * 2 + half) * 8 of its group index
+    const int vref_col = ((((tid % C::kGroups) >> 3) % (D / 16)) * 2 + (((tid % C::kGroups) >> 2) & 1)) * 8;
+    if constexpr (CENTER) {
+        // both reference rows are computed ONCE per workgroup (threads 0 .. D/4 - 1 the key's, the next D/4 the value's: three row loads and
+        // four v_med3_f32 each) and live in LDS: the conversions take their eight columns from there (into registers, or -- eight-wave
+        // tiling -- in front of every use), the epilogue its add-back and the row constant of the log-sum-exp
         if (tid < D / 4) *(f32x4*)&s_kref[tid * 4] = kref_at(tid * 4);
+        else if (tid < D / 2) *(f32x4*)&s_vref[(tid - D / 4) * 4] = vref_at((tid - D / 4) * 4);
         __syncthreads();
+        if constexpr (KREF_REG) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                krefp[e] = pack_f16(s_kref[kref_col + 2 * e], s_kref[kref_col + 2 * e + 1]);
+                vrefp[e] = pack_f16(s_vref[vref_col + 2 * e], s_vref[vref_col + 2 * e + 1]);
+            }
+        }
     }
     f32x4 kst[GPT][2], vst[GPT][2];
     auto load_tile = [&](int kv0) {
@@ -376,12 +421,15 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                 *(f32x4*)(stage + g_vdst[i]) = vst[i][0];
             } else {
                 bf16x8 h8, l8;
-                f32x4 r0 = kref0, r1 = kref1;
+                f32x4 r0 = {0.0f, 0.0f, 0.0f, 0.0f}, r1 = r0;
                 if constexpr (CENTER && !KREF_REG) r0 = *(const f32x4*)&s_kref[kref_col], r1 = *(const f32x4*)&s_kref[kref_col + 4];
+                if constexpr (CENTER && KREF_REG) sub_f16x4(vst[i][0], vrefp[0], vrefp[1]), sub_f16x4(vst[i][1], vrefp[2], vrefp[3]);
+                if constexpr (CENTER && !KREF_REG) vst[i][0] -= *(const f32x4*)&s_vref[vref_col], vst[i][1] -= *(const f32x4*)&s_vref[vref_col + 4];
                 split8(vst[i][0], vst[i][1], h8, l8);
                 *(bf16x8*)(stage + g_vdst[i]) = h8;
                 *(bf16x8*)(stage + C::kImageBytes + g_vdst[i]) = l8;
-                if constexpr (CENTER) kst[i][0] -= r0, kst[i][1] -= r1;
+                if constexpr (CENTER && KREF_REG) sub_f16x4(kst[i][0], krefp[0], krefp[1]), sub_f16x4(kst[i][1], krefp[2], krefp[3]);
+                if constexpr (CENTER && !KREF_REG) kst[i][0] -= r0, kst[i][1] -= r1;
                 if constexpr (GUARD) {
                     // (key rows past the share were loaded as zeros and are now -kbar: masked in the scores, and kept out of the range guard's max |k|)
                     if (!CENTER || kv0 + g_krow[i] < nk) {
@@ -432,7 +480,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
         double cacc = 0.0;
         for_each_index([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value;
-            const f32x4 r0 = kref_at(ks * 16 + hi * 8), r1 = kref_at(ks * 16 + hi * 8 + 4);
+            const f32x4 r0 = *(const f32x4*)&s_kref[ks * 16 + hi * 8], r1 = *(const f32x4*)&s_kref[ks * 16 + hi * 8 + 4];
             typedef __attribute__((ext_vector_type(8))) float f32x8_t;
             f32x8_t qe;   // the operand the matrix core sees: hi + lo, exact in fp32
             if constexpr (QK16) {
@@ -697,6 +745,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                             pk[e] = o[qb][db][4 * g + e] * inv;
                             if (OPT) mag += fabsf(pk[e]);
                         }
+                        if constexpr (CENTER) pk += *(const f32x4*)&s_vref[db * 32 + 8 * g + 4 * hi];   // value centering: the reference row back in
                         store4(p, o_off + db * 32 + 8 * g, pk);
                     }
                 if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = ((m[qb] + __builtin_amdgcn_logf(lt)) + crow) * kLn2;
@@ -795,7 +844,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                     *(f32x4*)(stage + g_kdst[i]) = kst[i][0];
                 } else {
                     bf16x8 h8, l8;
-                    if constexpr (CENTER) kst[i][0] -= kref0, kst[i][1] -= kref1;
+                    if constexpr (CENTER) sub_f16x4(kst[i][0], krefp[0], krefp[1]), sub_f16x4(kst[i][1], krefp[2], krefp[3]);
                     if constexpr (GUARD) {
 #pragma unroll
                         for (int e = 0; e < 4; e += 2) absmax2(kmax, kst[i][0][e], kst[i][0][e + 1]), absmax2(kmax, kst[i][1][e], kst[i][1][e + 1]);
@@ -814,6 +863,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                     *(f32x4*)(stage + g_vdst[i]) = vst[i][0];
                 } else {
                     bf16x8 h8, l8;
+                    if constexpr (CENTER) sub_f16x4(vst[i][0], vrefp[0], vrefp[1]), sub_f16x4(vst[i][1], vrefp[2], vrefp[3]);
                     split8c(vst[i][0], vst[i][1], h8, l8);
                     *(bf16x8*)(stage + g_vdst[i]) = h8;
                     *(bf16x8*)(stage + C::kImageBytes + g_vdst[i]) = l8;
@@ -1046,7 +1096,8 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                     } else {
                         constexpr int c = U - NU_S, gi = c / 4, which = (c % 4) / 2, half = c % 2;
                         f32x4 x = which ? vst[gi][half] : kst[gi][half];
-                        if constexpr (CENTER && which == 0) x -= (half ? kref1 : kref0);
+                        if constexpr (CENTER && which == 0) sub_f16x4(x, krefp[2 * half], krefp[2 * half + 1]);
+                        if constexpr (CENTER && which == 1) sub_f16x4(x, vrefp[2 * half], vrefp[2 * half + 1]);
                         if constexpr (GUARD && which == 0) absmax2(kmax, x[2 * H], x[2 * H + 1]);
                         bf16x2 h2, l2;
                         split2x<QK16 && which == 0, false>(x[2 * H], x[2 * H + 1], h2, l2);   // K pieces: fp16 terms (fp32 tensors)
@@ -1140,6 +1191,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                             pk[e] = o[qb][db][4 * g + e] * inv;
                             mag += fabsf(pk[e]);
                         }
+                        if constexpr (CENTER) pk += *(const f32x4*)&s_vref[db * 32 + 8 * g + 4 * hi];   // value centering: the reference row back in
                         store4(p, o_off + db * 32 + 8 * g, pk);
                     }
                 if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = ((mref[qb] + __builtin_amdgcn_logf(lt)) + crow) * kLn2;

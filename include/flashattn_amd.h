@@ -63,9 +63,10 @@ typedef enum fa_dtype {
                          is small), on keys CENTRED on a reference key (k_j - kbar, kbar = the coordinate-wise median of three keys of
                          the share: softmax only needs differences, and a magnitude all keys share then never enters a rounded sum; the
                          row constant q.kbar goes back into the LSE); P.V as three products of two-term BF16 splits (P needs fp32's
-                         exponent range); 3x faster than fp32 arithmetic.  GUARANTEED: the logit error of the operand terms is
+                         exponent range) of values centred the same way (v_j - vbar, vbar added back to O: the 16 bits cover the spread
+                         of V, not an offset all values share); 3x faster than fp32 arithmetic.  GUARANTEED: the logit error of the operand terms is
                          <= 3 * 2^-22 * sum |q_i (k_i - kbar_i)| * scale -- below the rounding bound d * 2^-24 * sum |q_i k_i| of the
-                         reference's own fp32 FMA chain for every d >= 12 -- and the P.V terms add <= 3 * 2^-17 * max|v|.  CONTRACT
+                         reference's own fp32 FMA chain for every d >= 12 -- and the P.V terms add <= 3 * 2^-17 * max|v - vbar|.  CONTRACT
                          (tests/test_gpu_adversarial.py): |O - O_fp64| and |LSE - LSE_fp64| are <= max(1e-3, E_ref) on every input, E_ref =
                          what the reference's own arithmetic (a k-ordered chain of rounding fp32 FMAs, flashattention.cu:236-252) leaves
                          on that input.  OBSERVED: <= 1e-4 on unit-variance data at scale 1 (c2, c3; FA_KERNEL_MFMA reads 2e-5 there),

@@ -172,6 +172,39 @@ def test_key_centring_removes_common_mode_and_keeps_the_guard_quiet(n):
         assert e_o < 0.2 * ce_o, (e_o, ce_o)
 
 
+@pytest.mark.parametrize("d", [32, 64, 128])
+def test_value_centring_makes_the_pv_terms_relative_to_the_spread_of_v(d):
+    """V = offset + N(0, 1) under a peaked softmax (scale 1: a row's weight sits on a few keys, nothing averages out).  The P.V terms are
+    bf16 hi + lo (16 bits): uncentred they cost 3 * 2^-17 * max|v| -- 1.6e-3 at offset 100, 1.6e-2 at 1000, ten times what the reference's
+    own fp32 recurrence leaves (profiles/r05_v_offset.txt) --; the kernel splits v_j - vbar (vbar: the median of three rows) and adds vbar
+    back, so what remains is the spread's 3 * 2^-17 * max|v - vbar| plus the output's own fp32 rounding at the offset's magnitude.  Also a V
+    that is constant over the slab (all zeros after centring: the redo path) and an outlier row in a reference position."""
+    rng = np.random.default_rng(d)
+    bh, n = 2, 700
+    q, k, x = (rng.standard_normal((bh, n, d)).astype(np.float32) for _ in range(3))
+    for off in (0.0, 100.0, 1000.0, -3000.0):
+        for causal in (False, True):
+            v = (x + np.float32(off)).astype(np.float32)
+            o_ref, _ = adv.attention_f64(q, k, v, causal)
+            o, _ = run(q, k, v, causal=causal)
+            tol = 2e-4 + 2.0 ** -22 * abs(off)       # (fp32 itself: half an ulp of |O| ~ |off| is 2^-24 |off|)
+            record(f"value centring, V = {off:g} + N(0,1), d={d}, causal={int(causal)}", float(np.abs(o - o_ref).max()), tol)
+    v = np.full((bh, n, d), 1.25, np.float32)
+    o, _ = run(q, k, v)
+    assert np.abs(o - 1.25).max() == 0.0, "a constant V must come back exactly"
+    v = (x + np.float32(500.0)).astype(np.float32)
+    v[:, 0] = -4.0e4                                  # an outlier in a reference position: rejected by the median
+    o_ref, _ = adv.attention_f64(q, k, v)
+    o, _ = run(q, k, v)
+    sc = np.einsum("bqd,bkd->bqk", q.astype(np.float64), k.astype(np.float64))
+    w0 = (np.exp(sc - sc.max(-1, keepdims=True)) / np.exp(sc - sc.max(-1, keepdims=True)).sum(-1, keepdims=True))[..., 0]   # weight on key 0
+    # a row pays for the outlier in proportion to the weight it puts on it (its 16-bit terms are relative to |v_0 - vbar| ~ 4e4), and for
+    # the ordinary rows as if the outlier were not there
+    tol_rows = 2e-4 + 2.0 ** -22 * 500 + w0 * 3 * 2.0 ** -17 * 4.05e4
+    ratio = float((np.abs(o - o_ref).max(axis=-1) / tol_rows).max())
+    record(f"value centring, outlier V row 0, d={d}: worst row error / its own bound", ratio, 1.0)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # fp32 tensors: the RANGE of the fp16 operand terms (what the guard of FA_KERNEL_AUTO bounds since round 5)
 # ---------------------------------------------------------------------------------------------------------------
