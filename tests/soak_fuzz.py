@@ -51,7 +51,8 @@ def draw_n(rng):
 
 
 COHERENT = ("const_two_keys", "const_many_keys", "few_valued", "broadcast_token", "quantised_offset")
-N_FAMILIES = 6 + len(COHERENT)
+V_OFFSET = 6 + len(COHERENT)          # family 11: V = offset + N(0, 1) (the fp32 default centres V; fp32 accumulation itself is relative to |v|)
+N_FAMILIES = V_OFFSET + 1
 
 
 def make_data(rng, g, family, bh, n, d, case_seed=0):
@@ -70,6 +71,8 @@ def make_data(rng, g, family, bh, n, d, case_seed=0):
     elif family == 5:    # large V (round 3's fp16-P chain had to hand |v| >= 2^16 to the split kernel; two bf16 terms of P take any V)
         vmag = float(rng.choice([300.0, 7.0e4]))
         v *= vmag
+    elif family == V_OFFSET:
+        v += float(rng.choice([100.0, 1000.0, -2500.0]))
     elif family >= 6:    # coherent rounding residuals (tests/adversarial.py) at a logit width the round-4 guard let through
         width = float(rng.uniform(20.0, 89.0))
         q, k, v = (torch.from_numpy(t) for t in adv.make(COHERENT[family - 6], d, width, n=n, bh=bh, seed=case_seed))
@@ -109,7 +112,7 @@ def run(cases=400, seed=1, out="", only=-1, max_n=0, verbose=True):
         causal = bool(rng.integers(0, 2))
         scale = float(rng.choice([1.0, 0.5, d ** -0.5]))
         family = int(rng.integers(0, N_FAMILIES))
-        if family >= 6:
+        if 6 <= family < V_OFFSET:
             scale = 1.0          # the families are built for a logit width at the reference's scale
             bh = min(bh, 8)
         g = torch.Generator(device="cpu").manual_seed(seed * 100003 + case)
@@ -144,7 +147,7 @@ def run(cases=400, seed=1, out="", only=-1, max_n=0, verbose=True):
         o64, l64 = adv.rows_f64(qs, ks, vs, rows, causal, scale)
         tol_o = tol_l = TOL_F32          # (also for the coherent families: the kernel works on centred keys -- observed <= 3e-4 there)
         ref_o = ref_l = TOL_F32          # what rung 0 (fp32 arithmetic itself) may be off by on this input
-        if family in (1, 2) or family >= 6:
+        if family in (1, 2) or 6 <= family < V_OFFSET:
             # wide or coherent logits: the reference's OWN arithmetic (a rounding fp32 FMA chain, flashattention.cu:236-252) may leave more
             # than 1e-3 against fp64 there; the general contract is max(1e-3, that) (tests/test_gpu_adversarial.py)
             oc, lc = adv.rows_f64(qs, ks, vs, rows, causal, scale, chain=True)
@@ -152,6 +155,8 @@ def run(cases=400, seed=1, out="", only=-1, max_n=0, verbose=True):
             ref_l = max(TOL_F32, float(np.abs(lc - l64).max()))
             if family in (1, 2):
                 tol_o, tol_l = ref_o, ref_l
+        if family == V_OFFSET:   # values are centred: what is left is the output's own fp32 rounding at the offset's magnitude
+            tol_o = ref_o = 2e-4 + 2.0 ** -21 * float(v.abs().max())
         note("fp32 tensors vs fp64 (sampled rows)", float(np.abs(res[sb].cpu().numpy()[rows] - o64).max()) / vmag, tol_o, desc)
         note("fp32 tensors, LSE vs fp64 (sampled rows)", float(np.abs(lse[sb].cpu().numpy()[rows] - l64).max()), tol_l, desc)
         # rung 0 is fp32 arithmetic itself (its own error against fp64 is the FMA chain's), and it is compared on EVERY slab and row where the
@@ -167,6 +172,8 @@ def run(cases=400, seed=1, out="", only=-1, max_n=0, verbose=True):
             want = fa.forward(qq, kk, vv, True, scale=d ** -0.5, kernel="naive").reshape(B, nh, T, d).permute(0, 2, 1, 3).reshape(B, T, nh * d)
             note("packed QKV (llm.c layout)", float((got - want).abs().max()), TOL_F32, desc + f" B={B} T={T} NH={nh}")
         # ---- bf16 tensors
+        if family == V_OFFSET:
+            vmag = float(v.abs().max())   # bf16 tensors: V of magnitude 1000 has an ulp of 4, and fp32 accumulation is relative to |v|: relative figures
         qb, kb, vb = (t.to(torch.bfloat16).to(dev) for t in (q, k, v))
         refb, lse_refb = fa.forward(qb.float(), kb.float(), vb.float(), causal, scale=scale, kernel="naive", return_lse=True)
         ob, lse_b = fa.forward(qb, kb, vb, causal, scale=scale, return_lse=True)                                  # bf16 out
@@ -186,7 +193,7 @@ def run(cases=400, seed=1, out="", only=-1, max_n=0, verbose=True):
         # ... and against the regression thresholds of seeded random data (wide logits sharpen the softmax: the scale-1 figure whatever the
         # nominal scale; coherent families put two keys at +-vmax on equal weights: the bound above is the statement there)
         eff_scale = 1.0 if family in (1, 2) or family >= 6 else scale
-        if family < 6:
+        if family < 6 or family == V_OFFSET:
             note("bf16 tensors, bf16 out", float((ob.float() - refb).abs().max()) / vmag, bf16_tol(eff_scale, False, causal, n), desc)
         # the accurate P of FA_KERNEL_AUTO (two bf16 terms, one launch): the fp32 bar with margin on every data family (round 2's one-term
         # fp16 P needed 2^-10 * max|v| on the hostile ones)
