@@ -24,8 +24,8 @@
 // RANGE GUARD (fp32 tensors under FA_KERNEL_AUTO, FwdParams::flag_mode = 4): fp16 terms hold |x| < 65520 (beyond: hi = inf, lo = -inf, NaN
 // scores) and give elements below 2^-3 a subnormal lo term (absolute error <= 2^-25, times the partner element).  Every workgroup sees all
 // keys of its slab and its own query rows; it tracks max |k| element-wise while converting K (one v_max3_f32 per four values) and the
-// 2-norms of its Q' rows, and when the first attempt produced a NaN or  D * max|k| + sqrt(D) * max|q'|_2  exceeds kSubnormalBudget (2048:
-// the subnormal terms stay below 2^-14 per logit) the workgroup redoes its own rows in exact fp32 arithmetic before it exits
+// 2-norms of its Q' rows, and when the first attempt produced a NaN or  D * max|k| + sqrt(D) * max|q'|_2  exceeds kSubnormalBudget (8192:
+// the subnormal terms stay below 2^-12 per logit in the worst case) the workgroup redoes its own rows in exact fp32 arithmetic before it exits
 // (f32_exact_rows, fa_f32_exact.h: the body of the exact kernel, in the LDS this kernel is done with) and sets the caller's report word.
 // Callers who know better select FA_KERNEL_SPLIT (no guard) or FA_KERNEL_MFMA.  fp32 range is kept for V, P (bf16 exponent) and, through
 // the redo of rows whose accumulators come out tiny, for O.
@@ -76,8 +76,11 @@ constexpr float kSplitTinyAcc = 0x1p-116f;   // sum of a row's unnormalised accu
 // 75 would put unit-variance data at d = 128, scale 1 (up to 78) on the fallback: 90.
 constexpr float kGuardLimit = 90.0f;   // (FA_SPLIT_QK16 = 0 builds only: the bf16-term form of rounds 1-4)
 // fp16-term form (round 5): D * max|k| + sqrt(D) * max|q'|_2 above which the subnormal lo terms of small elements could add more than
-// 2^-25 * 2048 = 2^-14 (4e-5 nat) to a logit; unit-variance data: ~520 at d = 64, ~860 at d = 128 (scale 1)
-constexpr float kSubnormalBudget = 2048.0f;
+// 2^-25 * 8192 = 2^-12 (1.7e-4 nat) to a logit -- in the WORST case: every element of q' below 2^-3 with the same sign of residual against keys
+// that all sit at max|k - kbar|; random data stays 30 .. 50 times below its bound.  Unit-variance data: ~600 at d = 64, ~1000 at d = 128 (scale 1);
+// keys with elements up to 60 at d = 128 (large activations in a few channels) still pass.  (2048 until the values were measured against
+// LLM-like key magnitudes: max|k| = 20 at d = 128 would have sent every workgroup to the three times slower fp32 rows.)
+constexpr float kSubnormalBudget = 8192.0f;
 
 // running maximum of |a|, |b|: one instruction (abs as source modifiers)
 __device__ __forceinline__ void absmax2(float& m, float a, float b)
@@ -1225,7 +1228,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
             // fp16 terms: what the guard bounds is the RANGE of fp16, not the logit width (3 * 2^-22 * sum |q'_i k_i| is below the rounding
             // bound of the fp32 FMA chain itself, d * 2^-24 * sum |q'_i k_i|, at every width).  (1) |x| >= 65520 -> hi = inf, lo = -inf ->
             // NaN scores -> saw_nan (as for NaN / inf inputs).  (2) an element below 2^-3 has a subnormal lo term, absolute error <= 2^-25,
-            // multiplied by its partner: sum <= 2^-25 (|k|_1 + |q'|_1) <= 2^-25 (D |k|_inf + sqrt(D) |q'|_2) per logit; kept <= 2^-14.
+            // multiplied by its partner: sum <= 2^-25 (|k|_1 + |q'|_1) <= 2^-25 (D |k|_inf + sqrt(D) |q'|_2) per logit; kept <= 2^-12.
             wide = p.flag_mode >= 3 && (saw_nan || !((float)D * __uint_as_float(s_kmax) + sqrtf((float)D * qn2) <= kSubnormalBudget));
         } else {
             wide = p.flag_mode >= 3 && (saw_nan || !(sqrtf(qn2) * __uint_as_float(s_kmax) <= kGuardLimit * kLog2e));

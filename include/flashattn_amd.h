@@ -74,8 +74,8 @@ typedef enum fa_dtype {
                          where FA_KERNEL_MFMA reads 8e-4 .. 5.9e-3.
                          RANGE GUARD: fp16 terms hold |x| < 65520 and lose elements below 2^-3 to subnormal lo terms (absolute error 2^-25
                          each); a workgroup whose first attempt produced a NaN, or whose D * max|k - kbar| + sqrt(D) * max|q * scale * log2 e|_2
-                         exceeds 2048 (the subnormal terms could then add more than 2^-14 to a logit; unit-variance data: ~520 at d = 64,
-                         ~860 at d = 128), redoes its rows in exact fp32 arithmetic before it exits -- ONE launch, no host round trip;
+                         exceeds 8192 (the subnormal terms could then add more than 2^-12 to a logit in the worst case; unit-variance data: ~600 at d = 64,
+                         ~1000 at d = 128; key elements up to 60 at d = 128 still pass), redoes its rows in exact fp32 arithmetic before it exits -- ONE launch, no host round trip;
                          fa_last_forward_route() tells whether any workgroup did.  (Rounds 1-4 used two BF16 terms, 16 bits, behind a
                          logit-width guard that bounded an RMS error model: coherent inputs under its limit read up to 6e-2.)
                          FA_KERNEL_SPLIT: the same products without the guard.  FA_KERNEL_MFMA: fp32 arithmetic (v_mfma_f32_32x32x2_f32),

@@ -155,8 +155,11 @@ def run(cases=400, seed=1, out="", only=-1, max_n=0, verbose=True):
             ref_l = max(TOL_F32, float(np.abs(lc - l64).max()))
             if family in (1, 2):
                 tol_o, tol_l = ref_o, ref_l
-        if family == V_OFFSET:   # values are centred: what is left is the output's own fp32 rounding at the offset's magnitude
-            tol_o = ref_o = 2e-4 + 2.0 ** -21 * float(v.abs().max())
+        if family == V_OFFSET:   # values are centred: what is left is the output's own fp32 rounding at the offset's magnitude ...
+            tol_o = 2e-4 + 2.0 ** -21 * float(v.abs().max())
+            # ... while rung 0 accumulates w_j v_j at the offset's magnitude in fp32 (6e-3 off fp64 at V = 1000 + N(0, 1) over 8617 keys,
+            # seed 42 case 14): its error MEASURED on the sampled rows is the yardstick of the coverage check below
+            ref_o = max(tol_o, float(np.abs(ref[sb].cpu().numpy()[rows] - o64).max()))
         note("fp32 tensors vs fp64 (sampled rows)", float(np.abs(res[sb].cpu().numpy()[rows] - o64).max()) / vmag, tol_o, desc)
         note("fp32 tensors, LSE vs fp64 (sampled rows)", float(np.abs(lse[sb].cpu().numpy()[rows] - l64).max()), tol_l, desc)
         # rung 0 is fp32 arithmetic itself (its own error against fp64 is the FMA chain's), and it is compared on EVERY slab and row where the

@@ -154,12 +154,26 @@ def test_key_centring_is_robust_to_outlier_reference_candidates(d):
 
 @pytest.mark.parametrize("n", [500, 512, 8192])
 def test_key_centring_removes_common_mode_and_keeps_the_guard_quiet(n):
-    """Constant-component rows whose UNCENTRED operands would trip the range guard (D max|k| + sqrt(D) |q'|_2 > 2048 at width 205, d = 128):
-    the guard looks at the centred keys, so the default stays on the 16-bit pipes (route 1) -- for a ragged length too (rows past the end are
-    kept out of the guard's max |k|), and over key shares (n = 8192 on one slab: every share centres on its own reference and adds its own
-    row constant back to its log-sum-exp before the combine) -- and reads far below the reference arithmetic's own error."""
+    """Keys with a large common offset (k = 64 + N(0, 1) at d = 128): UNCENTRED they would trip the range guard (D max|k| alone is 8700 > 8192)
+    and carry a row constant of several hundred into every partial sum; the guard looks at the centred keys, so the default stays on the
+    16-bit pipes (route 1) -- for a ragged length too (rows past the end are kept out of the guard's max |k|), and over key shares
+    (n = 8192 on one slab: every share centres on its own reference and adds its own row constant back to its log-sum-exp before the
+    combine) -- and reads far below the reference arithmetic's own error.  Then the constant-component family at width 205."""
+    rng = np.random.default_rng(n)
+    q = rng.standard_normal((1, n, 128)).astype(np.float32)
+    k = (64.0 + rng.standard_normal((1, n, 128))).astype(np.float32)
+    v = rng.standard_normal((1, n, 128)).astype(np.float32)
+    rows = np.unique(np.concatenate([[0, 1, 2, n - 1], rng.integers(0, n, 200)]))
+    for causal in (False, True):
+        o, lse = run(q, k, v, causal=causal)
+        assert fa.last_forward_route() == 1, (n, causal)
+        o_ref, l_ref = adv.rows_f64(q[0], k[0], v[0], rows, causal)
+        o_ch, l_ch = adv.rows_f64(q[0], k[0], v[0], rows, causal, chain=True)
+        record(f"key centring, k = 64 + N(0,1), d=128 n={n} causal={int(causal)}: O (fp32 FMA chain: {np.abs(o_ch - o_ref).max():.1e})",
+               float(np.abs(o[0][rows] - o_ref).max()), TOL)
+        record(f"key centring, k = 64 + N(0,1), d=128 n={n} causal={int(causal)}: LSE (fp32 FMA chain: {np.abs(l_ch - l_ref).max():.1e})",
+               float(np.abs(lse[0][rows] - l_ref).max()), TOL)
     q, k, v = adv.make("const_two_keys", 128, 205.0, n=n, bh=1, seed=n)
-    rows = np.unique(np.concatenate([[0, 1, 2, n - 1], np.random.default_rng(n).integers(0, n, 200)]))
     for causal in (False, True):
         o, lse = run(q, k, v, causal=causal)
         assert fa.last_forward_route() == 1, (n, causal)

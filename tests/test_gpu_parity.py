@@ -92,13 +92,14 @@ def randn(seed, *shape):
 
 
 RANGE_SHIFT = 2.0 ** 13
+WIDE = 400.0           # one key (or query) row times this leaves the fp32 default's range budget at every head dim: D * 400 * max|k_i| > 8192
 
 
 def range_hostile(q, k, slab):
     """In place: slab `slab` of q times 2^-13, of k times 2^13 -- powers of two, so the logits, the fp64 oracle and the exact kernel's result
     are what they were, but the fp16 operand terms of the fp32 default (round 5: K and Q' as fp16 hi + lo) lose the small side to fp16
     subnormals (absolute error 2^-25 per element, times a partner of ~2^13): the input on which the UNGUARDED split products are visibly
-    wrong (~1e-3) and the guard of FA_KERNEL_AUTO (D |k|_inf + sqrt(D) |q'|_2 <= 2048) must hand the workgroup to fp32 arithmetic.  (Until
+    wrong (~1e-3) and the guard of FA_KERNEL_AUTO (D |k - kref|_inf + sqrt(D) |q'|_2 <= 8192) must hand the workgroup to fp32 arithmetic.  (Until
     round 4 the hostile input was a wide logit -- one key times 40 --, which two fp16 terms now simply compute correctly.)"""
     q[slab] *= 1.0 / RANGE_SHIFT
     k[slab] *= RANGE_SHIFT
@@ -686,7 +687,7 @@ def test_fp32_key_split_launch(bh, n, d, causal):
     check(out[:1], orc.attention_f64(q[:1], k[:1], v[:1], causal=causal), TOL_F32, "vs fp64 oracle")
     # a wide key in the LAST share: that share's guard fires and its workgroups redo their partials in fp32 arithmetic (round 4: inside the
     # kernel; the other shares' logits are ordinary and stay on the bf16 pipe), the combine merges both kinds
-    k[0, n - 7] *= 40.0
+    k[0, n - 7] *= WIDE
     (kw,) = to_dev(k)
     o2 = fa.forward(qd, kw, vd, causal)
     assert fa.last_forward_route() == 2
@@ -1219,7 +1220,7 @@ def test_host_threads_feed_their_own_streams_concurrently():
     L = _cabi.lib()
     q, k, v = (torch.randn(4, 1024, 64, device=dev()) for _ in range(3))
     kw = k.clone()
-    kw[1, 33] *= 40.0
+    kw[1, 33] *= WIDE
     ref, ref_w = fa.forward(q, k, v, False, kernel="exact"), fa.forward(q, kw, v, False, kernel="exact")
     qb, kb, vb = (torch.randn(1, 4096, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
     refb = fa.forward(qb.float(), kb.float(), vb.float(), False, kernel="naive")
@@ -1307,7 +1308,7 @@ def test_guarded_fp32_chain_survives_graph_capture_and_other_streams():
     torch.cuda.synchronize()
     assert float((ob - fa.forward(qb, kb, vb, False, kernel="exact")).abs().max()) < TOL_F32
     kw = k.clone()
-    kw[3, 77] *= 40.0                                   # wide logits: slab 3 must come out of fp32 arithmetic
+    kw[3, 77] *= WIDE                                   # wide logits: slab 3 must come out of fp32 arithmetic
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     torch.cuda.synchronize()
     for _ in range(5):
@@ -1483,7 +1484,7 @@ def test_fp32_auto_holds_the_bar_on_wide_logits(d, causal):
 @pytest.mark.parametrize("bh,n,d", [(16, 8192, 64), (8, 1024, 64), (5, 1500, 64), (4, 2048, 128), (2, 8192, 128), (40, 700, 128), (4, 2048, 32), (3, 4100, 32)])
 def test_fp32_fallback_is_per_workgroup_and_inside_the_kernel(bh, n, d, causal):
     """Round 4: FA_KERNEL_AUTO for fp32 tensors is ONE launch.  A workgroup of the split kernel whose operands leave the range fp16 terms
-    hold (round 5: D |k|_inf of the keys it reads + sqrt(D) |q'|_2 of its rows > 2048; rounds 2-4: a logit-width bound) redoes its own rows
+    hold (round 5: D |k|_inf of the keys it reads + sqrt(D) |q'|_2 of its rows > 8192; rounds 2-4: a logit-width bound) redoes its own rows
     with the body of the exact fp32 kernel (fa_f32_exact.h) before it
     exits; round 3 queued the exact kernel behind every launch (a second dispatch, 3-10 us, that skipped itself) and, when one slab was
     hostile, recomputed ALL of them.  One hostile slab: its rows equal the exact kernel's, every other slab equals the unguarded split
@@ -1528,12 +1529,12 @@ def test_fp32_auto_guard_stays_quiet_on_the_reference_workloads():
             check(o, orc.attention_f64(q, k, v, causal=causal, scale=scale), TOL_F32)
     # one wide key anywhere in the slab is enough, also when only the LAST q tile's rows are long
     q, k, v = (randn(s, 2, 1024, 64) for s in (74, 75, 76))
-    k[1, 1000] *= 30.0
+    k[1, 1000] *= WIDE
     o = fa.forward(*to_dev(q, k, v), False)
     assert fa.last_forward_route() == 2
     check(o, orc.attention_f64(q, k, v), TOL_F32)
     q, k, v = (randn(s, 2, 1024, 64) for s in (74, 75, 76))
-    q[0, 1023] *= 40.0
+    q[0, 1023] *= WIDE
     o = fa.forward(*to_dev(q, k, v), True)
     assert fa.last_forward_route() == 2
     check(o, orc.attention_f64(q, k, v, causal=True), TOL_F32)
