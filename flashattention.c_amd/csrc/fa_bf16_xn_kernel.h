@@ -753,6 +753,7 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
     constexpr int KS = XShape<D, NB>::KS, DB = XShape<D, NB>::DB;
     constexpr float kBiasC = XSoft<OPT, PF>::kBias;
     const unsigned long long prof_entry = (ABL & 1024) ? stamp() : 0ull;
+    const unsigned long long prof_rt_in = (ABL & 2048) ? __builtin_amdgcn_s_memrealtime() : 0ull;   // timeline: 100 MHz ticks at entry
     using C = Bf16Cfg<D, NWAVES>;
     constexpr int BM = NWAVES * 32 * NB;
     constexpr int KR = 2 * G, VR = 2 * G;
@@ -1155,6 +1156,14 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
             dst[5] = (float)(prof_t0 - prof_landed);      // first scores: K fragments, K.Q^T of sub-tile 0, row maxima, references
             dst[6] = (float)(prof_tail - prof_t1);        // tail stages outside the fast loop
             dst[7] = (float)(t_issued - prof_tail);       // drain, O / l, packing, store issue (t2 - t_issued: stores landing)
+            if constexpr ((ABL & 2048) != 0) {   // timeline of the launch (fa_driver_ablation --mode timeline): where and when this workgroup ran
+                unsigned hwid, xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                unsigned* u = (unsigned*)dst;
+                u[0] = (unsigned)prof_rt_in, u[1] = (unsigned)__builtin_amdgcn_s_memrealtime(), u[2] = hwid, u[3] = xcc;
+                u[4] = (unsigned)qt, u[5] = (unsigned)slab, u[6] = blockIdx.x, u[7] = (unsigned)nst;
+            }
         }
     }
     if (OPT) {

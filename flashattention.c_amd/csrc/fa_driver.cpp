@@ -484,6 +484,31 @@ int main(int argc, char** argv)
         printf("  whole kernel per wave: min %.0f mean %.0f max %.0f cycles\n", mn, av, mx);
         return 0;
     }
+    if (a.mode == "timeline") {
+        // where and when every workgroup of a causal NB = 2 launch ran (ablation library, variant 71: the product's launch order with stamps):
+        // one line per workgroup -- block, xcc, se, cu, q tile, slab, 64-key stages, entry and exit in 10 ns ticks from the first entry
+        float* lse = nullptr;
+        HIP_OK(hipMalloc(&lse, (size_t)a.bh * a.n * 4));
+        for (int rep = 0; rep < 30; ++rep)   // warm clocks
+            fa_ok(fa_forward_ex(b.q, b.k, b.v, b.o, lse, a.bh, a.n, a.d, a.scale, a.causal, FA_DTYPE_BF16, FA_KERNEL_MFMA | (a.variant << 8), nullptr), "timeline");
+        HIP_OK(hipMemset(lse, 0, (size_t)a.bh * a.n * 4));
+        fa_ok(fa_forward_ex(b.q, b.k, b.v, b.o, lse, a.bh, a.n, a.d, a.scale, a.causal, FA_DTYPE_BF16, FA_KERNEL_MFMA | (a.variant << 8), nullptr), "timeline");
+        HIP_OK(hipDeviceSynchronize());
+        const size_t nwg = (size_t)a.bh * ((a.n + 255) / 256);
+        std::vector<unsigned> h(nwg * 4 * 8);
+        HIP_OK(hipMemcpy(h.data(), lse, h.size() * 4, hipMemcpyDeviceToHost));
+        unsigned t0 = 0xffffffffu;
+        for (size_t g = 0; g < nwg; ++g) t0 = h[g * 32] < t0 ? h[g * 32] : t0;
+        printf("# block xcc se cu qtile slab stages t_in t_out   (wave 0 of each workgroup; 10 ns ticks)\n");
+        for (size_t g = 0; g < nwg; ++g) {
+            const unsigned* u = &h[g * 32];
+            unsigned t_out = 0;
+            for (int wv = 0; wv < 4; ++wv) t_out = h[g * 32 + wv * 8 + 1] > t_out ? h[g * 32 + wv * 8 + 1] : t_out;
+            // HW_ID (gfx9): wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13
+            printf("%u %u %u %u %u %u %u %u %u\n", u[6], u[3] & 15u, (u[2] >> 13) & 7u, (u[2] >> 8) & 15u, u[4], u[5], u[7], u[0] - t0, t_out - t0);
+        }
+        return 0;
+    }
     if (a.mode == "prof4") {
         // cycle stamps around the fast loop of the NB = 4 kernel (ablation library; variants 60..68 write 4 floats per wave to the lse buffer)
         float* lse = nullptr;

@@ -616,6 +616,7 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
                 case 42: return launch_bf16_x4(p, causal, out_f32, 3, stream);   // x4, rescaling mix only
 #if FA_ABLATION
                 case 70: return launch_bf16_x2(p, 64, causal, out_f32, 40, stream);   // cycle-stamped NB = 2 kernel
+                case 71: return launch_bf16_x2(p, 64, causal, out_f32, 41, stream);   // ... in the product's causal launch order, with a timeline
 #endif
                 case 50: return launch_bf16_x2(p, 64, causal, out_f32, 0, stream);   // one wave per SIMD, 64 rows per wave, 256-row tiles
                 case 51: return launch_bf16_x2(p, 64, causal, out_f32, 1, stream);

@@ -23,6 +23,16 @@ hipError_t launch_bf16_x2(const FwdParams& p, int d, int causal, int out_f32, in
     }
 #endif
 #if FA_ABLATION
+    if (mode == 41 && d == 64 && causal) {   // timeline (fa_driver_ablation --mode timeline --variant 71): the PRODUCT's launch order, stamped
+        FwdParams q;
+        dim3 grid, block;
+        if (!xn_grid<2>(p, q, grid, block)) return hipErrorInvalidValue;
+        const unsigned solo = xn_launch_order<64, 2>(q, grid, causal, true);
+        hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<64, 4, true, false, 2, 1024 | 2048>), grid, block, solo, stream, q);
+        return hipGetLastError();
+    }
+#endif
+#if FA_ABLATION
     if (d == 32 && mode == 1) return launch_x2<32, 1>(p, causal, out_f32, stream);
     if (d == 32 && mode == 3) return launch_x2<32, 2, false>(p, causal, out_f32, stream);
     if (d == 64 && mode == 1) return launch_x2<64, 1>(p, causal, out_f32, stream);
