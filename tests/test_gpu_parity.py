@@ -975,6 +975,16 @@ def test_scratch_paths_under_graph_capture_through_the_workspace_entry():
     assert 0.0 < fa.time_forward(qf, kf, vf, False, warmup=0, iters=2, out=of, graph=True) < 50.0
     torch.cuda.synchronize()
     assert fa.last_forward_route() == 1 and float((of - ref[:1]).abs().max()) < TOL_F32
+    # ... and the exact fp32 kernel over key shares (round 5: shares + combine for idle grids; causal: complement pairs), captured
+    for causal in (False, True):
+        ref_x = fa.forward(qf, kf, vf, causal, kernel="naive")
+        assert fa.workspace_bytes(1, 8192, 64, causal, kernel="exact") > 256
+        for iters in (1, 3):
+            of.zero_()
+            torch.cuda.synchronize()
+            assert 0.0 < fa.time_forward(qf, kf, vf, causal, warmup=0, iters=iters, out=of, graph=True, kernel="exact") < 50.0
+            torch.cuda.synchronize()
+            assert float((of - ref_x).abs().max()) < TOL_F32, (causal, iters)
 
 
 def test_workspace_sizes_and_validation_of_the_non_allocating_entry():
