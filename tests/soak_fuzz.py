@@ -103,6 +103,32 @@ def run(cases=400, seed=1, out="", only=-1, max_n=0, verbose=True):
             print(msg, flush=True)
             raise AssertionError(msg)
 
+    def coverage(key, got, ref, qn, kn, vn, causal, scale, simple_tol, contract_tol, chain, vmag, desc, lse=False):
+        """Rung 0 (fp32 arithmetic on the device) covers EVERY slab and row, where the fp64 oracle saw ~200 rows of one slab: unwritten rows
+        and wrong tiles show up here.  It is itself a rounding fp32 chain, though: on coherent or wide inputs it can sit several 1e-3 off
+        fp64 on a slab the sample did not look at (seed 51, case 48: 7.4e-3 between the two on 5-key rows at d = 128).  So a difference
+        above the simple threshold is ADJUDICATED: the three rows where the two disagree most are recomputed in fp64, and the kernel
+        under test must hold its own contract there (max(tolerance, the emulated chain's error on that row) when `chain`)."""
+        diff = (got - ref).abs()
+        if not lse:
+            diff = diff.amax(dim=-1)
+        worst_diff = float(diff.max()) / (1.0 if lse else vmag)
+        if worst_diff < simple_tol:
+            note(key, worst_diff, simple_tol, desc)
+            return
+        flat = torch.topk(diff.flatten().nan_to_num(nan=float("inf")), k=min(3, diff.numel())).indices.cpu().numpy()
+        for idx in flat:
+            sl, row = int(idx) // diff.shape[1], int(idx) % diff.shape[1]
+            o64, l64 = adv.rows_f64(qn[sl], kn[sl], vn[sl], [row], causal, scale)
+            want = l64 if lse else o64
+            mine = got[sl, row].cpu().numpy()
+            err = float(np.abs(mine - want).max()) / (1.0 if lse else vmag)
+            tol = contract_tol
+            if chain:
+                oc, lc = adv.rows_f64(qn[sl], kn[sl], vn[sl], [row], causal, scale, chain=True)
+                tol = max(tol, float(np.abs((lc if lse else oc) - want).max()) / (1.0 if lse else vmag))
+            note(key + " -- adjudicated by fp64 at the rows of largest disagreement", err, tol, desc + f" slab {sl} row {row}: |kernel - rung 0| {worst_diff:.2e}")
+
     for case in range(cases):
         d = int(rng.choice([32, 64, 128]))
         n = draw_n(rng)
@@ -164,8 +190,10 @@ def run(cases=400, seed=1, out="", only=-1, max_n=0, verbose=True):
         note("fp32 tensors, LSE vs fp64 (sampled rows)", float(np.abs(lse[sb].cpu().numpy()[rows] - l64).max()), tol_l, desc)
         # rung 0 is fp32 arithmetic itself (its own error against fp64 is the FMA chain's), and it is compared on EVERY slab and row where the
         # fp64 sample above saw ~200 rows of one: a coverage check (unwritten rows, wrong tiles), at five times the chain's error on the sample
-        note("fp32 tensors vs rung 0", float((res - ref).abs().max()) / vmag, 5.0 * ref_o, desc)
-        note("fp32 tensors, LSE vs rung 0", float((lse - lse_ref).abs().max()), 5.0 * ref_l, desc)
+        wide = family in (1, 2) or 6 <= family < V_OFFSET
+        qn, kn, vn = q.numpy(), k.numpy(), v.numpy()
+        coverage("fp32 tensors vs rung 0", res, ref, qn, kn, vn, causal, scale, 5.0 * ref_o, tol_o, wide or family == V_OFFSET, vmag, desc)
+        coverage("fp32 tensors, LSE vs rung 0", lse, lse_ref, qn, kn, vn, causal, scale, 5.0 * ref_l, tol_l, wide, vmag, desc, lse=True)
         if pack_nh:    # the llm.c entry: packed (B, T, 3C) fp32, causal, 1/sqrt(d)
             nh = pack_nh
             B, T = max(1, bh // nh), min(n, 2048)
@@ -200,11 +228,13 @@ def run(cases=400, seed=1, out="", only=-1, max_n=0, verbose=True):
             note("bf16 tensors, bf16 out", float((ob.float() - refb).abs().max()) / vmag, bf16_tol(eff_scale, False, causal, n), desc)
         # the accurate P of FA_KERNEL_AUTO (two bf16 terms, one launch): the fp32 bar with margin on every data family (round 2's one-term
         # fp16 P needed 2^-10 * max|v| on the hostile ones)
-        note("bf16 tensors, fp32 out", float((of - refb).abs().max()) / vmag, TOL_PB2, desc)
+        # (against rung 0 on every slab; where rung 0's own fp32 chain is the larger error -- coherent inputs -- fp64 decides: coverage())
+        qbn, kbn, vbn = (t.float().cpu().numpy() for t in (qb, kb, vb))
+        coverage("bf16 tensors, fp32 out", of, refb, qbn, kbn, vbn, causal, scale, TOL_PB2, TOL_PB2, False, vmag, desc)
         if case % 3 == 0:    # the NB = 2 tiling forced, and the split kernel beside it
             o2, lse2 = fa.forward(qb, kb, vb, causal, scale=scale, out_dtype=torch.float32, kernel="pb2:1", return_lse=True)
-            note("kernel=pb2:1", float((o2 - refb).abs().max()) / vmag, TOL_PB2, desc)
-            note("kernel=pb2:1, LSE", float((lse2 - lse_refb).abs().max()), 2e-4, desc)
+            coverage("kernel=pb2:1", o2, refb, qbn, kbn, vbn, causal, scale, TOL_PB2, TOL_PB2, False, vmag, desc)
+            coverage("kernel=pb2:1, LSE", lse2, lse_refb, qbn, kbn, vbn, causal, scale, 2e-4, 2e-4, False, vmag, desc, lse=True)
         # the LSE sees what O / l hides (a clamped or saturated P): row sums of 8-bit-rounded P stay within 2e-2, of 11-bit ones 2e-3
         note("bf16 tensors, bf16 out, LSE", float((lse_b - lse_refb).abs().max()), 2e-2, desc)
         note("bf16 tensors, fp32 out, LSE", float((lse_f - lse_refb).abs().max()), 1e-3, desc)
