@@ -21,7 +21,8 @@ EXPORTED_SYMBOLS = (
 class FaStats(ctypes.Structure):
     """struct fa_stats of include/flashattn_amd.h"""
     _fields_ = [(n, ctypes.c_uint64) for n in ("forwards", "chains", "chains_degraded", "scratch_replans", "slot_evictions", "capture_slots_recycled",
-                                               "eager_slots_in_use", "capture_slots_in_use", "eager_slots_per_device", "capture_slots_per_device")]
+                                               "eager_slots_in_use", "capture_slots_in_use", "eager_slots_per_device", "capture_slots_per_device",
+                                               "tiles_redone", "workgroups_fp32")]
 
 
 class ExtensionMissing(RuntimeError):

@@ -158,6 +158,8 @@ int fa_get_stats(fa_stats* out)
         out->eager_slots_in_use += (uint64_t)g_slots[dev].eager.size();
         out->capture_slots_in_use += (uint64_t)(g_slots[dev].next_capture - (int)g_slots[dev].free_capture.size());
     }
+    out->tiles_redone = cliff_count(0);
+    out->workgroups_fp32 = cliff_count(1);
     out->eager_slots_per_device = kEagerSlots;
     out->capture_slots_per_device = kFlagSlots - kEagerSlots;
     return FA_OK;
@@ -175,9 +177,9 @@ int fa_device_count(void)
 const char* fa_version(void)
 {
 #if FA_ABLATION
-    return "flashattn_amd abi 4 gfx950 (hip, mfma f32 32x32x2 / bf16 32x32x16, lds-dma) +ablation";
+    return "flashattn_amd abi 5 gfx950 (hip, mfma f32 32x32x2 / bf16 32x32x16, lds-dma) +ablation";
 #else
-    return "flashattn_amd abi 4 gfx950 (hip, mfma f32 32x32x2 / bf16 32x32x16, lds-dma)";
+    return "flashattn_amd abi 5 gfx950 (hip, mfma f32 32x32x2 / bf16 32x32x16, lds-dma)";
 #endif
 }
 

@@ -1181,6 +1181,7 @@ __device__ __forceinline__ void xn_kernel_body(const FwdParams& p, char* smem)
 {
     if (OPTIMISTIC && ABL == 0) {
         if (xn_tile<D, NB, NWAVES, CAUSAL, OUT_F32, G, 0, true, PF>(p, smem)) return;
+        count_cliff(p, 0);
     }
     if (ABL != 0 && OPTIMISTIC) {
         (void)xn_tile<D, NB, NWAVES, CAUSAL, OUT_F32, G, ABL, true, PF>(p, smem);

@@ -461,6 +461,7 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
     __shared__ __attribute__((aligned(1024))) char smem[4 * G * C::kTileBytes];
     if (OPTIMISTIC && !PROF) {
         if (pp3_tile<D, NWAVES, CAUSAL, OUT_F32, false, G, true>(p, smem)) return;
+        count_cliff(p, 0);
     }
     (void)pp3_tile<D, NWAVES, CAUSAL, OUT_F32, PROF, G, false>(p, smem);
 }

@@ -88,6 +88,10 @@ extern thread_local int t_last_route;      // >= 0: the route of the last chain,
 
 int current_device();
 bool stream_is_capturing(hipStream_t stream);
+// The two cliff counters of FwdParams::cliffs (pinned, portable host memory, allocated by the first forward that is not being captured;
+// the kernels add to them with system-scope atomics) and what fa_get_stats() reads from them.
+unsigned long long* cliff_counters(bool capturing);
+unsigned long long cliff_count(int which);
 uint32_t next_serial();
 
 // The slots of one device.  Eager slots are keyed by stream (hipStreamPerThread is one handle for a different stream in every thread:

@@ -141,7 +141,7 @@ hipError_t launch_f32_t3_chain(const fa::FwdParams& p0, int32_t d, char* scratch
 
 // One forward.  ws == nullptr && !ws_mode: a convenience entry point -- scratch, if the plan wants any, comes from the private pool
 // (never while the stream is capturing: the plan is then made without scratch).  ws_mode: the caller's workspace or nothing.
-int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int32_t kernel, hipStream_t stream, void* ws, size_t ws_bytes,
+int launch(const fa::FwdParams& p_in, int32_t d, int32_t causal, int32_t dtype, int32_t kernel, hipStream_t stream, void* ws, size_t ws_bytes,
            bool ws_mode)
 {
     const KernelSel sel = decode_kernel(kernel);
@@ -149,6 +149,8 @@ int launch(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype, int
     t_last_route = -1;
     g_stats.forwards.fetch_add(1, std::memory_order_relaxed);
     const bool capturing = stream_is_capturing(stream);
+    fa::FwdParams p = p_in;
+    p.cliffs = cliff_counters(capturing);   // (nullptr until a forward outside a capture has allocated them: the kernels then do not count)
     Plan pl = make_plan(p, d, causal, dtype, kernel, ws_mode ? true : !capturing);
     if (pl.status != FA_OK) return pl.status;
     char* scratch = static_cast<char*>(ws);

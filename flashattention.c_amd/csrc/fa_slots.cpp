@@ -60,6 +60,42 @@ int current_device()
     return dev;
 }
 
+namespace {
+std::atomic<unsigned long long*> g_cliffs_dev{nullptr};    // what the kernels are handed
+std::atomic<unsigned long long*> g_cliffs_host{nullptr};   // the same memory as the host reads it
+std::mutex g_cliffs_mu;
+}  // namespace
+
+unsigned long long* cliff_counters(bool capturing)
+{
+    unsigned long long* d = g_cliffs_dev.load(std::memory_order_acquire);
+    if (d != nullptr || capturing) return d;   // (hipHostMalloc is not a call to make while a stream of this thread is capturing)
+    std::lock_guard<std::mutex> g(g_cliffs_mu);
+    d = g_cliffs_dev.load(std::memory_order_acquire);
+    if (d != nullptr) return d;
+    void* h = nullptr;
+    void* dv = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || h == nullptr) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    memset(h, 0, 64);
+    if (hipHostGetDevicePointer(&dv, h, 0) != hipSuccess || dv == nullptr) {
+        (void)hipGetLastError();
+        (void)hipHostFree(h);
+        return nullptr;
+    }
+    g_cliffs_host.store(static_cast<unsigned long long*>(h), std::memory_order_release);
+    g_cliffs_dev.store(static_cast<unsigned long long*>(dv), std::memory_order_release);
+    return static_cast<unsigned long long*>(dv);
+}
+
+unsigned long long cliff_count(int which)
+{
+    const unsigned long long* h = g_cliffs_host.load(std::memory_order_acquire);
+    return h == nullptr ? 0ull : __atomic_load_n(h + which, __ATOMIC_RELAXED);
+}
+
 bool stream_is_capturing(hipStream_t stream)
 {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;

@@ -1243,11 +1243,15 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                     if (qb > 0) __syncthreads();   // every wave is out of the previous block's last tile
                     f32_exact_rows<D, NWAVES, CAUSAL, false>(p, smem, qg, kg, vg, o_slab, slab, q0 + qb * 32, kbeg, nk, kv_end, wave, lane);
                 }
+                count_cliff(p, 1);
                 return;
             }
         }
     }
-    if (redo) run_tile(std::false_type{});
+    if (redo) {
+        run_tile(std::false_type{});
+        count_cliff(p, 0);   // (behind the redo: nothing is live here -- in front of it the causal 128-row tilings spilled 68 bytes)
+    }
 }
 
 template <int D, int NWAVES, int QB, int MINBLOCKS, bool PIPE, bool IN_BF16 = false>

@@ -206,7 +206,9 @@ def last_forward_route(stream: Optional[torch.cuda.Stream] = None) -> int:
 
 def stats() -> dict:
     """Process-wide counters of the launch machinery (``fa_get_stats``): forwards, forwards with a report word (fp32 ``"auto"``), those
-    that found no slot for it, re-plans without scratch, slot evictions, recycled capture slots."""
+    that found no slot for it, re-plans without scratch, slot evictions, recycled capture slots -- and the two counters the kernels bump on
+    their slow paths: ``tiles_redone`` (optimistic attempt failed, tile recomputed: ~2x) and ``workgroups_fp32`` (fp32 ``"auto"``
+    workgroups redone in fp32 arithmetic: ~3x)."""
     st = _cabi.FaStats()
     _cabi.check(_cabi.lib().fa_get_stats(ctypes.byref(st)))
     return {n: int(getattr(st, n)) for n, _ in _cabi.FaStats._fields_}

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define FLASHATTN_AMD_ABI_VERSION 4
+#define FLASHATTN_AMD_ABI_VERSION 5   /* 5: fa_stats gained tiles_redone, workgroups_fp32 (appended: a caller built against 4 must re-build) */
 
 typedef enum fa_status {
     FA_OK = 0,
@@ -246,6 +246,15 @@ typedef struct fa_stats {
     uint64_t slot_evictions;           /* eager slots that changed hands                                     */
     uint64_t capture_slots_recycled;   /* capture slots returned by destroyed graphs                         */
     uint64_t eager_slots_in_use, capture_slots_in_use, eager_slots_per_device, capture_slots_per_device;
+    /* ABI 5: the two performance cliffs of correct-but-slower paths, counted by the kernels themselves (system-scope atomics into pinned
+       host memory on the rare path only; 0 until a forward outside a graph capture has run, and forwards CAPTURED before that never count):
+       tiles_redone     workgroup tiles whose optimistic attempt failed its range check and were recomputed with the rescaled / textbook
+                        softmax (about 2x the tile's time): exponent references outgrown by 2^100, an all-zero or tiny V, for fp32 tensors a V
+                        that is constant over the keys of the share;
+       workgroups_fp32  workgroups of an fp32 FA_KERNEL_AUTO forward that redid their rows in fp32 arithmetic (about 3x): operands outside
+                        what fp16 terms hold -- the events fa_last_forward_route() == 2 reports per forward.
+       Read them before and after a call (synchronise the stream in between) to see whether it ran into either. */
+    uint64_t tiles_redone, workgroups_fp32;
 } fa_stats;
 int fa_get_stats(fa_stats* out);
 

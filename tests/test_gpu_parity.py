@@ -987,6 +987,46 @@ def test_scratch_paths_under_graph_capture_through_the_workspace_entry():
             assert float((of - ref_x).abs().max()) < TOL_F32, (causal, iters)
 
 
+def test_the_kernels_count_their_own_cliffs():
+    """ABI 5: fa_get_stats() carries two counters the KERNELS bump on their rare slow paths (system-scope atomics into pinned host memory):
+    tiles whose optimistic attempt failed and were redone with the rescaled / textbook softmax, and workgroups of an fp32 AUTO forward
+    redone in fp32 arithmetic.  Ordinary data moves neither; an all-zero V redoes every tile (bf16 kernels at 16 x 4096: 16 tiles of 256 rows per slab;
+    fp32 tensors likewise), a V that is constant over the keys is all zeros after the fp32 default's
+    centring, and a slab outside the fp16 range sends exactly its own workgroups to fp32 arithmetic."""
+    bh, n, d = 16, 1024, 64
+    q, k, v = (torch.randn(bh, n, d, device=dev()) for _ in range(3))
+
+    def moved(fn):
+        torch.cuda.synchronize()
+        a = fa.stats()
+        fn()
+        torch.cuda.synchronize()
+        b = fa.stats()
+        return b["tiles_redone"] - a["tiles_redone"], b["workgroups_fp32"] - a["workgroups_fp32"]
+
+    fa.forward(q, k, v, False)                                                  # (the first forward outside a capture allocates the counters)
+    assert moved(lambda: fa.forward(q, k, v, False)) == (0, 0)
+    assert moved(lambda: fa.forward(q, k, v, True)) == (0, 0)
+    qb, kb, vb = (torch.randn(bh, 4096, d, device=dev(), dtype=torch.bfloat16) for _ in range(3))   # (rows long enough for the optimistic kernels:
+    assert moved(lambda: fa.forward(qb, kb, vb, False)) == (0, 0)                                     # the phase kernel of short rows has no redo)
+    assert moved(lambda: fa.forward(qb, kb, vb, True, out_dtype=torch.float32)) == (0, 0)
+    zb = torch.zeros_like(vb)
+    t_bf16, w = moved(lambda: fa.forward(qb, kb, zb, False))
+    assert t_bf16 > 0 and t_bf16 % bh == 0 and w == 0, (t_bf16, w)                 # every tile of every slab, whatever the tiling
+    t_pb2, w = moved(lambda: fa.forward(qb, kb, zb, False, out_dtype=torch.float32))
+    assert t_pb2 > 0 and t_pb2 % bh == 0 and w == 0
+    const_v = torch.full_like(v, 1.25)
+    t_f32, w = moved(lambda: fa.forward(q, k, const_v, False))
+    assert t_f32 > 0 and t_f32 % bh == 0 and w == 0
+    assert float((fa.forward(q, k, const_v, False) - 1.25).abs().max()) == 0.0
+    qh, kh = q.clone(), k.clone()
+    qh[3] *= 1.0 / RANGE_SHIFT
+    kh[3] *= RANGE_SHIFT
+    t, w = moved(lambda: fa.forward(qh, kh, v, False))
+    assert fa.last_forward_route() == 2
+    assert t == 0 and w > 0 and w <= n // 128, (t, w)                               # slab 3's workgroups only (128- or 256-row tiles)
+
+
 def test_workspace_sizes_and_validation_of_the_non_allocating_entry():
     """fa_workspace_bytes is what fa_forward_ws uses: a buffer one byte short, a misaligned one and one overlapping a tensor are refused;
     shapes that need no scratch take workspace = NULL -- and so does FA_KERNEL_AUTO on a shape whose plan would use one: a binder that

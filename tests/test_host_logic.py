@@ -167,6 +167,8 @@ def test_cabi_rejects_bad_arguments_without_touching_a_device():
     st = _cabi.FaStats()
     assert L.fa_get_stats(ctypes.byref(st)) == 0 and st.eager_slots_per_device == 8192 and st.chains_degraded == 0
     assert L.fa_get_stats(None) == 1
+    assert (st.tiles_redone, st.workgroups_fp32) == (0, 0)          # (ABI 5: counted by the kernels; nothing ran here)
+    assert ctypes.sizeof(_cabi.FaStats) == 12 * 8 and b"abi 5" in L.fa_version()
     assert L.fa_forward_packed_qkv(p, o, 1, 8, 96, 5, None) == 1      # C % NH != 0
     assert L.fa_forward_packed_qkv(p, o, 1, 8, 96, 2, None) == 2      # hs = 48 not instantiated
     ms = ctypes.c_float()
