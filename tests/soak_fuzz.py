@@ -94,6 +94,7 @@ def run(cases=400, seed=1, out="", only=-1, max_n=0, verbose=True):
     worst = {}
     routes = {}
     lines = []
+    stats0 = fa.stats()
 
     def note(key, err, tol, desc):
         if err / tol > (worst[key][0] / worst[key][1] if key in worst else -1.0):
@@ -244,6 +245,9 @@ def run(cases=400, seed=1, out="", only=-1, max_n=0, verbose=True):
     for key, (err, tol, desc) in worst.items():
         lines.append(f"  worst {key}: {err:.3e} of {tol:.1e} ({err / tol:.2f})   ({desc})")
     lines.append("  routes (tensor kind, fa_last_forward_route): " + ", ".join(f"{k[0]}/{k[1]}: {v}" for k, v in sorted(routes.items())))
+    stats1 = fa.stats()
+    lines.append(f"  slow paths counted by the kernels during the run (fa_get_stats): tiles_redone {stats1['tiles_redone'] - stats0['tiles_redone']}, "
+                 f"workgroups_fp32 {stats1['workgroups_fp32'] - stats0['workgroups_fp32']}")
     text = "\n".join(lines)
     if verbose:
         print(text)
