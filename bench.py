@@ -352,6 +352,7 @@ def main():
                 torch.cuda.synchronize()
 
     prewarm(step)
+    slow0 = fa.stats()   # (after the warm-up forwards: the kernels' slow-path counters exist from the first forward outside a capture)
     # The line's two clocks -- K back-to-back forwards from Python between barriers (ms_per_step -> `value`) and the C ABI's event-timed
     # loops on the launch stream (kernel_ms -> `roofline`) -- are taken in ALTERNATION inside one warm state, and when they disagree by more
     # than 2 % (a clock ramp, a noisy neighbour on the box: round 4's line read 4.2 % between them) the pair is measured again, in this
@@ -387,6 +388,11 @@ def main():
     extras = {"per_rank_ms": per_rank_ms} if world > 1 else {}
     if rank == 0:
         extras["timing_attempts"] = attempts
+        # what the kernels themselves counted while both clocks ran (fa_get_stats, ABI 5): a timed launch that took a slow path -- a tile
+        # redone behind a failed optimistic attempt, a workgroup redone in fp32 arithmetic -- would show here
+        torch.cuda.synchronize()
+        slow1 = fa.stats()
+        extras["slow_paths_during_timing"] = {key: slow1[key] - slow0[key] for key in ("tiles_redone", "workgroups_fp32")}
     if world > 1:   # what the collective layer saw, not what the environment said
         extras["ranks_seen"] = int(dist.get_world_size())
         extras["dist_backend"] = str(dist.get_backend())
