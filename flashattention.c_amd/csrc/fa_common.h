@@ -64,16 +64,16 @@ struct FwdParams {
                                 // [s * n_kv, min((s + 1) * n_kv, n_kv_total)) -- kv_head_stride carries the offset; 0 = all n keys
     int32_t alt_order;     // causal NB = 2 launches with two workgroups per CU: odd rounds of a CU's workgroups walk their slab light-to-heavy
     const unsigned long long* stats;   // [0] (serial << 32) | bits of max |k|,  [1] (serial << 32) | bits of max |q * scale * log2 e|_2^2
-    // Nullable: two process-wide 64-bit counters in pinned host memory (fa_slots.cpp: cliff_counters) that the kernels bump on their RARE slow
-    // paths -- [0] tiles redone with the rescaled / textbook mix behind a failed optimistic attempt, [1] workgroups of an fp32 FA_KERNEL_AUTO
+    // Nullable: two 64-bit counters in the device's memory (fa_slots.cpp: cliff_counters) that the kernels bump on their RARE slow paths --
+    // [0] tiles redone with the rescaled / textbook mix behind a failed optimistic attempt, [1] workgroups of an fp32 FA_KERNEL_AUTO
     // forward redone in fp32 arithmetic -- so that the performance cliffs of DESIGN.md section 5 show up in fa_get_stats().
     unsigned long long* cliffs;
 };
 
-// one system-scope atomic per slow-path event, from one lane of the workgroup (see FwdParams::cliffs)
+// one device-scope atomic per slow-path event, from one lane of the workgroup (see FwdParams::cliffs)
 __device__ __forceinline__ void count_cliff(const FwdParams& p, int which)
 {
-    if (p.cliffs != nullptr && threadIdx.x == 0) __hip_atomic_fetch_add(p.cliffs + which, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (p.cliffs != nullptr && threadIdx.x == 0) __hip_atomic_fetch_add(p.cliffs + which, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Early exit of a conditionally launched kernel (wave-uniform scalar load; see FwdParams::flag_mode).

@@ -88,9 +88,9 @@ extern thread_local int t_last_route;      // >= 0: the route of the last chain,
 
 int current_device();
 bool stream_is_capturing(hipStream_t stream);
-// The two cliff counters of FwdParams::cliffs (pinned, portable host memory, allocated by the first forward that is not being captured;
-// the kernels add to them with system-scope atomics) and what fa_get_stats() reads from them.
-unsigned long long* cliff_counters(bool capturing);
+// The two slow-path counters of FwdParams::cliffs (a pair of device words per GPU, bumped by the kernels with device-scope atomics) and
+// what fa_get_stats() reads from them (a blocking copy per device in use).
+unsigned long long* cliff_counters();
 unsigned long long cliff_count(int which);
 uint32_t next_serial();
 

@@ -150,7 +150,7 @@ int launch(const fa::FwdParams& p_in, int32_t d, int32_t causal, int32_t dtype, 
     g_stats.forwards.fetch_add(1, std::memory_order_relaxed);
     const bool capturing = stream_is_capturing(stream);
     fa::FwdParams p = p_in;
-    p.cliffs = cliff_counters(capturing);   // (nullptr until a forward outside a capture has allocated them: the kernels then do not count)
+    p.cliffs = cliff_counters();            // (the current device's pair of counter words)
     Plan pl = make_plan(p, d, causal, dtype, kernel, ws_mode ? true : !capturing);
     if (pl.status != FA_OK) return pl.status;
     char* scratch = static_cast<char*>(ws);

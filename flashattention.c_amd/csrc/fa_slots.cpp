@@ -60,40 +60,44 @@ int current_device()
     return dev;
 }
 
+// The two slow-path counters of FwdParams::cliffs: one pair of device words per GPU (a __device__ symbol: nothing to allocate, legal while
+// capturing), bumped by the kernels with DEVICE-scope atomics.  (The first form of round 5 kept them in pinned host memory behind
+// system-scope atomics: every redone tile then paid a serialised PCIe round trip, ~1 us each -- a forward of 1024 redone tiles took 1 ms
+// longer, ten times its own time at 128 x 1024: profiles/r05_exp/exp9_redo_cost.py.)
+__device__ unsigned long long g_cliff_words[2];
 namespace {
-std::atomic<unsigned long long*> g_cliffs_dev{nullptr};    // what the kernels are handed
-std::atomic<unsigned long long*> g_cliffs_host{nullptr};   // the same memory as the host reads it
-std::mutex g_cliffs_mu;
+std::atomic<unsigned long long*> g_cliff_base[kMaxDevices];
 }  // namespace
 
-unsigned long long* cliff_counters(bool capturing)
+unsigned long long* cliff_counters()
 {
-    unsigned long long* d = g_cliffs_dev.load(std::memory_order_acquire);
-    if (d != nullptr || capturing) return d;   // (hipHostMalloc is not a call to make while a stream of this thread is capturing)
-    std::lock_guard<std::mutex> g(g_cliffs_mu);
-    d = g_cliffs_dev.load(std::memory_order_acquire);
-    if (d != nullptr) return d;
-    void* h = nullptr;
-    void* dv = nullptr;
-    if (hipHostMalloc(&h, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || h == nullptr) {
-        (void)hipGetLastError();
-        return nullptr;
+    const int dev = current_device();
+    if (dev < 0) return nullptr;
+    unsigned long long* base = g_cliff_base[dev].load(std::memory_order_acquire);
+    if (base == nullptr) {
+        void* sym = nullptr;
+        if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_cliff_words)) != hipSuccess || sym == nullptr) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        base = static_cast<unsigned long long*>(sym);
+        g_cliff_base[dev].store(base, std::memory_order_release);
     }
-    memset(h, 0, 64);
-    if (hipHostGetDevicePointer(&dv, h, 0) != hipSuccess || dv == nullptr) {
-        (void)hipGetLastError();
-        (void)hipHostFree(h);
-        return nullptr;
-    }
-    g_cliffs_host.store(static_cast<unsigned long long*>(h), std::memory_order_release);
-    g_cliffs_dev.store(static_cast<unsigned long long*>(dv), std::memory_order_release);
-    return static_cast<unsigned long long*>(dv);
+    return base;
 }
 
+// sum over the devices this process has launched on; a blocking 16-byte copy per device (like fa_last_forward_route)
 unsigned long long cliff_count(int which)
 {
-    const unsigned long long* h = g_cliffs_host.load(std::memory_order_acquire);
-    return h == nullptr ? 0ull : __atomic_load_n(h + which, __ATOMIC_RELAXED);
+    unsigned long long total = 0;
+    for (int dev = 0; dev < kMaxDevices; ++dev) {
+        const unsigned long long* base = g_cliff_base[dev].load(std::memory_order_acquire);
+        if (base == nullptr) continue;
+        unsigned long long w = 0;
+        if (hipMemcpy(&w, base + which, sizeof(w), hipMemcpyDeviceToHost) == hipSuccess) total += w;
+        else (void)hipGetLastError();
+    }
+    return total;
 }
 
 bool stream_is_capturing(hipStream_t stream)

@@ -514,6 +514,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     // no longer does: rows that outgrow the optimistic window have l = +inf and O = inf / inf, and belong to the textbook redo on the same
     // pipes, not to the three times slower fallback; a NaN in V gives the NaN it must give on either path.)
     bool saw_nan = false;
+    bool hard_fail = false;   // fast pass: some row failed its verification for another reason than accumulators that are EXACTLY zero
     auto run_tile = [&](auto opt_c) -> bool {
         constexpr bool OPT = decltype(opt_c)::value;
         // MREG: -m_ref of a row lives in a 16-register tuple, the accumulator the first product of every tile starts from (the
@@ -1202,7 +1203,10 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                 // round 3 tested against a fixed 2^-100 there and redid every tile whose reference key held most of a row's mass);
                 // mag * lt = the sum of the unnormalised accumulators: tiny or zero means the products p v of the terms that matter
                 // were near (or below) fp32's subnormal range (|v| below ~2^-30): the textbook redo (p <= 1) takes those -- an all-zero V too
-                ok = ok && (lt > lt_floor) && (lt < kSplitLimit) && (mag < INFINITY) && !(mag * lt < kSplitTinyAcc);   // false for NaN as well
+                const bool in_range = (lt > lt_floor) && (lt < kSplitLimit) && (mag < INFINITY);   // false for NaN as well
+                const float acc = mag * lt;
+                ok = ok && in_range && !(acc < kSplitTinyAcc);
+                if constexpr (CENTER) hard_fail = hard_fail || !in_range || (acc != 0.0f && acc < kSplitTinyAcc);
                 if (GUARD) saw_nan = saw_nan || (lt != lt);   // (a NaN row SUM: NaN logits -- an overflowed window gives +inf, which the redo handles)
             }
         }
@@ -1216,7 +1220,26 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     if constexpr (GUARD) {   // every thread converted its share of every K tile: fold the shares into the workgroup's maximum
         if (p.flag_mode >= 3) atomicMax(&s_kmax, __float_as_uint(kmax));   // non-negative floats order like their bit patterns
     }
-    const bool redo = __syncthreads_or(!ok);
+    bool redo = __syncthreads_or(!ok);
+    if constexpr (CENTER && PIPE) {
+        // Accumulators that are exactly zero: either every centred value the rows saw is exactly zero -- a V that is constant over the share
+        // at a value fp16 holds (zeros, ones: padding heads, sanity checks), and then vbar + 0, already stored, IS the result -- or products
+        // that underflowed as a whole (|v - vbar| below ~2^-53), which need the redo.  The rare path can afford to look: one pass over the
+        // share's V (L2 hits, a tenth of a tile's time) instead of recomputing the tile -- until this, a constant V cost fp32 tensors twice
+        // the time (profiles/r05_redo_rate.txt).
+        if (redo && !__syncthreads_or(hard_fail)) {
+            const float* vf = (const float*)vg;
+            int any = 0;   // (bitwise, no short circuit: the loads of an unrolled group are in flight together)
+#pragma unroll 4
+            for (int i = tid; i < kv_end * (D / 4); i += NWAVES * kWave) {
+                const int row = i / (D / 4), c4 = (i % (D / 4)) * 4;
+                const f32x4 x = *(const f32x4*)(vf + (int64_t)row * p.kv_row_stride + c4);
+                const f32x4 r = *(const f32x4*)&s_vref[c4];
+                any |= (int)(x[0] != r[0]) | (int)(x[1] != r[1]) | (int)(x[2] != r[2]) | (int)(x[3] != r[3]);   // (a NaN differs from everything)
+            }
+            if (!__syncthreads_or(any)) redo = false;
+        }
+    }
     if constexpr (GUARD) {
         // |q'|_2 carries scale * log2(e); +-inf on either side fails the comparison, a NaN is caught through the first attempt's
         // results (saw_nan): either way the output is then produced in fp32 arithmetic --

@@ -246,8 +246,9 @@ typedef struct fa_stats {
     uint64_t slot_evictions;           /* eager slots that changed hands                                     */
     uint64_t capture_slots_recycled;   /* capture slots returned by destroyed graphs                         */
     uint64_t eager_slots_in_use, capture_slots_in_use, eager_slots_per_device, capture_slots_per_device;
-    /* ABI 5: the two performance cliffs of correct-but-slower paths, counted by the kernels themselves (system-scope atomics into pinned
-       host memory on the rare path only; 0 until a forward outside a graph capture has run, and forwards CAPTURED before that never count):
+    /* ABI 5: the two performance cliffs of correct-but-slower paths, counted by the kernels themselves (device-scope atomics into two words
+       of the GPU's memory, on the rare path only; fa_get_stats() sums them over the devices this process has launched on with one blocking
+       16-byte copy per device -- it synchronises with the device like fa_last_forward_route()):
        tiles_redone     workgroup tiles whose optimistic attempt failed its range check and were recomputed with the rescaled / textbook
                         softmax (about 2x the tile's time): exponent references outgrown by 2^100, an all-zero or tiny V, for fp32 tensors a V
                         that is constant over the keys of the share;

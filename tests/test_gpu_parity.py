@@ -992,7 +992,7 @@ def test_the_kernels_count_their_own_cliffs():
     tiles whose optimistic attempt failed and were redone with the rescaled / textbook softmax, and workgroups of an fp32 AUTO forward
     redone in fp32 arithmetic.  Ordinary data moves neither; an all-zero V redoes every tile (bf16 kernels at 16 x 4096: 16 tiles of 256 rows per slab;
     fp32 tensors likewise), a V that is constant over the keys is all zeros after the fp32 default's
-    centring, and a slab outside the fp16 range sends exactly its own workgroups to fp32 arithmetic."""
+    centring (kept without a redo when the workgroup finds every centred value exactly zero), and a slab outside the fp16 range sends exactly its own workgroups to fp32 arithmetic."""
     bh, n, d = 16, 1024, 64
     q, k, v = (torch.randn(bh, n, d, device=dev()) for _ in range(3))
 
@@ -1015,10 +1015,28 @@ def test_the_kernels_count_their_own_cliffs():
     assert t_bf16 > 0 and t_bf16 % bh == 0 and w == 0, (t_bf16, w)                 # every tile of every slab, whatever the tiling
     t_pb2, w = moved(lambda: fa.forward(qb, kb, zb, False, out_dtype=torch.float32))
     assert t_pb2 > 0 and t_pb2 % bh == 0 and w == 0
-    const_v = torch.full_like(v, 1.25)
-    t_f32, w = moved(lambda: fa.forward(q, k, const_v, False))
-    assert t_f32 > 0 and t_f32 % bh == 0 and w == 0
-    assert float((fa.forward(q, k, const_v, False) - 1.25).abs().max()) == 0.0
+    # fp32 tensors: the default centres V, so a V that is constant at a value fp16 holds is exactly zero inside the kernel -- zero
+    # accumulators, which the verification cannot tell from products that underflowed.  The workgroup LOOKS (one pass over its share of V)
+    # and keeps the stored result when every centred value is exactly zero: no redo for zeros, ones, 1.25 ...
+    for cval in (1.25, 0.0, 1.0):
+        const_v = torch.full_like(v, cval)
+        for causal in (False, True):
+            assert moved(lambda: fa.forward(q, k, const_v, causal)) == (0, 0), (cval, causal)
+            assert float((fa.forward(q, k, const_v, causal) - cval).abs().max()) == 0.0
+    assert moved(lambda: fa.forward(q, k, torch.full_like(v, 0.1), False)) == (0, 0)       # (0.1 - fp16(0.1) is an ordinary number)
+    assert float((fa.forward(q, k, torch.full_like(v, 0.1), False) - 0.1).abs().max()) < 1e-7
+    # ... while zero accumulators from UNDERFLOW take the redo and come back with their relative accuracy (|v| ~ 2^-60: the products with
+    # P ~ 2^-96 are below the subnormals), and so does a V that is constant except for one key (the rows above it, causal, see zeros only)
+    tiny = (v * 2.0 ** -60).contiguous()
+    t_f32, w = moved(lambda: fa.forward(q, k, tiny, False))
+    assert t_f32 > 0 and t_f32 % bh == 0 and w == 0, (t_f32, w)
+    ref_tiny = fa.forward(q, k, tiny, False, kernel="naive")
+    assert float(((fa.forward(q, k, tiny, False) - ref_tiny).abs() / 2.0 ** -60).max()) < TOL_F32
+    one_key = torch.full_like(v, 1.0)
+    one_key[:, 700] = 3.0
+    t_f32, w = moved(lambda: fa.forward(q, k, one_key, True))
+    assert t_f32 > 0 and w == 0                                                               # (the tiles that end above key 700 keep their result)
+    assert float((fa.forward(q, k, one_key, True) - fa.forward(q, k, one_key, True, kernel="naive")).abs().max()) < TOL_F32
     qh, kh = q.clone(), k.clone()
     qh[3] *= 1.0 / RANGE_SHIFT
     kh[3] *= RANGE_SHIFT
