@@ -367,7 +367,8 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     // v_j - vbar into its two bf16 terms, so the 16 bits cover the SPREAD of V and not an offset all values share -- V = 100 + N(0, 1) under a
     // peaked softmax read 1.6e-3 (the terms' 3 * 2^-17 * max|v|) where the reference's own fp32 recurrence reads 1.4e-4, V = 1000 + N(0, 1)
     // 1.6e-2 (profiles/r05_v_offset.txt) -- and vbar, the same median of three rows as for the keys, is added back to O in the epilogue.
-    // A V that is CONSTANT over the share is all zeros after centring: such a tile takes the redo of the all-zero-V case (twice the time).
+    // A V that is CONSTANT over the share is all zeros after centring: zero accumulators, which the workgroup tells from underflow by looking at
+    // its share of V (see the vote behind the first attempt).
     auto vref_at = [&](int col0) {
         f32x4 r = {0.0f, 0.0f, 0.0f, 0.0f};
         if constexpr (CENTER) {
