@@ -748,7 +748,7 @@ __device__ __forceinline__ bool xn_step(const char* v_lds, const char* k_nxt, in
 // One (NWAVES * 32 * NB)-row tile.  OPT: optimistic mix; returns false when some row of the workgroup left the safe range (its
 // results were stored and are overwritten by the redo).
 template <int D, int NB, int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL, bool OPT, int PF = 0>
-__device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
+__device__ __forceinline__ int xn_tile(const FwdParams& p, char* smem)   // 1 = done; 0 = redo; 2 = redo unless V is exactly zero (xn_kernel_body)
 {
     constexpr int KS = XShape<D, NB>::KS, DB = XShape<D, NB>::DB;
     constexpr float kBiasC = XSoft<OPT, PF>::kBias;
@@ -1066,6 +1066,7 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
     }
 
     bool bad = false;
+    bool hard = false;   // ... for another reason than accumulators that are EXACTLY zero
 
     unsigned long long prof_tail = 0;
     if constexpr ((ABL & 1024) != 0) prof_tail = stamp();
@@ -1079,6 +1080,7 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
         // which the row sums prove (a term > 2^100, +inf or NaN makes its row sum fail this test)
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk) bad = bad || !(st[blk].lacc[0] < kOptLimit);
+        hard = bad;
     }
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
@@ -1099,7 +1101,9 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
             for (int db = 0; db < DB; ++db)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) amax = fmaxf(fmaxf(amax, fabsf(o[blk][db][r])), fabsf(o[blk][db][r + 1]));
-            bad = bad || (amax < tiny_acc && qi < n && !idle);
+            const bool tiny = amax < tiny_acc && qi < n && !idle;
+            bad = bad || tiny;
+            hard = hard || (tiny && amax != 0.0f);
         }
         if (qi < n && idle) {   // empty causal key share: only its log-sum-exp (-inf) is stored; the combine never reads its O
             if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = -INFINITY;
@@ -1168,19 +1172,42 @@ __device__ __forceinline__ bool xn_tile(const FwdParams& p, char* smem)
     }
     if (OPT) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // stores and DMA of this attempt done before a redo starts
-        if (__syncthreads_or(bad ? 1 : 0)) return false;             // workgroup-wide: the redo shares tiles and barriers
+        if (__syncthreads_or(bad ? 1 : 0)) return __syncthreads_or(hard ? 1 : 0) ? 0 : 2;   // workgroup-wide: the redo shares tiles and barriers
     }
-    return true;
+    return 1;
 }
 
 // ---- kernels -----------------------------------------------------------------------------------------------------------
 // OPTIMISTIC: try the fixed-reference mix first, redo the tile with the rescaling mix if its verification fails.  ABL != 0: the
 // timing-only ablations of DESIGN.md section 4 (results are garbage; instantiated in the ablation library only).
+// Zero accumulators behind an optimistic attempt: an all-zero V (padding heads, masked-out slabs) or products that underflowed as a whole
+// (|v| below ~2^-50).  The rare path can afford to look: is every value of this workgroup's slab / key share exactly zero (+-0)?  Then the
+// zeros it has stored ARE the result and the rescaled redo (the whole tile again) is not needed.  One pass over the share's V: L2 hits.
+template <int D, int NB, int NWAVES>
+__device__ __forceinline__ bool xn_v_is_zero(const FwdParams& p)
+{
+    const int total = p.bh * p.q_tiles;
+    const int slab = xcd_remap(blockIdx.x, total) / p.q_tiles;
+    const int b = slab / p.heads, h = slab % p.heads;
+    const __bf16* vg = (const __bf16*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
+    const int nk = p.n_kv > 0 ? min(p.n_kv, p.n_kv_total - h * p.n_kv) : p.n;
+    unsigned any = 0u;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < nk * (D / 8); i += NWAVES * kWave) {
+        const int row = i / (D / 8), c8 = (i % (D / 8)) * 8;
+        const u32x4 x = *(const u32x4*)(vg + (int64_t)row * p.kv_row_stride + c8);
+        any |= (x[0] | x[1] | x[2] | x[3]) & 0x7fff7fffu;
+    }
+    return __syncthreads_or(any != 0u ? 1 : 0) == 0;
+}
+
 template <int D, int NB, int NWAVES, bool CAUSAL, bool OUT_F32, int G, int ABL, bool OPTIMISTIC, int PF = 0>
 __device__ __forceinline__ void xn_kernel_body(const FwdParams& p, char* smem)
 {
     if (OPTIMISTIC && ABL == 0) {
-        if (xn_tile<D, NB, NWAVES, CAUSAL, OUT_F32, G, 0, true, PF>(p, smem)) return;
+        const int r = xn_tile<D, NB, NWAVES, CAUSAL, OUT_F32, G, 0, true, PF>(p, smem);
+        if (r == 1) return;
+        if (r == 2 && xn_v_is_zero<D, NB, NWAVES>(p)) return;
         count_cliff(p, 0);
     }
     if (ABL != 0 && OPTIMISTIC) {

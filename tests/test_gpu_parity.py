@@ -1010,11 +1010,28 @@ def test_the_kernels_count_their_own_cliffs():
     qb, kb, vb = (torch.randn(bh, 4096, d, device=dev(), dtype=torch.bfloat16) for _ in range(3))   # (rows long enough for the optimistic kernels:
     assert moved(lambda: fa.forward(qb, kb, vb, False)) == (0, 0)                                     # the phase kernel of short rows has no redo)
     assert moved(lambda: fa.forward(qb, kb, vb, True, out_dtype=torch.float32)) == (0, 0)
+    # bf16 tensors, an all-zero V (padding heads): zero accumulators behind the optimistic attempt, which the one-wave-per-SIMD kernels tell from
+    # underflow by looking at their share of V -- the stored zeros stand, no redo (round 5; it cost twice the time before) ...
     zb = torch.zeros_like(vb)
-    t_bf16, w = moved(lambda: fa.forward(qb, kb, zb, False))
-    assert t_bf16 > 0 and t_bf16 % bh == 0 and w == 0, (t_bf16, w)                 # every tile of every slab, whatever the tiling
-    t_pb2, w = moved(lambda: fa.forward(qb, kb, zb, False, out_dtype=torch.float32))
-    assert t_pb2 > 0 and t_pb2 % bh == 0 and w == 0
+    for causal in (False, True):
+        for odt in (torch.bfloat16, torch.float32):
+            assert moved(lambda: fa.forward(qb, kb, zb, causal, out_dtype=odt)) == (0, 0), (causal, odt)
+            assert float(fa.forward(qb, kb, zb, causal, out_dtype=odt).float().abs().max()) == 0.0
+    assert moved(lambda: fa.forward(qb[:1], kb[:1], zb[:1], False)) == (0, 0)                    # (over key shares + combine)
+    assert float(fa.forward(qb[:1], kb[:1], zb[:1], False).float().abs().max()) == 0.0
+    # ... while values that UNDERFLOW against P ~ 2^-100 (|v| ~ 2^-60) and a V that is zero except for one key take the redo: every tile
+    # of every slab, whatever the tiling, and the results keep their relative accuracy
+    tb = (vb.float() * 2.0 ** -60).to(torch.bfloat16)
+    t_bf16, w = moved(lambda: fa.forward(qb, kb, tb, False))
+    assert t_bf16 > 0 and t_bf16 % bh == 0 and w == 0, (t_bf16, w)
+    ref_tb = fa.forward(qb.float(), kb.float(), tb.float(), False, kernel="naive")
+    assert float(((fa.forward(qb, kb, tb, False, out_dtype=torch.float32) - ref_tb).abs() / 2.0 ** -60).max()) < TOL_PB2
+    one = zb.clone()
+    one[:, 3000] = 2.0
+    t_one, w = moved(lambda: fa.forward(qb, kb, one, True))
+    assert t_one > 0 and w == 0                                                   # (causal tiles that end above key 3000 see zeros only)
+    assert float((fa.forward(qb, kb, one, True, out_dtype=torch.float32) - fa.forward(qb.float(), kb.float(), one.float(), True, kernel="naive")).abs().max()) < TOL_PB2
+    # (the two-wave pp3 kernel of short causal rows keeps the plain redo)
     # fp32 tensors: the default centres V, so a V that is constant at a value fp16 holds is exactly zero inside the kernel -- zero
     # accumulators, which the verification cannot tell from products that underflowed.  The workgroup LOOKS (one pass over its share of V)
     # and keeps the stored result when every centred value is exactly zero: no redo for zeros, ones, 1.25 ...
