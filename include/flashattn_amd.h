@@ -250,8 +250,8 @@ typedef struct fa_stats {
        of the GPU's memory, on the rare path only; fa_get_stats() sums them over the devices this process has launched on with one blocking
        16-byte copy per device -- it synchronises with the device like fa_last_forward_route()):
        tiles_redone     workgroup tiles whose optimistic attempt failed its range check and were recomputed with the rescaled / textbook
-                        softmax (about 2x the tile's time): exponent references outgrown by 2^100, values below ~2^-30 (bf16 tensors: an
-                        all-zero V too; fp32 tensors keep a V that is exactly constant over the share without a redo);
+                        softmax (about 2x the tile's time): exponent references outgrown by 2^100, values below ~2^-30 (an all-zero V --
+                        fp32 tensors: any V that is exactly constant over the share -- is recognised by a look at V and costs no redo);
        workgroups_fp32  workgroups of an fp32 FA_KERNEL_AUTO forward that redid their rows in fp32 arithmetic (about 3x): operands outside
                         what fp16 terms hold -- the events fa_last_forward_route() == 2 reports per forward.
        Read them before and after a call (synchronise the stream in between) to see whether it ran into either. */
