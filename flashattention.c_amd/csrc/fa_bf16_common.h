@@ -238,6 +238,28 @@ constexpr float kOptBias = 100.0f;   // (the one-wave-per-SIMD kernels add up to
 constexpr float kOptLimit = 0x1p100f;
 constexpr float kOptTinyAcc = 0x1p-116f;   // an accumulator row below this had its dominant products near (or below) fp32's subnormals
 
+// Zero accumulators behind an optimistic attempt: an all-zero V (padding heads, masked-out slabs) or products that underflowed as a whole
+// (|v| below ~2^-50).  The rare path can afford to look: is every value of this workgroup's slab / key share exactly zero (+-0)?  Then the
+// zeros it has stored ARE the result and the rescaled redo (the whole tile again) is not needed.  One pass over the share's V: L2 hits.
+template <int D, int NWAVES>
+__device__ __forceinline__ bool bf16_v_is_zero(const FwdParams& p)
+{
+    const int total = p.bh * p.q_tiles;
+    const int slab = xcd_remap(blockIdx.x, total) / p.q_tiles;
+    const int b = slab / p.heads, h = slab % p.heads;
+    const __bf16* vg = (const __bf16*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
+    const int nk = p.n_kv > 0 ? min(p.n_kv, p.n_kv_total - h * p.n_kv) : p.n;
+    unsigned any = 0u;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < nk * (D / 8); i += NWAVES * kWave) {
+        const int row = i / (D / 8), c8 = (i % (D / 8)) * 8;
+        const u32x4 x = *(const u32x4*)(vg + (int64_t)row * p.kv_row_stride + c8);
+        any |= (x[0] | x[1] | x[2] | x[3]) & 0x7fff7fffu;
+    }
+    return __syncthreads_or(any != 0u ? 1 : 0) == 0;
+}
+
+
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 template <int PF = 0>

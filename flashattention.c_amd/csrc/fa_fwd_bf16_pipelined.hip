@@ -190,7 +190,7 @@ __device__ __forceinline__ void pp3_step(const char* v_lds, const char* k_lds2, 
 // One tile of NWAVES * 64 query rows.  OPT: optimistic mix (fa_bf16_common.h); returns false, with nothing stored, when some
 // row of the workgroup left its safe range.
 template <int D, int NWAVES, bool CAUSAL, bool OUT_F32, bool PROF, int G, bool OPT>
-__device__ __forceinline__ bool pp3_tile(const FwdParams& p, char* smem)
+__device__ __forceinline__ int pp3_tile(const FwdParams& p, char* smem)   // 1 = done; 0 = redo; 2 = redo unless V is exactly zero (kernel body)
 {
     using C = Bf16Cfg<D, NWAVES>;
     constexpr float kBias = OPT ? kOptBias : kLazyThr;
@@ -389,13 +389,27 @@ __device__ __forceinline__ bool pp3_tile(const FwdParams& p, char* smem)
     // and nothing of the first attempt is live across the vote.
     mfma_drain();  // the loop exit is a branch: the last P.V / row-sum MFMAs may still be in flight
     // the tile stands iff no term left the safe range, which the row sums prove (fa_bf16_common.h)
-    const bool bad = OPT && (!(sta.lacc[0] < kOptLimit) || !(stb.lacc[0] < kOptLimit));
+    bool bad = OPT && (!(sta.lacc[0] < kOptLimit) || !(stb.lacc[0] < kOptLimit));
+    bool hard = bad;   // ... for another reason than accumulators that are EXACTLY zero
     auto store_block = [&](const f32x16 (&o)[DB], const BlockState& st, int q0) {
         if constexpr (OPT) asm volatile("; store, optimistic mix");  // distinct text per mix: keeps hipcc from tail-merging the
         else asm volatile("; store, rescaled mix");                   // store code of the two inlined tiles (copies + scratch)
         const float lt = st.lacc[0];
         const float inv = 1.0f / lt;
         const int qi = q0 + lq;
+        if constexpr (OPT) {
+            // the tiny-accumulator vote of the one-wave-per-SIMD kernels (xn_tile), which this kernel lacked until the end of round 5: P sits
+            // near 2^-100, so the products of the terms that matter go subnormal when |v| is below ~2^-26 and vanish below ~2^-50 -- such rows
+            // came out with a meaningless relative error (profiles/r05_exp/exp10_tiny_v_by_kernel.py).  All tiny or zero: the rescaled redo.
+            float amax = 0.0f;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) amax = fmaxf(fmaxf(amax, fabsf(o[db][r])), fabsf(o[db][r + 1]));
+            const bool tiny = amax < kOptTinyAcc && qi < n;
+            bad = bad || tiny;
+            hard = hard || (tiny && amax != 0.0f);
+        }
         if (qi < n) {
             if constexpr (OPT) asm volatile("; rows, optimistic mix");
             else asm volatile("; rows, rescaled mix");
@@ -438,7 +452,7 @@ __device__ __forceinline__ bool pp3_tile(const FwdParams& p, char* smem)
     store_block(ob, stb, q0b);
     if (OPT) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // stores and DMA of this attempt done before a redo starts
-        if (__syncthreads_or(bad ? 1 : 0)) return false;             // workgroup-wide: the redo shares tiles and barriers
+        if (__syncthreads_or(bad ? 1 : 0)) return __syncthreads_or(hard ? 1 : 0) ? 0 : 2;   // workgroup-wide: the redo shares tiles and barriers
     }
     if (PROF && lane == 0 && p.lse != nullptr) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -450,7 +464,7 @@ __device__ __forceinline__ bool pp3_tile(const FwdParams& p, char* smem)
         dst[10] = (float)(((xcc & 0xf) << 16) | (((hwid >> 13) & 7) << 8) | (((hwid >> 8) & 0xf) << 4) | ((hwid >> 4) & 3));
         dst[11] = (float)(t_entry & 0xffffff);
     }
-    return true;
+    return 1;
 }
 
 // OPTIMISTIC: try the fixed-reference mix first, redo the tile with the lazily rescaled mix if its verification fails
@@ -460,7 +474,9 @@ __global__ __launch_bounds__(NWAVES* kWave, 2) void fa_fwd_bf16_pp3_kernel(FwdPa
     using C = Bf16Cfg<D, NWAVES>;
     __shared__ __attribute__((aligned(1024))) char smem[4 * G * C::kTileBytes];
     if (OPTIMISTIC && !PROF) {
-        if (pp3_tile<D, NWAVES, CAUSAL, OUT_F32, false, G, true>(p, smem)) return;
+        const int r = pp3_tile<D, NWAVES, CAUSAL, OUT_F32, false, G, true>(p, smem);
+        if (r == 1) return;
+        if (r == 2 && bf16_v_is_zero<D, NWAVES>(p)) return;   // an all-zero V: the stored zeros are the result
         count_cliff(p, 0);
     }
     (void)pp3_tile<D, NWAVES, CAUSAL, OUT_F32, PROF, G, false>(p, smem);

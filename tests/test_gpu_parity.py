@@ -987,6 +987,27 @@ def test_scratch_paths_under_graph_capture_through_the_workspace_entry():
             assert float((of - ref_x).abs().max()) < TOL_F32, (causal, iters)
 
 
+@pytest.mark.parametrize("bh,n,causal", [(128, 1024, False), (48, 4096, False), (128, 2048, True), (512, 256, False)])
+def test_tiny_values_keep_their_relative_accuracy_in_the_two_wave_kernel(bh, n, causal):
+    """fa_fwd_bf16_pp3_kernel (short rows, partly filled rounds) had no tiny-accumulator vote until the end of round 5: with P near 2^-100 the
+    products of |v| ~ 2^-60 vanish, and a third of the outputs came back exactly zero (relative error 4.7; absolute 1e-17).  Now such a
+    tile takes the rescaled redo like in the one-wave-per-SIMD kernels, and an all-zero V is recognised by a look at V."""
+    L = _cabi.lib()
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, int(causal), bh, n) == b"fa_fwd_bf16_pp3_kernel"
+    q, k, v = (torch.randn(bh, n, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
+    for e in (0, -40, -60, -90):
+        vv = (v.float() * 2.0 ** e).to(torch.bfloat16)
+        ref = fa.forward(q.float(), k.float(), vv.float(), causal, kernel="naive")
+        err = float((fa.forward(q, k, vv, causal).float() - ref).abs().max()) / 2.0 ** e
+        OBSERVED.append((f"pp3, V x 2^{e}, bh={bh} n={n} causal={causal}: relative to 2^{e}", err, bf16_tol(1.0, False, causal, n)))
+        assert err < bf16_tol(1.0, False, causal, n), (e, err)
+    torch.cuda.synchronize()
+    before = fa.stats()["tiles_redone"]
+    assert float(fa.forward(q, k, torch.zeros_like(v), causal).float().abs().max()) == 0.0
+    torch.cuda.synchronize()
+    assert fa.stats()["tiles_redone"] == before
+
+
 def test_the_kernels_count_their_own_cliffs():
     """ABI 5: fa_get_stats() carries two counters the KERNELS bump on their rare slow paths (system-scope atomics into pinned host memory):
     tiles whose optimistic attempt failed and were redone with the rescaled / textbook softmax, and workgroups of an fp32 AUTO forward
@@ -1031,7 +1052,6 @@ def test_the_kernels_count_their_own_cliffs():
     t_one, w = moved(lambda: fa.forward(qb, kb, one, True))
     assert t_one > 0 and w == 0                                                   # (causal tiles that end above key 3000 see zeros only)
     assert float((fa.forward(qb, kb, one, True, out_dtype=torch.float32) - fa.forward(qb.float(), kb.float(), one.float(), True, kernel="naive")).abs().max()) < TOL_PB2
-    # (the two-wave pp3 kernel of short causal rows keeps the plain redo)
     # fp32 tensors: the default centres V, so a V that is constant at a value fp16 holds is exactly zero inside the kernel -- zero
     # accumulators, which the verification cannot tell from products that underflowed.  The workgroup LOOKS (one pass over its share of V)
     # and keeps the stored result when every centred value is exactly zero: no redo for zeros, ones, 1.25 ...
