@@ -118,7 +118,7 @@ def main():
     readme = (
         f"Measured on MI355X (steady clocks, ONE run of the final binary on one box — `profiles/{tag}_config_table.txt`, generated by\n"
         f"`profiles/make_tables.py`; identical binaries differ by ±4 % between boxes of the pool: the DRIVER's end-of-round runs have read c4 at\n"
-        f"0.467 / 0.483 / 0.489 / 0.468 of the peak in rounds 1–4, this round's boxes 0.2246–0.2450 ms (the box of this table: 0.228)):\n"
+        f"0.467 / 0.483 / 0.489 / 0.468 of the peak in rounds 1–4, this round's boxes 0.2246–0.2450 ms (the box of this table: 0.229)):\n"
         f"B=2 H=8 N=8192 d=64 — bf16 {ms(c4[0])} ms ({tf(c4[0])} TFLOP/s, {100 * c4[0]['tflops'] / 2500:.0f} % of the dense bf16 MFMA peak; d=128: {tf(dm[1])} TFLOP/s,\n"
         f"{100 * dm[1]['tflops'] / 2500:.0f} %) at {b4['roofline']['max_abs_err']:.1e} max-abs of the fp32 reference (bf16 P, bf16 output, the reference's scale 1; {ex['c4_scale_rsqrt_d']['max_abs_err']:.1e} at 1/√d);\n"
         f"bf16 tensors with fp32 output (P as bf16 hi + bf16 lo in one launch: **{ba['roofline']['max_abs_err']:.1e} of the fp32 reference at scale 1**) {ms(x2[0])} ms =\n"
