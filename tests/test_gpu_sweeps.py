@@ -1,0 +1,88 @@
+"""GPU (-m gpu): exhaustive-by-construction sweeps through the dispatch of FA_KERNEL_AUTO -- bounded slices of the sweeps of
+profiles/r05_exp/ (exp11, exp13, exp14) so that the suite the driver runs walks EVERY sequence length of the short range, every head dim,
+the packed llm.c layout at every T, and tiny values through every kernel family, not only the shapes somebody thought of.  The reference
+runs any (BH, N) through one grid (flashattention.cu:592,599); here the grid, the tiling and the kernel family change with the shape
+(docs/results.md), so the walk is the test.  All comparisons against rung 0 (fp32 arithmetic on the device, itself pinned to the fp64 oracle
+in tests/test_gpu_parity.py); outputs are NaN-poisoned first, so an unwritten row shows."""
+import pytest
+import torch
+
+import flashattention_c_amd as fa
+from flashattention_c_amd import _cabi
+
+pytestmark = pytest.mark.gpu
+TOL_F32 = 3e-4        # fp32 default on N(0, 1) data: observed <= 1.1e-4 (profiles/r05_every_length.txt)
+TOL_PB2 = 2e-4        # bf16 tensors, fp32 out (two-term P): observed <= 3.3e-5
+TOL_BF16 = 2.5e-2     # bf16 P, bf16 out: the regression threshold of seeded N(0, 1) data (observed <= 1.8e-2)
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("d", [32, 64, 128])
+def test_every_sequence_length_of_the_short_range(d):
+    """n = 1 .. 320 (every value), then the neighbourhoods of the tile heights up to 640 and of 4096 / 8192 on an idle grid (key shares), causal
+    and not, the three tensor -> output paths: O and LSE against rung 0.  3 x 2 x ~380 launches per head dim, a few seconds."""
+    g = torch.Generator(device="cpu").manual_seed(1000 + d)
+    lengths = [(3, n) for n in range(1, 321)] + [(3, n) for n in (383, 384, 385, 447, 448, 449, 511, 512, 513, 575, 576, 577, 639, 640)]
+    lengths += [(1, n) for n in (4095, 4096, 4097, 8191, 8192, 8193)] + [(130, n) for n in (255, 256, 257)]
+    bad = []
+    for bh, n in lengths:
+        q, k, v = (torch.randn(bh, n, d, generator=g).to(dev()) for _ in range(3))
+        qb, kb, vb = (t.to(torch.bfloat16) for t in (q, k, v))
+        for causal in (False, True):
+            ref, lref = fa.forward(q, k, v, causal, kernel="naive", return_lse=True)
+            refb, lrefb = fa.forward(qb.float(), kb.float(), vb.float(), causal, kernel="naive", return_lse=True)
+            for name, args, r, lr, odt, tol, tol_l in (("fp32", (q, k, v), ref, lref, torch.float32, TOL_F32, TOL_F32),
+                                                      ("bf16->fp32", (qb, kb, vb), refb, lrefb, torch.float32, TOL_PB2, TOL_PB2),
+                                                      ("bf16", (qb, kb, vb), refb, lrefb, torch.bfloat16, TOL_BF16, 2e-2)):
+                out = torch.full((bh, n, d), float("nan"), device=dev(), dtype=odt)
+                _, lse = fa.forward(*args, causal, out=out, return_lse=True)
+                eo, el = float((out.float() - r).abs().max()), float((lse - lr).abs().max())
+                if not (eo < tol and el < tol_l):
+                    bad.append((name, causal, bh, n, eo, el))
+    assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("hs", [32, 64, 128])
+def test_packed_qkv_at_every_length(hs):
+    """The llm.c entry (attention_forward.cu:1106-1179: packed (B, T, 3C) fp32, causal, 1/sqrt(hs)) at every T in 1 .. 200 and around the tile
+    heights, NH in {1, 3, 12}, against rung 0 on the unpacked tensors, at the reference's own 1e-4 (observed <= 3.5e-5)."""
+    g = torch.Generator(device="cpu").manual_seed(2000 + hs)
+    bad = []
+    for nh in (1, 3, 12):
+        for T in list(range(1, 201)) + [255, 256, 257, 511, 512, 513, 1024, 1025, 2048]:
+            B = 2 if T <= 1025 else 1
+            inp = torch.randn(B, T, 3 * nh * hs, generator=g).to(dev())
+            got = fa.forward_packed_qkv(inp, nh)
+            qq, kk, vv = (inp[:, :, i * nh * hs:(i + 1) * nh * hs].reshape(B, T, nh, hs).permute(0, 2, 1, 3).reshape(B * nh, T, hs).contiguous() for i in range(3))
+            want = fa.forward(qq, kk, vv, True, scale=hs ** -0.5, kernel="naive").reshape(B, nh, T, hs).permute(0, 2, 1, 3).reshape(B, T, nh * hs)
+            e = float((got - want).abs().max())
+            if not e < 1e-4:
+                bad.append((nh, T, e))
+    assert not bad, bad[:10]
+
+
+SHAPES = [(1024, 128, 64), (512, 256, 64), (128, 1024, 64), (16, 8192, 64), (1, 8192, 64), (16, 1024, 64), (128, 1024, 128), (16, 4096, 128), (128, 1024, 32),
+          (40, 700, 128), (256, 100, 64)]
+
+
+@pytest.mark.parametrize("bh,n,d", SHAPES)
+def test_tiny_values_through_every_kernel_family(bh, n, d):
+    """V = N(0, 1) x 2^e for e down to -60 through whatever family the dispatch picks for the shape (phase, pp3, x2, x4, w4, the fp32 default's
+    tilings, key shares): the error RELATIVE to 2^e must be what it is at e = 0 -- products against P ~ 2^-100 underflow, and every family
+    has to notice (round 5 found the two-wave kernel did not: profiles/r05_exp/exp10_tiny_v_by_kernel.py)."""
+    L = _cabi.lib()
+    for dt, dtid in ((torch.float32, _cabi.FA_DTYPE_F32), (torch.bfloat16, _cabi.FA_DTYPE_BF16)):
+        for causal in (False, True):
+            q, k, v = (torch.randn(bh, n, d, device=dev(), dtype=dt) for _ in range(3))
+            name = L.fa_kernel_name_for(dtid, d, int(causal), bh, n).decode()
+            for e in (0, -45, -60):
+                vv = (v.float() * 2.0 ** e).to(dt)
+                ref = fa.forward(q.float(), k.float(), vv.float(), causal, kernel="naive")
+                err = float((fa.forward(q, k, vv, causal).float() - ref).abs().max()) / 2.0 ** e
+                assert err < (TOL_F32 if dt == torch.float32 else TOL_BF16), (name, causal, e, err)
+                if dt == torch.bfloat16:
+                    err2 = float((fa.forward(q, k, vv, causal, out_dtype=torch.float32) - ref).abs().max()) / 2.0 ** e
+                    assert err2 < TOL_PB2, (name, causal, e, err2)
