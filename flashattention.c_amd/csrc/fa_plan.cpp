@@ -123,6 +123,12 @@ int keysplit_factor(const fa::FwdParams& p, int32_t d, int32_t causal, bool f32,
     }
     if (!dense_layout(p, d) || p.n < 4096) return 1;
     if (((int64_t)(p.n - 1) * p.kv_row_stride + d) * 2 >= (int64_t)0xffffffffLL) return 1;   // the NB = 2 kernels' 32-bit slab offsets
+#if FA_ABLATION
+    {   // experiment switch (ablation library): FA_EXP_FORCE_S = S forces S key shares on causal launches of any grid size
+        static const int force = [] { const char* e = getenv("FA_EXP_FORCE_S"); return e ? atoi(e) : 0; }();
+        if (force > 1 && causal) return force;
+    }
+#endif
     const int64_t tiles = (int64_t)p.bh * ((p.n + 255) / 256);
     // bf16 tensors: causal launches of up to a full round of 256-row tiles are split (a causal launch lasts as long as its heaviest tile).
     // fp32 tensors (split kernel): its 128-row tiling, two workgroups per CU in the paired order, balances a causal round by itself --

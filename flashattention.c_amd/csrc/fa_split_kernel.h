@@ -60,6 +60,11 @@
 #ifndef FA_SPLIT_CENTER
 #define FA_SPLIT_CENTER 1  // 0: experiment switch -- keys are split as they come (rounds 1-4) instead of relative to a reference key
 #endif
+#ifndef FA_SPLIT_NOCVT
+#define FA_SPLIT_NOCVT 0   // 1: timing-only ablation (ablation library, VERDICT r05 #2: the kill test of a one-time K / V split pre-pass) -- the conversion of
+                           // a K / V piece costs 1 VALU per element instead of 3.5: hi = the rounded value, lo = hi with its exponent cleared (finite, tiny), no
+                           // centring, no guard maximum.  Results are those of one-term operands (~1e-3), the verification still passes.
+#endif
 #ifndef FA_SPLIT_QK16
 #define FA_SPLIT_QK16 1  // 0: experiment switch -- K and Q' of fp32 tensors as two BF16 terms (16 bits: rounds 1-4) instead of two FP16 terms
 #endif
@@ -170,6 +175,15 @@ __device__ __forceinline__ unsigned pack_f16(float a, float b)
 template <bool F16, bool ASM>
 __device__ __forceinline__ void split2x(float a, float b, bf16x2& hi, bf16x2& lo)
 {
+    if constexpr (FA_SPLIT_NOCVT != 0) {
+        const f32x2_t ab = {a, b};
+        unsigned h;
+        if constexpr (F16) h = __builtin_bit_cast(unsigned, __builtin_convertvector(ab, f16x2_t));
+        else h = __builtin_bit_cast(unsigned, __builtin_convertvector(ab, bf16x2));
+        hi = __builtin_bit_cast(bf16x2, h);
+        lo = __builtin_bit_cast(bf16x2, h & (F16 ? 0x83ff83ffu : 0x807f807fu));
+        return;
+    }
     if constexpr (F16) split2h(a, b, hi, lo);
     else if constexpr (ASM) split2(a, b, hi, lo);
     else split2c(a, b, hi, lo);
@@ -272,7 +286,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 31, hi = lane >> 5;
-    constexpr bool GUARD = !IN_BF16;   // tracked for every fp32 launch (4 VALU per K piece); acted upon under flag_mode 4 (FA_KERNEL_AUTO: the
+    constexpr bool GUARD = !IN_BF16 && !FA_SPLIT_NOCVT;   // tracked for every fp32 launch (4 VALU per K piece); acted upon under flag_mode 4 (FA_KERNEL_AUTO: the
                                        // workgroup redoes its rows in fp32 arithmetic on the spot) and 3 (ablation chains: raise the word)
     float kmax = 0.0f;
     if (GUARD && tid == 0) s_kmax = 0u;   // ordered before the first atomic by the barriers of the main loop
@@ -343,7 +357,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     // second largest of three actual values (centred magnitudes are at most twice the uncentred ones), and it costs three row loads and
     // one v_med3_f32 per column per workgroup + one v_sub_f32 per converted key element.  Coherent family at d = 128, causal: 3.5e-3 ->
     // below 1e-4 (profiles/r05_family_centered.txt); the reference's own fp32 FMA chain reads 5.7e-3 there.
-    constexpr bool CENTER = !IN_BF16 && FA_SPLIT_CENTER;
+    constexpr bool CENTER = !IN_BF16 && FA_SPLIT_CENTER && !FA_SPLIT_NOCVT;
     const int kref_r1 = nk >> 1, kref_r2 = nk - 1;   // (local key indices of the share)
     auto kref_at = [&](int col0) {                    // median-of-three reference for columns col0 .. col0 + 3
         f32x4 r = {0.0f, 0.0f, 0.0f, 0.0f};
