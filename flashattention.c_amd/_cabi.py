@@ -9,20 +9,18 @@ LIB_PATH = os.path.join(PKG_DIR, "libflashattn_amd.so")
 
 FA_OK = 0
 FA_DTYPE_F32, FA_DTYPE_BF16, FA_DTYPE_BF16_OUT_F32 = 0, 1, 2
-FA_KERNEL_AUTO, FA_KERNEL_NAIVE, FA_KERNEL_MFMA, FA_KERNEL_SPLIT, FA_KERNEL_P16, FA_KERNEL_P16X2, FA_KERNEL_PB2 = 0, 1, 2, 3, 4, 5, 6
+FA_KERNEL_AUTO, FA_KERNEL_NAIVE, FA_KERNEL_MFMA, FA_KERNEL_SPLIT, FA_KERNEL_PB2 = 0, 1, 2, 3, 6   # (4, 5: retired fp16-P kernels)
 
 # every symbol include/flashattn_amd.h declares
 EXPORTED_SYMBOLS = (
     "fa_forward", "fa_forward_ex", "fa_workspace_bytes", "fa_forward_ws", "fa_forward_sharded", "fa_forward_sharded_ex", "fa_forward_packed_qkv", "fa_time_forward", "fa_time_forward_graph",
-    "fa_last_forward_route", "fa_get_stats", "fa_last_error", "fa_device_count", "fa_version", "fa_kernel_name", "fa_kernel_name_for",
+    "fa_last_forward_route", "fa_get_stats", "fa_read_device_counters", "fa_last_error", "fa_device_count", "fa_version", "fa_kernel_name", "fa_kernel_name_for",
 )
 
 
 class FaStats(ctypes.Structure):
-    """struct fa_stats of include/flashattn_amd.h"""
-    _fields_ = [(n, ctypes.c_uint64) for n in ("forwards", "chains", "chains_degraded", "scratch_replans", "slot_evictions", "capture_slots_recycled",
-                                               "eager_slots_in_use", "capture_slots_in_use", "eager_slots_per_device", "capture_slots_per_device",
-                                               "tiles_redone", "workgroups_fp32")]
+    """struct fa_stats of include/flashattn_amd.h (ABI 6: carries its own size, fields are only ever appended)"""
+    _fields_ = [(n, ctypes.c_uint64) for n in ("struct_bytes", "forwards", "scratch_replans")]
 
 
 class ExtensionMissing(RuntimeError):
@@ -65,8 +63,10 @@ def lib() -> ctypes.CDLL:
     L.fa_time_forward_graph.restype = ctypes.c_int
     L.fa_last_forward_route.argtypes = [vp, ctypes.POINTER(i32)]
     L.fa_last_forward_route.restype = ctypes.c_int
-    L.fa_get_stats.argtypes = [ctypes.POINTER(FaStats)]
+    L.fa_get_stats.argtypes = [ctypes.POINTER(FaStats), ctypes.c_size_t]
     L.fa_get_stats.restype = ctypes.c_int
+    L.fa_read_device_counters.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    L.fa_read_device_counters.restype = ctypes.c_int
     L.fa_last_error.argtypes = []
     L.fa_last_error.restype = ctypes.c_char_p
     L.fa_device_count.argtypes = []

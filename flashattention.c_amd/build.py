@@ -11,9 +11,9 @@ hipcc cross-compiles for gfx950 without a GPU present.
 ``--ablation`` additionally builds ``libflashattn_amd_ablation.so`` (+ ``fa_driver_ablation``): the same sources compiled with
 ``-DFA_ABLATION=1`` plus the timing-only ablation instantiations quoted in DESIGN.md section 4 (results are garbage by design).
 They are NOT part of the product library: its ``fa_forward_ex`` rejects their variant numbers.
-``--sanitize`` builds ``libflashattn_amd_asan.so``: the host translation units (``fa_plan / fa_slots / fa_launch / fa_shard / fa_timing / fa_api .cpp`` + ``fa_selftest.cpp``) recompiled with ``-fsanitize=address,undefined``
+``--sanitize`` builds ``libflashattn_amd_asan.so``: the host translation units (``fa_plan / fa_counters / fa_launch / fa_shard / fa_timing / fa_api .cpp`` + ``fa_selftest.cpp``) recompiled with ``-fsanitize=address,undefined``
 (device code and every other object unchanged) and ``-DFA_HOST_TEST=1``, which adds ``fa_host_selftest()`` -- plans over a shape grid,
-key-split arithmetic and the verdict-slot table from several threads, none of which needs a device.  ``sanitize_selfcheck()`` runs it (and
+key-split arithmetic and the head-dim routing, none of which needs a device.  ``sanitize_selfcheck()`` runs it (and
 the no-device validation paths through ctypes) in a child process with the ASan runtime preloaded; ``__graft_entry__.build()`` calls it.
 ``--torch-binding`` builds ``flash_torch_binding*.so``, the compiled pybind translation unit of INTEGRATION.md section 1
 (``torch::Tensor forward(Q, K, V, bool causal)``, /root/reference/src/main.cpp:3-6) against the installed torch-ROCm.
@@ -37,14 +37,14 @@ DRIVER_PATH = os.path.join(PKG_DIR, "fa_driver")
 ARCH = "gfx950"
 
 # the host side behind include/flashattn_amd.h (csrc/fa_host.h lists what each holds)
-HOST_SOURCES = ["fa_plan.cpp", "fa_slots.cpp", "fa_launch.cpp", "fa_shard.cpp", "fa_timing.cpp", "fa_api.cpp"]
+HOST_SOURCES = ["fa_plan.cpp", "fa_counters.cpp", "fa_launch.cpp", "fa_shard.cpp", "fa_timing.cpp", "fa_api.cpp"]
 # longest translation units first: the thread pool starts them in this order
 LIB_SOURCES = ["fa_fwd_bf16_x4_pb2_f32out.hip", "fa_fwd_bf16_x4_pb2_bf16out.hip", "fa_fwd_bf16_x2.hip", "fa_fwd_bf16_x4.hip",
                "fa_fwd_bf16_x2_pb2_d128_f32out.hip", "fa_fwd_bf16_x2_pb2_d128_bf16out.hip", "fa_fwd_bf16_x2_pb2_d64_f32out.hip", "fa_fwd_bf16_x2_pb2_d64_bf16out.hip",
                "fa_fwd_bf16_pipelined.hip", "fa_split_f32_d64.hip", "fa_split_f32_d128.hip", "fa_split_f32_d32.hip",
                "fa_split_bf16_d64.hip", "fa_split_bf16_d128.hip", "fa_split_bf16_d32.hip", "fa_fwd_bf16.hip", "fa_combine.hip",
                "fa_fwd_bf16_x2_pb2_d32_f32out.hip", "fa_fwd_bf16_x2_pb2_d32_bf16out.hip",
-               "fa_fwd_f32.hip", "fa_fwd_f32_split.hip", "fa_fwd_bf16_split.hip", "fa_naive.hip", *HOST_SOURCES]
+               "fa_fwd_f32_wide.hip", "fa_fwd_f32.hip", "fa_fwd_f32_split.hip", "fa_fwd_bf16_split.hip", "fa_naive.hip", *HOST_SOURCES]
 # csrc/experiments/: only in libflashattn_amd_ablation.so -- timing-only instantiations (garbage results), superseded kernel generations
 # and the fp16-P families the round-4 accurate path (P as two bf16 terms) replaced (correct, tested through fa_driver_ablation)
 ABLATION_SOURCES = ["experiments/" + f for f in (
@@ -52,7 +52,7 @@ ABLATION_SOURCES = ["experiments/" + f for f in (
     "fa_fwd_bf16_x2_p16_d128.hip", "fa_fwd_bf16_x2_p16_d64.hip", "fa_fwd_bf16_x2_p16_d32.hip", "fa_fwd_bf16_x2_p16x2_d128.hip",
     "fa_fwd_bf16_x2_p16x2_d64.hip", "fa_fwd_bf16_x2_p16x2_d32.hip")]
 # product sources whose text depends on FA_ABLATION (the variant dispatch): recompiled for the ablation library, the rest is shared
-ABLATION_DEPENDENT = ["fa_fwd_bf16.hip", "fa_fwd_bf16_x4.hip", "fa_fwd_bf16_pipelined.hip", "fa_fwd_bf16_x2.hip", "fa_plan.cpp", "fa_slots.cpp", "fa_launch.cpp", "fa_api.cpp",
+ABLATION_DEPENDENT = ["fa_fwd_bf16.hip", "fa_fwd_bf16_x4.hip", "fa_fwd_bf16_pipelined.hip", "fa_fwd_bf16_x2.hip", "fa_plan.cpp", "fa_counters.cpp", "fa_launch.cpp", "fa_api.cpp",
                       "fa_split_f32_d32.hip", "fa_split_f32_d64.hip"]
 ABL_LIB_PATH = os.path.join(PKG_DIR, "libflashattn_amd_ablation.so")
 ABL_DRIVER_PATH = os.path.join(PKG_DIR, "fa_driver_ablation")
@@ -177,11 +177,11 @@ assert rc == 0, f"fa_host_selftest: check {rc} failed"
 # the no-device paths of the ABI through ctypes, as tests/test_host_logic.py drives them
 L.fa_workspace_bytes.restype = ctypes.c_size_t
 L.fa_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
-assert L.fa_workspace_bytes(1, 8192, 64, 0, 1, 0) == 256 + 8 * 8192 * 64 * 4 + 8 * 8192 * 4
+assert L.fa_workspace_bytes(1, 8192, 64, 0, 1, 0) == 8 * 8192 * 64 * 4 + 8 * 8192 * 4
 L.fa_kernel_name_for.restype = ctypes.c_char_p
 L.fa_kernel_name_for.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64]
 for dt in (0, 1, 2):
-    for d in (32, 64, 128, 48):
+    for d in (32, 64, 128, 48, 96, 256, 300):
         for c in (0, 1):
             for bh in (1, 16, 130, 70000):
                 for n in (1, 700, 8192, 40000, 1 << 24):

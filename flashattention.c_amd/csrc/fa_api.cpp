@@ -86,7 +86,7 @@ int fa_forward_packed_qkv(const float* inp, float* out, int32_t B, int32_t T, in
     if (B < 1 || T < 1 || C < 1 || NH < 1 || C % NH != 0)
         return fail(FA_ERR_INVALID_ARGUMENT, "bad shape B=%d T=%d C=%d NH=%d", B, T, C, NH);
     const int hs = C / NH;
-    if (!head_dim_supported(hs)) return fail(FA_ERR_UNSUPPORTED, "head size %d not instantiated (32, 64, 128)", hs);
+    if (!head_dim_naive(hs)) return fail(FA_ERR_UNSUPPORTED, "head size %d not supported (1 .. 256)", hs);
     if (!aligned16(inp) || !aligned16(out)) return fail(FA_ERR_INVALID_ARGUMENT, "buffers must be 16-byte aligned");
     if ((int64_t)B * NH > 0x7fffffffLL) return fail(FA_ERR_INVALID_ARGUMENT, "B*NH too large");
     // (B, T, 3C): q at column h*hs, k at C + h*hs, v at 2C + h*hs of each token row
@@ -131,37 +131,31 @@ int fa_last_forward_route(void* stream, int32_t* route)
     if (!route) return fail(FA_ERR_INVALID_ARGUMENT, "null route pointer");
     *route = 0;
     if (t_last_chain == 0) return FA_OK;
-    if (t_last_route >= 0) {
-        *route = t_last_route;
-        return FA_OK;
-    }
     uint32_t word = 0;
     hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
-    if (e == hipSuccess) e = hipMemcpy(&word, t_last_flag.word, sizeof(word), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return fail(FA_ERR_HIP, "reading the chain's flag word failed: %s", hipGetErrorString(e));
-    *route = word == t_last_flag.serial ? 2 : 1;
+    if (e == hipSuccess) e = hipMemcpy(&word, t_last_report.word, sizeof(word), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(FA_ERR_HIP, "reading the forward's report word failed: %s", hipGetErrorString(e));
+    *route = word == t_last_report.serial ? 2 : 1;
     return FA_OK;
 }
 
-int fa_get_stats(fa_stats* out)
+int fa_get_stats(fa_stats* out, size_t struct_bytes)
 {
-    if (!out) return fail(FA_ERR_INVALID_ARGUMENT, "null stats pointer");
-    memset(out, 0, sizeof(*out));
-    out->forwards = g_stats.forwards.load(std::memory_order_relaxed);
-    out->chains = g_stats.chains.load(std::memory_order_relaxed);
-    out->chains_degraded = g_stats.chains_degraded.load(std::memory_order_relaxed);
-    out->scratch_replans = g_stats.scratch_replans.load(std::memory_order_relaxed);
-    out->slot_evictions = g_stats.slot_evictions.load(std::memory_order_relaxed);
-    out->capture_slots_recycled = g_stats.capture_slots_recycled.load(std::memory_order_relaxed);
-    for (int dev = 0; dev < kMaxDevices; ++dev) {
-        std::lock_guard<std::mutex> g(g_slots[dev].mu);
-        out->eager_slots_in_use += (uint64_t)g_slots[dev].eager.size();
-        out->capture_slots_in_use += (uint64_t)(g_slots[dev].next_capture - (int)g_slots[dev].free_capture.size());
-    }
-    out->tiles_redone = cliff_count(0);
-    out->workgroups_fp32 = cliff_count(1);
-    out->eager_slots_per_device = kEagerSlots;
-    out->capture_slots_per_device = kFlagSlots - kEagerSlots;
+    if (!out || struct_bytes < sizeof(uint64_t)) return fail(FA_ERR_INVALID_ARGUMENT, "null stats pointer or struct_bytes below one field");
+    fa_stats st;
+    memset(&st, 0, sizeof(st));
+    st.struct_bytes = sizeof(st);
+    st.forwards = g_stats.forwards.load(std::memory_order_relaxed);
+    st.scratch_replans = g_stats.scratch_replans.load(std::memory_order_relaxed);
+    memcpy(out, &st, struct_bytes < sizeof(st) ? struct_bytes : sizeof(st));   // a caller built against a shorter struct gets its prefix
+    return FA_OK;
+}
+
+int fa_read_device_counters(uint64_t* tiles_redone, uint64_t* workgroups_fp32)
+{
+    g_err[0] = 0;
+    if (tiles_redone) *tiles_redone = cliff_count(0);
+    if (workgroups_fp32) *workgroups_fp32 = cliff_count(1);
     return FA_OK;
 }
 
@@ -177,15 +171,17 @@ int fa_device_count(void)
 const char* fa_version(void)
 {
 #if FA_ABLATION
-    return "flashattn_amd abi 5 gfx950 (hip, mfma f32 32x32x2 / bf16 32x32x16, lds-dma) +ablation";
+    return "flashattn_amd abi 6 gfx950 (hip, mfma f32 32x32x2 / bf16 32x32x16, lds-dma) +ablation";
 #else
-    return "flashattn_amd abi 5 gfx950 (hip, mfma f32 32x32x2 / bf16 32x32x16, lds-dma)";
+    return "flashattn_amd abi 6 gfx950 (hip, mfma f32 32x32x2 / bf16 32x32x16, lds-dma)";
 #endif
 }
 
 const char* fa_kernel_name_for(int32_t dtype, int32_t d, int32_t causal, int64_t bh, int64_t n)
 {
-    if (!head_dim_supported(d) || bh < 1 || n < 1) return nullptr;
+    if (bh < 1 || n < 1 || !head_dim_naive(d)) return nullptr;
+    if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_BF16_OUT_F32) return nullptr;
+    if (!head_dim_supported(d)) return (dtype == FA_DTYPE_F32 && head_dim_exact_f32(d)) ? "fa_fwd_f32_kernel" : "fa_naive_f32_kernel";
     if (dtype == FA_DTYPE_F32) {
         if (f32_auto_is_exact()) return "fa_fwd_f32_kernel";
         return "fa_fwd_f32_split_kernel";

@@ -202,8 +202,8 @@ static void run_one(const Args& a, Buffers& b, int variant, const std::vector<fl
     if (a.kernel == "auto") family = FA_KERNEL_AUTO;
     else if (a.kernel == "mfma") family = FA_KERNEL_MFMA;
     else if (a.kernel == "split") family = FA_KERNEL_SPLIT;
-    else if (a.kernel == "p16") family = FA_KERNEL_P16;
-    else if (a.kernel == "p16x2") family = FA_KERNEL_P16X2;
+    else if (a.kernel == "p16") family = 4;     // (ablation library only: P and V in fp16, one term)
+    else if (a.kernel == "p16x2") family = 5;   // (ablation library only: two fp16 terms of P)
     else if (a.kernel == "pb2") family = FA_KERNEL_PB2;
     else if (!a.kernel.empty()) {
         fprintf(stderr, "unknown --kernel %s\n", a.kernel.c_str());

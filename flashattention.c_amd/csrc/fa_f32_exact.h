@@ -16,9 +16,12 @@ template <int D>
 __device__ __forceinline__ int k_swizzle_f32(int row)
 {
     constexpr int RB = 4 * D;
-    constexpr int S = RB / 16;
+    constexpr int S = RB / 16;                       // 16-byte slots per row
     constexpr int R = (RB >= 256) ? 1 : 256 / RB;
-    constexpr int M = (S >= 16) ? 15 : S - 1;
+    // the XOR must keep a slot inside its row: the mask is the largest 2^k - 1 (at most 15) with 2^k dividing S -- 7 at D = 32, 96, 160, 224
+    // (8, 24, 40, 56 slots), 15 at D = 64, 128, 192, 256
+    constexpr int M = (S % 16 == 0) ? 15 : (S % 8 == 0) ? 7 : (S % 4 == 0) ? 3 : 1;
+    static_assert(S % (M + 1) == 0, "K swizzle leaves the row");
     return (row / R) & M;
 }
 

@@ -1,5 +1,5 @@
 // fa_launch.cpp -- one forward: its plan (fa_plan.cpp) executed on a stream -- the kernel families' launchers, key shares + combine,
-// the report word of an fp32 FA_KERNEL_AUTO forward, and (ablation library) the conditional launch chains (fa_host.h).
+// the report word of an fp32 FA_KERNEL_AUTO forward (fa_counters.cpp), and (ablation library) the conditional launch chains (fa_host.h).
 // Replaces run_flash_tiled_coarse{,_causal} (/root/reference/src/flashattention.cu:590-602): no device sync, status codes.
 #include "fa_host.h"
 
@@ -80,7 +80,7 @@ hipError_t launch_f32_keysplit(const fa::FwdParams& p0, int32_t d, int32_t causa
 
 #if FA_ABLATION
 // bf16 tensors, fp16 P (ablation library): V -> fp16 copy in scratch, fp16-P kernel, split kernel as the conditional fallback
-hipError_t launch_p16_chain(const fa::FwdParams& p0, int32_t d, int32_t causal, int32_t out_f32, const Plan& pl, char* ws, const FlagRef& f,
+hipError_t launch_p16_chain(const fa::FwdParams& p0, int32_t d, int32_t causal, int32_t out_f32, const Plan& pl, char* ws, const ReportRef& f,
                             hipStream_t stream)
 {
     void* v16 = ws + pl.v16_off;
@@ -110,7 +110,7 @@ hipError_t launch_p16_chain(const fa::FwdParams& p0, int32_t d, int32_t causal, 
 // The pre-pass moves 2.5 x sizeof(K + V) + sizeof(Q) through HBM (~40 us at c3).
 // The experimental three-product kernel of fa_f32_t3_kernel.h (ablation library only; FA_KERNEL_SPLIT tilings 8 = guarded chain with the exact
 // kernel as fallback, 9 = the kernel alone, 16 + a = timing-only ablation a of the kernel alone)
-hipError_t launch_f32_t3_chain(const fa::FwdParams& p0, int32_t d, char* scratch, const FlagRef& f, hipStream_t stream, bool guarded, int abl)
+hipError_t launch_f32_t3_chain(const fa::FwdParams& p0, int32_t d, char* scratch, const ReportRef& f, hipStream_t stream, bool guarded, int abl)
 {
     const int64_t count = (int64_t)p0.bh * p0.n * d;
     hipError_t e = fa::launch_t3_prepass(p0.q, p0.k, p0.v, scratch, count, p0.scale_log2e, f.stats, f.serial, stream);
@@ -146,7 +146,6 @@ int launch(const fa::FwdParams& p_in, int32_t d, int32_t causal, int32_t dtype, 
 {
     const KernelSel sel = decode_kernel(kernel);
     t_last_chain = 0;
-    t_last_route = -1;
     g_stats.forwards.fetch_add(1, std::memory_order_relaxed);
     const bool capturing = stream_is_capturing(stream);
     fa::FwdParams p = p_in;
@@ -155,12 +154,13 @@ int launch(const fa::FwdParams& p_in, int32_t d, int32_t causal, int32_t dtype, 
     if (pl.status != FA_OK) return pl.status;
     char* scratch = static_cast<char*>(ws);
     bool owned = false;
+    // the routes that cannot run without their scratch (ablation library); every other plan has an unsplit form
+    const bool needs_scratch = pl.route == kRouteP16Chain || pl.route == kRouteF32T3;
     if (pl.total > 0 && ws_mode) {
         if (scratch == nullptr || ws_bytes == 0) {
-            // a binder that skips fa_workspace_bytes(): FA_KERNEL_AUTO runs without scratch (the unsplit launch; the verdict word of a
-            // chain from the slot table) instead of refusing -- an explicit kernel that cannot do without scratch still says so
+            // a binder that skips fa_workspace_bytes(): the forward runs without scratch (the unsplit launch) instead of failing
             scratch = nullptr;
-            if (sel.kind != FA_KERNEL_AUTO) return fail(FA_ERR_INVALID_ARGUMENT, "this kernel choice needs a workspace of fa_workspace_bytes() = %zu bytes", pl.total);
+            if (needs_scratch) return fail(FA_ERR_INVALID_ARGUMENT, "this kernel choice needs a workspace of fa_workspace_bytes() = %zu bytes", pl.total);
             pl = make_plan(p, d, causal, dtype, kernel, false);
             if (pl.status != FA_OK) return pl.status;
             g_stats.scratch_replans.fetch_add(1, std::memory_order_relaxed);
@@ -168,15 +168,13 @@ int launch(const fa::FwdParams& p_in, int32_t d, int32_t causal, int32_t dtype, 
             if (ws_bytes < pl.total) return fail(FA_ERR_INVALID_ARGUMENT, "workspace of %zu bytes is too small: this call needs fa_workspace_bytes() = %zu", ws_bytes, pl.total);
             if ((reinterpret_cast<uintptr_t>(scratch) & 255u) != 0) return fail(FA_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
         }
-    } else if (pl.total > kWsHeader) {   // (a header-only plan needs no allocation: the word of an owned chain comes from the slot table)
+    } else if (pl.total > 0) {
         void* ptr = nullptr;
         const hipError_t ea = scratch_alloc(&ptr, pl.total, stream);
         if (ea != hipSuccess || ptr == nullptr) {
             (void)hipGetLastError();
-            // the scratch paths are optimisations (and the fp16-P kernels of the ablation library an explicit request): AUTO falls back to
-            // the kernels without scratch
-            if (sel.kind == FA_KERNEL_P16 || sel.kind == FA_KERNEL_P16X2 || pl.route == kRouteF32T3)
-                return fail(FA_ERR_HIP, "stream-ordered allocation of %zu scratch bytes failed: %s", pl.total, hipGetErrorString(ea));
+            // the scratch paths are optimisations: the forward falls back to the launch without scratch
+            if (needs_scratch) return fail(FA_ERR_HIP, "stream-ordered allocation of %zu scratch bytes failed: %s", pl.total, hipGetErrorString(ea));
             pl = make_plan(p, d, causal, dtype, kernel, false);
             if (pl.status != FA_OK) return pl.status;
             g_stats.scratch_replans.fetch_add(1, std::memory_order_relaxed);
@@ -188,73 +186,51 @@ int launch(const fa::FwdParams& p_in, int32_t d, int32_t causal, int32_t dtype, 
     const int out_f32 = dtype == FA_DTYPE_BF16_OUT_F32 ? 1 : 0;
     const int c = causal ? 1 : 0;
     hipError_t e = hipSuccess;
-    // The chain's flag word: in the CALLER's workspace when the call has one, else the slot of (device, stream) / a capture slot.  Never
-    // in scratch this call owns: that goes back to the pool behind the last kernel, and fa_last_forward_route() reads the word later
-    // (round 3 put it there and read freed memory).
-    std::unique_lock<std::mutex> hold;   // slot table of the device, locked from taking a slot to the chain's last launch
-    auto chain_flag = [&](FlagRef& f) -> bool {
-        bool ok;
-        if (ws_mode && scratch != nullptr && ws_bytes >= kWsHeader) {
-            f = FlagRef{};
-            f.word = reinterpret_cast<uint32_t*>(scratch);
-            f.serial = next_serial();
-            ok = true;
-        } else {
-            ok = next_flag(f, stream, capturing, hold);
-        }
-        // a captured chain is replayed with the same serial: clear the word first, or a verdict of an earlier replay would stand
-        if (ok && capturing) ok = hipMemsetAsync(f.word, 0, sizeof(uint32_t), stream) == hipSuccess;
-        g_stats.chains.fetch_add(1, std::memory_order_relaxed);
-        if (!ok) g_stats.chains_degraded.fetch_add(1, std::memory_order_relaxed);
-        return ok;
-    };
     switch (pl.route) {
-        case kRouteNaive: e = fa::launch_naive_f32(p, d, c, stream); break;
+        case kRouteNaive: e = fa::launch_naive(p, d, c, dtype, stream); break;
         case kRouteF32Exact:
             if (pl.S > 1) e = launch_f32_keysplit(p, d, causal, pl.S, scratch + pl.part_off, stream, true);
             else e = fa::launch_fwd_f32(p, d, c, sel.variant, stream);
             break;
         case kRouteF32Split: e = fa::launch_f32_split(p, d, c, sel.variant, stream); break;
-        case kRouteF32Guarded: {   // split products behind the range guard: ONE launch (round 4) -- a workgroup whose operands leave what fp16
-            FlagRef f;              // terms hold (or met a NaN) redoes its own rows in fp32 arithmetic inside the kernel (flag_mode 4).  The word
-            const bool have = chain_flag(f);   // only REPORTS that (fa_last_forward_route); without one the launch is the same
+        case kRouteF32Guarded: {   // split products behind the range guard: ONE launch -- a workgroup whose operands leave what fp16 terms hold
+            ReportRef f;            // (or met a NaN) redoes its own rows in fp32 arithmetic inside the kernel (flag_mode 4).  The word only
+            // REPORTS that (fa_last_forward_route); a captured forward takes none: its replays would all raise the same word
+            const bool have = !capturing && next_report(f);
             fa::FwdParams pg = p;
             pg.flag = have ? f.word : nullptr;
             pg.flag_serial = have ? f.serial : 0u;
             pg.flag_mode = 4;
             if (pl.S > 1) e = launch_f32_keysplit(pg, d, causal, pl.S, scratch + pl.part_off, stream);   // (every share guards its own keys)
             else e = fa::launch_f32_split(pg, d, c, 0, stream);
-            if (have) {
-                chain_enqueued(f, stream);
-                if (e == hipSuccess) {
-                    t_last_flag = f;
-                    t_last_chain = 1;
-                }
+            if (have && e == hipSuccess) {
+                t_last_report = f;
+                t_last_chain = 1;
             }
             break;
         }
 #if FA_ABLATION
         case kRouteF32T3: {
-            FlagRef f;
-            if (!next_flag(f, stream, capturing, hold)) return fail(FA_ERR_HIP, "no device flag slot (hipGetSymbolAddress failed or slots exhausted)");
+            ReportRef f;
+            if (!next_report(f)) return fail(FA_ERR_HIP, "no report word (hipGetSymbolAddress failed)");
+            // a captured chain is replayed with the same serial: clear the word first, or the verdict of an earlier replay would stand
+            if (capturing && hipMemsetAsync(f.word, 0, sizeof(uint32_t), stream) != hipSuccess) return fail(FA_ERR_HIP, "memset node of the chain's word failed");
             e = launch_f32_t3_chain(p, d, scratch + pl.part_off, f, stream, sel.variant == 8, sel.variant >= 16 ? sel.variant - 16 : 0);
-            chain_enqueued(f, stream);
             if (e == hipSuccess) {
-                t_last_flag = f;
+                t_last_report = f;
                 t_last_chain = 1;
             }
             break;
         }
         case kRouteP16Chain: {
-            FlagRef f;
-            if (!chain_flag(f)) {
-                e = fa::launch_bf16_split(p, d, c, out_f32, 0, stream);
+            ReportRef f;
+            if (!next_report(f) || (capturing && hipMemsetAsync(f.word, 0, sizeof(uint32_t), stream) != hipSuccess)) {
+                e = fa::launch_bf16_split(p, d, c, out_f32, 0, stream);   // the chain's always-correct kernel alone
                 break;
             }
             e = launch_p16_chain(p, d, causal, out_f32, pl, scratch, f, stream);
-            chain_enqueued(f, stream);
             if (e == hipSuccess) {
-                t_last_flag = f;
+                t_last_report = f;
                 t_last_chain = 2;
             }
             break;
@@ -269,7 +245,6 @@ int launch(const fa::FwdParams& p_in, int32_t d, int32_t causal, int32_t dtype, 
             break;
         default: return fail(FA_ERR_UNSUPPORTED, "kernel id %d is not in this build", sel.kind);
     }
-    if (hold.owns_lock()) hold.unlock();
     if (owned) {
         const hipError_t ef = hipFreeAsync(scratch, stream);
         if (e == hipSuccess) e = ef;

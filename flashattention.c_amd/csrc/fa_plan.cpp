@@ -27,7 +27,11 @@ int fail(int code, const char* fmt, ...)
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// head dims every kernel family is instantiated for / the exact fp32 kernel is (fa_fwd_f32_wide.hip: the other multiples of 32 up to 256,
+// the head dims the reference can be compiled for by editing `#define d`, flashattention.cu:15) / the rung-0 kernel takes
 bool head_dim_supported(int d) { return d == 32 || d == 64 || d == 128; }
+bool head_dim_exact_f32(int d) { return d >= 32 && d <= 256 && d % 32 == 0; }
+bool head_dim_naive(int d) { return d >= 1 && d <= 256; }
 
 
 int validate_common(const void* q, const void* k, const void* v, const void* o, int64_t bh, int64_t n, int32_t d,
@@ -181,23 +185,41 @@ Plan make_plan(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype,
     Plan pl;
     const KernelSel sel = decode_kernel(kernel);
     if (sel.kind == FA_KERNEL_NAIVE) {
-        if (dtype != FA_DTYPE_F32) pl.status = fail(FA_ERR_UNSUPPORTED, "the naive kernel is fp32 only");
-        else if (d > 256) pl.status = fail(FA_ERR_UNSUPPORTED, "naive kernel supports head dim <= 256 (got %d)", d);
+        if (!head_dim_naive(d)) pl.status = fail(FA_ERR_UNSUPPORTED, "the rung-0 kernel supports head dims 1 .. 256 (got %d)", d);
         pl.route = kRouteNaive;
         return pl;
     }
-    if (sel.kind != FA_KERNEL_AUTO && sel.kind != FA_KERNEL_MFMA && sel.kind != FA_KERNEL_SPLIT && sel.kind != FA_KERNEL_P16 && sel.kind != FA_KERNEL_P16X2 &&
+    if (sel.kind != FA_KERNEL_AUTO && sel.kind != FA_KERNEL_MFMA && sel.kind != FA_KERNEL_SPLIT && sel.kind != kKernelP16 && sel.kind != kKernelP16x2 &&
         sel.kind != FA_KERNEL_PB2) {
         pl.status = fail(FA_ERR_UNSUPPORTED, "unknown kernel id %d", sel.kind);
         return pl;
     }
     if (!head_dim_supported(d)) {
-        pl.status = fail(FA_ERR_UNSUPPORTED, "head dim %d not instantiated for the MFMA kernels (32, 64, 128)", d);
+        // Head dims outside {32, 64, 128} (round 6): the reference is generic over d % 32 == 0 by editing one macro (flashattention.cu:15,164).
+        // fp32 tensors, d a multiple of 32 up to 256: the exact fp32 MFMA kernel (AUTO and MFMA alike); every other head dim up to 256, and
+        // bf16 tensors at any of them: FA_KERNEL_AUTO runs the rung-0 kernel (fp32 arithmetic, correct, slow) instead of refusing the call.
+        if (dtype == FA_DTYPE_F32 && head_dim_exact_f32(d) && sel.variant == 0 && (sel.kind == FA_KERNEL_AUTO || sel.kind == FA_KERNEL_MFMA)) {
+            pl.route = kRouteF32Exact;
+            const int S = scratch_ok ? keysplit_factor_exact(p, d, causal) : 1;
+            if (S > 1) {
+                pl.S = S;
+                pl.part_off = kWsHeader;
+                pl.part_bytes = (size_t)S * p.bh * p.n * d * 4u + (size_t)S * p.bh * p.n * 4u;
+                pl.total = pl.part_off + align256(pl.part_bytes);
+            }
+            return pl;
+        }
+        if (sel.kind == FA_KERNEL_AUTO && sel.variant == 0 && head_dim_naive(d)) {
+            pl.route = kRouteNaive;
+            return pl;
+        }
+        pl.status = fail(FA_ERR_UNSUPPORTED, "head dim %d: this kernel family is instantiated for 32, 64, 128 (FA_KERNEL_AUTO takes any head dim up to 256; "
+                                             "FA_KERNEL_MFMA fp32 tensors at multiples of 32 up to 256)", d);
         return pl;
     }
     if (dtype == FA_DTYPE_F32) {
-        if (sel.kind == FA_KERNEL_P16 || sel.kind == FA_KERNEL_P16X2 || sel.kind == FA_KERNEL_PB2)
-            pl.status = fail(FA_ERR_UNSUPPORTED, "FA_KERNEL_P16 / FA_KERNEL_P16X2 / FA_KERNEL_PB2 are bf16-tensor kernels");
+        if (sel.kind == kKernelP16 || sel.kind == kKernelP16x2 || sel.kind == FA_KERNEL_PB2)
+            pl.status = fail(FA_ERR_UNSUPPORTED, "FA_KERNEL_PB2 (and the ablation library's fp16-P kernels, ids 4 / 5) are bf16-tensor kernels");
         else if (sel.kind == FA_KERNEL_MFMA || (sel.kind == FA_KERNEL_AUTO && f32_auto_is_exact())) {
             pl.route = kRouteF32Exact;
             const int S = (scratch_ok && sel.variant == 0) ? keysplit_factor_exact(p, d, causal) : 1;
@@ -210,7 +232,6 @@ Plan make_plan(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype,
         }
         else if (sel.kind == FA_KERNEL_AUTO && sel.variant == 0) {
             pl.route = kRouteF32Guarded;
-            if (scratch_ok) pl.total = kWsHeader;   // the chain's verdict word (a caller-owned workspace keeps it off the slot table)
             // grids that leave the chip idle: the split kernel over key shares + combine (flag_mode 4: the workgroups of a share guard the
             // keys of THAT share and redo their own partial rows in fp32 arithmetic; the combine merges both kinds; the word only reports)
             const int S = scratch_ok ? keysplit_factor(p, d, causal, true) : 1;
@@ -237,10 +258,10 @@ Plan make_plan(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype,
     // bf16 tensors.  AUTO: a caller who asks for the fp32 accumulator gets the accurate P (two bf16 terms: ~3e-5); a bf16 output rounds
     // at 2^-9 of |O| anyway and takes the fastest kernels (bf16 P).  MFMA / SPLIT / PB2 force one family.
     const int out_f32 = dtype == FA_DTYPE_BF16_OUT_F32 ? 1 : 0;
-    const bool p16_kind = sel.kind == FA_KERNEL_P16 || sel.kind == FA_KERNEL_P16X2;
+    const bool p16_kind = sel.kind == kKernelP16 || sel.kind == kKernelP16x2;
 #if !FA_ABLATION
     if (p16_kind) {
-        pl.status = fail(FA_ERR_UNSUPPORTED, "FA_KERNEL_P16 / FA_KERNEL_P16X2 (P and V in fp16) were replaced by FA_KERNEL_PB2 (P as two bf16 terms: faster, one launch, "
+        pl.status = fail(FA_ERR_UNSUPPORTED, "kernel ids 4 / 5 (P and V in fp16, rounds 2-3) were replaced by FA_KERNEL_PB2 (P as two bf16 terms: faster, one launch, "
                                              "no scratch) and are built into libflashattn_amd_ablation.so only");
         return pl;
     }
@@ -250,7 +271,7 @@ Plan make_plan(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype,
         return pl;
     }
     if (p16_kind && !scratch_ok) {
-        pl.status = fail(FA_ERR_UNSUPPORTED, "FA_KERNEL_P16 / FA_KERNEL_P16X2 need scratch, and stream-ordered allocations are not reliable inside a captured graph on this runtime: "
+        pl.status = fail(FA_ERR_UNSUPPORTED, "the fp16-P kernels need scratch, and stream-ordered allocations are not reliable inside a captured graph on this runtime: "
                                              "call fa_forward_ws with a workspace of fa_workspace_bytes() (legal under capture), or use FA_KERNEL_AUTO, which picks a "
                                              "kernel without scratch while the stream is capturing");
         return pl;
@@ -277,7 +298,7 @@ Plan make_plan(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype,
     const size_t part = (size_t)S * p.bh * p.n * d * 4u + (size_t)S * p.bh * p.n * 4u;
     if (p16_kind) {
         pl.route = kRouteP16Chain;
-        pl.terms = sel.kind == FA_KERNEL_P16 ? 1 : 2;
+        pl.terms = sel.kind == kKernelP16 ? 1 : 2;
         pl.S = S;
         pl.v16_off = kWsHeader;
         pl.v16_bytes = (size_t)p.bh * p.n * d * 2u;

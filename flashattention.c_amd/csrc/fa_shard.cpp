@@ -131,7 +131,6 @@ int forward_sharded(int32_t n_shards, const int32_t* device_ids, const void* con
     int prev = 0;
     if (hipGetDevice(&prev) != hipSuccess) return fail(FA_ERR_HIP, "hipGetDevice failed");
     t_last_chain = 0;   // the shards' chains belong to their worker threads: fa_last_forward_route() of this thread reports "no chain"
-    t_last_route = -1;
     // One host thread per shard (run_on_shard_threads).  The current device is per host thread in HIP, so the workers do not disturb the
     // caller's; each worker's scratch comes from its shard's workspace, or from its own device's private pool.
     std::vector<int> rcs((size_t)n_shards, FA_OK);

@@ -358,7 +358,10 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     // one v_med3_f32 per column per workgroup + one v_sub_f32 per converted key element.  Coherent family at d = 128, causal: 3.5e-3 ->
     // below 1e-4 (profiles/r05_family_centered.txt); the reference's own fp32 FMA chain reads 5.7e-3 there.
     constexpr bool CENTER = !IN_BF16 && FA_SPLIT_CENTER && !FA_SPLIT_NOCVT;
-    const int kref_r1 = nk >> 1, kref_r2 = nk - 1;   // (local key indices of the share)
+    // (local key indices, among the keys THIS workgroup reads: a causal tile takes them below its own horizon -- until round 6 they were
+    // rows 0, nk / 2, nk - 1 of the share, i.e. future tokens or padding for most causal tiles, and two outliers among rows no row of the
+    // tile attends to could become the reference of everything it does attend to: ADVICE r05)
+    const int kref_r1 = kv_end >> 1, kref_r2 = kv_end - 1;
     auto kref_at = [&](int col0) {                    // median-of-three reference for columns col0 .. col0 + 3
         f32x4 r = {0.0f, 0.0f, 0.0f, 0.0f};
         if constexpr (CENTER) {
@@ -376,6 +379,9 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     // KREF_REG: the thread's eight reference values live in registers; the eight-wave D = 128 tiling (256 registers per lane, all in use)
     // reads them from LDS in front of every conversion instead -- behind the V piece's conversion, which hides the latency
     constexpr bool KREF_REG = !(D == 128 && NWAVES == 8);
+    // (the pipelined pass subtracts the references from registers only: an instantiation without them would skip the centring silently and
+    // still add vbar back to O -- ADVICE r05)
+    static_assert(!PIPE || KREF_REG || !CENTER, "the pipelined pass needs the reference rows in registers");
     unsigned krefp[4] = {0u, 0u, 0u, 0u}, vrefp[4] = {0u, 0u, 0u, 0u};   // the thread's eight reference values each, as packed fp16 pairs
     // VALUE CENTERING (round 5).  sum_j w_j v_j = vbar + sum_j w_j (v_j - vbar) for softmax weights (they add up to one): the kernel splits
     // v_j - vbar into its two bf16 terms, so the 16 bits cover the SPREAD of V and not an offset all values share -- V = 100 + N(0, 1) under a

@@ -83,11 +83,6 @@ int time_forward_impl(const void* q, const void* k, const void* v, void* o, int6
     (void)hipEventDestroy(e1);
     if (ws) {
         (void)hipStreamSynchronize(s);
-        // the chain's verdict word lives in the workspace: read it for fa_last_forward_route before the buffer goes away
-        if (rc == FA_OK && t_last_chain != 0 && t_last_flag.word != nullptr) {
-            uint32_t word = 0;
-            if (hipMemcpy(&word, t_last_flag.word, sizeof(word), hipMemcpyDeviceToHost) == hipSuccess) t_last_route = word == t_last_flag.serial ? 2 : 1;
-        }
         (void)hipFree(ws);
     }
     return rc;

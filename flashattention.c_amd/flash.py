@@ -11,14 +11,13 @@ This module provides the same call with the same positional meaning, backed by t
 handle only.  Defaults reproduce the reference: ``scale = 1.0`` (``flashattention.cu:593,600``), fp32 in -> fp32 out.
 Differences, all deliberate (DESIGN.md "boundary"): the call is asynchronous on the current stream (the reference
 ends with ``cudaDeviceSynchronize``), invalid input raises ``ValueError``/``TypeError`` instead of tripping a device
-``assert`` (``flashattention.cu:606``), head dims 32/64/128 are all compiled in (the reference needs ``#define d``
-edited, ``:15``), any sequence length is exact (the reference needs N % 32 == 0), and bf16 tensors
-are accepted (bf16 MFMA path).
+``assert`` (``flashattention.cu:606``), every head dim up to 256 runs (32/64/128 on every kernel family, the other multiples of 32
+on the exact fp32 kernel, the rest on the rung-0 kernel; the reference needs ``#define d`` edited, ``:15``), any sequence length is exact
+(the reference needs N % 32 == 0), and bf16 tensors are accepted (bf16 MFMA path).
 """
 from __future__ import annotations
 
 import ctypes
-import threading
 from types import SimpleNamespace
 from typing import Optional, Tuple, Union
 
@@ -28,12 +27,11 @@ from . import _cabi
 
 __all__ = ["forward", "forward_packed_qkv", "load", "time_forward", "last_forward_route", "workspace_bytes", "stats", "SUPPORTED_HEAD_DIMS"]
 
-SUPPORTED_HEAD_DIMS = (32, 64, 128)
-_tls = threading.local()
+SUPPORTED_HEAD_DIMS = (32, 64, 128)   # ... by every kernel family; ``kernel="auto"`` takes any head dim up to MAX_HEAD_DIM
+MAX_HEAD_DIM = 256
 _DTYPES = {torch.float32: _cabi.FA_DTYPE_F32, torch.bfloat16: _cabi.FA_DTYPE_BF16}
 _KERNELS = {"auto": _cabi.FA_KERNEL_AUTO, "naive": _cabi.FA_KERNEL_NAIVE, "mfma": _cabi.FA_KERNEL_MFMA,
-            "exact": _cabi.FA_KERNEL_MFMA, "split": _cabi.FA_KERNEL_SPLIT, "p16": _cabi.FA_KERNEL_P16, "p16x2": _cabi.FA_KERNEL_P16X2,
-            "pb2": _cabi.FA_KERNEL_PB2}
+            "exact": _cabi.FA_KERNEL_MFMA, "split": _cabi.FA_KERNEL_SPLIT, "pb2": _cabi.FA_KERNEL_PB2}
 
 
 def _kernel_id(kernel: Union[str, int]) -> int:
@@ -77,27 +75,25 @@ def forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = Fa
     enough because every element is written).  ``return_lse=True`` additionally returns the (BH, N) fp32 row
     log-sum-exp -- the quantity the reference's unused ``O_l`` buffer was reserved for.
 
-    Kernel choice (include/flashattn_amd.h has the full rules).  fp32 tensors: ``kernel="auto"`` runs Q.K^T as three matrix products
-    of two-term FP16 splits (22 bits) of Q and of the keys centred on a reference key, P.V as three products of two-term BF16 splits:
-    <= 1e-4 of the fp32 reference on unit-variance data, <= 3e-4 on coherent inputs where fp32 arithmetic itself reads up to 6e-3, never
-    further from fp64 than the reference's own fp32 arithmetic on any input, behind a device-side RANGE guard: a workgroup
-    whose operands leave what fp16 terms hold redoes its rows in exact fp32 arithmetic inside the same launch;
-    ``"split"`` is the same without the guard,
-    ``"exact"`` (= ``"mfma"``) computes in fp32 arithmetic.  bf16 tensors: ``out_dtype=torch.float32`` stores the fp32
-    accumulator (FA_DTYPE_BF16_OUT_F32) and, under ``"auto"``, selects the accurate P -- bf16 hi + bf16 lo terms in one launch
-    (``"pb2"``), within 1e-4 of the fp32 reference at scale 1 (2.4e-5 on B=2 H=8 d=64 N=8192); a bf16 output keeps the fastest
-    kernels (bf16 P, ``"mfma"``: ~8e-3 in the accumulator at scale 1, ~1.5e-2 after the output's own rounding; 4e-4 at 1/sqrt(d)).
-    ``"p16"`` / ``"p16x2"`` (P in fp16, round 3) exist in the ablation library only.  ``out`` must not overlap q, k or v.
+    Kernel choice and accuracy: ``include/flashattn_amd.h`` sections 1-2 are the contract.  fp32 tensors: ``kernel="auto"`` computes on
+    the 16-bit matrix pipes with split operands (Q.K^T: two-term fp16 splits of Q' and of the keys centred on a reference key; P.V: two-term
+    bf16 splits of P and of the centred values): ``|O - O64| <= max(1e-3, E_ref) + 3 * 2^-17 * max|v - vbar|`` on every input, ``E_ref`` =
+    what the reference's own fp32 FMA chain leaves on that input; <= 1e-4 on unit-variance data; a workgroup whose operands leave what the
+    16-bit terms hold redoes its rows in fp32 arithmetic inside the same launch.  ``"split"`` is the same without that guard, ``"exact"``
+    (= ``"mfma"``) computes in fp32 arithmetic (head dims 32 .. 256 in steps of 32).  bf16 tensors: ``out_dtype=torch.float32`` stores the
+    fp32 accumulator and, under ``"auto"``, selects the accurate P -- bf16 hi + bf16 lo terms in one launch (``"pb2"``: 2e-5 on
+    B=2 H=8 d=64 N=8192); a bf16 output keeps the fastest kernels (bf16 P, ``"mfma"``: 1.5e-2 there, 3e-4 at 1/sqrt(d)).  Head dims
+    outside 32 / 64 / 128: see the module docstring.  ``out`` must not overlap q, k or v.
 
-    The call goes through ``fa_forward_ws``: scratch (key-split partials, the report word of an fp32 ``"auto"`` forward), when the call
-    needs any, is a ``torch.empty`` byte tensor from torch's caching allocator on the current stream -- the C ABI itself allocates
-    nothing, which also makes every kernel family legal under ``torch.cuda.graph`` capture.  ``workspace`` may pass a preallocated
-    ``torch.uint8`` tensor of at least ``workspace_bytes(...)`` bytes instead.
+    The call goes through ``fa_forward_ws``: scratch (the partials of a key-split launch), when the call can use any, is a ``torch.empty``
+    byte tensor from torch's caching allocator on the current stream -- the C ABI itself allocates nothing, which also makes every kernel
+    family legal under ``torch.cuda.graph`` capture.  ``workspace`` may pass a preallocated ``torch.uint8`` tensor of at least
+    ``workspace_bytes(...)`` bytes instead.
     """
     bh, n, d = _check_qkv(q, k, v)
     kid = _kernel_id(kernel)
-    if (kid & 0xff) != _cabi.FA_KERNEL_NAIVE and d not in SUPPORTED_HEAD_DIMS:
-        raise ValueError(f"head_dim {d} not supported by the MFMA kernels {SUPPORTED_HEAD_DIMS}")
+    if d > MAX_HEAD_DIM:
+        raise ValueError(f"head_dim {d} not supported (1 .. {MAX_HEAD_DIM})")
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     if out_dtype is None:
         out_dtype = out.dtype if out is not None else q.dtype
@@ -126,9 +122,6 @@ def forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = Fa
                              workspace.data_ptr() if workspace is not None else None,
                              workspace.numel() if workspace is not None else 0, ctypes.c_void_p(stream))
     _cabi.check(rc)
-    # the forward's report word lives in the workspace: keep the buffer referenced until this thread's next forward, so that
-    # last_forward_route() reads the word and not whatever the caching allocator put there since
-    _tls.last_workspace = workspace
     return (out, lse) if return_lse else out
 
 
@@ -196,8 +189,9 @@ def time_forward(q, k, v, causal: bool = False, *, scale: float = 1.0, kernel: U
 
 def last_forward_route(stream: Optional[torch.cuda.Stream] = None) -> int:
     """Which arithmetic produced this thread's most recent forward (blocking; diagnostics): 0 = nothing to report (every bf16 path,
-    explicit kernels), 1 = fp32 tensors under ``"auto"``: split products throughout, 2 = the range guard fired (operands outside what fp16
-    terms hold, or a NaN) and at least one workgroup redid its rows in exact fp32 arithmetic (inside the same launch)."""
+    explicit kernels, other head dims, forwards enqueued under graph capture), 1 = fp32 tensors under ``"auto"``: split products throughout,
+    2 = the range guard fired (operands outside what fp16 terms hold, or a NaN) and at least one workgroup redid its rows in exact fp32
+    arithmetic (inside the same launch)."""
     r = ctypes.c_int32(0)
     s = (stream or torch.cuda.current_stream()).cuda_stream
     _cabi.check(_cabi.lib().fa_last_forward_route(ctypes.c_void_p(s), ctypes.byref(r)))
@@ -205,13 +199,16 @@ def last_forward_route(stream: Optional[torch.cuda.Stream] = None) -> int:
 
 
 def stats() -> dict:
-    """Process-wide counters of the launch machinery (``fa_get_stats``): forwards, forwards with a report word (fp32 ``"auto"``), those
-    that found no slot for it, re-plans without scratch, slot evictions, recycled capture slots -- and the two counters the kernels bump on
-    their slow paths: ``tiles_redone`` (optimistic attempt failed, tile recomputed: ~2x) and ``workgroups_fp32`` (fp32 ``"auto"``
-    workgroups redone in fp32 arithmetic: ~3x)."""
+    """Host counters (``fa_get_stats``: forwards, re-plans without scratch) merged with the two counters the kernels bump on their slow
+    paths (``fa_read_device_counters``, BLOCKING): ``tiles_redone`` (optimistic attempt failed, tile recomputed: ~2x) and
+    ``workgroups_fp32`` (fp32 ``"auto"`` workgroups redone in fp32 arithmetic: ~3x)."""
     st = _cabi.FaStats()
-    _cabi.check(_cabi.lib().fa_get_stats(ctypes.byref(st)))
-    return {n: int(getattr(st, n)) for n, _ in _cabi.FaStats._fields_}
+    _cabi.check(_cabi.lib().fa_get_stats(ctypes.byref(st), ctypes.sizeof(st)))
+    out = {n: int(getattr(st, n)) for n, _ in _cabi.FaStats._fields_}
+    t, w = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    _cabi.check(_cabi.lib().fa_read_device_counters(ctypes.byref(t), ctypes.byref(w)))
+    out["tiles_redone"], out["workgroups_fp32"] = int(t.value), int(w.value)
+    return out
 
 
 def load(name: str = "flash", sources=None, extra_cuda_cflags=None, **_ignored):

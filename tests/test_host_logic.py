@@ -34,7 +34,12 @@ def test_library_exports_every_declared_symbol():
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 128, 0, 16, 8192) == b"fa_fwd_bf16_x2_kernel"
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 128, 0, 2, 300) == b"fa_fwd_bf16_w4_kernel"      # too few workgroups
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 128, 1, 2, 300) == b"fa_fwd_bf16_kernel"
-    assert L.fa_kernel_name(_cabi.FA_DTYPE_F32, 48, 0) is None
+    # head dims outside {32, 64, 128} (round 6): fp32 tensors at the other multiples of 32 up to 256 run the exact fp32 MFMA kernel, every
+    # other head dim up to 256 (and bf16 tensors at any of them) the rung-0 kernel -- the reference compiles any d % 32 == 0 (flashattention.cu:15)
+    assert L.fa_kernel_name(_cabi.FA_DTYPE_F32, 48, 0) == b"fa_naive_f32_kernel" and L.fa_kernel_name(_cabi.FA_DTYPE_F32, 300, 0) is None
+    for d in (96, 160, 192, 224, 256):
+        assert L.fa_kernel_name(_cabi.FA_DTYPE_F32, d, 1) == b"fa_fwd_f32_kernel" and L.fa_kernel_name(_cabi.FA_DTYPE_BF16, d, 0) == b"fa_naive_f32_kernel"
+    assert L.fa_kernel_name(7, 64, 0) is None and L.fa_kernel_name_for(_cabi.FA_DTYPE_F32, 64, 0, 0, 5) is None
     # bf16 tensors with fp32 output (round 4): P as two bf16 terms in one launch -- the tilings of the bf16-P one-wave-per-SIMD kernels
     assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0) == b"fa_fwd_bf16_x4_pb2_kernel"     # c4: 512-row workgroups
     assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 1) == b"fa_fwd_bf16_x2_pb2_kernel"
@@ -58,7 +63,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_kernel_ids_match_the_header_and_the_python_names():
     hdr = open(os.path.join(ROOT, "include", "flashattn_amd.h")).read()
-    for name in ("FA_KERNEL_AUTO", "FA_KERNEL_NAIVE", "FA_KERNEL_MFMA", "FA_KERNEL_SPLIT", "FA_KERNEL_P16", "FA_KERNEL_P16X2", "FA_KERNEL_PB2", "FA_DTYPE_F32", "FA_DTYPE_BF16",
+    for name in ("FA_KERNEL_AUTO", "FA_KERNEL_NAIVE", "FA_KERNEL_MFMA", "FA_KERNEL_SPLIT", "FA_KERNEL_PB2", "FA_DTYPE_F32", "FA_DTYPE_BF16",
                  "FA_DTYPE_BF16_OUT_F32"):
         m = re.search(name + r"\s*=\s*(\d+)\b", hdr)
         assert m and int(m.group(1)) == getattr(_cabi, name), name
@@ -66,7 +71,10 @@ def test_kernel_ids_match_the_header_and_the_python_names():
     assert flash._kernel_id("split:4") == _cabi.FA_KERNEL_SPLIT | (4 << 8)
     assert flash._kernel_id("exact") == flash._kernel_id("mfma") == _cabi.FA_KERNEL_MFMA
     assert flash._kernel_id("auto") == _cabi.FA_KERNEL_AUTO
-    assert flash._kernel_id("p16") == _cabi.FA_KERNEL_P16 and flash._kernel_id("p16x2") == _cabi.FA_KERNEL_P16X2 and flash._kernel_id("pb2") == _cabi.FA_KERNEL_PB2
+    assert flash._kernel_id("pb2") == _cabi.FA_KERNEL_PB2 == 6
+    assert "FA_KERNEL_P16" not in hdr            # the retired fp16-P kernel ids (4, 5) are not part of the product header
+    with pytest.raises(ValueError):
+        flash._kernel_id("p16x2")
     with pytest.raises(ValueError):
         flash._kernel_id("fast")
     L = _cabi.lib()
@@ -79,43 +87,46 @@ def test_workspace_sizes_are_host_arithmetic():
     L = _cabi.lib()
     B16, B16F, F32 = _cabi.FA_DTYPE_BF16, _cabi.FA_DTYPE_BF16_OUT_F32, _cabi.FA_DTYPE_F32
     A = _cabi.FA_KERNEL_AUTO
-    assert L.fa_workspace_bytes(16, 8192, 64, 0, F32, A) == 256                     # fp32 tensors: the guarded chain's verdict word (header only)
+    assert L.fa_workspace_bytes(16, 8192, 64, 0, F32, A) == 0                       # fp32 tensors: ONE launch, no scratch (ABI 6: no report-word header)
     assert L.fa_workspace_bytes(16, 8192, 64, 0, F32, _cabi.FA_KERNEL_SPLIT) == 0 and L.fa_workspace_bytes(16, 8192, 64, 0, F32, _cabi.FA_KERNEL_MFMA) == 0
     assert L.fa_workspace_bytes(16, 8192, 64, 0, B16, A) == 0                       # c4, bf16 output: one launch
     for shape in ((16, 8192, 64, 0), (16, 8192, 64, 1), (32, 1024, 64, 0), (16, 1024, 64, 1), (16, 1023, 64, 0), (128, 8192, 64, 0), (4, 300, 32, 0), (16, 8192, 128, 1)):
         assert L.fa_workspace_bytes(*shape, B16F, A) == 0                           # fp32 output (round 4): P as two bf16 terms -- one launch, no scratch
         assert L.fa_workspace_bytes(*shape, B16F, _cabi.FA_KERNEL_PB2) == 0
     part = lambda S, bh, n, d: S * bh * n * d * 4 + S * bh * n * 4
-    assert L.fa_workspace_bytes(1, 8192, 64, 0, B16, A) == 256 + part(8, 1, 8192, 64)         # idle grid: key-split partials
-    assert L.fa_workspace_bytes(2, 8192, 64, 0, B16, A) == 256 + part(4, 2, 8192, 64)
-    assert L.fa_workspace_bytes(1, 8192, 64, 1, B16, A) == 256 + part(8, 1, 8192, 64)         # causal: shares of 1024 keys (multiples of the tile height)
-    assert L.fa_workspace_bytes(8, 8192, 64, 1, B16, A) == 256 + part(2, 8, 8192, 64)         # causal: up to 256 tiles are split
+    assert L.fa_workspace_bytes(1, 8192, 64, 0, B16, A) == part(8, 1, 8192, 64)         # idle grid: key-split partials
+    assert L.fa_workspace_bytes(2, 8192, 64, 0, B16, A) == part(4, 2, 8192, 64)
+    assert L.fa_workspace_bytes(1, 8192, 64, 1, B16, A) == part(8, 1, 8192, 64)         # causal: shares of 1024 keys (multiples of the tile height)
+    assert L.fa_workspace_bytes(8, 8192, 64, 1, B16, A) == part(2, 8, 8192, 64)         # causal: up to 256 tiles are split
     assert L.fa_workspace_bytes(8, 8192, 64, 0, B16, A) == 0 and L.fa_workspace_bytes(16, 8192, 64, 1, B16, A) == 0
-    assert L.fa_workspace_bytes(1, 8192, 64, 0, F32, A) == 256 + part(8, 1, 8192, 64)         # fp32 tensors: the split kernel over key shares
-    assert L.fa_workspace_bytes(1, 8192, 64, 1, F32, A) == 256 + part(8, 1, 8192, 64)         # ... causal too
-    assert L.fa_workspace_bytes(16, 8192, 64, 1, F32, A) == 256
+    assert L.fa_workspace_bytes(1, 8192, 64, 0, F32, A) == part(8, 1, 8192, 64)         # fp32 tensors: the split kernel over key shares
+    assert L.fa_workspace_bytes(1, 8192, 64, 1, F32, A) == part(8, 1, 8192, 64)         # ... causal too
+    assert L.fa_workspace_bytes(16, 8192, 64, 1, F32, A) == 0
     # exact fp32 arithmetic (round 5): fewer than 256 tiles of 128 rows -> key shares until the launch has 256 .. 512 workgroups
     M = _cabi.FA_KERNEL_MFMA
-    assert L.fa_workspace_bytes(1, 8192, 64, 0, F32, M) == 256 + part(8, 1, 8192, 64) and L.fa_workspace_bytes(2, 8192, 64, 0, F32, M) == 256 + part(4, 2, 8192, 64)
-    assert L.fa_workspace_bytes(4, 8192, 64, 0, F32, M) == 0 and L.fa_workspace_bytes(4, 8192, 64, 1, F32, M) == 256 + part(4, 4, 8192, 64)   # (a causal round is still split)
+    assert L.fa_workspace_bytes(1, 8192, 64, 0, F32, M) == part(8, 1, 8192, 64) and L.fa_workspace_bytes(2, 8192, 64, 0, F32, M) == part(4, 2, 8192, 64)
+    assert L.fa_workspace_bytes(4, 8192, 64, 0, F32, M) == 0 and L.fa_workspace_bytes(4, 8192, 64, 1, F32, M) == part(4, 4, 8192, 64)   # (a causal round is still split)
     assert L.fa_workspace_bytes(16, 8192, 64, 0, F32, M) == 0 and L.fa_workspace_bytes(1, 1024, 64, 0, F32, M) == 0
     assert L.fa_workspace_bytes(1, 8192, 64, 0, F32, M | (1 << 8)) == 0                                 # an explicit tiling runs unsplit
-    assert L.fa_workspace_bytes(1, 8192, 64, 0, B16F, A) == 256 + part(8, 1, 8192, 64)        # the accurate path splits idle grids the same way
-    assert L.fa_workspace_bytes(1, 8192, 64, 0, B16F, _cabi.FA_KERNEL_PB2) == 256 + part(8, 1, 8192, 64)
+    assert L.fa_workspace_bytes(1, 8192, 64, 0, B16F, A) == part(8, 1, 8192, 64)        # the accurate path splits idle grids the same way
+    assert L.fa_workspace_bytes(1, 8192, 64, 0, B16F, _cabi.FA_KERNEL_PB2) == part(8, 1, 8192, 64)
     assert L.fa_workspace_bytes(1, 8192, 64, 0, B16, _cabi.FA_KERNEL_SPLIT) == 0
     # the two-term kernel has one tiling: short non-causal rows (1024 .. 4095 keys) on at most 64 tiles are key-split too (shares >= 256 keys)
-    assert L.fa_workspace_bytes(16, 1024, 64, 0, B16F, A) == 256 + part(4, 16, 1024, 64)
-    assert L.fa_workspace_bytes(8, 2048, 128, 0, B16F, _cabi.FA_KERNEL_PB2) == 256 + part(4, 8, 2048, 128)
-    assert L.fa_workspace_bytes(1, 1024, 32, 0, B16F, A) == 256 + part(4, 1, 1024, 32)        # (shares of 256 keys at least)
+    assert L.fa_workspace_bytes(16, 1024, 64, 0, B16F, A) == part(4, 16, 1024, 64)
+    assert L.fa_workspace_bytes(8, 2048, 128, 0, B16F, _cabi.FA_KERNEL_PB2) == part(4, 8, 2048, 128)
+    assert L.fa_workspace_bytes(1, 1024, 32, 0, B16F, A) == part(4, 1, 1024, 32)        # (shares of 256 keys at least)
     assert L.fa_workspace_bytes(16, 1024, 64, 0, B16, A) == 0                                  # bf16 P has finer tilings for these
     # the fp16-P kernels left the product library in round 4 (ablation library only): a size query answers 0, a forward FA_ERR_UNSUPPORTED
-    assert L.fa_workspace_bytes(4, 300, 32, 0, B16F, _cabi.FA_KERNEL_P16) == 0 and L.fa_workspace_bytes(4, 300, 32, 0, B16F, _cabi.FA_KERNEL_P16X2) == 0
+    assert L.fa_workspace_bytes(4, 300, 32, 0, B16F, 4) == 0 and L.fa_workspace_bytes(4, 300, 32, 0, B16F, 5) == 0
+    # head dims outside {32, 64, 128}: the exact kernel splits idle grids like at 64; the rung-0 kernel needs nothing
+    assert L.fa_workspace_bytes(1, 8192, 96, 0, F32, A) == part(8, 1, 8192, 96) == L.fa_workspace_bytes(1, 8192, 96, 0, F32, M)
+    assert L.fa_workspace_bytes(16, 8192, 256, 0, F32, A) == 0 and L.fa_workspace_bytes(16, 8192, 48, 0, F32, A) == 0 and L.fa_workspace_bytes(1, 8192, 96, 0, B16, A) == 0
     # arguments fa_forward_ws would reject size to 0 and leave fa_last_error alone
-    assert L.fa_workspace_bytes(0, 8192, 64, 0, B16F, A) == 0 and L.fa_workspace_bytes(16, 8192, 48, 0, B16F, A) == 0
+    assert L.fa_workspace_bytes(0, 8192, 64, 0, B16F, A) == 0 and L.fa_workspace_bytes(16, 8192, 300, 0, B16F, A) == 0
     assert L.fa_workspace_bytes(16, 8192, 64, 0, 7, A) == 0 and L.fa_workspace_bytes(16, 8192, 64, 0, F32, _cabi.FA_KERNEL_PB2) == 0
     import torch
     assert fa.workspace_bytes(16, 8192, 64, dtype=torch.bfloat16, out_dtype=torch.float32) == 0
-    assert fa.workspace_bytes(1, 8192, 64, dtype=torch.bfloat16, out_dtype=torch.float32) == 256 + part(8, 1, 8192, 64)
+    assert fa.workspace_bytes(1, 8192, 64, dtype=torch.bfloat16, out_dtype=torch.float32) == part(8, 1, 8192, 64)
 
 
 def test_fp32_auto_choice_follows_the_environment_switch():
@@ -154,23 +165,32 @@ def test_cabi_rejects_bad_arguments_without_touching_a_device():
         assert L.fa_forward(p, k, v, alias, 1, 32, 64, 1.0, 0, 0, None) == 1
         assert b"overlaps" in L.fa_last_error()
     # inputs may alias each other (self-attention on one tensor: the reference's own test.cu passes Q = K)
-    assert L.fa_forward(p, p, p, o, 1, 32, 48, 1.0, 0, 0, None) == 2
-    # unsupported head dim for the MFMA kernels, unknown kernel id
-    assert L.fa_forward(p, k, v, o, 1, 32, 48, 1.0, 0, 0, None) == 2
-    assert b"48" in L.fa_last_error()
+    assert L.fa_forward(p, p, p, o, 1, 8, 300, 1.0, 0, 0, None) == 2
+    # unsupported head dim (above 256 for FA_KERNEL_AUTO; outside {32, 64, 128} for a family that is instantiated there only), unknown kernel id
+    assert L.fa_forward(p, k, v, o, 1, 8, 300, 1.0, 0, 0, None) == 2
+    assert b"300" in L.fa_last_error()
+    assert L.fa_forward_ex(p, k, v, o, None, 1, 32, 48, 1.0, 0, 0, _cabi.FA_KERNEL_SPLIT, None) == 2 and b"48" in L.fa_last_error()
+    assert L.fa_forward_ex(p, k, v, o, None, 1, 32, 48, 1.0, 0, 0, _cabi.FA_KERNEL_MFMA, None) == 2      # exact kernel: multiples of 32
     assert L.fa_forward_ex(p, k, v, o, None, 1, 32, 64, 1.0, 0, 0, 9, None) == 2
     # the two-term-P kernel exists for bf16 tensors only (head dims 32, 64, 128); the fp16-P kernels are not in the product library
     assert L.fa_forward_ex(p, k, v, o, None, 1, 32, 64, 1.0, 0, _cabi.FA_DTYPE_F32, _cabi.FA_KERNEL_PB2, None) == 2
     assert L.fa_forward_ex(p, k, v, o, None, 1, 32, 48, 1.0, 0, _cabi.FA_DTYPE_BF16, _cabi.FA_KERNEL_PB2, None) == 2
-    assert L.fa_forward_ex(p, k, v, o, None, 1, 32, 64, 1.0, 0, _cabi.FA_DTYPE_BF16, _cabi.FA_KERNEL_P16X2, None) == 2
+    assert L.fa_forward_ex(p, k, v, o, None, 1, 32, 64, 1.0, 0, _cabi.FA_DTYPE_BF16, 5, None) == 2                    # retired kernel id
     assert b"ablation" in L.fa_last_error()
+    # fa_stats carries its size (ABI 6): host counters only, never blocks; a caller built against a shorter struct gets its prefix
     st = _cabi.FaStats()
-    assert L.fa_get_stats(ctypes.byref(st)) == 0 and st.eager_slots_per_device == 8192 and st.chains_degraded == 0
-    assert L.fa_get_stats(None) == 1
-    assert (st.tiles_redone, st.workgroups_fp32) == (0, 0)          # (ABI 5: counted by the kernels; nothing ran here)
-    assert ctypes.sizeof(_cabi.FaStats) == 12 * 8 and b"abi 5" in L.fa_version()
+    assert L.fa_get_stats(ctypes.byref(st), ctypes.sizeof(st)) == 0 and st.struct_bytes == ctypes.sizeof(st) == 3 * 8
+    first = ctypes.c_uint64(0)
+    assert L.fa_get_stats(ctypes.cast(ctypes.byref(first), ctypes.POINTER(_cabi.FaStats)), 8) == 0 and first.value == 24
+    assert L.fa_get_stats(None, 24) == 1 and L.fa_get_stats(ctypes.byref(st), 4) == 1
+    t, w = ctypes.c_uint64(7), ctypes.c_uint64(7)
+    assert L.fa_read_device_counters(ctypes.byref(t), ctypes.byref(w)) == 0 and (t.value, w.value) == (0, 0)   # nothing ran here
+    assert L.fa_read_device_counters(None, None) == 0
+    assert b"abi 6" in L.fa_version()
+    hdr = open(os.path.join(ROOT, "include", "flashattn_amd.h")).read()
+    assert "#define FLASHATTN_AMD_ABI_VERSION 6" in hdr and max(len(l) for l in hdr.splitlines()) <= 120
     assert L.fa_forward_packed_qkv(p, o, 1, 8, 96, 5, None) == 1      # C % NH != 0
-    assert L.fa_forward_packed_qkv(p, o, 1, 8, 96, 2, None) == 2      # hs = 48 not instantiated
+    assert L.fa_forward_packed_qkv(p, o, 1, 8, 600, 2, None) == 2     # hs = 300: above the largest head dim
     ms = ctypes.c_float()
     assert L.fa_time_forward(p, k, v, o, 1, 32, 64, 1.0, 0, 0, 0, None, 0, 0, ctypes.byref(ms)) == 1
     r = ctypes.c_int32(7)
