@@ -127,7 +127,7 @@ def timed_region(step_fn, steps: int, warmup: int, sync_fn, world: int, dist=Non
 
 
 PER_RANK_S = []   # seconds of the last timed_region on every rank (filled on all ranks)
-C4_ONE_GPU_TFLOPS = 1190.0   # the c4 headline on one MI355X: mean of the driver's four records (BENCH_r01 .. r04: 1164, 1212, 1220, 1171)
+C4_ONE_GPU_TFLOPS = 1190.0   # the c4 headline on one MI355X: mean of the driver's five records (BENCH_r01 .. r05: 1164, 1212, 1220, 1171, 1192)
 C5_ONE_GPU_MS = 14.6   # all 1024 slabs of config 5 on one MI355X (driver, r04: 14.59 ms; profiles/: 14.57 - 14.77 over three rounds' boxes, +- 4 % between boxes)
 
 
@@ -388,7 +388,7 @@ def main():
     extras = {"per_rank_ms": per_rank_ms} if world > 1 else {}
     if rank == 0:
         extras["timing_attempts"] = attempts
-        # what the kernels themselves counted while both clocks ran (fa_get_stats, ABI 5): a timed launch that took a slow path -- a tile
+        # what the kernels themselves counted while both clocks ran (fa_read_device_counters): a timed launch that took a slow path -- a tile
         # redone behind a failed optimistic attempt, a workgroup redone in fp32 arithmetic -- would show here
         torch.cuda.synchronize()
         slow1 = fa.stats()
@@ -448,9 +448,8 @@ def main():
         traffic = (pmc.get(f"{tkey}_hbm_bytes_per_launch")
                    if pmc.get(f"{tkey}_kernel") == kname and pmc.get("lib_sha256") == sha and not causal else None)
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4),
-                # the same fraction from the line's two clocks (they agree to 2 % or `timing_note` below says how far apart they stayed)
-                "frac_from_kernel_ms": round(achieved / peak, 4),
+                "frac": round(achieved / peak, 4),   # (from kernel_ms, the event-timed loop on the launch stream)
+                # the same fraction from the line's other clock (the two agree to 2 % or `timing_note` below says how far apart they stayed)
                 "frac_from_ms_per_step": round(fwd_flop(bh, n, d, causal) / (ms_per_step * 1e-3) / 1e12 / peak, 4),
                 "traffic": traffic,
                 "traffic_source": (f"profiles/pmc_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "

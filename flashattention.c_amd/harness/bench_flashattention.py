@@ -115,8 +115,11 @@ def main():
         row("manual matmul->softmax->matmul (fp32, GPU)", time_gpu(lambda: manual_attention(qd.float(), kd.float(), vd.float(), args.masking, args.scale), 1, 3))
     else:
         print("  skipped: score matrix would not fit")
-    row(f"PyTorch-ROCm SDPA ({args.dtype})",
+    row(f"PyTorch-ROCm SDPA ({args.dtype}) [*]",
         time_gpu(lambda: F.scaled_dot_product_attention(qd, kd, vd, is_causal=args.masking, scale=args.scale), args.warmup, args.iters))
+    print("  [*] the comparison column of the reference script, NOT a tuned competitor: on this image (torch 2.10 + ROCm 7.0 wheels) SDPA times like\n"
+          "      its math backend (scores materialised: 30-50 TFLOP/s at the README shapes) -- the ratio to it says nothing about kernel quality;\n"
+          "      the roofline fraction below does.")
 
     print("=== profiling minimal flash attention ===")
     out = torch.empty_like(qd)

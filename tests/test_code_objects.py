@@ -148,3 +148,36 @@ def test_inspecting_the_library_does_not_modify_it(tmp_path):
     before = hashlib.sha256(open(LIB, "rb").read()).hexdigest()
     assert len(codeobj.kernels_of(LIB, str(tmp_path))) > 60
     assert hashlib.sha256(open(LIB, "rb").read()).hexdigest() == before
+
+
+def test_no_agpr_operand_of_an_asm_mfma_is_written_right_in_front_of_it(kernels):
+    """The other hazard hipcc cannot pad for an inline-asm MFMA (found in round 6, profiles/r06_exp3_d32_q2.txt): when register pressure
+    makes it keep a B-operand fragment (Q) in VGPRs, it stages the fragment through AGPRs with v_accvgpr_write immediately in front of
+    the asm statement -- a VALU write two wait states too close to the matrix instruction that reads it (wrong scores, no fault).  In the
+    shipped kernels every Q fragment lives in its AGPRs from the prologue on: no v_accvgpr_write into an AGPR range within two wait states
+    in front of an MFMA that reads that range."""
+    dis_cache = {}
+    checked = 0
+    for k in kernels.values():
+        if not re.search(r"fa_fwd_bf16_x[24](_pb2)?_kernel<", k.name):
+            continue
+        dis = dis_cache.setdefault(k.code_object, codeobj.disassemble(k.code_object))
+        i = dis.index("<" + k.mangled + ">:")
+        body = [line.split("//")[0].strip() for line in dis[i:dis.find("\n\n", i)].splitlines()[1:]]
+        body = [b for b in body if b]
+        for j, ins in enumerate(body):
+            if not ins.startswith("v_mfma"):
+                continue
+            ranges = [(int(a), int(b)) for a, b in re.findall(r"a\[(\d+):(\d+)\]", ins.split(",", 1)[1] if "," in ins else "")]   # source operands
+            wait = 0
+            for prev in reversed(body[max(0, j - 4):j]):
+                if prev.startswith("v_mfma") or wait >= 2:
+                    break
+                if prev.startswith("s_nop"):
+                    wait += int(prev.split()[1]) + 1
+                    continue
+                w = re.match(r"v_accvgpr_write_b32 a(\d+),", prev)
+                assert not (w and any(a <= int(w.group(1)) <= b for a, b in ranges)), f"{k.name}: `{prev}` {wait} wait state(s) in front of `{ins}`"
+                wait += 1
+        checked += 1
+    assert checked >= 28

@@ -81,4 +81,4 @@ def test_bench_with_two_ranks_on_the_one_gpu():
     assert line["config"]["global_bh"] == 32 and line["scaling"] == "weak" and "weak_scaling" in ex
     assert ex["c5"]["n_gpus"] == 2 and ex["c5"]["bh_per_gpu"] == 512 and len(ex["c5"]["per_rank_ms"]) == 2
     assert 1 <= len(ex["timing_attempts"]) <= 3 and line["validation"]["status"] == "ok"
-    assert line["roofline"]["frac_from_kernel_ms"] > 0.1 and line["roofline"]["frac_from_ms_per_step"] > 0.05
+    assert line["roofline"]["frac"] > 0.1 and line["roofline"]["frac_from_ms_per_step"] > 0.05
