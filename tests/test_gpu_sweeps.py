@@ -86,3 +86,31 @@ def test_tiny_values_through_every_kernel_family(bh, n, d):
                 if dt == torch.bfloat16:
                     err2 = float((fa.forward(q, k, vv, causal, out_dtype=torch.float32) - ref).abs().max()) / 2.0 ** e
                     assert err2 < TOL_PB2, (name, causal, e, err2)
+
+
+@pytest.mark.parametrize("d", [96, 160, 192, 224, 256])
+def test_every_sequence_length_at_the_wide_head_dims(d):
+    """Round 6: the exact fp32 MFMA kernel at the other multiples of 32 (fa_fwd_f32_wide.hip) at every n in 1 .. 160, around its tile
+    heights and on an idle grid (key shares + combine, causal pairs), causal and not, O and LSE against rung 0 -- NaN-poisoned outputs.
+    Also: tiny values (V x 2^-60), a NaN-free result for an all-zero V, and scale 1/sqrt(d)."""
+    g = torch.Generator(device="cpu").manual_seed(3000 + d)
+    lengths = [(3, n) for n in range(1, 161)] + [(3, n) for n in (255, 256, 257, 383, 384, 385, 511, 512, 513)] + [(1, n) for n in (2047, 2048, 2049, 8192, 8193)]
+    lengths += [(140, 128), (70, 300)]
+    bad = []
+    for bh, n in lengths:
+        q, k, v = (torch.randn(bh, n, d, generator=g).to(dev()) for _ in range(3))
+        for causal in (False, True):
+            for scale in ((1.0, d ** -0.5) if n in (7, 128, 300, 8192) else (1.0,)):
+                ref, lref = fa.forward(q, k, v, causal, kernel="naive", return_lse=True, scale=scale)
+                out = torch.full((bh, n, d), float("nan"), device=dev())
+                _, lse = fa.forward(q, k, v, causal, out=out, return_lse=True, scale=scale)
+                eo, el = float((out - ref).abs().max()), float((lse - lref).abs().max())
+                if not (eo < TOL_F32 and el < TOL_F32):   # (two fp32-arithmetic kernels with different summation orders: observed <= 1.1e-4 at d = 256)
+                    bad.append((causal, bh, n, scale, eo, el))
+    assert not bad, bad[:10]
+    q, k, v = (torch.randn(4, 700, d, generator=g).to(dev()) for _ in range(3))
+    tiny = v * 2.0 ** -60
+    err = float((fa.forward(q, k, tiny, True) - fa.forward(q, k, tiny, True, kernel="naive")).abs().max()) / 2.0 ** -60
+    assert err < TOL_F32, err
+    z = fa.forward(q, k, torch.zeros_like(v), False)
+    assert float(z.abs().max()) == 0.0
