@@ -26,4 +26,6 @@ sample "c4 at scale 4 (sparser P)" --dtype bf16 --bh 16 --n 8192 --d 64 --scale 
 sample "c3 fp32 tensors (split kernel: fp16 terms for Q.K^T since round 5)" --dtype f32s --kernel auto --bh 16 --n 8192 --d 64 --iters 12000
 sample "c3 exact fp32" --dtype f32 --bh 16 --n 8192 --d 64 --iters 4000
 sample "d128" --dtype bf16 --bh 16 --n 8192 --d 128 --iters 20000
+sample "d32 (round 6: is the d = 32 loop at the power cap too?)" --dtype bf16 --bh 16 --n 8192 --d 32 --iters 40000
+sample "c4 causal" --dtype bf16 --bh 16 --n 8192 --d 64 --causal 1 --iters 50000
 cat $out
