@@ -676,6 +676,22 @@ def c4_side_measurements(fa, _cabi, q, k, v, causal, args, device):
             except Exception as e:  # pragma: no cover - informational only
                 ex[name]["exact"]["unsplit_ms"] = repr(e)
         del q2, k2, v2
+    # head dims outside {32, 64, 128} (round 6): the reference compiles any d % 32 == 0 (flashattention.cu:15,164); fp32 tensors through the plain
+    # call run the exact fp32 MFMA kernel there (fa_fwd_f32_wide.hip) -- d = 96 and 256 at B=2 H=8 N=8192, validated like every other figure
+    for d2 in (96, 256):
+        try:
+            q2, k2, v2 = make_inputs(16, 8192, d2, "f32", device, seed=8)
+            o2 = torch.empty_like(q2)
+            st2 = time_stats(fa, (q2, k2, v2), reps=3, causal=False, scale=args.scale, kernel="auto", warmup=4, iters=3, out=o2)
+            chk2 = validate_output(fa, q2, k2, v2, o2, False, args.scale, TOLERANCE["f32"], f"f32_d{d2}")
+            tf2 = fwd_flop(16, 8192, d2, False) / (st2["median"] * 1e-3) / 1e12
+            ex[f"f32_d{d2}"] = {"workload": f"BH=16 d={d2} N=8192 f32", "ms": round(st2["median"], 4), "tflops": round(tf2, 2),
+                                "frac_f32_mfma_peak": round(tf2 / PEAK_TFLOPS["f32"], 4), "max_abs_err": chk2["max_abs_err"], "tolerance": chk2["tolerance"],
+                                "kernel": _cabi.lib().fa_kernel_name_for(_cabi.FA_DTYPE_F32, d2, 0, 16, 8192).decode(),
+                                "what": "FA_KERNEL_AUTO at a head dim outside {32, 64, 128}: v_mfma_f32_32x32x2_f32 for both contractions (fp32 arithmetic)"}
+            del q2, k2, v2, o2
+        except Exception as e:  # pragma: no cover - informational only
+            ex[f"f32_d{d2}"] = {"error": repr(e)}
     # llm.c harness size (attention_forward.cu:1217-1220): B=6 T=4096 C=768 NH=12, packed (B, T, 3C) fp32, causal, 1/sqrt(hs); mean of
     # 100 launches like benchmark_kernel (:1279-1288)
     try:
