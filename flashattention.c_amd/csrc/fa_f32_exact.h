@@ -113,7 +113,9 @@ __device__ __forceinline__ void f32_exact_rows(const FwdParams& p, char* smem, c
         const char* ks_lds = smem + (j & 1) * C::kStageBytes;
         const char* vs_lds = ks_lds + C::kTileBytes;
 
-        // ---- S^T = K Q^T : D/2 MFMAs of k = 2
+        // ---- S^T = K Q^T : D/2 MFMAs of k = 2, one k-ordered chain on one accumulator (the reference's own summation order,
+        // flashattention.cu:236-252).  (Round 6 tried four partial accumulators at head dims above 128, where one wave owns a SIMD: 4-19 %
+        // SLOWER -- 64 more registers push the output accumulators' traffic through AGPRs; a chain on one accumulator costs nothing extra.)
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.0f;
@@ -151,10 +153,14 @@ __device__ __forceinline__ void f32_exact_rows(const FwdParams& p, char* smem, c
             rs += s[r];
         }
         l = fmaf(l, alpha, rs);
+        // (the running maximum of a row settles within its first tiles: a wave whose 64 lanes all keep theirs has alpha == 1 exactly and skips the
+        // D / 2 multiplications per lane -- bit-identical, and at head dims above 128, where the accumulators live in AGPRs, 3 instructions each)
+        if (__any(alpha != 1.0f)) {
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+            for (int db = 0; db < DB; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
 
         // ---- O^T += V^T P^T : MFMA #r contracts keys {r-th of hi=0, r-th of hi=1}
 #pragma unroll
