@@ -87,8 +87,10 @@ __global__ __launch_bounds__(NWAVES* kWave, MINWAVES) void fa_fwd_f32_kernel(Fwd
             if (qi < n && p.lse != nullptr && lane < 32) p.lse[(int64_t)slab * n + qi] = -INFINITY;
             continue;
         }
-        // (head dims above 128: the Q fragments would take D / 2 registers beside D / 2 of output accumulators -- they are re-read per tile, L2 hits)
-        f32_exact_rows<D, NWAVES, CAUSAL, (D <= 128)>(p, smem, qg, kg, vg, o_slab, slab, q0, kbeg, nk, kv_end, wave, lane);
+        // (Q fragments in registers at every head dim: at 256 they take 128 beside 128 of output accumulators -- one wave owns its SIMD's 512 there.
+        //  The first form of the wide instantiations re-read them from L2 in every tile: 32 exposed loads per tile, d = 256 at 0.56 of the fp32
+        //  peak instead of 0.80: profiles/r06_exp5_exact_alpha_skip.txt)
+        f32_exact_rows<D, NWAVES, CAUSAL, true>(p, smem, qg, kg, vg, o_slab, slab, q0, kbeg, nk, kv_end, wave, lane);
     }
 }
 
