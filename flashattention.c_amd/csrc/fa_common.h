@@ -47,7 +47,7 @@ struct FwdParams {
     int64_t kv_head_stride;
     int64_t o_head_stride;
     int32_t o_is_bf16;      // split kernel only: O is bf16 (bf16 tensors); 0 = fp32
-    // The report word of an fp32 FA_KERNEL_AUTO forward, and the ablation library's conditional launch chains (fa_slots.cpp, fa_launch.cpp): one 32-bit
+    // The report word of an fp32 FA_KERNEL_AUTO forward, and the ablation library's conditional launch chains (fa_counters.cpp, fa_launch.cpp): one 32-bit
     // device word per call; "set" means *flag == flag_serial
     // (serials are unique per call, so the word never needs clearing).
     //   flag_mode 0  ignore the word;   1  run only while the word is NOT set;   2  run only if the word IS set;
@@ -64,7 +64,7 @@ struct FwdParams {
                                 // [s * n_kv, min((s + 1) * n_kv, n_kv_total)) -- kv_head_stride carries the offset; 0 = all n keys
     int32_t alt_order;     // causal NB = 2 launches with two workgroups per CU: odd rounds of a CU's workgroups walk their slab light-to-heavy
     const unsigned long long* stats;   // [0] (serial << 32) | bits of max |k|,  [1] (serial << 32) | bits of max |q * scale * log2 e|_2^2
-    // Nullable: two 64-bit counters in the device's memory (fa_slots.cpp: cliff_counters) that the kernels bump on their RARE slow paths --
+    // Nullable: two 64-bit counters in the device's memory (fa_counters.cpp: cliff_counters) that the kernels bump on their RARE slow paths --
     // [0] tiles redone with the rescaled / textbook mix behind a failed optimistic attempt, [1] workgroups of an fp32 FA_KERNEL_AUTO
     // forward redone in fp32 arithmetic -- so that the performance cliffs of DESIGN.md section 5 show up in fa_get_stats().
     unsigned long long* cliffs;

@@ -939,8 +939,8 @@ def test_pb2_takes_any_bf16_v_and_any_launch_size_without_scratch():
 
 
 def test_scratch_paths_under_graph_capture_through_the_workspace_entry():
-    """fa_forward_ws never allocates: the key-split launches (partials in the caller's workspace) and the fp32 chain (verdict word cleared
-    by a memset node) are legal inside a captured graph.  16 x 8192 is the size at which stream-ordered GRAPH allocations lost their
+    """fa_forward_ws never allocates: the key-split launches (partials in the caller's workspace) and the fp32 default (one launch; a captured
+    forward takes no report word) are legal inside a captured graph.  16 x 8192 is the size at which stream-ordered GRAPH allocations lost their
     data on ROCm 7.2 (round 2); one-launch and four-launch graphs, output zeroed first.  (fa_time_forward_graph captures on a
     private stream with a workspace the measurement owns.)"""
     q, k, v = (torch.randn(16, 8192, 64, device=dev(), dtype=torch.bfloat16) for _ in range(3))
