@@ -30,6 +30,9 @@
 #include "fa_bf16_step.h"
 #include "fa_kernels.h"
 
+#ifndef FA_OPT_RECENTRE
+#define FA_OPT_RECENTRE 1   // 0: experiment switch -- the optimistic mix keeps its sampled exponent reference for the whole tile (rounds 2-5)
+#endif
 #ifndef FA_OPT_SAMPLE
 #define FA_OPT_SAMPLE 1   // 0: experiment switch -- the optimistic mix takes its exponent reference from the first sub-tile only (round 2)
 #endif
@@ -223,6 +226,40 @@ __device__ __forceinline__ void xn_rescale(const float (&mx)[NB], float c, Block
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) off[b] = st[b].m + SM::kBias;
+}
+
+// Optimistic mix, round 6: RE-CENTRE the exponent reference on the row sum a few times per long tile.  The reference of a row starts as a
+// sampled score (192 keys: ~2.7 sigma on unit-variance data where the row maximum over 8192 keys sits at ~3.9 sigma -- 14 binades higher), and
+// every term more than T binades below the reference is an exact zero, which is what the power budget likes.  After K1 keys
+// the row sum l1 itself is a better anchor: the new reference is 2^(floor(log2 l1) - 1) <= l1 / 2 -- the dropped mass of the remaining keys is
+// then bounded by nk * 2^-T * l1 / 2 <= 2^-(T + 1 - log2 nk) of the FINAL row sum (2^-11 for bf16 P, 2^-14 for two-term P: the same bound the
+// sampled reference gives relative to the largest term, stated against the row sum, which is what O / l divides by).  The shift is an exact power
+// of two in O, l and every later P: nothing is rounded.  Wave-uniform call between two groups of stages; per lane: its own row's shift.
+template <int NB, int DB>
+__device__ __forceinline__ void xn_recentre(BlockState (&st)[NB], f32x16 (&o)[NB][DB], float (&off)[NB], int bias)
+{
+    asm volatile("; optimistic mix: re-centre on the row sum" ::: "memory");
+    drain_accumulators<NB, DB>(o, st);   // the accumulators read and scaled below may have an MFMA in flight
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const float lt = st[b].lacc[0];
+        // P lives near 2^-bias (the reference term is exactly 2^-bias): the row sum is re-anchored at 2^(1 - bias) .. 2^(2 - bias)
+        const int e = (int)((__float_as_uint(lt) >> 23) & 0xffu) - 127;   // floor(log2 lt) for a normal lt
+        const int sh = e + bias - 1;
+        const int shift = (lt > 0.0f && e < 0 && sh > 0) ? min(sh, 64) : 0;   // (zero, NaN, inf, a window about to overflow: left for the tile's verification)
+        // block by block (like xn_rescale: fewer registers alive, which is what lets the NB = 2 kernels at d = 64 fit a CU twice); a block whose
+        // rows already have their reference at their sum (scaled logits: 1 / sqrt(d)) has nothing to gain and skips the D-wide multiply
+        if (!__any(shift >= 3)) continue;
+        const float a = __uint_as_float((unsigned)(127 - shift) << 23);   // 2^-shift
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[b][db][r] *= a;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[b].lacc[r] *= a;
+        st[b].m += (float)shift;
+        off[b] += (float)shift;
+    }
 }
 
 // ---- static schedule of one step -------------------------------------------------------------------------------------
@@ -1016,6 +1053,9 @@ __device__ __forceinline__ int xn_tile(const FwdParams& p, char* smem)   // 1 = 
         prof_t0 = stamp();
         prof_r0 = __builtin_amdgcn_s_memrealtime();
     }
+    // (re-centring pays on long tiles whose scores spread over enough binades for anything to underflow -- the prologue's `wide`, which also gates
+    // the sampled reference: at 1 / sqrt(d) scaling nothing does and the tile keeps its reference, at no cost; 8 is a multiple of G)
+    int next_rc = (jf >= 32 && OPT && FA_OPT_SAMPLE && __any(wide)) ? 8 : 0x7fffffff;
     for (int j = 0; j < jf; j += G) {
         sync_top(j);
 #pragma unroll
@@ -1035,6 +1075,12 @@ __device__ __forceinline__ int xn_tile(const FwdParams& p, char* smem)   // 1 = 
 #pragma unroll
                 for (int blk = 0; blk < NB; ++blk) mx[blk] = xhalf_max(lm[blk]);
                 xn_rescale<NB, DB, PF>(mx, c, st, o, off);
+            }
+        }
+        if constexpr (OPT && ABL == 0 && FA_OPT_RECENTRE) {   // after 8, 24, 72, ... stages of a long tile (wave-uniform)
+            if (__builtin_expect(j + G == next_rc, 0)) {
+                xn_recentre<NB, DB>(st, o, off, (int)kBias);
+                next_rc *= 3;
             }
         }
     }
