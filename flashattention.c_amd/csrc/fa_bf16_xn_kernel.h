@@ -33,6 +33,9 @@
 #ifndef FA_OPT_RECENTRE
 #define FA_OPT_RECENTRE 1   // 0: experiment switch -- the optimistic mix keeps its sampled exponent reference for the whole tile (rounds 2-5)
 #endif
+#ifndef FA_XN_TAKE_TURNS
+#define FA_XN_TAKE_TURNS 1   // 0: experiment switch -- two workgroups sharing a CU leave the issue priority to the arbiter (oldest wave first)
+#endif
 #ifndef FA_OPT_SAMPLE
 #define FA_OPT_SAMPLE 1   // 0: experiment switch -- the optimistic mix takes its exponent reference from the first sub-tile only (round 2)
 #endif
@@ -1056,8 +1059,33 @@ __device__ __forceinline__ int xn_tile(const FwdParams& p, char* smem)   // 1 = 
     // (re-centring pays on long tiles whose scores spread over enough binades for anything to underflow -- the prologue's `wide`, which also gates
     // the sampled reference: at 1 / sqrt(d) scaling nothing does and the tile keeps its reference, at no cost; 8 is a multiple of G)
     int next_rc = (jf >= 32 && OPT && FA_OPT_SAMPLE && __any(wide)) ? 8 : 0x7fffffff;
+    // Two workgroups share a CU where the registers allow (NB = 2, d <= 64): two waves per SIMD, and the arbiter serves the OLDER one first --
+    // it runs at nearly the speed of a lone wave, finishes early, and the younger one spends the rest of the launch alone at the lower
+    // efficiency of one wave per SIMD (stamped kernel, 16 x 8192 d = 32: 760 against 1290 cycles per step, half of the waves each; tiles end
+    // after 205k and 342k cycles).  The two take turns instead, by the CLOCK -- a turn counted in own steps lets the favoured wave run ahead just
+    // the same --, the wave slot's parity saying whose the even periods are; about four periods per tile (periods of 1k - 4k cycles: half the
+    // effect; of 16k and more: tiles end after 290k - 322k cycles, the launch 3.5 % shorter at the same power cap).  Causal launches keep the
+    // arbiter's order: their pairs are a heavy and a light tile, and the older one is the heavy one (all periods measured 0.5 - 2 % slower).
+    constexpr bool TURNS = FA_XN_TAKE_TURNS != 0 && NB == 2 && D <= 64 && !CAUSAL && (ABL & ~(1024 | 2048)) == 0;
+    unsigned turn = 0, turn_bit = 0;
+    bool turns = false;
+    if constexpr (TURNS) {
+        turns = p.take_turns != 0 && nst >= D;   // rows of 2048 (d = 64: 4096) keys and more: below, nothing to gain (128 x 1024: d = 32 -2.9 ... +1.0 %, d = 64 +1.7 ... +2.9 %)
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        turn = hwid & 1u;                                                   // wave slot of the SIMD, bit 0
+        turn_bit = min(17, max(12, 31 - __builtin_clz(max(nst, 1) * 600)));  // a stage is two steps of ~1200 cycles with both resident
+    }
     for (int j = 0; j < jf; j += G) {
-        sync_top(j);
+        unsigned long long now = 0;
+        if constexpr (TURNS) if (turns) now = __builtin_readcyclecounter();   // (an s_memtime in front of the wait is ~1 % of a lone wave's group: only where it pays)
+        sync_top(j);   // (its s_waitcnt lgkmcnt(0) covers the clock read)
+        if constexpr (TURNS) {
+            if (turns) {
+                if ((((unsigned)now >> turn_bit) ^ turn) & 1u) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+        }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const char* v_lds = v_slot(j + g);
@@ -1373,6 +1401,10 @@ static unsigned xn_launch_order(FwdParams& p, const dim3& grid, int causal, bool
     constexpr int ring = 4 * G * Bf16Cfg<D, 4>::kTileBytes;
     const long wgs = (long)grid.x * grid.y * grid.z;
     p.alt_order = 0;
+    // Non-causal, every workgroup resident from the start with a partner of equal work: the pair takes turns at the issue priority (xn_tile).
+    // Launches of several rounds keep the arbiter's oldest-first -- staggered pairs overlap one tile's prologue and epilogue with the other's
+    // loop, and pairs that end together leave the last partial round alone on its CUs (40 x 8192 d = 32: +12.6 % with turns, 128 x 8192 +2.3 %).
+    p.take_turns = (!causal && co_resident && ring < 84 * 1024 && wgs > 256 && wgs <= 2 * 256) ? 1 : 0;
     if (!causal || !co_resident || ring >= 84 * 1024 || wgs > 2 * 256) return 0;
     // Nearly two full rounds: pair the tiles, whatever the row length (short rows too: 128 x 1024 d = 64 0.040 -> 0.034 ms, 64 x 2048
     // 0.065 -> 0.054, d = 32 64 x 2048 0.050 -> 0.039).  A half-filled second round leaves too many heavy tiles without a partner:

@@ -63,6 +63,7 @@ struct FwdParams {
     int32_t n_kv, n_kv_total;   // key-split launches (non-causal NB = 2 kernels): a workgroup whose "head" index is s reads the keys
                                 // [s * n_kv, min((s + 1) * n_kv, n_kv_total)) -- kv_head_stride carries the offset; 0 = all n keys
     int32_t alt_order;     // causal NB = 2 launches with two workgroups per CU: odd rounds of a CU's workgroups walk their slab light-to-heavy
+    int32_t take_turns;    // non-causal NB = 2 launches whose whole grid is resident, two workgroups per CU: the pair shares the issue priority by the clock
     const unsigned long long* stats;   // [0] (serial << 32) | bits of max |k|,  [1] (serial << 32) | bits of max |q * scale * log2 e|_2^2
     // Nullable: two 64-bit counters in the device's memory (fa_counters.cpp: cliff_counters) that the kernels bump on their RARE slow paths --
     // [0] tiles redone with the rescaled / textbook mix behind a failed optimistic attempt, [1] workgroups of an fp32 FA_KERNEL_AUTO

@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "flashattn_amd.h"
@@ -533,6 +534,17 @@ int main(int argc, char** argv)
                "\"inputs_landed\": %.0f, \"first_scores\": %.0f, \"tail_stages\": %.0f, \"epilogue_issue\": %.0f, \"stores_landing\": %.0f}\n", a.variant, nw, steps / nw,
                cyc / steps, mx / (steps / nw), real / nw / 100.0, cyc / real * 100.0, whole / nw, whole_mx, (whole - cyc) / nw,
                ph[0] / nw, ph[1] / nw, ph[2] / nw, ph[3] / nw, (whole - cyc - ph[0] - ph[1] - ph[2] - ph[3]) / nw);
+        {   // spread of the per-wave loop time (two workgroups sharing a CU: who gets the issue slots?)
+            std::vector<float> per(nw), life(nw);
+            for (size_t w = 0; w < nw; ++w) per[w] = h[w * 8] / (h[w * 8 + 2] > 0 ? h[w * 8 + 2] : 1.0f), life[w] = h[w * 8 + 3];
+            std::sort(per.begin(), per.end());
+            std::sort(life.begin(), life.end());
+            printf("#  loop cycles per step, percentiles 0 10 25 50 75 90 100: ");
+            for (double q : {0.0, 0.10, 0.25, 0.50, 0.75, 0.90, 1.0}) printf("%.0f ", per[(size_t)(q * (nw - 1))]);
+            printf("\n#  tile cycles, the same percentiles: ");
+            for (double q : {0.0, 0.10, 0.25, 0.50, 0.75, 0.90, 1.0}) printf("%.0f ", life[(size_t)(q * (nw - 1))]);
+            printf("\n");
+        }
         if (a.causal) {   // per q tile of slab 0 (tiles are launched heaviest first: tile index = q_tiles - 1 - launch position)
             const size_t qt = (a.n + rows_per_wg - 1) / rows_per_wg;
             printf("# slab 0, per launch position: steps, loop cycles, inputs_landed, first_scores, tail, epilogue_issue, whole tile\n");

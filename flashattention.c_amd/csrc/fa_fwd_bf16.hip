@@ -592,6 +592,9 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
         case 32:
             if (variant == 50) return launch_bf16_x2(p, 32, causal, out_f32, 0, stream);
             if (variant == 52) return launch_bf16_x2(p, 32, causal, out_f32, 3, stream);
+#if FA_ABLATION
+            if (variant == 70) return launch_bf16_x2(p, 32, causal, out_f32, 40, stream);   // cycle-stamped NB = 2 kernel (non-causal)
+#endif
             if (variant == 24) return launch_bf16_pipelined(p, 32, 2, causal, out_f32, 0, stream);
             // lockstep/pipelined kernel for the non-causal case; its 256-row workgroups waste more of the causal
             // triangle than the 128-row phase-structured kernel recovers at D = 32

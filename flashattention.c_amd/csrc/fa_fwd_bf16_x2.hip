@@ -17,8 +17,19 @@ hipError_t launch_bf16_x2(const FwdParams& p, int d, int causal, int out_f32, in
         FwdParams q;
         dim3 grid, block;
         if (!xn_grid<2>(p, q, grid, block)) return hipErrorInvalidValue;
+        if (!causal) (void)xn_launch_order<64, 2>(q, grid, 0, true);
         if (causal) hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<64, 4, true, false, 2, 1024>), grid, block, 0, stream, q);
         else hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<64, 4, false, false, 2, 1024>), grid, block, 0, stream, q);
+        return hipGetLastError();
+    }
+#endif
+#if FA_ABLATION
+    if (mode == 40 && d == 32 && !causal) {   // ... at d = 32 (round 6: where a short-row launch spends its time)
+        FwdParams q;
+        dim3 grid, block;
+        if (!xn_grid<2>(p, q, grid, block)) return hipErrorInvalidValue;
+        (void)xn_launch_order<32, 2>(q, grid, 0, true);
+        hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<32, 4, false, false, 2, 1024>), grid, block, 0, stream, q);
         return hipGetLastError();
     }
 #endif
