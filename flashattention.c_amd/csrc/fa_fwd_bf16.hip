@@ -618,6 +618,7 @@ hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, i
                 case 31: return launch_bf16_x4(p, causal, out_f32, 1, stream);
                 case 42: return launch_bf16_x4(p, causal, out_f32, 3, stream);   // x4, rescaling mix only
 #if FA_ABLATION
+                case 53: return launch_bf16_x2(p, 64, causal, out_f32, 8, stream);    // eight waves per workgroup
                 case 70: return launch_bf16_x2(p, 64, causal, out_f32, 40, stream);   // cycle-stamped NB = 2 kernel
                 case 71: return launch_bf16_x2(p, 64, causal, out_f32, 41, stream);   // ... in the product's causal launch order, with a timeline
 #endif

@@ -44,6 +44,16 @@ hipError_t launch_bf16_x2(const FwdParams& p, int d, int causal, int out_f32, in
     }
 #endif
 #if FA_ABLATION
+    if (mode == 8 && !causal && !out_f32 && d == 64) {   // round 6: EIGHT waves (two per SIMD) sharing the K / V tiles of a 512-row workgroup
+        constexpr int BM = 8 * 32 * 2;
+        FwdParams q = p;
+        q.q_tiles = (p.n + BM - 1) / BM;
+        const dim3 grid((unsigned)(q.bh * q.q_tiles)), block(8 * kWave);
+        hipLaunchKernelGGL((fa_fwd_bf16_x2_kernel<64, 8, false, false, 2, 0, true>), grid, block, 0, stream, q);
+        return hipGetLastError();
+    }
+#endif
+#if FA_ABLATION
     if (d == 32 && mode == 1) return launch_x2<32, 1>(p, causal, out_f32, stream);
     if (d == 32 && mode == 3) return launch_x2<32, 2, false>(p, causal, out_f32, stream);
     if (d == 64 && mode == 1) return launch_x2<64, 1>(p, causal, out_f32, stream);
