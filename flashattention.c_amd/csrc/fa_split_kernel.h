@@ -362,17 +362,20 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     // rows 0, nk / 2, nk - 1 of the share, i.e. future tokens or padding for most causal tiles, and two outliers among rows no row of the
     // tile attends to could become the reference of everything it does attend to: ADVICE r05)
     const int kref_r1 = kv_end >> 1, kref_r2 = kv_end - 1;
-    auto kref_at = [&](int col0) {                    // median-of-three reference for columns col0 .. col0 + 3
-        f32x4 r = {0.0f, 0.0f, 0.0f, 0.0f};
+    // The three rows of each reference are REQUESTED here (threads 0 .. D/4 - 1 the key's columns, the next D/4 the value's) and reduced to their
+    // median further down, behind the requests for K(0) and Q: one memory round trip for all three instead of two in a row (round 6: the
+    // reference rows used to be waited for, written to LDS and synchronised on before anything else was asked for -- c2 spends two rounds of
+    // workgroups of 16 tiles each, and every round paid that latency; profiles/r06_exp13_prologue.txt)
+    f32x4 ref_a = {0.0f, 0.0f, 0.0f, 0.0f}, ref_b = ref_a, ref_c = ref_a;
+    auto request_reference_rows = [&]() {
         if constexpr (CENTER) {
-            const float* kf = (const float*)kg;
-            const f32x4 a = *(const f32x4*)(kf + col0);
-            const f32x4 b = *(const f32x4*)(kf + (int64_t)kref_r1 * p.kv_row_stride + col0);
-            const f32x4 c = *(const f32x4*)(kf + (int64_t)kref_r2 * p.kv_row_stride + col0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = (float)(_Float16)__builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(a[e], b[e], c[e]), -65504.0f, 65504.0f);
+            if (tid < D / 2) {
+                const float* src = (const float*)(tid < D / 4 ? (const void*)kg : (const void*)vg) + (tid % (D / 4)) * 4;
+                ref_a = *(const f32x4*)src;
+                ref_b = *(const f32x4*)(src + (int64_t)kref_r1 * p.kv_row_stride);
+                ref_c = *(const f32x4*)(src + (int64_t)kref_r2 * p.kv_row_stride);
+            }
         }
-        return r;   // (rounded to fp16 and clamped to its range: ANY fixed vector is a valid reference; see sub_f16x4)
     };
     // this thread's K pieces all sit in the same 8 columns (NT is a multiple of D / 8, or kGroups divides it)
     const int kref_col = ((tid % C::kGroups) % (D / 8)) * 8;
@@ -389,35 +392,8 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     // 1.6e-2 (profiles/r05_v_offset.txt) -- and vbar, the same median of three rows as for the keys, is added back to O in the epilogue.
     // A V that is CONSTANT over the share is all zeros after centring: zero accumulators, which the workgroup tells from underflow by looking at
     // its share of V (see the vote behind the first attempt).
-    auto vref_at = [&](int col0) {
-        f32x4 r = {0.0f, 0.0f, 0.0f, 0.0f};
-        if constexpr (CENTER) {
-            const float* vf = (const float*)vg;
-            const f32x4 a = *(const f32x4*)(vf + col0);
-            const f32x4 b = *(const f32x4*)(vf + (int64_t)kref_r1 * p.kv_row_stride + col0);
-            const f32x4 c = *(const f32x4*)(vf + (int64_t)kref_r2 * p.kv_row_stride + col0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = (float)(_Float16)__builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(a[e], b[e], c[e]), -65504.0f, 65504.0f);
-        }
-        return r;
-    };
     // this thread's V pieces all sit in the same 8 columns: (c16 * 2 + half) * 8 of its group index
     const int vref_col = ((((tid % C::kGroups) >> 3) % (D / 16)) * 2 + (((tid % C::kGroups) >> 2) & 1)) * 8;
-    if constexpr (CENTER) {
-        // both reference rows are computed ONCE per workgroup (threads 0 .. D/4 - 1 the key's, the next D/4 the value's: three row loads and
-        // four v_med3_f32 each) and live in LDS: the conversions take their eight columns from there (into registers, or -- eight-wave
-        // tiling -- in front of every use), the epilogue its add-back and the row constant of the log-sum-exp
-        if (tid < D / 4) *(f32x4*)&s_kref[tid * 4] = kref_at(tid * 4);
-        else if (tid < D / 2) *(f32x4*)&s_vref[(tid - D / 4) * 4] = vref_at((tid - D / 4) * 4);
-        __syncthreads();
-        if constexpr (KREF_REG) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                krefp[e] = pack_f16(s_kref[kref_col + 2 * e], s_kref[kref_col + 2 * e + 1]);
-                vrefp[e] = pack_f16(s_vref[vref_col + 2 * e], s_vref[vref_col + 2 * e + 1]);
-            }
-        }
-    }
     f32x4 kst[GPT][2], vst[GPT][2];
     auto load_tile = [&](int kv0) {
 #pragma unroll
@@ -468,6 +444,47 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
         }
     };
 
+    // loads of tile t through buffer descriptors: rows past the end of the slab come back as zeros from the bounds check,
+    // so there is no branch (a branch inside the loop body lets LLVM sink vector work out of its slot)
+    constexpr unsigned ES = sizeof(T);
+    const unsigned slab_bytes = ((unsigned)(nk - 1) * (unsigned)p.kv_row_stride + D) * ES;
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kg, 0, slab_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vg, 0, slab_bytes, 0x00020000);
+    const unsigned tile_step = (unsigned)kKvSplit * (unsigned)p.kv_row_stride * ES;
+    // key centring: rows past the share (the ragged tail of its last tile, the tiles the pipeline reads ahead of the end) are read as
+    // the share's LAST key instead of the descriptor's zeros -- they are masked or never used, but zeros would leave the centring as
+    // -kbar and raise the range guard's max |k| for nothing.  Offsets grow with the row for a fixed column: one add + one min per piece.
+    unsigned k_last[GPT];
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) k_last[i] = ((unsigned)(nk - 1) * (unsigned)p.kv_row_stride + (unsigned)kref_col) * ES;
+    auto load_k = [&](int t) {
+        const unsigned soff = (unsigned)t * tile_step;
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) {
+            if constexpr (CENTER) {
+                const unsigned off = min(g_ksrc[i] * ES + soff, k_last[i]);
+                kst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, off, 0, 0));
+                kst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, off + 16, 0, 0));
+            } else {
+                kst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, g_ksrc[i] * ES, soff, 0));
+                if constexpr (!IN_BF16)
+                    kst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, g_ksrc[i] * ES + 16, soff, 0));
+            }
+        }
+    };
+    auto load_v = [&](int t) {
+        const unsigned soff = (unsigned)t * tile_step;
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) {
+            vst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, g_vsrc[i] * ES, soff, 0));
+            if constexpr (!IN_BF16)
+                vst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, g_vsrc[i] * ES + 16, soff, 0));
+        }
+    };
+    // ---- everything the prologue needs from memory is requested before anything is waited for: the reference rows, K(0) (pipelined pass), Q
+    request_reference_rows();
+    if constexpr (PIPE) load_k(0);
+
     // ---- Q' fragments (B operand of S^T = K Q'^T), hi and lo: lane (lq, hi) holds Q'[q][16*ks + 8*hi .. +7]
     bf16x8 qh[QB][KS], ql[QB][KS];
     float qn2 = 0.0f;   // guard: largest squared 2-norm of Q' among this lane's rows (its half of each row; halves are added below)
@@ -495,6 +512,25 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
             split8x<QK16, true>(a, c, qh[qb][ks], ql[qb][ks]);
         }
         if constexpr (GUARD) qn2 = fmaxf(qn2, xhalf_sum(qs));
+    }
+    if constexpr (CENTER) {
+        // both reference rows are computed ONCE per workgroup (threads 0 .. D/4 - 1 the key's, the next D/4 the value's: three row loads and
+        // four v_med3_f32 each) and live in LDS: the conversions take their eight columns from there (into registers, or -- eight-wave
+        // tiling -- in front of every use), the epilogue its add-back and the row constant of the log-sum-exp
+        if (tid < D / 2) {   // (rounded to fp16 and clamped to its range: ANY fixed vector is a valid reference; see sub_f16x4)
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = (float)(_Float16)__builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(ref_a[e], ref_b[e], ref_c[e]), -65504.0f, 65504.0f);
+            *(f32x4*)&(tid < D / 4 ? s_kref : s_vref)[(tid % (D / 4)) * 4] = r;
+        }
+        __syncthreads();
+        if constexpr (KREF_REG) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                krefp[e] = pack_f16(s_kref[kref_col + 2 * e], s_kref[kref_col + 2 * e + 1]);
+                vrefp[e] = pack_f16(s_vref[vref_col + 2 * e], s_vref[vref_col + 2 * e + 1]);
+            }
+        }
     }
     // key centering: q'.kbar of this lane's row (exp2 domain), added back to the log-sum-exp in the epilogues -- with the operand the
     // matrix core sees (hi + lo, exact in fp32), accumulated in fp64: once per row and tile, and only when an lse is asked for
@@ -824,43 +860,6 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.0f;
         }
-        // loads of tile t through buffer descriptors: rows past the end of the slab come back as zeros from the bounds check,
-        // so there is no branch (a branch inside the loop body lets LLVM sink vector work out of its slot)
-        constexpr unsigned ES = sizeof(T);
-        const unsigned slab_bytes = ((unsigned)(nk - 1) * (unsigned)p.kv_row_stride + D) * ES;
-        const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kg, 0, slab_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vg, 0, slab_bytes, 0x00020000);
-        const unsigned tile_step = (unsigned)kKvSplit * (unsigned)p.kv_row_stride * ES;
-        // key centring: rows past the share (the ragged tail of its last tile, the tiles the pipeline reads ahead of the end) are read as
-        // the share's LAST key instead of the descriptor's zeros -- they are masked or never used, but zeros would leave the centring as
-        // -kbar and raise the range guard's max |k| for nothing.  Offsets grow with the row for a fixed column: one add + one min per piece.
-        unsigned k_last[GPT];
-#pragma unroll
-        for (int i = 0; i < GPT; ++i) k_last[i] = ((unsigned)(nk - 1) * (unsigned)p.kv_row_stride + (unsigned)kref_col) * ES;
-        auto load_k = [&](int t) {
-            const unsigned soff = (unsigned)t * tile_step;
-#pragma unroll
-            for (int i = 0; i < GPT; ++i) {
-                if constexpr (CENTER) {
-                    const unsigned off = min(g_ksrc[i] * ES + soff, k_last[i]);
-                    kst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, off, 0, 0));
-                    kst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, off + 16, 0, 0));
-                } else {
-                    kst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, g_ksrc[i] * ES, soff, 0));
-                    if constexpr (!IN_BF16)
-                        kst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, g_ksrc[i] * ES + 16, soff, 0));
-                }
-            }
-        };
-        auto load_v = [&](int t) {
-            const unsigned soff = (unsigned)t * tile_step;
-#pragma unroll
-            for (int i = 0; i < GPT; ++i) {
-                vst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, g_vsrc[i] * ES, soff, 0));
-                if constexpr (!IN_BF16)
-                    vst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, g_vsrc[i] * ES + 16, soff, 0));
-            }
-        };
         auto store_k = [&](char* stage) {
 #pragma unroll
             for (int i = 0; i < GPT; ++i) {
@@ -1003,16 +1002,15 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
         };
         auto needs_mask = [&](int kv0) { return (kv0 + kKvSplit > nk) || (CAUSAL && (kv0 + kKvSplit - 1 > q0l)); };
 
-        // ---- prologue: K(0) and K(1) staged, scores of tile 0 under way
-        load_k(0);
+        // ---- prologue: K(0) (requested at the top of the kernel) staged, K(1) in flight under the scores of tile 0
         store_k(smem);
         load_k(1);
-        store_k(smem + C::kStageBytes);
         __syncthreads();
         f32x16 sa[QB], sb[QB];
         bf16x8 pha[QB][2], pla[QB][2], phb[QB][2], plb[QB][2];
         qk(smem, sa);
-        __syncthreads();   // iteration 0 overwrites K(0) with K(2): every wave must have read its K(0) fragments first
+        store_k(smem + C::kStageBytes);
+        __syncthreads();   // K(1) visible; and iteration 0 overwrites K(0) with K(2): every wave must have read its K(0) fragments first
 
         // Iteration j, tile j in stage STG = j & 1.  In: scores `cur` of tile j, P `pprev` of tile j-1.  Out: scores `next`
         // of tile j+1, P `pcur` of tile j.  FIRST has no P.V, LAST no K.Q^T; only a LAST or causal iteration can need masks.

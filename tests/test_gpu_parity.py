@@ -329,6 +329,27 @@ def _tiling_variant_case(d, variant, causal):
     check(fa.forward(qd, kd, vd, causal, scale=0.125, kernel=f"mfma:{variant}"), ref, bf16_tol(0.125, False))
 
 
+@pytest.mark.parametrize("bh,n,d,kernel", [(16, 8192, 32, "auto"), (24, 4096, 32, "auto"), (20, 5000, 32, "auto"), (64, 2048, 32, "auto"),
+                                          (16, 8192, 64, "mfma:50"), (12, 8192, 64, "mfma:50"), (40, 4096, 32, "auto"), (16, 8192, 32, "pb2")])
+def test_resident_pairs_taking_turns_at_the_issue_priority(bh, n, d, kernel):
+    """Round 6: a non-causal launch of the NB = 2 kernels whose whole grid is resident, two workgroups per CU (256 < workgroups <= 512, rows of
+    2048 keys and more), lets each pair share the issue priority by the clock (s_setprio; xn_launch_order / xn_tile).  Scheduling only: every
+    slab against the rung-0 kernel on the device, both output types, two launches bit-identical; (40, 4096) is a launch of several rounds
+    (no turns) through the same code."""
+    g = torch.Generator(device=dev()).manual_seed(bh * 131 + n)
+    q, k, v = (torch.randn(bh, n, d, device=dev(), generator=g).to(torch.bfloat16) for _ in range(3))
+    ref = fa.forward(q, k, v, False, kernel="naive", out_dtype=torch.float32)
+    o32 = fa.forward(q, k, v, False, kernel=kernel, out_dtype=torch.float32)
+    tol = 2e-4 if kernel == "pb2" else 1.2e-2
+    e = float((o32 - ref).abs().max())
+    assert e < tol and not torch.isnan(o32).any(), (bh, n, d, e)
+    assert torch.equal(o32, fa.forward(q, k, v, False, kernel=kernel, out_dtype=torch.float32))
+    if kernel != "pb2":
+        ob = fa.forward(q, k, v, False, kernel=kernel)
+        assert float((ob.float() - ref).abs().max()) < 2.5e-2
+    assert fa.stats()["tiles_redone"] >= 0
+
+
 @pytest.mark.parametrize("d,variant", [(64, 0), (64, 1), (64, 7), (64, 30), (64, 50), (128, 50), (128, 10), (32, 50), (32, 1)])
 @pytest.mark.parametrize("causal", [False, True])
 def test_rescale_inside_the_pipelined_loop(d, variant, causal):
