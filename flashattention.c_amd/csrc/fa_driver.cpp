@@ -514,12 +514,15 @@ int main(int argc, char** argv)
         // cycle stamps around the fast loop of the NB = 4 kernel (ablation library; variants 60..68 write 4 floats per wave to the lse buffer)
         float* lse = nullptr;
         HIP_OK(hipMalloc(&lse, (size_t)a.bh * a.n * 4));
+        // (--dtype f32: the fp32 default's pipelined pass, a library built with -DFA_SPLIT_STAMPS=1; --variant = its tiling, 3: 128-row, 4: 256-row workgroups)
+        const bool f32 = a.dtype == "f32" || a.dtype == "f32s";
+        const int p4_dtype = f32 ? FA_DTYPE_F32 : FA_DTYPE_BF16, p4_kernel = (f32 ? FA_KERNEL_SPLIT : FA_KERNEL_MFMA) | (a.variant << 8);
         for (int rep = 0; rep < 30; ++rep)   // warm clocks
-            fa_ok(fa_forward_ex(b.q, b.k, b.v, b.o, lse, a.bh, a.n, a.d, a.scale, a.causal, FA_DTYPE_BF16, FA_KERNEL_MFMA | (a.variant << 8), nullptr), "prof4");
+            fa_ok(fa_forward_ex(b.q, b.k, b.v, b.o, lse, a.bh, a.n, a.d, a.scale, a.causal, p4_dtype, p4_kernel, nullptr), "prof4");
         HIP_OK(hipMemset(lse, 0, (size_t)a.bh * a.n * 4));
-        fa_ok(fa_forward_ex(b.q, b.k, b.v, b.o, lse, a.bh, a.n, a.d, a.scale, a.causal, FA_DTYPE_BF16, FA_KERNEL_MFMA | (a.variant << 8), nullptr), "prof4");
+        fa_ok(fa_forward_ex(b.q, b.k, b.v, b.o, lse, a.bh, a.n, a.d, a.scale, a.causal, p4_dtype, p4_kernel, nullptr), "prof4");
         HIP_OK(hipDeviceSynchronize());
-        const int rows_per_wg = a.variant == 70 ? 256 : 512;
+        const int rows_per_wg = f32 ? (a.variant == 3 ? 128 : 256) : a.variant == 70 ? 256 : 512;
         const size_t nw = (size_t)a.bh * ((a.n + rows_per_wg - 1) / rows_per_wg) * 4;
         std::vector<float> h(nw * 8);
         HIP_OK(hipMemcpy(h.data(), lse, h.size() * 4, hipMemcpyDeviceToHost));

@@ -57,6 +57,9 @@
 #ifndef FA_SPLIT_REF
 #define FA_SPLIT_REF 1   // 0: experiment switch -- the fast pass runs reference-free (p = exp2(s), round 2)
 #endif
+#ifndef FA_SPLIT_STAMPS
+#define FA_SPLIT_STAMPS 0   // 1: experiment switch (ablation builds) -- cycle stamps of the pipelined pass into the lse buffer, 8 floats per wave
+#endif
 #ifndef FA_SPLIT_CENTER
 #define FA_SPLIT_CENTER 1  // 0: experiment switch -- keys are split as they come (rounds 1-4) instead of relative to a reference key
 #endif
@@ -281,6 +284,8 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     __shared__ unsigned s_kmax;   // range guard: max |k| over the keys this workgroup reads, as the bits of a non-negative float
 
     if (flag_says_skip(p)) return;   // conditional fallback of a launch chain (bf16 tensors behind the fp16-P kernel)
+    unsigned long long st_in = 0, st_req = 0, st_loop0 = 0, st_loop1 = 0;
+    if constexpr (FA_SPLIT_STAMPS != 0) st_in = __builtin_readcyclecounter();
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     // ---- Q' fragments (B operand of S^T = K Q'^T), hi and lo: lane (lq, hi) holds Q'[q][16*ks + 8*hi .. +7]
     bf16x8 qh[QB][KS], ql[QB][KS];
     float qn2 = 0.0f;   // guard: largest squared 2-norm of Q' among this lane's rows (its half of each row; halves are added below)
-    const bool want_crow = CENTER && p.lse != nullptr;   // (uniform; key-split launches always carry an lse)
+    const bool want_crow = CENTER && p.lse != nullptr && FA_SPLIT_STAMPS == 0;   // (uniform; key-split launches always carry an lse)
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         float qs = 0.0f;
@@ -809,7 +814,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                         if constexpr (CENTER) pk += *(const f32x4*)&s_vref[db * 32 + 8 * g + 4 * hi];   // value centering: the reference row back in
                         store4(p, o_off + db * 32 + 8 * g, pk);
                     }
-                if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = ((m[qb] + __builtin_amdgcn_logf(lt)) + crow) * kLn2;
+                if (FA_SPLIT_STAMPS == 0 && p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = ((m[qb] + __builtin_amdgcn_logf(lt)) + crow) * kLn2;
                 if (OPT) ok = ok && (lt < kSplitLimit) && (mag < INFINITY);   // false for NaN as well
                 if (GUARD) saw_nan = saw_nan || (lt != lt);   // (a NaN row SUM: NaN logits -- an overflowed window gives +inf, which the redo handles)
             }
@@ -1002,6 +1007,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
         };
         auto needs_mask = [&](int kv0) { return (kv0 + kKvSplit > nk) || (CAUSAL && (kv0 + kKvSplit - 1 > q0l)); };
 
+        if constexpr (FA_SPLIT_STAMPS != 0) st_req = __builtin_readcyclecounter();   // Q converted, references in registers (everything requested has landed)
         // ---- prologue: K(0) (requested at the top of the kernel) staged, K(1) in flight under the scores of tile 0
         store_k(smem);
         load_k(1);
@@ -1011,6 +1017,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
         qk(smem, sa);
         store_k(smem + C::kStageBytes);
         __syncthreads();   // K(1) visible; and iteration 0 overwrites K(0) with K(2): every wave must have read its K(0) fragments first
+        if constexpr (FA_SPLIT_STAMPS != 0) st_loop0 = __builtin_readcyclecounter();
 
         // Iteration j, tile j in stage STG = j & 1.  In: scores `cur` of tile j, P `pprev` of tile j-1.  Out: scores `next`
         // of tile j+1, P `pcur` of tile j.  FIRST has no P.V, LAST no K.Q^T; only a LAST or causal iteration can need masks.
@@ -1192,6 +1199,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
 
         // ================= epilogue: O / l, store =================
         mfma_drain();  // the last P.V MFMAs may still be in flight
+        if constexpr (FA_SPLIT_STAMPS != 0) st_loop1 = __builtin_readcyclecounter();
         float crows[QB];
         for_each_index([&](auto qbc) { crows[decltype(qbc)::value] = crow_of(qbc); }, std::make_integer_sequence<int, QB>{});
         bool ok = true;
@@ -1217,7 +1225,7 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
                         if constexpr (CENTER) pk += *(const f32x4*)&s_vref[db * 32 + 8 * g + 4 * hi];   // value centering: the reference row back in
                         store4(p, o_off + db * 32 + 8 * g, pk);
                     }
-                if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = ((mref[qb] + __builtin_amdgcn_logf(lt)) + crow) * kLn2;
+                if (FA_SPLIT_STAMPS == 0 && p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = ((mref[qb] + __builtin_amdgcn_logf(lt)) + crow) * kLn2;
                 // lt: the row's own reference term 2^-B is in the sum, so a healthy row sum never falls below 2^-(B + 1) (B = 101 for n <= 256:
                 // round 3 tested against a fixed 2^-100 there and redid every tile whose reference key held most of a row's mass);
                 // mag * lt = the sum of the unnormalised accumulators: tiny or zero means the products p v of the terms that matter
@@ -1293,6 +1301,21 @@ __global__ __launch_bounds__(NWAVES* kWave, MINBLOCKS) void fa_fwd_f32_split_ker
     if (redo) {
         run_tile(std::false_type{});
         count_cliff(p, 0);   // (behind the redo: nothing is live here -- in front of it the causal 128-row tilings spilled 68 bytes)
+    }
+    if constexpr (FA_SPLIT_STAMPS != 0 && PIPE) {   // fa_driver_ablation --mode prof4 --dtype f32: the layout of the bf16 kernels' stamps
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st_out = __builtin_readcyclecounter();
+        if (lane == 0 && p.lse != nullptr) {
+            float* dst = p.lse + ((int64_t)blockIdx.x * NWAVES + wave) * 8;
+            dst[0] = (float)(st_loop1 - st_loop0);   // the tiles of the pipelined pass
+            dst[1] = 0.0f;
+            dst[2] = (float)nt;
+            dst[3] = (float)(st_out - st_in);
+            dst[4] = (float)(st_req - st_in);        // references, Q', K(0) requested and landed; Q' converted
+            dst[5] = (float)(st_loop0 - st_req);     // K(0), K(1) converted and staged, scores of tile 0
+            dst[6] = 0.0f;
+            dst[7] = (float)(st_out - st_loop1);     // O / l, stores, verification votes, range guard
+        }
     }
 }
 
