@@ -692,6 +692,19 @@ def c4_side_measurements(fa, _cabi, q, k, v, causal, args, device):
             del q2, k2, v2, o2
         except Exception as e:  # pragma: no cover - informational only
             ex[f"f32_d{d2}"] = {"error": repr(e)}
+        try:   # the same call on bf16 tensors: the same kernel, the tensors widened on load (until the end of round 6: the rung-0 kernel, 75x slower)
+            q2, k2, v2 = make_inputs(16, 8192, d2, "bf16", device, seed=8)
+            o2 = torch.empty_like(q2)
+            st2 = time_stats(fa, (q2, k2, v2), reps=3, causal=False, scale=args.scale, kernel="auto", warmup=4, iters=3, out=o2)
+            chk2 = validate_output(fa, q2, k2, v2, o2, False, args.scale, TOLERANCE["bf16_p_bf16_out"], f"bf16_d{d2}")
+            tf2 = fwd_flop(16, 8192, d2, False) / (st2["median"] * 1e-3) / 1e12
+            ex[f"bf16_d{d2}"] = {"workload": f"BH=16 d={d2} N=8192 bf16", "ms": round(st2["median"], 4), "tflops": round(tf2, 2),
+                                 "frac_f32_mfma_peak": round(tf2 / PEAK_TFLOPS["f32"], 4), "max_abs_err": chk2["max_abs_err"], "tolerance": chk2["tolerance"],
+                                 "kernel": _cabi.lib().fa_kernel_name_for(_cabi.FA_DTYPE_BF16, d2, 0, 16, 8192).decode(),
+                                 "what": "bf16 tensors at a head dim outside {32, 64, 128}: widened on load into the exact kernel's fp32 LDS images, fp32 arithmetic, bf16 output"}
+            del q2, k2, v2, o2
+        except Exception as e:  # pragma: no cover - informational only
+            ex[f"bf16_d{d2}"] = {"error": repr(e)}
     # llm.c harness size (attention_forward.cu:1217-1220): B=6 T=4096 C=768 NH=12, packed (B, T, 3C) fp32, causal, 1/sqrt(hs); mean of
     # 100 launches like benchmark_kernel (:1279-1288)
     try:

@@ -44,7 +44,7 @@ LIB_SOURCES = ["fa_fwd_bf16_x4_pb2_f32out.hip", "fa_fwd_bf16_x4_pb2_bf16out.hip"
                "fa_fwd_bf16_pipelined.hip", "fa_split_f32_d64.hip", "fa_split_f32_d128.hip", "fa_split_f32_d32.hip",
                "fa_split_bf16_d64.hip", "fa_split_bf16_d128.hip", "fa_split_bf16_d32.hip", "fa_fwd_bf16.hip", "fa_combine.hip",
                "fa_fwd_bf16_x2_pb2_d32_f32out.hip", "fa_fwd_bf16_x2_pb2_d32_bf16out.hip",
-               "fa_fwd_f32_wide.hip", "fa_fwd_f32.hip", "fa_fwd_f32_split.hip", "fa_fwd_bf16_split.hip", "fa_naive.hip", *HOST_SOURCES]
+               "fa_fwd_f32_wide.hip", "fa_fwd_f32_wide_bf16.hip", "fa_fwd_f32.hip", "fa_fwd_f32_split.hip", "fa_fwd_bf16_split.hip", "fa_naive.hip", *HOST_SOURCES]
 # csrc/experiments/: only in libflashattn_amd_ablation.so -- timing-only instantiations (garbage results), superseded kernel generations
 # and the fp16-P families the round-4 accurate path (P as two bf16 terms) replaced (correct, tested through fa_driver_ablation)
 ABLATION_SOURCES = ["experiments/" + f for f in (

@@ -181,7 +181,7 @@ const char* fa_kernel_name_for(int32_t dtype, int32_t d, int32_t causal, int64_t
 {
     if (bh < 1 || n < 1 || !head_dim_naive(d)) return nullptr;
     if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_BF16_OUT_F32) return nullptr;
-    if (!head_dim_supported(d)) return (dtype == FA_DTYPE_F32 && head_dim_exact_f32(d)) ? "fa_fwd_f32_kernel" : "fa_naive_f32_kernel";
+    if (!head_dim_supported(d)) return head_dim_exact_f32(d) ? "fa_fwd_f32_kernel" : "fa_naive_f32_kernel";
     if (dtype == FA_DTYPE_F32) {
         if (f32_auto_is_exact()) return "fa_fwd_f32_kernel";
         return "fa_fwd_f32_split_kernel";

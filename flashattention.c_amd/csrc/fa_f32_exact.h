@@ -66,11 +66,31 @@ __device__ __forceinline__ void issue_kv_tile_f32(const float* __restrict__ kg, 
 // log-sum-exp (natural log) at p.lse[slab * n + row].  Workgroup-uniform control flow (barriers inside).
 // QREG = false (the in-kernel fallback, a cold path inside a kernel that is register-bound elsewhere): the Q fragments are re-read from
 // global memory (L2) in every tile instead of living in D / 2 registers.
-template <int D, int NWAVES, bool CAUSAL, bool QREG = true>
-__device__ __forceinline__ void f32_exact_rows(const FwdParams& p, char* smem, const float* qg, const float* kg, const float* vg, int64_t o_slab,
+// bf16 tensors (round 6: head dims 96 ... 256 of bf16 tensors ran on the rung-0 kernel, 75x slower than the same call on fp32 tensors): TIN = __bf16.
+// The arithmetic and the LDS images are the fp32 kernel's; the tiles come through registers (four bf16 values -> one 16-byte piece of the
+// fp32 image: a shift or a mask each) instead of by LDS-DMA, Q is widened on load, FwdParams::o_is_bf16 rounds the normalised output once.
+__device__ __forceinline__ f32x4 widen_bf16x4(const u32x2 v)
+{
+    f32x4 r;
+    r[0] = __uint_as_float(v[0] << 16);
+    r[1] = __uint_as_float(v[0] & 0xffff0000u);
+    r[2] = __uint_as_float(v[1] << 16);
+    r[3] = __uint_as_float(v[1] & 0xffff0000u);
+    return r;
+}
+template <class TIN>
+__device__ __forceinline__ f32x4 load_f32x4(const TIN* src)
+{
+    if constexpr (sizeof(TIN) == 4) return *(const f32x4*)src;
+    else return widen_bf16x4(*(const u32x2*)src);
+}
+
+template <int D, int NWAVES, bool CAUSAL, bool QREG = true, class TIN = float>
+__device__ __forceinline__ void f32_exact_rows(const FwdParams& p, char* smem, const TIN* qg, const TIN* kg, const TIN* vg, int64_t o_slab,
                                                int slab, int q0, int kbeg, int nk, int kv_end, int wave, int lane)
 {
     using C = F32Cfg<D, NWAVES>;
+    constexpr bool IN_BF16 = sizeof(TIN) == 2;
     constexpr int G = D / 8;    // ds_read_b128 groups per key row half (4 floats each)
     constexpr int DB = D / 32;  // 32-wide head-dim blocks of O^T
     const int lq = lane & 31, hi = lane >> 5;
@@ -78,15 +98,41 @@ __device__ __forceinline__ void f32_exact_rows(const FwdParams& p, char* smem, c
     const int q0l = q0 - kbeg;  // this wave's first row in local key coordinates
     const int nt = (kv_end + kKvBlkF32 - 1) / kKvBlkF32;
 
-    issue_kv_tile_f32<D, NWAVES>(kg, vg, 0, nk, p.kv_row_stride, smem, wave, lane);
+    // bf16 tensors: this thread's 16-byte pieces of the two fp32 images of a tile, as the four bf16 values they are widened from.  Up to d = 160
+    // they are requested at the top of the previous tile and held across it; above, the registers are the output accumulators' and Q's (472 -
+    // 506 of 512 at d = 256): requested behind the previous tile's last product, their latency in the open.
+    constexpr int NP = IN_BF16 ? C::kChunksPerWave : 1;
+    constexpr bool HOLD = D <= 160;
+    u32x2 kreg[NP], vreg[NP];
+    auto request_tile = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int off = (wave + i * NWAVES) * 1024 + lane * 16;
+            const int row = off / C::kRowBytes, phys = (off % C::kRowBytes) / 16;
+            const int grow = min(kv0 + row, nk - 1);
+            kreg[i] = *(const u32x2*)(kg + (int64_t)grow * p.kv_row_stride + (phys ^ k_swizzle_f32<D>(row)) * 4);
+            vreg[i] = *(const u32x2*)(vg + (int64_t)grow * p.kv_row_stride + phys * 4);
+        }
+    };
+    auto stage_tile = [&](char* stage) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int off = (wave + i * NWAVES) * 1024 + lane * 16;
+            *(f32x4*)(stage + off) = widen_bf16x4(kreg[i]);
+            *(f32x4*)(stage + C::kTileBytes + off) = widen_bf16x4(vreg[i]);
+        }
+    };
+    if constexpr (IN_BF16) request_tile(0);
+    else issue_kv_tile_f32<D, NWAVES>((const float*)kg, (const float*)vg, 0, nk, p.kv_row_stride, smem, wave, lane);
 
     // Q fragments: lane (lq, hi) holds Q[q][8g + 4hi .. +3]; MFMA #(4g+e) uses element e
     f32x4 qf[QREG ? G : 1];
-    const float* qr = qg + (int64_t)min(q0 + lq, n - 1) * p.q_row_stride + hi * 4;
+    const TIN* qr = qg + (int64_t)min(q0 + lq, n - 1) * p.q_row_stride + hi * 4;
     if constexpr (QREG) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) qf[g] = *(const f32x4*)(qr + g * 8) * p.scale_log2e;
+        for (int g = 0; g < G; ++g) qf[g] = load_f32x4(qr + g * 8) * p.scale_log2e;
     }
+    if constexpr (IN_BF16) stage_tile(smem);
     // Q is pre-multiplied by scale*log2(e) (one fp32 rounding per element, once per workgroup), so the MFMA chain
     // delivers scores directly in the exp2 domain and p = exp2(s - m) is exact at the row maximum for any magnitude.
 
@@ -102,13 +148,17 @@ __device__ __forceinline__ void f32_exact_rows(const FwdParams& p, char* smem, c
     const int v_lane_off = (4 * hi) * C::kRowBytes + lq * 4;
 
     for (int j = 0; j < nt; ++j) {
-        wait_lds_dma();   // own LDS-DMA pieces of tile j have landed (hipcc does not insert this wait itself) ...
+        if constexpr (!IN_BF16) wait_lds_dma();   // own LDS-DMA pieces of tile j have landed (hipcc does not insert this wait itself) ...
         __syncthreads();  // ... and so have everybody else's; all waves are done with the stage tile j+1 overwrites
-        if (j + 1 < nt)
-            issue_kv_tile_f32<D, NWAVES>(kg, vg, (j + 1) * kKvBlkF32, nk, p.kv_row_stride,
-                                         smem + ((j + 1) & 1) * C::kStageBytes, wave, lane);
+        if constexpr (IN_BF16) {
+            if (HOLD && j + 1 < nt) request_tile((j + 1) * kKvBlkF32);
+        } else {
+            if (j + 1 < nt)
+                issue_kv_tile_f32<D, NWAVES>((const float*)kg, (const float*)vg, (j + 1) * kKvBlkF32, nk, p.kv_row_stride,
+                                             smem + ((j + 1) & 1) * C::kStageBytes, wave, lane);
+        }
         const int kv0 = j * kKvBlkF32;
-        if (CAUSAL && kv0 > q0l + 31) continue;
+        if (!(CAUSAL && kv0 > q0l + 31)) {   // (else: tile above this wave's rows -- the other waves of the workgroup still need the next one staged)
 
         const char* ks_lds = smem + (j & 1) * C::kStageBytes;
         const char* vs_lds = ks_lds + C::kTileBytes;
@@ -172,6 +222,14 @@ __device__ __forceinline__ void f32_exact_rows(const FwdParams& p, char* smem, c
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, s[r], o[db], 0, 0, 0);
             }
         }
+
+        }   // tile not above the wave's rows
+        if constexpr (IN_BF16) {
+            if (j + 1 < nt) {
+                if constexpr (!HOLD) request_tile((j + 1) * kKvBlkF32);
+                stage_tile(smem + ((j + 1) & 1) * C::kStageBytes);
+            }
+        }
     }
 
     // ---- epilogue
@@ -180,7 +238,7 @@ __device__ __forceinline__ void f32_exact_rows(const FwdParams& p, char* smem, c
     const float inv = 1.0f / lt;
     const int qi = q0 + lq;
     if (qi < n) {
-        float* orow = (float*)p.o + o_slab + (int64_t)qi * p.o_row_stride + 4 * hi;
+        const int64_t o_off = o_slab + (int64_t)qi * p.o_row_stride + 4 * hi;
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -188,7 +246,14 @@ __device__ __forceinline__ void f32_exact_rows(const FwdParams& p, char* smem, c
                 f32x4 pk;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) pk[e] = o[db][4 * g + e] * inv;
-                *(f32x4*)(orow + db * 32 + 8 * g) = pk;
+                if (IN_BF16 && p.o_is_bf16) {   // (uniform; bf16 tensors only: one kernel per head dim serves both output types)
+                    bf16x4 pb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pb[e] = (__bf16)pk[e];
+                    *(bf16x4*)((__bf16*)p.o + o_off + db * 32 + 8 * g) = pb;
+                } else {
+                    *(f32x4*)((float*)p.o + o_off + db * 32 + 8 * g) = pk;
+                }
             }
         if (p.lse != nullptr && hi == 0) p.lse[(int64_t)slab * n + qi] = (m + __builtin_amdgcn_logf(lt)) * kLn2;
     }

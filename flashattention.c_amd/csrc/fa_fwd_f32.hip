@@ -4,14 +4,15 @@
 
 namespace fa {
 
-hipError_t launch_fwd_f32(const FwdParams& p, int d, int causal, int variant, hipStream_t stream)
+hipError_t launch_fwd_f32(const FwdParams& p, int d, int causal, int variant, hipStream_t stream, int io)
 {
     if (variant < 0 || variant > 2 || (variant == 2 && !causal)) return hipErrorInvalidValue;   // 1 / 2: one tile per workgroup / paired tiles
+    if (io != 0) return launch_fwd_f32_wide(p, d, causal, variant, io, stream);                  // bf16 tensors: the wide head dims only
     switch (d) {
         case 32: return launch_cfg_f32<32, 4, 4>(p, causal, variant, stream);
         case 64: return launch_cfg_f32<64, 4, 4, 3>(p, causal, variant, stream);
         case 128: return launch_cfg_f32<128, 4, 2>(p, causal, variant, stream);
-        default: return launch_fwd_f32_wide(p, d, causal, variant, stream);
+        default: return launch_fwd_f32_wide(p, d, causal, variant, 0, stream);
     }
 }
 

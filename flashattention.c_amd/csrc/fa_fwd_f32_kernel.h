@@ -1,5 +1,6 @@
 // fa_fwd_f32_kernel.h -- fused flash-attention forward in exact fp32 (the reference's dtype) for gfx950: the kernel and its launcher,
-// instantiated per head dim in fa_fwd_f32.hip (32, 64, 128) and fa_fwd_f32_wide.hip (96, 160, 192, 224, 256).
+// instantiated per head dim in fa_fwd_f32.hip (32, 64, 128), fa_fwd_f32_wide.hip (96, 160, 192, 224, 256) and, for bf16 tensors at those five,
+// fa_fwd_f32_wide_bf16.hip.
 //
 // Replaces flash_tiled_coarse{,_causal} (/root/reference/src/flashattention.cu:139-579) for fp32 tensors.  Both
 // contractions run on v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate, bit-for-bit a k-ordered fmaf chain, at the
@@ -28,7 +29,8 @@ namespace fa {
 // non-causal launch reads 0.85, all of it load imbalance (the masked diagonal costs ~1 %).
 // Key shares (FwdParams::n_kv > 0, round 5): as in the split kernel -- the "head" index of a slab is the share, kv_head_stride carries the
 // key offset, the kernel works in the share's local key coordinates and leaves a normalised partial + its log-sum-exp for the combine.
-template <int D, int NWAVES, bool CAUSAL, int MINWAVES, bool PAIRED>
+// TIN = __bf16 (round 6, the wide head dims only): bf16 tensors widened on load, fp32 arithmetic; FwdParams::o_is_bf16: the output rounded once.
+template <int D, int NWAVES, bool CAUSAL, int MINWAVES, bool PAIRED, class TIN = float>
 __global__ __launch_bounds__(NWAVES* kWave, MINWAVES) void fa_fwd_f32_kernel(FwdParams p)
 {
     using C = F32Cfg<D, NWAVES>;
@@ -73,9 +75,9 @@ __global__ __launch_bounds__(NWAVES* kWave, MINWAVES) void fa_fwd_f32_kernel(Fwd
         const int t = idx % tiles;
         const int slab = unit * S + idx / tiles;
         const int b = slab / p.heads, h = slab % p.heads;
-        const float* qg = (const float*)p.q + b * p.q_batch_stride + h * p.q_head_stride;
-        const float* kg = (const float*)p.k + b * p.kv_batch_stride + h * p.kv_head_stride;
-        const float* vg = (const float*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
+        const TIN* qg = (const TIN*)p.q + b * p.q_batch_stride + h * p.q_head_stride;
+        const TIN* kg = (const TIN*)p.k + b * p.kv_batch_stride + h * p.kv_head_stride;
+        const TIN* vg = (const TIN*)p.v + b * p.kv_batch_stride + h * p.kv_head_stride;
         const int64_t o_slab = b * p.o_batch_stride + h * p.o_head_stride;
         const int kbeg = p.n_kv > 0 ? h * p.n_kv : 0;
         const int nk = p.n_kv > 0 ? min(p.n_kv, p.n_kv_total - kbeg) : n;
@@ -90,14 +92,14 @@ __global__ __launch_bounds__(NWAVES* kWave, MINWAVES) void fa_fwd_f32_kernel(Fwd
         // (Q fragments in registers at every head dim: at 256 they take 128 beside 128 of output accumulators -- one wave owns its SIMD's 512 there.
         //  The first form of the wide instantiations re-read them from L2 in every tile: 32 exposed loads per tile, d = 256 at 0.56 of the fp32
         //  peak instead of 0.80: profiles/r06_exp5_exact_alpha_skip.txt)
-        f32_exact_rows<D, NWAVES, CAUSAL, true>(p, smem, qg, kg, vg, o_slab, slab, q0, kbeg, nk, kv_end, wave, lane);
+        f32_exact_rows<D, NWAVES, CAUSAL, true, TIN>(p, smem, qg, kg, vg, o_slab, slab, q0, kbeg, nk, kv_end, wave, lane);
     }
 }
 
 // MINWAVES_C: the occupancy hint of the causal instantiation (the mask code needs a few registers more: at 4 waves per SIMD, i.e.
 // 128 registers, the D = 64 causal kernel spilled 56 bytes per lane)
 // order: 0 = the product choice, 1 = one tile per workgroup, 2 = paired tiles (causal only)
-template <int D, int NWAVES, int MINWAVES, int MINWAVES_C = MINWAVES>
+template <int D, int NWAVES, int MINWAVES, int MINWAVES_C = MINWAVES, class TIN = float>
 static hipError_t launch_cfg_f32(const FwdParams& p0, int causal, int order, hipStream_t stream)
 {
     FwdParams p = p0;
@@ -125,11 +127,11 @@ static hipError_t launch_cfg_f32(const FwdParams& p0, int causal, int order, hip
     // 16 x 8192 d = 32 0.848 -> 0.630, 16 x 8192 d = 64 1.338 -> 1.308, 128 x 1024 0.248 -> 0.236, d = 128 2.45 -> 2.47.
     p.alt_order = (causal && !paired) ? 1 : 0;
     if (paired)
-        hipLaunchKernelGGL((fa_fwd_f32_kernel<D, NWAVES, true, MINWAVES_C, true>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((fa_fwd_f32_kernel<D, NWAVES, true, MINWAVES_C, true, TIN>), grid, block, 0, stream, p);
     else if (causal)
-        hipLaunchKernelGGL((fa_fwd_f32_kernel<D, NWAVES, true, MINWAVES_C, false>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((fa_fwd_f32_kernel<D, NWAVES, true, MINWAVES_C, false, TIN>), grid, block, 0, stream, p);
     else
-        hipLaunchKernelGGL((fa_fwd_f32_kernel<D, NWAVES, false, MINWAVES, false>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((fa_fwd_f32_kernel<D, NWAVES, false, MINWAVES, false, TIN>), grid, block, 0, stream, p);
     return hipGetLastError();
 }
 

@@ -7,8 +7,10 @@
 
 namespace fa {
 
-hipError_t launch_fwd_f32_wide(const FwdParams& p, int d, int causal, int variant, hipStream_t stream)
+// io: 0 = fp32 tensors; 1 = bf16 tensors, bf16 output; 2 = bf16 tensors, fp32 output (also the partials of a key-split launch)
+hipError_t launch_fwd_f32_wide(const FwdParams& p, int d, int causal, int variant, int io, hipStream_t stream)
 {
+    if (io != 0) return launch_fwd_f32_wide_bf16(p, d, causal, variant, io == 1 ? 1 : 0, stream);
     switch (d) {
         case 96: return launch_cfg_f32<96, 4, 2>(p, causal, variant, stream);
         case 160: return launch_cfg_f32<160, 4, 1>(p, causal, variant, stream);

@@ -8,8 +8,10 @@ namespace fa {
 // Each launcher enqueues one forward on `stream` and returns hipGetLastError().
 // `variant` selects among co-compiled tilings of the same kernel (0 = default); used by the ablation driver.
 hipError_t launch_naive(const FwdParams& p, int d, int causal, int dtype, hipStream_t stream);   // rung 0: fp32 arithmetic, fp32 or bf16 tensors, any d <= 256
-hipError_t launch_fwd_f32(const FwdParams& p, int d, int causal, int variant, hipStream_t stream);        // exact fp32: d in {32, 64, 128} + the wide set
-hipError_t launch_fwd_f32_wide(const FwdParams& p, int d, int causal, int variant, hipStream_t stream);   // d in {96, 160, 192, 224, 256}
+hipError_t launch_fwd_f32(const FwdParams& p, int d, int causal, int variant, hipStream_t stream, int io = 0);        // exact fp32: d in {32, 64, 128} + the wide set
+hipError_t launch_fwd_f32_wide(const FwdParams& p, int d, int causal, int variant, int io, hipStream_t stream);   // d in {96, 160, 192, 224, 256}
+// ... on bf16 tensors (io = 1: bf16 output, 2: fp32 output / key-share partials): fa_fwd_f32_wide_bf16.hip
+hipError_t launch_fwd_f32_wide_bf16(const FwdParams& p, int d, int causal, int variant, int out_bf16, hipStream_t stream);
 hipError_t launch_fwd_bf16(const FwdParams& p, int d, int causal, int out_f32, int variant, hipStream_t stream);
 // fp32 tensors on the bf16 matrix pipe (three products of two-term bf16 splits); called by launch_fwd_f32
 hipError_t launch_f32_split(const FwdParams& p, int d, int causal, int mode, hipStream_t stream);

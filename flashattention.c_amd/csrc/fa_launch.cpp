@@ -53,7 +53,9 @@ hipError_t launch_bf16_keysplit(const fa::FwdParams& p0, int32_t d, int32_t caus
 
 // fp32 tensors, key-split launch of the split kernel: p0 carries the chain's flag fields (flag_mode 3: every share bounds the logit
 // width of its own keys)
-hipError_t launch_f32_keysplit(const fa::FwdParams& p0, int32_t d, int32_t causal, int S, char* part, hipStream_t stream, bool exact = false)
+// exact: the exact fp32 kernel (io_in: 0 = fp32 tensors, 2 = bf16 tensors -- the partials are fp32 either way; out_f32: what the combine stores)
+hipError_t launch_f32_keysplit(const fa::FwdParams& p0, int32_t d, int32_t causal, int S, char* part, hipStream_t stream, bool exact = false, int io_in = 0,
+                               int out_f32 = 1)
 {
     const int n_kv = keysplit_rows(p0, S, causal);
     const size_t o_bytes = (size_t)S * p0.bh * p0.n * d * 4u;
@@ -71,10 +73,10 @@ hipError_t launch_f32_keysplit(const fa::FwdParams& p0, int32_t d, int32_t causa
     p.lse = lse_part;
     p.n_kv = n_kv;
     p.n_kv_total = p0.n;
-    hipError_t e = exact ? fa::launch_fwd_f32(p, d, causal ? 1 : 0, 0, stream) : fa::launch_f32_split(p, d, causal ? 1 : 0, 0, stream);
+    hipError_t e = exact ? fa::launch_fwd_f32(p, d, causal ? 1 : 0, 0, stream, io_in) : fa::launch_f32_split(p, d, causal ? 1 : 0, 0, stream);
     fa::FwdParams pc = p0;
     pc.flag_mode = 0;
-    if (e == hipSuccess) e = fa::launch_combine_splits(pc, o_part, lse_part, S, d, 1, stream);
+    if (e == hipSuccess) e = fa::launch_combine_splits(pc, o_part, lse_part, S, d, out_f32, stream);
     return e;
 }
 
@@ -188,10 +190,12 @@ int launch(const fa::FwdParams& p_in, int32_t d, int32_t causal, int32_t dtype, 
     hipError_t e = hipSuccess;
     switch (pl.route) {
         case kRouteNaive: e = fa::launch_naive(p, d, c, dtype, stream); break;
-        case kRouteF32Exact:
-            if (pl.S > 1) e = launch_f32_keysplit(p, d, causal, pl.S, scratch + pl.part_off, stream, true);
-            else e = fa::launch_fwd_f32(p, d, c, sel.variant, stream);
+        case kRouteF32Exact: {   // (bf16 tensors: the wide head dims, widened on load; partials of a key-split launch are fp32 either way)
+            const bool in_bf16 = dtype != FA_DTYPE_F32;
+            if (pl.S > 1) e = launch_f32_keysplit(p, d, causal, pl.S, scratch + pl.part_off, stream, true, in_bf16 ? 2 : 0, dtype == FA_DTYPE_BF16 ? 0 : 1);
+            else e = fa::launch_fwd_f32(p, d, c, sel.variant, stream, !in_bf16 ? 0 : out_f32 ? 2 : 1);
             break;
+        }
         case kRouteF32Split: e = fa::launch_f32_split(p, d, c, sel.variant, stream); break;
         case kRouteF32Guarded: {   // split products behind the range guard: ONE launch -- a workgroup whose operands leave what fp16 terms hold
             ReportRef f;            // (or met a NaN) redoes its own rows in fp32 arithmetic inside the kernel (flag_mode 4).  The word only

@@ -196,9 +196,10 @@ Plan make_plan(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype,
     }
     if (!head_dim_supported(d)) {
         // Head dims outside {32, 64, 128} (round 6): the reference is generic over d % 32 == 0 by editing one macro (flashattention.cu:15,164).
-        // fp32 tensors, d a multiple of 32 up to 256: the exact fp32 MFMA kernel (AUTO and MFMA alike); every other head dim up to 256, and
-        // bf16 tensors at any of them: FA_KERNEL_AUTO runs the rung-0 kernel (fp32 arithmetic, correct, slow) instead of refusing the call.
-        if (dtype == FA_DTYPE_F32 && head_dim_exact_f32(d) && sel.variant == 0 && (sel.kind == FA_KERNEL_AUTO || sel.kind == FA_KERNEL_MFMA)) {
+        // d a multiple of 32 up to 256: the exact fp32 MFMA kernel (AUTO and MFMA alike) -- fp32 tensors as they are, bf16 tensors widened on
+        // load (fp32 arithmetic on both); every other head dim up to 256: FA_KERNEL_AUTO runs the rung-0 kernel (fp32 arithmetic, correct, slow)
+        // instead of refusing the call.
+        if (head_dim_exact_f32(d) && sel.variant == 0 && (sel.kind == FA_KERNEL_AUTO || sel.kind == FA_KERNEL_MFMA)) {
             pl.route = kRouteF32Exact;
             const int S = scratch_ok ? keysplit_factor_exact(p, d, causal) : 1;
             if (S > 1) {
@@ -214,7 +215,7 @@ Plan make_plan(const fa::FwdParams& p, int32_t d, int32_t causal, int32_t dtype,
             return pl;
         }
         pl.status = fail(FA_ERR_UNSUPPORTED, "head dim %d: this kernel family is instantiated for 32, 64, 128 (FA_KERNEL_AUTO takes any head dim up to 256; "
-                                             "FA_KERNEL_MFMA fp32 tensors at multiples of 32 up to 256)", d);
+                                             "FA_KERNEL_MFMA multiples of 32 up to 256)", d);
         return pl;
     }
     if (dtype == FA_DTYPE_F32) {

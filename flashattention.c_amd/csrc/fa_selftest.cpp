@@ -32,7 +32,7 @@ extern "C" int fa_host_selftest(void)
             const Plan pl = make_plan(p, d, causal, dt, kind, scratch_ok);
             if (kind == FA_KERNEL_AUTO) FA_CHECK((pl.status == FA_OK) == (d <= 256));          // AUTO takes every head dim up to 256
             if (kind == FA_KERNEL_AUTO && d == 48) FA_CHECK(pl.route == kRouteNaive);
-            if (kind == FA_KERNEL_AUTO && (d == 96 || d == 256)) FA_CHECK(pl.route == (dt == FA_DTYPE_F32 ? kRouteF32Exact : kRouteNaive));
+            if (kind == FA_KERNEL_AUTO && (d == 96 || d == 256)) FA_CHECK(pl.route == kRouteF32Exact);
             if (pl.status != FA_OK) continue;
             FA_CHECK(scratch_ok || pl.total == 0);                                   // no scratch, no bytes
             FA_CHECK(pl.S >= 1 && pl.S <= 8);

@@ -12,7 +12,7 @@ handle only.  Defaults reproduce the reference: ``scale = 1.0`` (``flashattentio
 Differences, all deliberate (DESIGN.md "boundary"): the call is asynchronous on the current stream (the reference
 ends with ``cudaDeviceSynchronize``), invalid input raises ``ValueError``/``TypeError`` instead of tripping a device
 ``assert`` (``flashattention.cu:606``), every head dim up to 256 runs (32/64/128 on every kernel family, the other multiples of 32
-on the exact fp32 kernel, the rest on the rung-0 kernel; the reference needs ``#define d`` edited, ``:15``), any sequence length is exact
+on the exact fp32 kernel -- fp32 or bf16 tensors --, the rest on the rung-0 kernel; the reference needs ``#define d`` edited, ``:15``), any sequence length is exact
 (the reference needs N % 32 == 0), and bf16 tensors are accepted (bf16 MFMA path).
 """
 from __future__ import annotations

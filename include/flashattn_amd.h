@@ -18,10 +18,11 @@
  *   math       O = softmax(scale * Q K^T  [causal: key index <= query index]) V, per (batch*head)
  *   scale      explicit; the reference hard-wires 1.0 (flashattention.cu:593,600) -- pass 1.0f for parity
  *   N          any N >= 1, exactly (tail keys are masked; the reference zero-fills, flashattention.cu:224-231)
- *   d          32, 64, 128: every kernel family.  fp32 tensors, other multiples of 32 up to 256 (the head dims the
- *              reference compiles by editing `#define d`, flashattention.cu:15,164): the exact fp32 MFMA kernel.
- *              Any other d <= 256, and bf16 tensors outside {32, 64, 128}: FA_KERNEL_AUTO runs the rung-0 kernel
- *              (fp32 arithmetic; correct, slow).  fa_kernel_name_for() names what runs.
+ *   d          32, 64, 128: every kernel family.  The other multiples of 32 up to 256 (the head dims the reference
+ *              compiles by editing `#define d`, flashattention.cu:15,164): the exact fp32 MFMA kernel, for fp32
+ *              tensors and (widened on load, fp32 arithmetic) for bf16 tensors.  Any other d <= 256:
+ *              FA_KERNEL_AUTO runs the rung-0 kernel (fp32 arithmetic; correct, slow).  fa_kernel_name_for()
+ *              names what runs.
  *   ownership  the caller owns every buffer.  fa_forward_ws, the boundary proper, allocates nothing: scratch is
  *              needed only by key-split launches (long rows on grids that leave the chip idle);
  *              fa_workspace_bytes() sizes it (0 for every other call).  The convenience entries (fa_forward,
@@ -52,7 +53,8 @@
  *   FA_DTYPE_BF16_OUT_F32  weights to 2^-17, fp32 output: <= 2e-4 on every data family tested, 2e-5 on
  *                          unit-variance data at scale 1 -- the path inside the 1e-3 of the north star; ~1.5x the
  *                          time of FA_DTYPE_BF16
- *   other head dims        exact fp32 MFMA kernel / rung-0 kernel: fp32 arithmetic, E_ref-class error (<= 1e-4)
+ *   other head dims        exact fp32 MFMA kernel / rung-0 kernel: fp32 arithmetic, E_ref-class error (<= 1e-4);
+ *                          bf16 tensors: plus the one rounding of a bf16 output, 2^-9 |O|
  */
 #ifndef FLASHATTN_AMD_H
 #define FLASHATTN_AMD_H

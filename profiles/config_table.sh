@@ -79,13 +79,13 @@ $DA --mode rand --bh 16 --n 8192 --d 128 $P
 $DA --mode rand --bh 16 --n 8192 --d 128 $P --causal 1
 $DA --mode rand --bh 16 --n 8192 --d 32 $P
 $DA --mode rand --bh 128 --n 1024 --d 64 $P
-echo "== wide head dims (round 6): fp32 tensors, FA_KERNEL_AUTO = the exact fp32 MFMA kernel: d = 96, 160, 192, 224, 256 at BH=16 N=8192; d = 96, 256 causal; d = 96 BH=1 (key shares); then rung 0 at d = 80 (BH=16 N=2048) and bf16 tensors at d = 96 (rung 0)"
+echo "== wide head dims (round 6): fp32 tensors, FA_KERNEL_AUTO = the exact fp32 MFMA kernel: d = 96, 160, 192, 224, 256 at BH=16 N=8192; d = 96, 256 causal; d = 96 BH=1 (key shares); then rung 0 at d = 80 (BH=16 N=2048) and bf16 tensors at d = 96, 256 (the same kernel, widened on load)"
 E="--dtype f32 --kernel auto --check 0 --warmup 10 --iters 6"
 for hd in 96 160 192 224 256; do $D --mode rand --bh 16 --n 8192 --d $hd $E; done
 for hd in 96 256; do $D --mode rand --bh 16 --n 8192 --d $hd $E --causal 1; done
 $D --mode rand --bh 1 --n 8192 --d 96 $E --warmup 50 --iters 30
 $D --mode rand --bh 16 --n 2048 --d 80 $E --warmup 3 --iters 3
-$D --mode rand --bh 16 --n 2048 --d 96 --dtype bf16 --kernel auto --check 0 --warmup 3 --iters 3
+for hd in 96 256; do $D --mode rand --bh 16 --n 8192 --d $hd --dtype bf16 --kernel auto --check 0 --warmup 10 --iters 6; done
 echo "== llm.c harness size"
 $D --mode llmc | tail -1
 H="python3 -m flashattention_c_amd.harness.bench_flashattention --iters 50 --warmup 100"

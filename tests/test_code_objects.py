@@ -90,7 +90,8 @@ def test_every_kernel_of_the_product_library_is_reachable_or_documented(kernels)
         m = re.search(r"fa_fwd_bf16_x2(?:_pb2)?_kernel<(32|64), ", k.name)
         if m:
             assert k.vgprs <= 256, f"{k.name}: {k.vgprs} registers -- no longer fits a CU twice"
-    assert os.path.getsize(LIB) < 4 * 1024 * 1024, "the product library grew past 4 MB (it was 5.7 MB with every round-2 tiling in it)"
+    # (3.7 MB through round 5; round 6 added the exact kernel at five more head dims, for fp32 and for bf16 tensors: 30 kernels, 4.3 MB)
+    assert os.path.getsize(LIB) < 4.5 * 1024 * 1024, "the product library grew past 4.5 MB (it was 5.7 MB with every round-2 tiling in it)"
 
 
 def test_timing_only_ablations_are_not_in_the_product_library(kernels):

@@ -2,8 +2,8 @@
 (ADVICE r05).
 
 The reference is generic over ``d % 32 == 0`` by editing one macro (/root/reference/src/flashattention.cu:15, ``num_tiles = d / BK`` at :164);
-here ``forward(q, k, v, causal)`` takes every head dim up to 256: fp32 tensors at the other multiples of 32 run the exact fp32 MFMA kernel
-(fa_fwd_f32_wide.hip), every other head dim -- and bf16 tensors outside {32, 64, 128} -- the rung-0 kernel.  Everything is checked against the
+here ``forward(q, k, v, causal)`` takes every head dim up to 256: the other multiples of 32 run the exact fp32 MFMA kernel (fa_fwd_f32_wide*.hip;
+bf16 tensors widened on load), every other head dim the rung-0 kernel.  Everything is checked against the
 fp64 oracle on the same inputs."""
 import ctypes
 
@@ -83,8 +83,9 @@ def test_any_other_head_dim_runs_on_the_rung_0_kernel(d):
 
 @pytest.mark.parametrize("d", [48, 96, 256])
 def test_bf16_tensors_outside_the_instantiated_head_dims(d):
-    """bf16 tensors: fp32 arithmetic in the rung-0 kernel, bf16 or fp32 output (the explicit kernel="naive" takes bf16 tensors at 64 too)."""
-    assert _cabi.lib().fa_kernel_name_for(_cabi.FA_DTYPE_BF16, d, 1, 2, 300) == b"fa_naive_f32_kernel"
+    """bf16 tensors: fp32 arithmetic -- the exact MFMA kernel at multiples of 32 (widened on load), the rung-0 kernel elsewhere --, bf16 or fp32
+    output (the explicit kernel="naive" takes bf16 tensors at 64 too)."""
+    assert _cabi.lib().fa_kernel_name_for(_cabi.FA_DTYPE_BF16, d, 1, 2, 300) == (b"fa_naive_f32_kernel" if d % 32 else b"fa_fwd_f32_kernel")
     q, k, v = (rand(3 * d + i, 2, 300, d).to(torch.bfloat16) for i in range(3))
     for causal in (False, True):
         ref = orc.attention_f64(q.float().numpy(), k.float().numpy(), v.float().numpy(), causal=causal, scale=1.0)
@@ -95,6 +96,42 @@ def test_bf16_tensors_outside_the_instantiated_head_dims(d):
     q64, k64, v64 = (rand(9 + i, 2, 200, 64).to(torch.bfloat16) for i in range(3))
     o64 = fa.forward(q64.to(dev()), k64.to(dev()), v64.to(dev()), True, kernel="naive", out_dtype=torch.float32)
     assert err(o64, orc.attention_f64(q64.float().numpy(), k64.float().numpy(), v64.float().numpy(), causal=True, scale=1.0)) < TOL
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("d", [96, 160, 192, 224, 256])
+def test_bf16_tensors_on_the_exact_kernel_at_the_wide_head_dims(d, causal):
+    """Round 6: bf16 tensors at the other multiples of 32 ran on the rung-0 kernel (16 x 8192 x 96: 246 ms where fp32 tensors took 3.3).  Now the
+    exact fp32 MFMA kernel widens them on their way into its fp32 LDS images: ragged lengths, a single key, both output types, the LSE; AUTO
+    and kernel="exact" are the same launch."""
+    for n in (1, 31, 333, 1024, 1300):
+        q, k, v = (rand(7 * d + n + i, 3, n, d).to(torch.bfloat16) for i in range(3))
+        ref, lref = orc.attention_f64(q.float().numpy(), k.float().numpy(), v.float().numpy(), causal=causal, scale=1.0, return_lse=True)
+        of, lse = fa.forward(q.to(dev()), k.to(dev()), v.to(dev()), causal, out_dtype=torch.float32, return_lse=True)
+        assert of.dtype == torch.float32 and err(of, ref) < TOL and err(lse, lref) < TOL, (d, n, causal)
+        ob = fa.forward(q.to(dev()), k.to(dev()), v.to(dev()), causal)
+        assert ob.dtype == torch.bfloat16 and err(ob, ref) < 2.0 ** -8 * max(1.0, float(np.abs(ref).max())), (d, n, causal)
+        oe = fa.forward(q.to(dev()), k.to(dev()), v.to(dev()), causal, kernel="exact", scale=0.125, out_dtype=torch.float32)
+        assert err(oe, orc.attention_f64(q.float().numpy(), k.float().numpy(), v.float().numpy(), causal=causal, scale=0.125)) < TOL
+
+
+@pytest.mark.parametrize("d", [96, 256])
+def test_bf16_tensors_wide_heads_long_rows_and_key_shares(d):
+    """Rows of 8192 keys: a full grid against the rung-0 kernel on every slab, idle grids over key shares + combine (fp32 partials, the combine
+    stores the caller's output type), causal pairs."""
+    for bh, causal in ((16, False), (1, False), (1, True), (4, True)):
+        n = 8192 if bh <= 4 else 2048
+        q, k, v = (torch.randn(bh, n, d, device=dev(), generator=torch.Generator(device=dev()).manual_seed(5 * bh + d)).to(torch.bfloat16) for _ in range(3))
+        if bh == 1:
+            assert fa.workspace_bytes(bh, n, d, causal, dtype=torch.bfloat16) > 0
+        ref = fa.forward(q, k, v, causal, kernel="naive", out_dtype=torch.float32)
+        of = fa.forward(q, k, v, causal, out_dtype=torch.float32)
+        assert float((of - ref).abs().max()) < 2 * TOL, (bh, causal, d)
+        ob = fa.forward(q, k, v, causal)
+        assert ob.dtype == torch.bfloat16 and float((ob.float() - ref).abs().max()) < 2.0 ** -8 * max(1.0, float(ref.abs().max()))
+        rows = [0, 1, n // 2, n - 1]
+        r64 = orc.attention_f64(q[:1].float().cpu().numpy(), k[:1].float().cpu().numpy(), v[:1].float().cpu().numpy(), causal=causal, scale=1.0)
+        assert float(np.abs(of[0, rows].cpu().numpy().astype(np.float64) - r64[0, rows]).max()) < TOL
 
 
 def test_packed_qkv_entry_at_a_head_size_of_96():

@@ -35,10 +35,10 @@ def test_library_exports_every_declared_symbol():
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 128, 0, 2, 300) == b"fa_fwd_bf16_w4_kernel"      # too few workgroups
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 128, 1, 2, 300) == b"fa_fwd_bf16_kernel"
     # head dims outside {32, 64, 128} (round 6): fp32 tensors at the other multiples of 32 up to 256 run the exact fp32 MFMA kernel, every
-    # other head dim up to 256 (and bf16 tensors at any of them) the rung-0 kernel -- the reference compiles any d % 32 == 0 (flashattention.cu:15)
+    # other head dim up to 256 the rung-0 kernel -- the reference compiles any d % 32 == 0 (flashattention.cu:15)
     assert L.fa_kernel_name(_cabi.FA_DTYPE_F32, 48, 0) == b"fa_naive_f32_kernel" and L.fa_kernel_name(_cabi.FA_DTYPE_F32, 300, 0) is None
     for d in (96, 160, 192, 224, 256):
-        assert L.fa_kernel_name(_cabi.FA_DTYPE_F32, d, 1) == b"fa_fwd_f32_kernel" and L.fa_kernel_name(_cabi.FA_DTYPE_BF16, d, 0) == b"fa_naive_f32_kernel"
+        assert L.fa_kernel_name(_cabi.FA_DTYPE_F32, d, 1) == b"fa_fwd_f32_kernel" and L.fa_kernel_name(_cabi.FA_DTYPE_BF16, d, 0) == b"fa_fwd_f32_kernel"
     assert L.fa_kernel_name(7, 64, 0) is None and L.fa_kernel_name_for(_cabi.FA_DTYPE_F32, 64, 0, 0, 5) is None
     # bf16 tensors with fp32 output (round 4): P as two bf16 terms in one launch -- the tilings of the bf16-P one-wave-per-SIMD kernels
     assert L.fa_kernel_name(_cabi.FA_DTYPE_BF16_OUT_F32, 64, 0) == b"fa_fwd_bf16_x4_pb2_kernel"     # c4: 512-row workgroups
@@ -120,7 +120,8 @@ def test_workspace_sizes_are_host_arithmetic():
     assert L.fa_workspace_bytes(4, 300, 32, 0, B16F, 4) == 0 and L.fa_workspace_bytes(4, 300, 32, 0, B16F, 5) == 0
     # head dims outside {32, 64, 128}: the exact kernel splits idle grids like at 64; the rung-0 kernel needs nothing
     assert L.fa_workspace_bytes(1, 8192, 96, 0, F32, A) == part(8, 1, 8192, 96) == L.fa_workspace_bytes(1, 8192, 96, 0, F32, M)
-    assert L.fa_workspace_bytes(16, 8192, 256, 0, F32, A) == 0 and L.fa_workspace_bytes(16, 8192, 48, 0, F32, A) == 0 and L.fa_workspace_bytes(1, 8192, 96, 0, B16, A) == 0
+    assert L.fa_workspace_bytes(16, 8192, 256, 0, F32, A) == 0 and L.fa_workspace_bytes(16, 8192, 48, 0, F32, A) == 0 and L.fa_workspace_bytes(1, 8192, 80, 0, B16, A) == 0
+    assert L.fa_workspace_bytes(1, 8192, 96, 0, B16, A) == part(8, 1, 8192, 96)   # bf16 tensors on the exact kernel: the same fp32 partials
     # arguments fa_forward_ws would reject size to 0 and leave fa_last_error alone
     assert L.fa_workspace_bytes(0, 8192, 64, 0, B16F, A) == 0 and L.fa_workspace_bytes(16, 8192, 300, 0, B16F, A) == 0
     assert L.fa_workspace_bytes(16, 8192, 64, 0, 7, A) == 0 and L.fa_workspace_bytes(16, 8192, 64, 0, F32, _cabi.FA_KERNEL_PB2) == 0
