@@ -85,7 +85,7 @@ def main():
         f"| same, **fp32 arithmetic** (`FA_KERNEL_MFMA` — the figure to quote for \"c3 fp32\" in the reference's sense: bench `extra.c3.reference_arithmetic`) | `fa_fwd_f32_kernel` | {ms(exa[0])} | {exa[0]['tflops']:.1f} | **{fr(exa[0], 157.3)}** of fp32 peak |",
         f"| c3 shape causal; d=128; d=32 (fp32 tensors, split) | `fa_fwd_f32_split_kernel` | {ms(f3[4])}; {ms(f3[6])}; {ms(f3[7])} | {tf(f3[4])}; {tf(f3[6])}; {tf(f3[7])} | — |",
         f"| **c2** B=8 H=16 N=1024 d=64 fp32 | split (AUTO: {ex['c2']['ms']:.3f} bench) / exact (`extra.c2.reference_arithmetic`) | {ms(f3[5])} / {ms(exa[1])} | {tf(f3[5])} / {tf(exa[1])} | {fr(f3[5], third)} of bf16 peak at 3× FLOP / {fr(exa[1], 157.3)} of fp32 peak |",
-        (f"| head dims outside 32 / 64 / 128 (round 6), fp32 tensors through `forward()`: d = 96, 160, 192, 224, 256 at BH=16 N=8192; d = 96, 256 causal; d = 96 one slab (key shares); d = 80 (rung 0, BH=16 N=2048); bf16 tensors d = 96, 256 at BH=16 N=8192 | `fa_fwd_f32_kernel` (exact fp32 MFMA, `fa_fwd_f32_wide{,_bf16}.hip`); `fa_naive_f32_kernel` | "
+        (f"| head dims outside 32 / 64 / 128 (round 6), fp32 tensors through `forward()`: d = 96, 160, 192, 224, 256 at BH=16 N=8192; d = 96, 256 causal; d = 96 one slab (key shares); d = 80 (rung 0, BH=16 N=2048); bf16 tensors d = 96, 256 at BH=16 N=8192 | `fa_fwd_f32_kernel` (exact fp32 MFMA, `fa_fwd_f32_wide{{,_bf16}}.hip`); `fa_naive_f32_kernel` | "
          + ", ".join(ms(w, 2) for w in s["wide"][:5]) + "; " + ", ".join(ms(w, 2) for w in s["wide"][5:7]) + f"; {ms(s['wide'][7])}; {ms(s['wide'][8], 1)}; " + ", ".join(ms(w, 2) for w in s["wide"][9:11]) + " | "
          + ", ".join(f"{w['tflops']:.0f}" for w in s["wide"][:5]) + "; " + ", ".join(f"{w['tflops']:.0f}" for w in s["wide"][5:7]) + f"; {s['wide'][7]['tflops']:.0f}; {s['wide'][8]['tflops']:.1f}; " + ", ".join(f"{w['tflops']:.0f}" for w in s["wide"][9:11]) + " | "
          + ", ".join(fr(w, 157.3) for w in s["wide"][:5]) + " of the fp32 MFMA peak |") if "wide" in s and len(s["wide"]) >= 11 else "| head dims outside 32 / 64 / 128 | not in this collection | | | |",
