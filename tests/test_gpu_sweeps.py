@@ -114,3 +114,30 @@ def test_every_sequence_length_at_the_wide_head_dims(d):
     assert err < TOL_F32, err
     z = fa.forward(q, k, torch.zeros_like(v), False)
     assert float(z.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("d", [96, 160, 192, 224, 256])
+def test_every_sequence_length_at_the_wide_head_dims_bf16_tensors(d):
+    """The same sweep on bf16 tensors (round 6, last day: widened on load into the exact kernel's fp32 LDS images -- tiles through registers, held
+    across a tile up to d = 160, requested late above): every n in 1 .. 160, the tile-height neighbourhoods, idle grids (key shares: fp32
+    partials, the combine stores the caller's type), causal and not; fp32 output and LSE against rung 0 on the same bf16 tensors, NaN-poisoned
+    outputs; the bf16 output against its one rounding."""
+    g = torch.Generator(device="cpu").manual_seed(4000 + d)
+    lengths = [(3, n) for n in range(1, 161)] + [(3, n) for n in (255, 256, 257, 383, 384, 385, 511, 512, 513)] + [(1, n) for n in (2047, 2048, 2049, 8192, 8193)]
+    lengths += [(140, 128), (70, 300)]
+    bad = []
+    for bh, n in lengths:
+        q, k, v = (torch.randn(bh, n, d, generator=g).to(torch.bfloat16).to(dev()) for _ in range(3))
+        for causal in (False, True):
+            for scale in ((1.0, d ** -0.5) if n in (7, 128, 300, 8192) else (1.0,)):
+                ref, lref = fa.forward(q, k, v, causal, kernel="naive", return_lse=True, scale=scale, out_dtype=torch.float32)
+                out = torch.full((bh, n, d), float("nan"), device=dev())
+                _, lse = fa.forward(q, k, v, causal, out=out, return_lse=True, scale=scale, out_dtype=torch.float32)
+                eo, el = float((out - ref).abs().max()), float((lse - lref).abs().max())
+                ob = fa.forward(q, k, v, causal, scale=scale)
+                eb = float((ob.float() - ref).abs().max())
+                if not (eo < TOL_F32 and el < TOL_F32 and ob.dtype == torch.bfloat16 and eb < 2.0 ** -8 * max(1.0, float(ref.abs().max()))):
+                    bad.append((causal, bh, n, scale, eo, el, eb))
+    assert not bad, bad[:10]
+    z = fa.forward(q, k, torch.zeros_like(v), False)
+    assert float(z.float().abs().max()) == 0.0
