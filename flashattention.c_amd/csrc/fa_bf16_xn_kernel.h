@@ -36,6 +36,15 @@
 #ifndef FA_XN_TAKE_TURNS
 #define FA_XN_TAKE_TURNS 1   // 0: experiment switch -- two workgroups sharing a CU leave the issue priority to the arbiter (oldest wave first)
 #endif
+#ifndef FA_OPT_SAMPLE_SUBTILES
+#define FA_OPT_SAMPLE_SUBTILES 99   // experiment switch: at most this many sub-tiles BEYOND the first go into the sampled reference (0: none)
+#endif
+#ifndef FA_OPT_SAMPLE_WHEN_RECENTRED
+#define FA_OPT_SAMPLE_WHEN_RECENTRED 0   // 1: experiment switch -- tiles that re-centre their reference sample it in the prologue as well (round 6 until its last day)
+#endif
+#ifndef FA_OPT_RC_FIRST
+#define FA_OPT_RC_FIRST 8           // experiment switch: stages into a long tile at which the reference is re-centred for the first time (then x 3)
+#endif
 #ifndef FA_OPT_SAMPLE
 #define FA_OPT_SAMPLE 1   // 0: experiment switch -- the optimistic mix takes its exponent reference from the first sub-tile only (round 2)
 #endif
@@ -1019,10 +1028,20 @@ __device__ __forceinline__ int xn_tile(const FwdParams& p, char* smem)   // 1 = 
         // random data.  Costs 2 G + 1 phase-structured K.Q^T passes, so only long tiles take it (measured on one box, sampled / not:
         // c4 0.2319 / 0.2363 ms, c5's shard 1.806 / 1.845, d = 128 0.4136 / 0.4203, but 16 x 2048 0.0364 / 0.0347), and only waves whose
         // first sub-tile spreads over enough binades for anything to underflow (at 1/sqrt(d) scaling nothing does: 0.2400 / 0.2380).
+        // Round 6, last day: with the reference RE-CENTRED on the row sum eight stages into the tile (xn_recentre) the sample only shapes the first
+        // 512 of 8192 keys, and its five extra K.Q^T passes cost ~1 % of a c4 tile: without it c4 -1.4 % (ablation libraries; product libraries -0.5 %),
+        // c5's shard -1.6 %, d = 128 -1.0 %, d = 32 -1.4 %, 32 x 4096 -2.3 %, errors identical; re-centring earlier (2 or 4 stages in) buys nothing
+        // on top (profiles/r06_exp15_sample_vs_recentre.txt).  So a tile that is going to re-centre does not sample -- which today is every long
+        // tile of the product's launches; the sample remains the reference of tiles that do not (the ablation library's forms), and `wide`
+        // (the first sub-tile's spread) still gates the re-centring.
         bool sampled = false;
         if constexpr (OPT && FA_OPT_SAMPLE) {
-            if (nst >= kSampleMinStages && __any(wide)) {
-                const int ts = min(nsub, 2 * min(G + 1, nst));   // sub-tiles of the K stages the prologue requested
+            // (rows of kSampleMinStages stages have their 32 fast stages, causal or not: every tile that would sample re-centres)
+            // (the two-term NB = 2 kernels keep their sample: at d = 64 they sit at exactly 256 registers, and without the sampling loop hipcc's
+            // allocation of the fp32-output instantiation lands on 260 -- one workgroup per CU instead of two; they gain 0.5 % at most)
+            constexpr bool kRecentres = ABL == 0 && FA_OPT_RECENTRE != 0 && !(PF == 3 && NB == 2);
+            if ((FA_OPT_SAMPLE_WHEN_RECENTRED != 0 || !kRecentres) && nst >= kSampleMinStages && __any(wide)) {
+                const int ts = min(min(nsub, 2 * min(G + 1, nst)), FA_OPT_SAMPLE_SUBTILES + 1);   // sub-tiles of the K stages the prologue requested
 #pragma unroll 1
                 for (int t = ts - 1; t >= 1; --t) {              // ends with sub-tile 1: its fragments stay in kf for the first step
                     load_kf(t);
@@ -1058,7 +1077,7 @@ __device__ __forceinline__ int xn_tile(const FwdParams& p, char* smem)   // 1 = 
     }
     // (re-centring pays on long tiles whose scores spread over enough binades for anything to underflow -- the prologue's `wide`, which also gates
     // the sampled reference: at 1 / sqrt(d) scaling nothing does and the tile keeps its reference, at no cost; 8 is a multiple of G)
-    int next_rc = (jf >= 32 && OPT && FA_OPT_SAMPLE && __any(wide)) ? 8 : 0x7fffffff;
+    int next_rc = (jf >= 32 && OPT && FA_OPT_SAMPLE && __any(wide)) ? FA_OPT_RC_FIRST : 0x7fffffff;   // (== recentres && any(wide) where the product is concerned)
     // Two workgroups share a CU where the registers allow (NB = 2, d <= 64): two waves per SIMD, and the arbiter serves the OLDER one first --
     // it runs at nearly the speed of a lone wave, finishes early, and the younger one spends the rest of the launch alone at the lower
     // efficiency of one wave per SIMD (stamped kernel, 16 x 8192 d = 32: 760 against 1290 cycles per step, half of the waves each; tiles end
