@@ -127,9 +127,10 @@ def main():
         f"  The path INSIDE 1e-3 (bf16 tensors, fp32 output, P as bf16 hi + bf16 lo in one launch: {acc['max_abs_err']:.1e} at the reference's scale 1):\n"
         f"  {ms(x2[0])} ms = **{fr(x2[0])}** of the dense bf16 MFMA peak here; round 6's boxes read 0.325–0.338 with the re-centred reference (A/B on one box: −3.3 % time), the boxes of rounds 4–5 0.30–0.33 (`roofline_at_1e-3` of the bench line).\n"
         f"  The fastest path (bf16 P, bf16 output: {b4['roofline']['max_abs_err']:.1e} there — 15× outside that bar; {ex['c4_scale_rsqrt_d']['max_abs_err']:.1e} at 1/√d): {ms(c4[0])} ms =\n"
-        f"  **{fr(c4[0])}** here, 0.483–0.503 on round 6's boxes; the DRIVER's end-of-round runs read 0.466 / 0.485 / 0.488 / 0.468 / 0.477 in rounds 1–5 (0.47–0.49).  `DESIGN.md` §5 / §5.1: the loops\n"
+        f"  **{fr(c4[0])}** here, 0.483–0.505 on round 6's boxes; the DRIVER's end-of-round runs read 0.466 / 0.485 / 0.488 / 0.468 / 0.477 in rounds 1–5 (0.47–0.49).  `DESIGN.md` §5 / §5.1: the loops\n"
         f"  run at the 1.4 kW package cap; the three sized ideas of VERDICT r05 were taken to their kill tests and measured negative; re-centring the\n"
-        f"  optimistic reference on the row sum (more exact zeros in P) bought 2.0 % on this line and 3.3 % on the one above (A/B, `profiles/r06_exp9_recentre.txt`);\n"
+        f"  optimistic reference on the row sum (more exact zeros in P) bought 2.0 % on this line and 3.3 % on the one above (A/B, `profiles/r06_exp9_recentre.txt`),\n"
+        f"  dropping the prologue's sampled reference where the tile re-centres anyway another 1.7 % (`profiles/r06_exp15_sample_vs_recentre.txt`);\n"
         f"  two workgroups sharing a CU taking turns at the issue priority another 2.6 % at d = 32 (`profiles/r06_exp12_take_turns.txt`).\n"
         f"* d=128: {ms(dm[1])} ms ({tf(dm[1])} TFLOP/s, {fr(dm[1])}); causal d=64: {ms(ca[0])} ms ({fr(ca[0])}); d=32: {ms(dm[0])} ms ({fr(dm[0])}); all 1024 slabs of config 5 on one GPU: {c5['ms_per_step']:.2f} ms ({c5['frac_bf16_mfma_peak_per_gpu']:.3f}).\n"
         f"* fp32 tensors (the reference's dtype) {ms(f3[0])} ms = {tf(f3[0])} TFLOP/s (0.667–0.736 ms by box): Q·Kᵀ as three fp16 MFMA products of fp16 hi/lo terms, P·V as three\n"
