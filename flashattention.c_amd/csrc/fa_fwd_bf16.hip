@@ -495,8 +495,11 @@ static Bf16Choice choose_bf16(int64_t bh, int64_t n, int d, int causal, bool add
     // Round 3: the NB = 2 kernel takes its exponent reference from 192 sampled keys on rows of 4096 keys and more (more zero operands, more
     // clock: DESIGN.md 4.6), the two-wave kernel does not -- on long rows it is now 2-3 % ahead of pp3 at every partly filled round
     // (ms pp3 / x2, BH x N: 24 x 8192 0.407 / 0.399, 40 x 8192 0.635 / 0.619, 16 x 12288 0.579 / 0.561, 48 x 12288 0.649 / 0.607, 12 x 16384
-    // 0.762 / 0.736, 20 x 16384 1.228 / 1.199; at 4096 keys they alternate: 12 x 4096 0.078 / 0.075, 24 x 4096 0.139 / 0.134, 32 x 4096 0.164 / 0.168)
-    if (n >= 8192) return kChooseX2D64;
+    // 0.762 / 0.736, 20 x 16384 1.228 / 1.199; at 4096 keys they alternated: 12 x 4096 0.078 / 0.075, 24 x 4096 0.139 / 0.134, 32 x 4096 0.164 / 0.168)
+    // Round 6: the NB = 2 kernel re-centres that reference on the row sum and no longer pays for sampling it; from 4096 keys on it now leads at
+    // every partly filled round of the sweep (ms pp3 / x2: 40 x 4096 0.208 / 0.201, 48 x 4096 0.201 / 0.192, 24 x 6144 0.258 / 0.247, 32 x 6144
+    // 0.283 / 0.270, 48 x 6144 0.430 / 0.413; at 3072 keys they still alternate: 48 x 3072 0.137 / 0.140, 64 x 3072 0.160 / 0.153)
+    if (n >= 4096) return kChooseX2D64;
     return kChoosePipelined4;
 }
 

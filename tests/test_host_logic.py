@@ -29,7 +29,8 @@ def test_library_exports_every_declared_symbol():
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, 0, 3, 700) == b"fa_fwd_bf16_kernel"      # at most 128 tiles of 256 rows: 128-row workgroups (round 3)
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, 0, 48, 1024) == b"fa_fwd_bf16_x2_kernel"  # at most one round of 256-row tiles
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, 0, 24, 8192) == b"fa_fwd_bf16_x2_kernel"   # 1.5 rounds of 512-row tiles, long rows: NB = 2 (round 3)
-    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, 0, 48, 4096) == b"fa_fwd_bf16_pp3_kernel"  # ... rows below 8192 keys: the two-wave kernel
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, 0, 48, 3072) == b"fa_fwd_bf16_pp3_kernel"  # ... rows below 4096 keys: the two-wave kernel
+    assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, 0, 48, 4096) == b"fa_fwd_bf16_x2_kernel"   # (round 6: from 4096 keys on the re-centring kernel)
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 64, 0, 12, 8192) == b"fa_fwd_bf16_x4_kernel"
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 128, 0, 16, 8192) == b"fa_fwd_bf16_x2_kernel"
     assert L.fa_kernel_name_for(_cabi.FA_DTYPE_BF16, 128, 0, 2, 300) == b"fa_fwd_bf16_w4_kernel"      # too few workgroups
