@@ -1008,7 +1008,7 @@ def test_scratch_paths_under_graph_capture_through_the_workspace_entry():
             assert float((of - ref_x).abs().max()) < TOL_F32, (causal, iters)
 
 
-@pytest.mark.parametrize("bh,n,causal", [(128, 1024, False), (48, 4096, False), (128, 2048, True), (512, 256, False)])
+@pytest.mark.parametrize("bh,n,causal", [(128, 1024, False), (48, 3072, False), (128, 2048, True), (512, 256, False)])
 def test_tiny_values_keep_their_relative_accuracy_in_the_two_wave_kernel(bh, n, causal):
     """fa_fwd_bf16_pp3_kernel (short rows, partly filled rounds) had no tiny-accumulator vote until the end of round 5: with P near 2^-100 the
     products of |v| ~ 2^-60 vanish, and a third of the outputs came back exactly zero (relative error 4.7; absolute 1e-17).  Now such a
