@@ -127,8 +127,9 @@ def timed_region(step_fn, steps: int, warmup: int, sync_fn, world: int, dist=Non
 
 
 PER_RANK_S = []   # seconds of the last timed_region on every rank (filled on all ranks)
-C4_ONE_GPU_TFLOPS = 1190.0   # the c4 headline on one MI355X: mean of the driver's five records (BENCH_r01 .. r05: 1164, 1212, 1220, 1171, 1192)
-C5_ONE_GPU_MS = 14.6   # all 1024 slabs of config 5 on one MI355X (driver, r04: 14.59 ms; profiles/: 14.57 - 14.77 over three rounds' boxes, +- 4 % between boxes)
+C4_ONE_GPU_TFLOPS = 1245.0   # the c4 headline on one MI355X with round 6's kernels: 1207 - 1275 over its last five boxes (the driver's records of rounds 1 - 5,
+                             # BENCH_r01 .. r05: 1164, 1212, 1220, 1171, 1192 -- mean 1190 -- times the 4.5 % the round's A/B runs add up to)
+C5_ONE_GPU_MS = 14.3   # all 1024 slabs of config 5 on one MI355X: 14.16 - 14.48 ms over round 6's collections (rounds 3 - 5: 14.57 - 14.77), +- 4 % between boxes
 
 
 def make_inputs(bh: int, n: int, d: int, dtype: str, device, seed: int):
